@@ -1,0 +1,133 @@
+/* osk.h — C ABI of libosk_hip.so: the MI355X (gfx950) kernels of the Open-Sora denoise path.
+ *
+ * The reference (hpcaitech/Open-Sora v2.0, /root/reference) has no native code and no FFI: every GPU
+ * kernel on its hot path is imported from a pip dependency (flash-attn, liger-kernel, cuBLAS/cuDNN via
+ * torch).  Each entry point below therefore cites the reference *call site* whose arithmetic it replaces
+ * (paths relative to /root/reference).  INTEGRATION.md shows the ctypes binding a reference maintainer
+ * would add (it is the binding open_sora_amd/_C.py uses).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers unless noted.
+ *  - `stream` is a hipStream_t passed as void*.  Every function only ENQUEUES work on `stream`:
+ *    no allocation, no synchronisation, no global state -> safe under hipGraph capture.
+ *  - bf16 tensors are passed as `const void*` / `void*` (16-bit storage); f32 as float*.
+ *  - Strides are in ELEMENTS of the tensor's dtype.  "rows_per_batch" addressing: logical row m of a
+ *    [B*L, ...] matrix lives at  base + (m / L) * batch_stride + (m % L) * row_stride, so that streams
+ *    stored inside larger joint buffers need no copies.
+ *  - Return value: 0 = OSK_OK, <0 = invalid argument / unsupported shape (nothing was launched),
+ *    >0 = hipError_t from the launch.
+ */
+#ifndef OSK_H
+#define OSK_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSK_ABI_VERSION 1
+int osk_abi_version(void);
+/* name of the arch the library was compiled for ("gfx950") — host-only, no GPU needed */
+const char* osk_arch(void);
+
+/* ---- LayerNorm(no affine, eps) + adaLN modulate:  out = (1 + scale[b]) * LN(x) + shift[b]
+ * replaces nn.LayerNorm + the bf16 elementwise chain at opensora/models/mmdit/layers.py:205-206,
+ * 223-224, 248, 252, 311-312 and LastLayer layers.py:400.  x/out bf16 [B*L, D]; shift/scale f32,
+ * element (b, d) at ptr[b * mod_batch_stride + d].  Statistics and modulate in f32, one rounding. */
+int osk_ln_modulate_bf16(const void* x, int64_t x_batch_stride, int64_t x_row_stride,
+                         void* out, int64_t out_batch_stride, int64_t out_row_stride,
+                         const float* shift, const float* scale, int64_t mod_batch_stride,
+                         int B, int L, int D, float eps, void* stream);
+
+/* ---- C = epilogue(A @ W^T + bias) on MFMA bf16 (f32 accumulate).
+ * replaces every nn.Linear on the path: layers.py:146-152,209-215,226-232,247-252,314-320,332-333,
+ * 401; model.py:176-180,191.  A bf16 [M, K] (rows_per_batch addressing), W bf16 [N, K] row-major
+ * (nn.Linear.weight layout), bias f32 [N] or NULL.
+ * Epilogue, in f32, in this order:
+ *   v = acc + bias[n];  if (n >= gelu_from) v = gelu_tanh(v);
+ *   if (gate) v = res[m, n] + gate[b * gate_batch_stride + n] * v;      (res bf16, same addressing as C)
+ *   C[m, n] = bf16(v)            (or f32 when out_f32 != 0)
+ * K % 64 == 0 required; any M, N >= 1.  gelu_from = N disables GELU.  res may alias C. */
+int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride, int a_rows_per_batch,
+                  const void* W, int64_t w_row_stride, const float* bias,
+                  void* C, int64_t c_batch_stride, int64_t c_row_stride, int c_rows_per_batch,
+                  const void* res, const float* gate, int64_t gate_batch_stride,
+                  int M, int N, int K, int gelu_from, int out_f32, void* stream);
+
+/* ---- skinny matrix-vector batch (M = Bv <= 8 rows): out[b, n] (+)= act_in(x[b, :]) . W[n, :] + bias[n]
+ * replaces Modulation (layers.py:184-191), MLPEmbedder (layers.py:91-99) and LastLayer.adaLN_modulation
+ * (layers.py:396,399): weight-bandwidth bound.  One launch covers a LIST of layers that share x:
+ * descriptor arrays (device memory, n_tasks entries each, one task = up to 64 consecutive rows of one
+ * layer):  w_ptrs[i] -> bf16 W rows [rows, K];  b_ptrs[i] -> bf16 bias or 0;  out_cols[i] = column
+ * offset in out;  n_rows[i].  x f32 [Bv, K], out f32 [Bv, out_batch_stride].
+ * act_in: 0 none, 1 SiLU.  accumulate != 0 adds into out. */
+int osk_gemv_tasks_bf16(const float* x, int64_t x_batch_stride, int Bv, int K,
+                        const uint64_t* w_ptrs, const uint64_t* b_ptrs, const int32_t* out_cols,
+                        const int32_t* n_rows, int n_tasks,
+                        float* out, int64_t out_batch_stride, int act_in, int accumulate, void* stream);
+
+/* ---- sinusoidal timestep embedding: out[b] = [cos(a) | sin(a)], a = time_factor * t[b] * exp(-ln(max_period) i / half)
+ * replaces timestep_embedding, layers.py:68-88 (f32). */
+int osk_timestep_embedding(const float* t, int B, int dim, float max_period, float time_factor,
+                           float* out, void* stream);
+
+/* ---- RoPE angle tables from integer (t, h, w) position ids.
+ * replaces EmbedND / rope (layers.py:31-44, math.py:50-57; f64 angles) and LigerEmbedND / liger_rope
+ * (layers.py:47-65, math.py:39-47; f32 angles).  ids f32 [n_rows, n_axes]; axes_dim[n_axes] host ints;
+ * cos/sin f32 [n_rows, sum(axes_dim)/2] with pair index j ordered axis-major.  f32_angles selects the
+ * liger arithmetic. */
+int osk_rope_table(const float* ids, int64_t n_rows, int n_axes, const int32_t* axes_dim_host,
+                   double theta, int f32_angles, float* cos_out, float* sin_out, void* stream);
+
+/* ---- per-head RMSNorm (QK-norm) + RoPE on q and k, in place, inside a [B, L, ld] projection buffer.
+ * replaces QKNorm/FusedRMSNorm (layers.py:114-135 -> liger RMSNorm "llama") followed by apply_rope
+ * (math.py:60-65, rope_mode 0 = interleaved pairs (2j,2j+1)) or LigerRopeFunction (math.py:27,
+ * rope_mode 1 = half-split pairs (j, j+hd/2)).
+ * q row (b,l) head h at q + b*batch_stride + l*row_stride + h*hd (same for k).  Rows l < l_split use
+ * (q_scale0,k_scale0) (the txt stream's norm weights), rows >= l_split use (q_scale1,k_scale1).
+ * Scales bf16 [hd].  cos/sin f32 [*, L, hd/2] with batch stride cs_batch_stride (0 = shared).
+ * Rounding points follow the reference: bf16(x*rrms) * bf16 scale -> bf16, rotate in f32, -> bf16. */
+int osk_qknorm_rope_bf16(void* q, void* k, int64_t batch_stride, int64_t row_stride,
+                         const void* q_scale0, const void* k_scale0,
+                         const void* q_scale1, const void* k_scale1, int l_split,
+                         const float* cos_t, const float* sin_t, int64_t cs_batch_stride,
+                         int B, int L, int H, int hd, int rope_mode, float eps, void* stream);
+
+/* ---- V -> key-major transposed copy for the attention kernel's PV operand.
+ * (internal layout, no reference counterpart: flash-attn does this transpose in shared memory.)
+ * v row (b,l) head h at v + b*batch_stride + l*row_stride + h*hd.
+ * vt [B, H, hd, Lp], Lp = round_up(L, 64), zero-filled for keys >= L; inside every group of 16 keys the
+ * two middle quads are swapped (k0-3, k8-11, k4-7, k12-15): the order the 32x32x16 MFMA accumulator
+ * hands P back to the next MFMA, so no cross-lane shuffle is needed. */
+int osk_v_transpose_bf16(const void* v, int64_t batch_stride, int64_t row_stride,
+                         void* vt, int B, int L, int H, int hd, void* stream);
+
+/* ---- flash attention forward, non-causal: out = softmax(q k^T * scale) v, bf16 I/O, f32 softmax.
+ * replaces flash_attn_func (math.py:16-19,33) and _flash_attn_forward with LSE
+ * (distributed.py:148-161).
+ * q  row (b,i) head h at q + b*q_batch_stride + i*q_row_stride + h*hd           (i < Lq)
+ * k  key j lives in segment s = j / seg_len, r = j % seg_len (sequence-parallel all-gather layout;
+ *    n_seg = 1, seg_len = Lk for one GPU): k + s*k_seg_stride + b*k_batch_stride + r*k_row_stride + h*hd
+ * vt as written by osk_v_transpose_bf16 per segment: vt + s*vt_seg_stride + ((b*H + h)*hd + d)*seg_lp + r'
+ *    with seg_lp = round_up(seg_len, 64).
+ * out row (b,i) head h at out + b*o_batch_stride + i*o_row_stride + h*hd (may alias the dead v slot).
+ * lse f32 [B, H, Lq] (natural log of the softmax denominator incl. scale) or NULL.
+ * hd in {64, 72, 128}. */
+int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+                           const void* k, int64_t k_seg_stride, int64_t k_batch_stride, int64_t k_row_stride,
+                           const void* vt, int64_t vt_seg_stride,
+                           void* out, int64_t o_batch_stride, int64_t o_row_stride,
+                           float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                           float scale, void* stream);
+
+/* ---- classifier-free-guidance combine + Euler step of the rectified-flow sampler (f32 math):
+ *   v = u2 + g_img*(u - u2) + g_txt*(c - u);  x_out = x + dt * v
+ * replaces opensora/utils/sampling.py:217-222.  pred bf16 [3, n] = (cond, uncond, uncond_2) chunks,
+ * x bf16 [n], x_out bf16 [n].  g_img_vec (f32 [n]) overrides the scalar g_img when non-NULL
+ * (temporal guidance ramp, sampling.py:209-216). */
+int osk_cfg_euler_bf16(const void* pred, int64_t n, const void* x, void* x_out,
+                       float g_txt, float g_img, const float* g_img_vec, float dt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSK_H */

@@ -1,0 +1,196 @@
+"""ctypes binding of libosk_hip.so (include/osk.h).  No torch types cross the boundary: tensors are
+unwrapped to (data_ptr, strides) here; the stream is torch's current HIP stream.
+
+There is NO fallback: if the library is missing or an entry point is absent the import fails loudly,
+and a non-zero status from a kernel launch raises RuntimeError (binding layer translates C status ->
+Python exception, SURVEY.md §8(b) "Error conventions").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from .build import LIB_PATH
+
+_i64, _i32, _f32, _f64, _vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_void_p
+
+# symbol -> argtypes, exactly the declarations of include/osk.h
+SIGNATURES = {
+    "osk_abi_version": [],
+    "osk_arch": [],
+    "osk_ln_modulate_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
+    "osk_gemm_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
+                      _i32, _i32, _i32, _i32, _i32, _vp],
+    "osk_gemv_tasks_bf16": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp],
+    "osk_timestep_embedding": [_vp, _i32, _i32, _f32, _f32, _vp, _vp],
+    "osk_rope_table": [_vp, _i64, _i32, C.POINTER(_i32), _f64, _i32, _vp, _vp, _vp],
+    "osk_qknorm_rope_bf16": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64,
+                             _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "osk_v_transpose_bf16": [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
+    "osk_attention_fwd_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
+                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m open_sora_amd.build` (hipcc, gfx950). "
+            "open_sora_amd has no CPU or eager fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "osk_arch" else _i32
+    if lib.osk_abi_version() != 1:
+        raise ImportError("libosk_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def _check(status: int, what: str) -> None:
+    if status != 0:
+        kind = "invalid argument / unsupported shape" if status < 0 else "HIP error"
+        raise RuntimeError(f"{what} failed: status {status} ({kind})")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+# ----------------------------------------------------------------------------------------------
+# thin wrappers (shape logic only)
+# ----------------------------------------------------------------------------------------------
+def ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: torch.Tensor,
+                mod_batch_stride: int, eps: float = 1e-6) -> torch.Tensor:
+    """x, out: bf16 [B, L, D] views with contiguous last dim; shift/scale f32 views whose row b starts at
+    data_ptr + b*mod_batch_stride."""
+    B, L, D = x.shape
+    _check(lib.osk_ln_modulate_bf16(x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), out.stride(0),
+                                    out.stride(1), shift.data_ptr(), scale.data_ptr(), mod_batch_stride,
+                                    B, L, D, eps, _stream()), "osk_ln_modulate_bf16")
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, *, res=None, gate=None,
+         gate_batch_stride: int = 0, gelu_from: int | None = None) -> torch.Tensor:
+    """a bf16 [B, L, K] view (last dim contiguous), w bf16 [N, K] (row stride arbitrary), bias f32 [N] | None,
+    out bf16/f32 [B, L, N] view.  res (bf16 view shaped like out, same strides) and gate (f32, row b at
+    data_ptr + b*gate_batch_stride) select the gate*x + residual epilogue."""
+    B, L, K = a.shape
+    N = w.shape[0]
+    assert out.shape[0] == B and out.shape[1] == L and out.shape[2] == N
+    if res is not None:
+        assert res.stride() == out.stride()
+    _check(lib.osk_gemm_bf16(a.data_ptr(), a.stride(0), a.stride(1), L, w.data_ptr(), w.stride(0), _p(bias),
+                             out.data_ptr(), out.stride(0), out.stride(1), L, _p(res), _p(gate),
+                             gate_batch_stride, B * L, N, K, N if gelu_from is None else gelu_from,
+                             1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_bf16")
+    return out
+
+
+def gemv_tasks(x: torch.Tensor, tasks, out: torch.Tensor, act_in: int = 0, accumulate: bool = False):
+    """tasks: GemvTasks (device descriptor arrays).  x f32 [Bv, K], out f32 [Bv, *]."""
+    Bv, K = x.shape
+    _check(lib.osk_gemv_tasks_bf16(x.data_ptr(), x.stride(0), Bv, K, tasks.w_ptrs.data_ptr(),
+                                   tasks.b_ptrs.data_ptr(), tasks.out_cols.data_ptr(),
+                                   tasks.n_rows.data_ptr(), tasks.n_tasks, out.data_ptr(), out.stride(0),
+                                   act_in, 1 if accumulate else 0, _stream()), "osk_gemv_tasks_bf16")
+    return out
+
+
+class GemvTasks:
+    """Device-side task list for osk_gemv_tasks_bf16: a list of (weight bf16 [N, K], bias bf16 [N] | None,
+    out column offset); each layer is cut into tasks of <= 64 rows.  Keeps the tensors alive."""
+
+    ROWS = 64
+
+    def __init__(self, layers, device):
+        wp, bp, oc, nr = [], [], [], []
+        self._keep = []
+        for w, b, col in layers:
+            assert w.dtype == torch.bfloat16 and w.is_contiguous()
+            self._keep.append((w, b))
+            N, K = w.shape
+            for r0 in range(0, N, self.ROWS):
+                n = min(self.ROWS, N - r0)
+                wp.append(w.data_ptr() + r0 * K * 2)
+                bp.append(0 if b is None else b.data_ptr() + r0 * 2)
+                oc.append(col + r0)
+                nr.append(n)
+        self.n_tasks = len(wp)
+        # uint64 pointers stored bit-exactly in int64 tensors
+        to_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v
+        self.w_ptrs = torch.tensor([to_i64(v) for v in wp], dtype=torch.int64, device=device)
+        self.b_ptrs = torch.tensor([to_i64(v) for v in bp], dtype=torch.int64, device=device)
+        self.out_cols = torch.tensor(oc, dtype=torch.int32, device=device)
+        self.n_rows = torch.tensor(nr, dtype=torch.int32, device=device)
+
+
+def timestep_embedding(t: torch.Tensor, out: torch.Tensor, max_period: float = 10000.0,
+                       time_factor: float = 1000.0) -> torch.Tensor:
+    B, dim = out.shape
+    _check(lib.osk_timestep_embedding(t.data_ptr(), B, dim, max_period, time_factor, out.data_ptr(), _stream()),
+           "osk_timestep_embedding")
+    return out
+
+
+def rope_table(ids: torch.Tensor, axes_dim, theta: float, f32_angles: bool, cos: torch.Tensor, sin: torch.Tensor):
+    """ids f32 [n_rows, n_axes] contiguous -> cos/sin f32 [n_rows, sum(axes)/2]."""
+    n_rows, n_axes = ids.shape
+    arr = (_i32 * n_axes)(*[int(a) for a in axes_dim])
+    _check(lib.osk_rope_table(ids.data_ptr(), n_rows, n_axes, arr, float(theta), 1 if f32_angles else 0,
+                              cos.data_ptr(), sin.data_ptr(), _stream()), "osk_rope_table")
+
+
+def qknorm_rope(q: torch.Tensor, k: torch.Tensor, qs0, ks0, qs1, ks1, l_split: int, cos, sin,
+                cs_batch_stride: int, H: int, hd: int, rope_mode: int, eps: float = 1e-6):
+    """q, k: bf16 [B, L, H*hd] views (same strides, last dim contiguous) rewritten in place."""
+    B, L, _ = q.shape
+    assert q.stride() == k.stride()
+    _check(lib.osk_qknorm_rope_bf16(q.data_ptr(), k.data_ptr(), q.stride(0), q.stride(1), qs0.data_ptr(),
+                                    ks0.data_ptr(), qs1.data_ptr(), ks1.data_ptr(), l_split, cos.data_ptr(),
+                                    sin.data_ptr(), cs_batch_stride, B, L, H, hd, rope_mode, eps, _stream()),
+           "osk_qknorm_rope_bf16")
+
+
+def v_transpose(v: torch.Tensor, vt: torch.Tensor, H: int, hd: int):
+    """v bf16 [B, L, H*hd] view -> vt bf16 [B, H, hd, round_up(L, 64)] contiguous."""
+    B, L, _ = v.shape
+    _check(lib.osk_v_transpose_bf16(v.data_ptr(), v.stride(0), v.stride(1), vt.data_ptr(), B, L, H, hd, _stream()),
+           "osk_v_transpose_bf16")
+
+
+def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, H: int, hd: int,
+                  scale: float, *, lse=None, n_seg: int = 1, seg_len: int | None = None,
+                  k_seg_stride: int = 0, vt_seg_stride: int = 0):
+    """q bf16 [B, Lq, H*hd] view; k bf16 [B, seg_len, H*hd] view of segment 0 (further segments k_seg_stride
+    elements apart); vt from v_transpose (per segment); out bf16 [B, Lq, H*hd] view."""
+    B, Lq, _ = q.shape
+    if seg_len is None:
+        seg_len = k.shape[1]
+    _check(lib.osk_attention_fwd_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
+                                      k.stride(0), k.stride(1), vt.data_ptr(), vt_seg_stride, out.data_ptr(),
+                                      out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg, seg_len, hd,
+                                      scale, _stream()), "osk_attention_fwd_bf16")
+    return out
+
+
+def cfg_euler(pred: torch.Tensor, x: torch.Tensor, x_out: torch.Tensor, g_txt: float, g_img: float, dt: float,
+              g_img_vec=None):
+    """pred bf16 [3, ...] contiguous (cond, uncond, uncond_2); x, x_out bf16 [...] contiguous."""
+    n = x.numel()
+    assert pred.numel() == 3 * n and pred.is_contiguous() and x.is_contiguous() and x_out.is_contiguous()
+    _check(lib.osk_cfg_euler_bf16(pred.data_ptr(), n, x.data_ptr(), x_out.data_ptr(), g_txt, g_img,
+                                  _p(g_img_vec), dt, _stream()), "osk_cfg_euler_bf16")
+    return x_out

@@ -1,0 +1,480 @@
+// HBM-bound kernels of the MMDiT denoise step for gfx950: LayerNorm+modulate, QK-RMSNorm+RoPE,
+// V transpose, skinny GEMV task list (adaLN modulation / embedders), timestep embedding, RoPE tables,
+// CFG + Euler update.  All loads/stores are 16 B per lane (8 bf16) where the layout allows (guide G13).
+#include "osk_common.h"
+#include "../../include/osk.h"
+
+// =============================================================================================
+// LayerNorm (no affine) + modulate.  One wave per row, row kept in registers (<= 8 chunks of 8 per
+// lane -> D <= 4096), two-pass mean/variance in f32.  Algorithmic bytes: 4*D per row (2 in, 2 out).
+// =============================================================================================
+template <int MAXC>
+__global__ void __launch_bounds__(256) ln_modulate_kernel(
+    const unsigned short* __restrict__ x, int64_t xbs, int64_t xrs, unsigned short* __restrict__ out,
+    int64_t obs, int64_t ors, const float* __restrict__ shift, const float* __restrict__ scale,
+    int64_t mbs, int M, int L, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int b = row / L, l = row - b * L;
+  const unsigned short* xr = x + b * xbs + l * xrs;
+  unsigned short* orow = out + b * obs + l * ors;
+  const int nchunk = D >> 3;
+  float v[MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      uint4 u = *reinterpret_cast<const uint4*>(xr + c * 8);
+      unpack8(u, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float* sh = shift + b * mbs;
+  const float* sc = scale + b * mbs;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      const float4 s0 = *reinterpret_cast<const float4*>(sc + c * 8);
+      const float4 s1 = *reinterpret_cast<const float4*>(sc + c * 8 + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(sh + c * 8);
+      const float4 h1 = *reinterpret_cast<const float4*>(sh + c * 8 + 4);
+      const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (1.0f + scv[j]) * ((v[i][j] - mean) * rstd) + shv[j];
+      *reinterpret_cast<uint4*>(orow + c * 8) = pack8(o);
+    }
+  }
+}
+
+extern "C" int osk_ln_modulate_bf16(const void* x, int64_t xbs, int64_t xrs, void* out, int64_t obs,
+                                    int64_t ors, const float* shift, const float* scale, int64_t mbs,
+                                    int B, int L, int D, float eps, void* stream) {
+  if (!x || !out || !shift || !scale || B <= 0 || L <= 0 || D <= 0) return OSK_EINVAL;
+  if ((D & 7) || D > 8 * 64 * 8 || (xrs & 7) || (ors & 7) || (xbs & 7) || (obs & 7) || (mbs & 3)) return OSK_EINVAL;
+  const int M = B * L;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (D / 8 + 63) / 64;
+#define LAUNCH(MC)                                                                              \
+  hipLaunchKernelGGL(ln_modulate_kernel<MC>, grid, block, 0, st, (const unsigned short*)x, xbs, xrs, \
+                     (unsigned short*)out, obs, ors, shift, scale, mbs, M, L, D, eps)
+  if (nch <= 1) LAUNCH(1);
+  else if (nch <= 2) LAUNCH(2);
+  else if (nch <= 3) LAUNCH(3);
+  else if (nch <= 4) LAUNCH(4);
+  else if (nch <= 6) LAUNCH(6);
+  else LAUNCH(8);
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+// =============================================================================================
+// QK RMSNorm + RoPE, in place.  A group of LPR lanes owns one (token, head) row of hd elements,
+// CW elements per lane.  rope_mode 0: pairs (2j, 2j+1) are lane-local.  rope_mode 1: pair (j, j+hd/2)
+// lives NCH/2 lanes away inside the group -> one shuffle per element.
+// Algorithmic bytes: 2 tensors * (read + write) * 2 B = 8*hd per (token, head) + the cos/sin rows.
+// =============================================================================================
+template <int HD, int CW, int MODE>
+__global__ void __launch_bounds__(256) qknorm_rope_kernel(
+    unsigned short* __restrict__ q, unsigned short* __restrict__ k, int64_t bs, int64_t rs,
+    const unsigned short* __restrict__ qs0, const unsigned short* __restrict__ ks0,
+    const unsigned short* __restrict__ qs1, const unsigned short* __restrict__ ks1, int l_split,
+    const float* __restrict__ cos_t, const float* __restrict__ sin_t, int64_t csb, int B, int L, int H,
+    float eps) {
+  constexpr int NCH = HD / CW;  // active lanes per row
+  constexpr int LPR = NCH <= 8 ? 8 : (NCH <= 16 ? 16 : 32);
+  constexpr int RPB = 256 / LPR;  // rows per block
+  const int g = threadIdx.x / LPR, c = threadIdx.x % LPR;
+  const int64_t ridx = (int64_t)blockIdx.x * RPB + g;  // over B*L*H
+  const int64_t total = (int64_t)B * L * H;
+  const bool rvalid = ridx < total;
+  const int64_t rr = rvalid ? ridx : total - 1;
+  const int h = (int)(rr % H);
+  const int64_t tok = rr / H;
+  const int l = (int)(tok % L), b = (int)(tok / L);
+  const bool act = c < NCH;
+  const int cc = act ? c : 0;
+  const float* cr = cos_t + b * csb + (int64_t)l * (HD / 2);
+  const float* sr = sin_t + b * csb + (int64_t)l * (HD / 2);
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    unsigned short* p = (which ? k : q) + b * bs + (int64_t)l * rs + h * HD + cc * CW;
+    const unsigned short* sc = which ? (l < l_split ? ks0 : ks1) : (l < l_split ? qs0 : qs1);
+    float v[CW];
+    if constexpr (CW == 8) {
+      uint4 u = *reinterpret_cast<const uint4*>(p);
+      unpack8(u, v);
+    } else {
+      uint2 u = *reinterpret_cast<const uint2*>(p);
+      v[0] = bf16_lo(u.x); v[1] = bf16_hi(u.x); v[2] = bf16_lo(u.y); v[3] = bf16_hi(u.y);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < CW; ++j) ss += act ? v[j] * v[j] : 0.f;
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rrms = rsqrtf(ss / (float)HD + eps);
+    float y[CW];
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+      // reference rounding points: (x*rrms).to(bf16) * scale(bf16) -> bf16   (layers.py:107-111)
+      const float t = bf16_bits_to_f32(f32_to_bf16_bits(v[j] * rrms));
+      const float w = bf16_bits_to_f32(sc[cc * CW + j]);
+      y[j] = bf16_bits_to_f32(f32_to_bf16_bits(t * w));
+    }
+    float o[CW];
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < CW; j += 2) {
+        const int pj = (cc * CW + j) >> 1;
+        const float cs = cr[pj], sn = sr[pj];
+        o[j] = cs * y[j] - sn * y[j + 1];
+        o[j + 1] = sn * y[j] + cs * y[j + 1];
+      }
+    } else {
+      // partner chunk NCH/2 lanes further (mod NCH) inside this row's lane group
+      const int pc = (cc + NCH / 2) % NCH;
+      const int src_lane = (threadIdx.x & 63) - c + pc;
+      const bool first = cc < NCH / 2;
+#pragma unroll
+      for (int j = 0; j < CW; ++j) {
+        const float other = __shfl(y[j], src_lane, 64);
+        const int pj = (first ? cc : pc) * CW + j;  // index in [0, hd/2)
+        const float cs = cr[pj], sn = sr[pj];
+        o[j] = first ? (y[j] * cs - other * sn) : (y[j] * cs + other * sn);
+      }
+    }
+    if (act && rvalid) {
+      if constexpr (CW == 8) {
+        *reinterpret_cast<uint4*>(p) = pack8(o);
+      } else {
+        uint2 u;
+        u.x = pack_bf16x2(o[0], o[1]);
+        u.y = pack_bf16x2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(p) = u;
+      }
+    }
+  }
+}
+
+extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, const void* qs0,
+                                    const void* ks0, const void* qs1, const void* ks1, int l_split,
+                                    const float* cos_t, const float* sin_t, int64_t csb, int B, int L,
+                                    int H, int hd, int rope_mode, float eps, void* stream) {
+  if (!q || !k || !qs0 || !ks0 || !qs1 || !ks1 || !cos_t || !sin_t) return OSK_EINVAL;
+  if (B <= 0 || L <= 0 || H <= 0 || (bs & 7) || (rs & 7)) return OSK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)B * L * H;
+#define LAUNCH(HD, CW, MODE)                                                                          \
+  {                                                                                                   \
+    constexpr int NCH = HD / CW;                                                                      \
+    constexpr int LPR = NCH <= 8 ? 8 : (NCH <= 16 ? 16 : 32);                                         \
+    constexpr int RPB = 256 / LPR;                                                                    \
+    dim3 grid((unsigned)((total + RPB - 1) / RPB)), block(256);                                       \
+    hipLaunchKernelGGL((qknorm_rope_kernel<HD, CW, MODE>), grid, block, 0, st, (unsigned short*)q,    \
+                       (unsigned short*)k, bs, rs, (const unsigned short*)qs0,                        \
+                       (const unsigned short*)ks0, (const unsigned short*)qs1,                        \
+                       (const unsigned short*)ks1, l_split, cos_t, sin_t, csb, B, L, H, eps);         \
+  }
+  if (rope_mode == 0) {
+    if (hd == 64) LAUNCH(64, 8, 0)
+    else if (hd == 72) LAUNCH(72, 8, 0)
+    else if (hd == 128) LAUNCH(128, 8, 0)
+    else return OSK_EUNSUPPORTED;
+  } else if (rope_mode == 1) {
+    if (hd == 64) LAUNCH(64, 8, 1)
+    else if (hd == 72) LAUNCH(72, 4, 1)
+    else if (hd == 128) LAUNCH(128, 8, 1)
+    else return OSK_EUNSUPPORTED;
+  } else {
+    return OSK_EINVAL;
+  }
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+// =============================================================================================
+// V [B, L, H, hd] (strided) -> VT [B, H, hd, Lp] with the per-16-key quad swap.  One block = 64 keys x
+// one head; staged through LDS so both the read (hd contiguous) and the write (keys contiguous) are
+// coalesced 16 B accesses.  Bytes: 2*hd read + 2*hd written per (key, head).
+// =============================================================================================
+template <int HD>
+__global__ void __launch_bounds__(256) v_transpose_kernel(const unsigned short* __restrict__ v,
+                                                          int64_t bs, int64_t rs,
+                                                          unsigned short* __restrict__ vt, int L,
+                                                          int Lp, int H) {
+  __shared__ unsigned short tile[64][HD + 2];  // +2: odd dword stride -> conflict-free column reads
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int key0 = kt * 64;
+  constexpr int CPR = HD / 8;
+  for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
+    const int r = i / CPR, c = i % CPR;
+    const int key = key0 + r;
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (key < L) u = *reinterpret_cast<const uint4*>(v + b * bs + (int64_t)key * rs + h * HD + c * 8);
+    unsigned* dst = reinterpret_cast<unsigned*>(&tile[r][c * 8]);
+    dst[0] = u.x; dst[1] = u.y; dst[2] = u.z; dst[3] = u.w;
+  }
+  __syncthreads();
+  // output: HD rows of 64 keys = 8 chunks of 8 keys; position p in a 16-key group holds key perm(p)
+  unsigned short* obase = vt + ((int64_t)(b * H + h) * HD) * Lp + key0;
+  for (int i = threadIdx.x; i < HD * 8; i += 256) {
+    const int d = i >> 3, pc = i & 7;  // pc: 8-position chunk within the 64-key row
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = pc * 8 + j;                  // position within tile
+      const int p16 = p & 15, grp = p & ~15;
+      // positions 0-3 -> keys 0-3, 4-7 -> keys 8-11, 8-11 -> keys 4-7, 12-15 -> keys 12-15
+      const int k16 = (p16 < 4 || p16 >= 12) ? p16 : (p16 < 8 ? p16 + 4 : p16 - 4);
+      e[j] = tile[grp + k16][d];
+    }
+    uint4 u;
+    u.x = e[0] | ((unsigned)e[1] << 16);
+    u.y = e[2] | ((unsigned)e[3] << 16);
+    u.z = e[4] | ((unsigned)e[5] << 16);
+    u.w = e[6] | ((unsigned)e[7] << 16);
+    *reinterpret_cast<uint4*>(obase + (int64_t)d * Lp + pc * 8) = u;
+  }
+}
+
+extern "C" int osk_v_transpose_bf16(const void* v, int64_t bs, int64_t rs, void* vt, int B, int L,
+                                    int H, int hd, void* stream) {
+  if (!v || !vt || B <= 0 || L <= 0 || H <= 0 || (bs & 7) || (rs & 7)) return OSK_EINVAL;
+  const int Lp = (L + 63) / 64 * 64;
+  dim3 grid(Lp / 64, H, B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (hd == 64)
+    hipLaunchKernelGGL(v_transpose_kernel<64>, grid, block, 0, st, (const unsigned short*)v, bs, rs, (unsigned short*)vt, L, Lp, H);
+  else if (hd == 72)
+    hipLaunchKernelGGL(v_transpose_kernel<72>, grid, block, 0, st, (const unsigned short*)v, bs, rs, (unsigned short*)vt, L, Lp, H);
+  else if (hd == 128)
+    hipLaunchKernelGGL(v_transpose_kernel<128>, grid, block, 0, st, (const unsigned short*)v, bs, rs, (unsigned short*)vt, L, Lp, H);
+  else
+    return OSK_EUNSUPPORTED;
+  return (int)hipGetLastError();
+}
+
+// =============================================================================================
+// Skinny GEMV over a task list.  One block (256 threads = 4 waves) per task of <= 64 weight rows;
+// x (with optional SiLU) staged once per block in LDS as f32; each wave streams whole weight rows with
+// 16 B loads.  Weight-bandwidth bound: bytes = 2*K per output row.
+// =============================================================================================
+template <int MB>
+__global__ void __launch_bounds__(256) gemv_tasks_kernel(
+    const float* __restrict__ x, int64_t xbs, int Bv, int K, const uint64_t* __restrict__ w_ptrs,
+    const uint64_t* __restrict__ b_ptrs, const int* __restrict__ out_cols,
+    const int* __restrict__ n_rows, float* __restrict__ out, int64_t obs, int act_in, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [MB][K]
+  const int task = blockIdx.x;
+  for (int i = threadIdx.x; i < MB * K; i += 256) {
+    const int b = i / K, kk = i - b * K;
+    float t = 0.f;
+    if (b < Bv) {
+      t = x[b * xbs + kk];
+      if (act_in == 1) t = silu(t);
+    }
+    xs[i] = t;
+  }
+  __syncthreads();
+  const unsigned short* W = reinterpret_cast<const unsigned short*>(w_ptrs[task]);
+  const unsigned short* bias = reinterpret_cast<const unsigned short*>(b_ptrs[task]);
+  const int nr = n_rows[task];
+  const int col0 = out_cols[task];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nchunk = K >> 3;
+  for (int r = wave; r < nr; r += 4) {
+    const unsigned short* wr = W + (int64_t)r * K;
+    float acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+      uint4 u = *reinterpret_cast<const uint4*>(wr + c * 8);
+      float w[8];
+      unpack8(u, w);
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        const float4 x0 = *reinterpret_cast<const float4*>(&xs[b * K + c * 8]);
+        const float4 x1 = *reinterpret_cast<const float4*>(&xs[b * K + c * 8 + 4]);
+        acc[b] += w[0] * x0.x + w[1] * x0.y + w[2] * x0.z + w[3] * x0.w + w[4] * x1.x + w[5] * x1.y +
+                  w[6] * x1.z + w[7] * x1.w;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = wave_sum(acc[b]);
+    if (lane == 0) {
+      const float bv = bias ? bf16_bits_to_f32(bias[r]) : 0.f;
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        if (b < Bv) {
+          float* o = out + b * obs + col0 + r;
+          const float val = acc[b] + bv;
+          *o = accumulate ? (*o + val) : val;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int osk_gemv_tasks_bf16(const float* x, int64_t xbs, int Bv, int K, const uint64_t* w_ptrs,
+                                   const uint64_t* b_ptrs, const int32_t* out_cols,
+                                   const int32_t* n_rows, int n_tasks, float* out, int64_t obs,
+                                   int act_in, int accumulate, void* stream) {
+  if (!x || !w_ptrs || !b_ptrs || !out_cols || !n_rows || !out) return OSK_EINVAL;
+  if (Bv <= 0 || Bv > 8 || K <= 0 || (K & 7) || n_tasks <= 0) return OSK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(n_tasks), block(256);
+  if (Bv <= 4) {
+    const size_t sm = (size_t)4 * K * sizeof(float);
+    if (sm > 64 * 1024) return OSK_EINVAL;
+    hipLaunchKernelGGL(gemv_tasks_kernel<4>, grid, block, sm, st, x, xbs, Bv, K, w_ptrs, b_ptrs,
+                       out_cols, n_rows, out, obs, act_in, accumulate);
+  } else {
+    const size_t sm = (size_t)8 * K * sizeof(float);
+    if (sm > 64 * 1024) return OSK_EINVAL;
+    hipLaunchKernelGGL(gemv_tasks_kernel<8>, grid, block, sm, st, x, xbs, Bv, K, w_ptrs, b_ptrs,
+                       out_cols, n_rows, out, obs, act_in, accumulate);
+  }
+  return (int)hipGetLastError();
+}
+
+// =============================================================================================
+// timestep embedding and RoPE tables (tiny)
+// =============================================================================================
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int B, int dim, float max_period,
+                                          float time_factor, float* __restrict__ out) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, j = i - b * half;
+  const float freq = expf(-logf(max_period) * (float)j / (float)half);
+  const float a = (time_factor * t[b]) * freq;
+  out[b * dim + j] = cosf(a);
+  out[b * dim + half + j] = sinf(a);
+  if ((dim & 1) && j == 0) out[b * dim + dim - 1] = 0.f;
+}
+
+extern "C" int osk_timestep_embedding(const float* t, int B, int dim, float max_period,
+                                      float time_factor, float* out, void* stream) {
+  if (!t || !out || B <= 0 || dim < 2) return OSK_EINVAL;
+  const int n = B * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     t, B, dim, max_period, time_factor, out);
+  return (int)hipGetLastError();
+}
+
+struct AxesDesc {
+  int n_axes;
+  int dim[4];
+  int start[4];  // pair-index start per axis
+};
+
+__global__ void rope_table_kernel(const float* __restrict__ ids, int64_t n_rows, AxesDesc ax, int half,
+                                  double theta, int f32_angles, float* __restrict__ cos_out,
+                                  float* __restrict__ sin_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows * half) return;
+  const int64_t row = i / half;
+  const int j = (int)(i - row * half);
+  int a = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t)
+    if (t < ax.n_axes && j >= ax.start[t]) a = t;
+  const int jj = j - ax.start[a];
+  const float pos = ids[row * ax.n_axes + a];
+  if (f32_angles) {
+    // liger_rope, math.py:39-47: scale = arange(0,d,2,f32)/d; omega = 1/theta**scale; angle = pos*omega (f32)
+    const float sc = (float)(2 * jj) / (float)ax.dim[a];
+    const float omega = 1.0f / powf((float)theta, sc);
+    const float ang = pos * omega;
+    cos_out[i] = cosf(ang);
+    sin_out[i] = sinf(ang);
+  } else {
+    // rope, math.py:50-57: everything in f64, result cast to f32
+    const double sc = (double)(2 * jj) / (double)ax.dim[a];
+    const double omega = 1.0 / pow(theta, sc);
+    const double ang = (double)pos * omega;
+    cos_out[i] = (float)cos(ang);
+    sin_out[i] = (float)sin(ang);
+  }
+}
+
+extern "C" int osk_rope_table(const float* ids, int64_t n_rows, int n_axes, const int32_t* axes_dim_host,
+                              double theta, int f32_angles, float* cos_out, float* sin_out,
+                              void* stream) {
+  if (!ids || !axes_dim_host || !cos_out || !sin_out || n_rows <= 0 || n_axes <= 0 || n_axes > 4) return OSK_EINVAL;
+  AxesDesc ax;
+  ax.n_axes = n_axes;
+  int half = 0;
+  for (int a = 0; a < 4; ++a) {
+    ax.dim[a] = a < n_axes ? axes_dim_host[a] : 2;
+    ax.start[a] = half;
+    if (a < n_axes) {
+      if (axes_dim_host[a] <= 0 || (axes_dim_host[a] & 1)) return OSK_EINVAL;
+      half += axes_dim_host[a] / 2;
+    }
+  }
+  const int64_t n = n_rows * half;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, ids, n_rows, ax, half, theta, f32_angles, cos_out, sin_out);
+  return (int)hipGetLastError();
+}
+
+// =============================================================================================
+// CFG combine + Euler update.  Bytes: 3 pred reads + x read + x write = 10 B per element.
+// =============================================================================================
+__global__ void __launch_bounds__(256) cfg_euler_kernel(const unsigned short* __restrict__ pred, int64_t n,
+                                                        const unsigned short* __restrict__ x,
+                                                        unsigned short* __restrict__ xo, float g_txt,
+                                                        float g_img, const float* __restrict__ g_img_vec,
+                                                        float dt) {
+  const int64_t nchunk = n >> 3;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * 256) {
+    float pc[8], pu[8], p2[8], xv[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(pred + c * 8), pc);
+    unpack8(*reinterpret_cast<const uint4*>(pred + n + c * 8), pu);
+    unpack8(*reinterpret_cast<const uint4*>(pred + 2 * n + c * 8), p2);
+    unpack8(*reinterpret_cast<const uint4*>(x + c * 8), xv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gi = g_img_vec ? g_img_vec[c * 8 + j] : g_img;
+      const float v = p2[j] + gi * (pu[j] - p2[j]) + g_txt * (pc[j] - pu[j]);
+      o[j] = xv[j] + dt * v;
+    }
+    *reinterpret_cast<uint4*>(xo + c * 8) = pack8(o);
+  }
+}
+
+extern "C" int osk_cfg_euler_bf16(const void* pred, int64_t n, const void* x, void* x_out, float g_txt,
+                                  float g_img, const float* g_img_vec, float dt, void* stream) {
+  if (!pred || !x || !x_out || n <= 0 || (n & 7)) return OSK_EINVAL;
+  int64_t nb = (n / 8 + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)pred, n, (const unsigned short*)x, (unsigned short*)x_out,
+                     g_txt, g_img, g_img_vec, dt);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osk_abi_version(void) { return OSK_ABI_VERSION; }
+extern "C" const char* osk_arch(void) { return "gfx950"; }

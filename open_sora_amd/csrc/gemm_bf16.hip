@@ -1,0 +1,262 @@
+// bf16 GEMM with fused epilogues for gfx950:  C = epi(A[M,K] @ W[N,K]^T + bias)
+//
+// Tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA
+// v_mfma_f32_32x32x16_bf16 tiles.  Operands are SWAPPED in the MFMA (A-operand = W fragment, B-operand
+// = activation fragment) so that a lane of the accumulator owns one output ROW m and 4 consecutive
+// columns n per register quad: the epilogue (bias / GELU / gate*x+residual) is lane-local in m and
+// stores 8 B (4 bf16) contiguous pieces.
+//
+// Staging: HBM -> LDS with global_load_lds_dwordx4 (16 B per lane, LDS image lane-linear), double
+// buffered, one barrier per K tile.  The 128-B LDS rows are XOR-swizzled on the SOURCE side
+// (chunk' = chunk ^ ((row >> 1) & 7)) and un-swizzled on the ds_read_b128 side: conflict-free for the
+// 32-row x 16-B fragment reads of the 32x32x16 MFMA (see DESIGN.md "LDS layouts").
+// A register-staged variant (same LDS image) is kept for A/B testing (OSK_GEMM_VARIANT=1).
+//
+// Roofline: MFMA bf16 (2.5 PFLOP/s dense).  Algorithmic FLOPs = 2*M*N*K.
+#include "osk_common.h"
+#include "../../include/osk.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
+constexpr int SMEM_BYTES = 2 * 2 * TILE_BYTES;
+
+struct GemmParams {
+  const unsigned short* A;
+  int64_t abs_, ars;
+  int arpb;
+  const unsigned short* W;
+  int64_t wrs;
+  const float* bias;
+  void* C;
+  int64_t cbs, crs;
+  int crpb;
+  const unsigned short* res;
+  const float* gate;
+  int64_t gbs;
+  int M, N, K, gelu_from;
+};
+
+OSK_DEV void glds16(const unsigned short* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool GLDS, bool OUT_F32>
+__global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  // ---- staging addresses: 4 row-blocks of 8 rows per wave per operand
+  const unsigned short* ga[4];
+  const unsigned short* gw[4];
+  int lds_off[4];  // byte offset of this wave's 1-KiB row block inside a tile (wave-uniform)
+  const int srow8 = lane >> 3, spos = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rb = i * 4 + wave;
+    const int r = rb * 8 + srow8;
+    const int c = spos ^ ((r >> 1) & 7);  // source chunk that must land at LDS position spos
+    int m = m0 + r;
+    m = m < p.M ? m : p.M - 1;
+    const int b = m / p.arpb, l = m - b * p.arpb;
+    ga[i] = p.A + b * p.abs_ + (int64_t)l * p.ars + c * 8;
+    int n = n0 + r;
+    n = n < p.N ? n : p.N - 1;
+    gw[i] = p.W + (int64_t)n * p.wrs + c * 8;
+    lds_off[i] = rb * 1024;
+  }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  const int sw = (l31 >> 1) & 7;
+  // fragment read offsets (bytes) inside a tile for ks = 0; other ks: chunk = (ks*2+hi) ^ sw
+  const int a_row_off = (wm * 64 + l31) * 128;
+  const int w_row_off = (wn * 64 + l31) * 128;
+
+  uint4 ra0 = make_uint4(0, 0, 0, 0), ra1 = ra0, ra2 = ra0, ra3 = ra0, rw0 = ra0, rw1 = ra0, rw2 = ra0,
+        rw3 = ra0;  // register staging (variant !GLDS); named scalars, arrays went to scratch
+  // (macros rather than lambdas: by-reference captured arrays were placed in scratch by hipcc)
+#define STAGE_ISSUE(BUFI, KT)                                                                  \
+  {                                                                                            \
+    const int k0_ = (KT) * BK;                                                                 \
+    unsigned char* ta_ = smem + (BUFI) * 2 * TILE_BYTES;                                       \
+    unsigned char* tw_ = ta_ + TILE_BYTES;                                                     \
+    if constexpr (GLDS) {                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16(ga[i] + k0_, ta_ + lds_off[i]);     \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16(gw[i] + k0_, tw_ + lds_off[i]);     \
+    } else {                                                                                   \
+      ra0 = *reinterpret_cast<const uint4*>(ga[0] + k0_);                                      \
+      ra1 = *reinterpret_cast<const uint4*>(ga[1] + k0_);                                      \
+      ra2 = *reinterpret_cast<const uint4*>(ga[2] + k0_);                                      \
+      ra3 = *reinterpret_cast<const uint4*>(ga[3] + k0_);                                      \
+      rw0 = *reinterpret_cast<const uint4*>(gw[0] + k0_);                                      \
+      rw1 = *reinterpret_cast<const uint4*>(gw[1] + k0_);                                      \
+      rw2 = *reinterpret_cast<const uint4*>(gw[2] + k0_);                                      \
+      rw3 = *reinterpret_cast<const uint4*>(gw[3] + k0_);                                      \
+    }                                                                                          \
+  }
+#define STAGE_COMMIT(BUFI)                                                                     \
+  {                                                                                            \
+    if constexpr (!GLDS) {                                                                     \
+      unsigned char* ta_ = smem + (BUFI) * 2 * TILE_BYTES;                                     \
+      unsigned char* tw_ = ta_ + TILE_BYTES;                                                   \
+      *reinterpret_cast<uint4*>(ta_ + lds_off[0] + lane * 16) = ra0;                           \
+      *reinterpret_cast<uint4*>(ta_ + lds_off[1] + lane * 16) = ra1;                           \
+      *reinterpret_cast<uint4*>(ta_ + lds_off[2] + lane * 16) = ra2;                           \
+      *reinterpret_cast<uint4*>(ta_ + lds_off[3] + lane * 16) = ra3;                           \
+      *reinterpret_cast<uint4*>(tw_ + lds_off[0] + lane * 16) = rw0;                           \
+      *reinterpret_cast<uint4*>(tw_ + lds_off[1] + lane * 16) = rw1;                           \
+      *reinterpret_cast<uint4*>(tw_ + lds_off[2] + lane * 16) = rw2;                           \
+      *reinterpret_cast<uint4*>(tw_ + lds_off[3] + lane * 16) = rw3;                           \
+    }                                                                                          \
+  }
+
+  STAGE_ISSUE(0, 0);
+  STAGE_COMMIT(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) STAGE_ISSUE(cur ^ 1, kt + 1);
+    const unsigned char* ta = smem + cur * 2 * TILE_BYTES;
+    const unsigned char* tw = ta + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = (((ks << 1) | hi) ^ sw) << 4;
+      bf16x8_t af[2], wf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = *reinterpret_cast<const bf16x8_t*>(ta + a_row_off + t * 32 * 128 + coff);
+        wf[t] = *reinterpret_cast<const bf16x8_t*>(tw + w_row_off + t * 32 * 128 + coff);
+      }
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+    }
+    if (more) STAGE_COMMIT(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane owns row m = ... + l31, columns n = quad*8 + hi*4 + {0..3}
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int m = m0 + wm * 64 + tm * 32 + l31;
+    if (m >= p.M) continue;
+    const int b = m / p.crpb, l = m - b * p.crpb;
+    const int64_t roff = b * p.cbs + (int64_t)l * p.crs;
+    const float* grow = p.gate ? p.gate + b * p.gbs : nullptr;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int n = n0 + wn * 64 + tn * 32 + qd * 8 + hi * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][qd * 4 + j];
+        if (n + 3 < p.N) {
+          if (p.bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n + j >= p.gelu_from) v[j] = gelu_tanh(v[j]);
+          if (grow) {
+            const float4 gv = *reinterpret_cast<const float4*>(grow + n);
+            const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+            v[0] = bf16_lo(rv.x) + gv.x * v[0];
+            v[1] = bf16_hi(rv.x) + gv.y * v[1];
+            v[2] = bf16_lo(rv.y) + gv.z * v[2];
+            v[3] = bf16_hi(rv.y) + gv.w * v[3];
+          }
+          if constexpr (OUT_F32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + roff + n) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + roff + n) = o;
+          }
+        } else {
+          for (int j = 0; j < 4 && n + j < p.N; ++j) {
+            float t = v[j] + (p.bias ? p.bias[n + j] : 0.f);
+            if (n + j >= p.gelu_from) t = gelu_tanh(t);
+            if (grow) t = bf16_bits_to_f32(p.res[roff + n + j]) + grow[n + j] * t;
+            if constexpr (OUT_F32) reinterpret_cast<float*>(p.C)[roff + n + j] = t;
+            else reinterpret_cast<unsigned short*>(p.C)[roff + n + j] = f32_to_bf16_bits(t);
+          }
+        }
+      }
+    }
+  }
+}
+
+int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OSK_GEMM_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+}  // namespace
+
+extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride,
+                             int a_rows_per_batch, const void* W, int64_t w_row_stride,
+                             const float* bias, void* C, int64_t c_batch_stride, int64_t c_row_stride,
+                             int c_rows_per_batch, const void* res, const float* gate,
+                             int64_t gate_batch_stride, int M, int N, int K, int gelu_from,
+                             int out_f32, void* stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return OSK_EINVAL;
+  if (K % BK) return OSK_EINVAL;
+  if (a_rows_per_batch <= 0 || c_rows_per_batch <= 0) return OSK_EINVAL;
+  if ((a_batch_stride & 7) || (a_row_stride & 7) || (w_row_stride & 7)) return OSK_EINVAL;
+  if ((c_batch_stride & 3) || (c_row_stride & 3)) return OSK_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) || ((uintptr_t)bias & 15)) return OSK_EINVAL;
+  if (gate && (!res || ((uintptr_t)gate & 15) || (gate_batch_stride & 3) || ((uintptr_t)res & 7))) return OSK_EINVAL;
+  GemmParams p;
+  p.A = (const unsigned short*)A; p.abs_ = a_batch_stride; p.ars = a_row_stride; p.arpb = a_rows_per_batch;
+  p.W = (const unsigned short*)W; p.wrs = w_row_stride; p.bias = bias;
+  p.C = C; p.cbs = c_batch_stride; p.crs = c_row_stride; p.crpb = c_rows_per_batch;
+  p.res = (const unsigned short*)res; p.gate = gate; p.gbs = gate_batch_stride;
+  p.M = M; p.N = N; p.K = K; p.gelu_from = gelu_from;
+  const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  dim3 grid(nblk), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const bool glds = gemm_variant() == 0;
+  if (glds) {
+    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, SMEM_BYTES, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, SMEM_BYTES, st, p);
+  } else {
+    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, SMEM_BYTES, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, SMEM_BYTES, st, p);
+  }
+  return (int)hipGetLastError();
+}

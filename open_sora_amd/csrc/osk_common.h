@@ -1,0 +1,76 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the Open-Sora denoise path.
+// gfx950 only: wave64, MFMA 32x32x16 bf16, 160 KiB LDS.  No portability layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define OSK_OK 0
+#define OSK_EINVAL (-1)       // bad shape / alignment / unsupported configuration
+#define OSK_EUNSUPPORTED (-2) // head_dim / dtype combination not compiled
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+#define OSK_DEV static __device__ __forceinline__
+
+OSK_DEV float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+OSK_DEV float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+OSK_DEV float bf16_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+// round-to-nearest-even pack of two fp32 into one dword of two bf16 (lo = a): v_cvt_pk_bf16_f32 on gfx950
+OSK_DEV unsigned pack_bf16x2(float a, float b) {
+  f32x2_t v = {a, b};
+  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(unsigned, r);
+}
+OSK_DEV unsigned short f32_to_bf16_bits(float a) {
+  __bf16 r = (__bf16)a;
+  return __builtin_bit_cast(unsigned short, r);
+}
+
+// 8 bf16 (one uint4) -> 8 fp32
+OSK_DEV void unpack8(const uint4& u, float* f) {
+  f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x);
+  f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+  f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z);
+  f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+}
+OSK_DEV uint4 pack8(const float* f) {
+  uint4 u;
+  u.x = pack_bf16x2(f[0], f[1]);
+  u.y = pack_bf16x2(f[2], f[3]);
+  u.z = pack_bf16x2(f[4], f[5]);
+  u.w = pack_bf16x2(f[6], f[7]);
+  return u;
+}
+
+OSK_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+OSK_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+OSK_DEV float gelu_tanh(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2 u)
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+OSK_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// Bijective XCD-aware remap of a 1-D block id (block b is observed on XCD b % 8): give every XCD a
+// contiguous range of logical tiles so neighbouring tiles share that XCD's private 4 MiB L2.
+OSK_DEV int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

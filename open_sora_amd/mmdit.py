@@ -1,0 +1,683 @@
+"""MI355X-native MMDiT denoiser behind the reference's module API.
+
+Mirrors, by name and call signature (state-dict keys unchanged, so reference checkpoints load):
+    MMDiTConfig / MMDiTModel / Flux()        /root/reference/opensora/models/mmdit/model.py:40-303
+    DoubleStreamBlock / SingleStreamBlock     /root/reference/opensora/models/mmdit/layers.py:256-306,337-388
+    set_processor()/get_processor() plug-in   layers.py:299-303,381-385
+    MLPEmbedder, Modulation, QKNorm, SelfAttention, LastLayer   layers.py:91-192,391-402
+
+The nn.Modules here only HOLD parameters.  All arithmetic runs in hand-written gfx950 kernels reached
+through the C ABI of include/osk.h (open_sora_amd/_C.py); there is no eager/PyTorch compute fallback —
+if libosk_hip.so is missing the import of this module fails.
+
+Two entry levels, same kernels:
+  * MMDiTModel.forward(...)  — whole-step engine: one batched adaLN GEMV for all 57 blocks, activations
+    kept in pre-allocated joint [txt;img] buffers so no torch.cat / rearrange copy is ever materialised.
+  * HipDoubleStreamBlockProcessor / HipSingleStreamBlockProcessor — callables with the reference
+    processor signature `(block, img, txt, vec, pe)` / `(block, x, vec, pe)`; they read weights from the
+    block's submodules by the reference's attribute names, so they can be installed with
+    `block.set_processor(...)` on the reference's own DoubleStreamBlock / SingleStreamBlock as well.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+from torch import Tensor, nn
+
+from . import _C
+
+BF16 = torch.bfloat16
+
+
+# =============================================================================================
+# parameter containers (names == reference state-dict keys)
+# =============================================================================================
+@dataclass
+class MMDiTConfig:
+    """Field-for-field the reference MMDiTConfig (model.py:40-67)."""
+
+    model_type = "MMDiT"
+    from_pretrained: str | None
+    cache_dir: str | None
+    in_channels: int
+    vec_in_dim: int
+    context_in_dim: int
+    hidden_size: int
+    mlp_ratio: float
+    num_heads: int
+    depth: int
+    depth_single_blocks: int
+    axes_dim: list
+    theta: int
+    qkv_bias: bool
+    guidance_embed: bool
+    cond_embed: bool = False
+    fused_qkv: bool = True
+    grad_ckpt_settings: tuple | None = None
+    use_liger_rope: bool = False
+    patch_size: int = 2
+
+    def get(self, attribute_name, default=None):
+        return getattr(self, attribute_name, default)
+
+    def __contains__(self, attribute_name):
+        return hasattr(self, attribute_name)
+
+
+class _Holder(nn.Module):
+    """A module that owns parameters but whose arithmetic lives in the HIP engine."""
+
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError(
+            f"{type(self).__name__} holds parameters only; its arithmetic runs in libosk_hip.so via the "
+            "block processor / MMDiTModel.forward (no eager fallback)."
+        )
+
+
+class MLPEmbedder(_Holder):
+    def __init__(self, in_dim: int, hidden_dim: int):
+        super().__init__()
+        self.in_layer = nn.Linear(in_dim, hidden_dim, bias=True)
+        self.silu = nn.SiLU()
+        self.out_layer = nn.Linear(hidden_dim, hidden_dim, bias=True)
+
+
+class RMSNorm(_Holder):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.scale = nn.Parameter(torch.ones(dim))
+
+
+class QKNorm(_Holder):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.query_norm = RMSNorm(dim)
+        self.key_norm = RMSNorm(dim)
+
+
+class SelfAttention(_Holder):
+    def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = False, fused_qkv: bool = True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.fused_qkv = fused_qkv
+        if fused_qkv:
+            self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        else:
+            self.q_proj = nn.Linear(dim, dim, bias=qkv_bias)
+            self.k_proj = nn.Linear(dim, dim, bias=qkv_bias)
+            self.v_proj = nn.Linear(dim, dim, bias=qkv_bias)
+        self.norm = QKNorm(dim // num_heads)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Modulation(_Holder):
+    def __init__(self, dim: int, double: bool):
+        super().__init__()
+        self.is_double = double
+        self.multiplier = 6 if double else 3
+        self.lin = nn.Linear(dim, self.multiplier * dim, bias=True)
+
+
+class _NoParamNorm(_Holder):
+    """Stands for nn.LayerNorm(D, elementwise_affine=False, eps=1e-6): no parameters, fused into osk_ln_modulate."""
+
+    def __init__(self, dim: int, eps: float = 1e-6):
+        super().__init__()
+        self.normalized_shape = (dim,)
+        self.eps = eps
+
+
+class DoubleStreamBlock(nn.Module):
+    def __init__(self, hidden_size: int, num_heads: int, mlp_ratio: float, qkv_bias: bool = False,
+                 fused_qkv: bool = True):
+        super().__init__()
+        mlp_hidden = int(hidden_size * mlp_ratio)
+        self.num_heads = num_heads
+        self.hidden_size = hidden_size
+        self.head_dim = hidden_size // num_heads
+        for s in ("img", "txt"):
+            setattr(self, f"{s}_mod", Modulation(hidden_size, double=True))
+            setattr(self, f"{s}_norm1", _NoParamNorm(hidden_size))
+            setattr(self, f"{s}_attn", SelfAttention(hidden_size, num_heads, qkv_bias, fused_qkv))
+            setattr(self, f"{s}_norm2", _NoParamNorm(hidden_size))
+            setattr(self, f"{s}_mlp", nn.Sequential(
+                nn.Linear(hidden_size, mlp_hidden, bias=True),
+                nn.GELU(approximate="tanh"),
+                nn.Linear(mlp_hidden, hidden_size, bias=True),
+            ))
+        self.set_processor(HipDoubleStreamBlockProcessor())
+
+    def set_processor(self, processor) -> None:
+        self.processor = processor
+
+    def get_processor(self):
+        return self.processor
+
+    def forward(self, img: Tensor, txt: Tensor, vec: Tensor, pe, **kwargs):
+        return self.processor(self, img, txt, vec, pe)
+
+
+class SingleStreamBlock(nn.Module):
+    def __init__(self, hidden_size: int, num_heads: int, mlp_ratio: float = 4.0, qk_scale: float | None = None,
+                 fused_qkv: bool = True):
+        super().__init__()
+        self.hidden_dim = hidden_size
+        self.hidden_size = hidden_size
+        self.num_heads = num_heads
+        self.head_dim = hidden_size // num_heads
+        self.scale = qk_scale or self.head_dim ** -0.5
+        self.fused_qkv = fused_qkv
+        self.mlp_hidden_dim = int(hidden_size * mlp_ratio)
+        if fused_qkv:
+            self.linear1 = nn.Linear(hidden_size, hidden_size * 3 + self.mlp_hidden_dim)
+        else:
+            self.q_proj = nn.Linear(hidden_size, hidden_size)
+            self.k_proj = nn.Linear(hidden_size, hidden_size)
+            self.v_mlp = nn.Linear(hidden_size, hidden_size + self.mlp_hidden_dim)
+        self.linear2 = nn.Linear(hidden_size + self.mlp_hidden_dim, hidden_size)
+        self.norm = QKNorm(self.head_dim)
+        self.pre_norm = _NoParamNorm(hidden_size)
+        self.mlp_act = nn.GELU(approximate="tanh")
+        self.modulation = Modulation(hidden_size, double=False)
+        self.set_processor(HipSingleStreamBlockProcessor())
+
+    def set_processor(self, processor) -> None:
+        self.processor = processor
+
+    def get_processor(self):
+        return self.processor
+
+    def forward(self, x: Tensor, vec: Tensor, pe, **kwargs) -> Tensor:
+        return self.processor(self, x, vec, pe)
+
+
+class LastLayer(_Holder):
+    def __init__(self, hidden_size: int, patch_size: int, out_channels: int):
+        super().__init__()
+        self.norm_final = _NoParamNorm(hidden_size)
+        self.linear = nn.Linear(hidden_size, patch_size * patch_size * out_channels, bias=True)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
+
+
+# =============================================================================================
+# weight preparation helpers
+# =============================================================================================
+def _w(t: Tensor) -> Tensor:
+    t = t.detach()
+    return t if (t.dtype == BF16 and t.is_contiguous()) else t.to(BF16).contiguous()
+
+
+def _b32(t: Tensor | None) -> Tensor | None:
+    return None if t is None else t.detach().float().contiguous()
+
+
+def _cat_linear(*lins):
+    w = torch.cat([_w(l.weight) for l in lins], 0).contiguous() if len(lins) > 1 else _w(lins[0].weight)
+    if lins[0].bias is None:
+        return w, None
+    b = torch.cat([l.bias.detach().float() for l in lins], 0).contiguous()
+    return w, b
+
+
+def _pad_k(w: Tensor, mult: int = 64) -> Tensor:
+    N, K = w.shape
+    Kp = (K + mult - 1) // mult * mult
+    if Kp == K:
+        return w
+    out = torch.zeros(N, Kp, dtype=w.dtype, device=w.device)
+    out[:, :K] = w
+    return out
+
+
+@dataclass
+class _AttnW:
+    qkv_w: Tensor
+    qkv_b: Tensor | None
+    q_scale: Tensor
+    k_scale: Tensor
+    proj_w: Tensor | None = None
+    proj_b: Tensor | None = None
+
+
+@dataclass
+class _DoublePlan:
+    img: _AttnW
+    txt: _AttnW
+    img_mlp: tuple = ()
+    txt_mlp: tuple = ()
+    mod_layers: list = field(default_factory=list)  # [(w bf16, b bf16)] img then txt
+
+
+@dataclass
+class _SinglePlan:
+    w1: Tensor
+    b1: Tensor | None
+    w2: Tensor
+    b2: Tensor | None
+    q_scale: Tensor
+    k_scale: Tensor
+    mod_layers: list = field(default_factory=list)
+
+
+def _attn_weights(sa) -> _AttnW:
+    if getattr(sa, "fused_qkv", hasattr(sa, "qkv")):
+        w, b = _cat_linear(sa.qkv)
+    else:
+        w, b = _cat_linear(sa.q_proj, sa.k_proj, sa.v_proj)
+    return _AttnW(w, b, _w(sa.norm.query_norm.scale), _w(sa.norm.key_norm.scale), _w(sa.proj.weight), _b32(sa.proj.bias))
+
+
+def _mod_layer(mod) -> tuple:
+    return (_w(mod.lin.weight), None if mod.lin.bias is None else _w(mod.lin.bias))
+
+
+def plan_double(block) -> _DoublePlan:
+    p = getattr(block, "_osk_plan", None)
+    if p is None:
+        p = _DoublePlan(
+            img=_attn_weights(block.img_attn),
+            txt=_attn_weights(block.txt_attn),
+            img_mlp=(_w(block.img_mlp[0].weight), _b32(block.img_mlp[0].bias), _w(block.img_mlp[2].weight), _b32(block.img_mlp[2].bias)),
+            txt_mlp=(_w(block.txt_mlp[0].weight), _b32(block.txt_mlp[0].bias), _w(block.txt_mlp[2].weight), _b32(block.txt_mlp[2].bias)),
+            mod_layers=[_mod_layer(block.img_mod), _mod_layer(block.txt_mod)],
+        )
+        object.__setattr__(block, "_osk_plan", p)
+    return p
+
+
+def plan_single(block) -> _SinglePlan:
+    p = getattr(block, "_osk_plan", None)
+    if p is None:
+        if getattr(block, "fused_qkv", hasattr(block, "linear1")):
+            w1, b1 = _cat_linear(block.linear1)
+        else:
+            w1, b1 = _cat_linear(block.q_proj, block.k_proj, block.v_mlp)
+        p = _SinglePlan(w1, b1, _w(block.linear2.weight), _b32(block.linear2.bias),
+                        _w(block.norm.query_norm.scale), _w(block.norm.key_norm.scale),
+                        mod_layers=[_mod_layer(block.modulation)])
+        object.__setattr__(block, "_osk_plan", p)
+    return p
+
+
+# =============================================================================================
+# workspace: activations for one (B, L_img, L_txt) geometry, allocated once and reused every step
+# =============================================================================================
+class _Workspace:
+    def __init__(self, B, L_txt, L_img, D, R, H, hd, device):
+        L = L_txt + L_img
+        self.B, self.L_txt, self.L_img, self.L = B, L_txt, L_img, L
+        self.x = torch.empty(B, L, D, dtype=BF16, device=device)        # residual stream, joint [txt; img]
+        self.xm = torch.empty(B, L, D, dtype=BF16, device=device)       # LN+modulate output
+        self.y = torch.empty(B * L * (3 * D + R), dtype=BF16, device=device)  # [q|k|v(attn out)|mlp] rows
+        self.h = torch.empty(B, L, R, dtype=BF16, device=device)        # double-block MLP hidden
+        Lp = (L + 63) // 64 * 64
+        self.vt = torch.empty(B, H, hd, Lp, dtype=BF16, device=device)
+
+    def y_double(self, D):
+        return self.y[: self.B * self.L * 3 * D].view(self.B, self.L, 3 * D)
+
+    def y_single(self, D, R):
+        return self.y.view(self.B, self.L, 3 * D + R)
+
+
+_WS_CACHE: dict = {}
+
+
+def _workspace(B, L_txt, L_img, D, R, H, hd, device) -> _Workspace:
+    key = (B, L_txt, L_img, D, R, H, hd, str(device))
+    ws = _WS_CACHE.get(key)
+    if ws is None:
+        if len(_WS_CACHE) > 4:
+            _WS_CACHE.clear()
+        ws = _Workspace(B, L_txt, L_img, D, R, H, hd, device)
+        _WS_CACHE[key] = ws
+    return ws
+
+
+# =============================================================================================
+# RoPE table handling
+# =============================================================================================
+def _pe_to_cos_sin(pe, hd: int):
+    """Reference positional-embedding formats -> (cos, sin) f32 [B, L, hd/2], rope_mode.
+    EmbedND tensor [B,1,L,hd/2,2,2] (layers.py:38-44; entries cos,-sin,sin,cos) -> mode 0 (interleaved);
+    LigerEmbedND tuple of [B,L,hd] (layers.py:55-65; halves repeated)           -> mode 1 (half-split)."""
+    if isinstance(pe, _RopeTable):
+        return pe.cos, pe.sin, pe.mode
+    if isinstance(pe, torch.Tensor):
+        cos = pe[:, 0, :, :, 0, 0].float().contiguous()
+        sin = pe[:, 0, :, :, 1, 0].float().contiguous()
+        return cos, sin, 0
+    cos, sin = pe
+    return cos[..., : hd // 2].float().contiguous(), sin[..., : hd // 2].float().contiguous(), 1
+
+
+@dataclass
+class _RopeTable:
+    cos: Tensor  # f32 [B, L, hd/2]
+    sin: Tensor
+    mode: int    # 0 interleaved (EmbedND), 1 half-split (LigerEmbedND)
+
+
+class HipEmbedND(nn.Module):
+    """EmbedND / LigerEmbedND (layers.py:31-65): ids [B, L, n_axes] -> RoPE tables, computed by osk_rope_table."""
+
+    def __init__(self, dim: int, theta: int, axes_dim, liger: bool):
+        super().__init__()
+        self.dim, self.theta, self.axes_dim, self.liger = dim, theta, list(axes_dim), liger
+
+    def forward(self, ids: Tensor) -> _RopeTable:
+        B, L, n_axes = ids.shape
+        idf = ids.float().contiguous().view(B * L, n_axes)
+        half = sum(self.axes_dim) // 2
+        cos = torch.empty(B, L, half, dtype=torch.float32, device=ids.device)
+        sin = torch.empty_like(cos)
+        _C.rope_table(idf, self.axes_dim, self.theta, self.liger, cos, sin)
+        return _RopeTable(cos, sin, 1 if self.liger else 0)
+
+
+# =============================================================================================
+# the block arithmetic (shared by the engine and the processors)
+# =============================================================================================
+def _mod_views(mod: Tensor, col: int, n: int, D: int):
+    """mod f32 [B, Ntot]; returns n views (pointer carriers) at columns col + i*D, and the batch stride."""
+    return [mod[:, col + i * D: col + (i + 1) * D] for i in range(n)], mod.stride(0)
+
+
+def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: int, col_txt: int, rope: _RopeTable,
+                     H: int, hd: int):
+    """DoubleStreamBlockProcessor.__call__ (layers.py:195-253) on the workspace's joint buffers.
+    Residual streams live in ws.x ([:, :L_txt] txt, [:, L_txt:] img) and are updated in place."""
+    D = H * hd
+    Lt = ws.L_txt
+    x_txt, x_img = ws.x[:, :Lt], ws.x[:, Lt:]
+    xm_txt, xm_img = ws.xm[:, :Lt], ws.xm[:, Lt:]
+    y = ws.y_double(D)
+    (i_sh1, i_sc1, i_g1, i_sh2, i_sc2, i_g2), mbs = _mod_views(mod, col_img, 6, D)
+    (t_sh1, t_sc1, t_g1, t_sh2, t_sc2, t_g2), _ = _mod_views(mod, col_txt, 6, D)
+    r_img, r_txt = x_img, x_txt
+
+    _C.ln_modulate(r_img, i_sh1, i_sc1, xm_img, mbs)
+    _C.ln_modulate(r_txt, t_sh1, t_sc1, xm_txt, mbs)
+    _C.gemm(xm_img, plan.img.qkv_w, plan.img.qkv_b, y[:, Lt:])
+    _C.gemm(xm_txt, plan.txt.qkv_w, plan.txt.qkv_b, y[:, :Lt])
+    q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D:]
+    _C.qknorm_rope(q, k, plan.txt.q_scale, plan.txt.k_scale, plan.img.q_scale, plan.img.k_scale, Lt,
+                   rope.cos, rope.sin, rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0, H, hd, rope.mode)
+    _C.v_transpose(v, ws.vt, H, hd)
+    _C.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)  # output overwrites the (dead) v slot
+    # img stream
+    _C.gemm(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=r_img, gate=i_g1, gate_batch_stride=mbs)
+    _C.ln_modulate(x_img, i_sh2, i_sc2, xm_img, mbs)
+    w0, b0, w2, b2 = plan.img_mlp
+    _C.gemm(xm_img, w0, b0, ws.h[:, Lt:], gelu_from=0)
+    _C.gemm(ws.h[:, Lt:], w2, b2, x_img, res=x_img, gate=i_g2, gate_batch_stride=mbs)
+    # txt stream
+    _C.gemm(v[:, :Lt], plan.txt.proj_w, plan.txt.proj_b, x_txt, res=r_txt, gate=t_g1, gate_batch_stride=mbs)
+    _C.ln_modulate(x_txt, t_sh2, t_sc2, xm_txt, mbs)
+    w0, b0, w2, b2 = plan.txt_mlp
+    _C.gemm(xm_txt, w0, b0, ws.h[:, :Lt], gelu_from=0)
+    _C.gemm(ws.h[:, :Lt], w2, b2, x_txt, res=x_txt, gate=t_g2, gate_batch_stride=mbs)
+
+
+def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, rope: _RopeTable, H: int, hd: int,
+                     R: int):
+    """SingleStreamBlockProcessor.__call__ (layers.py:309-334).  linear1's output row is [q|k|v|mlp]; attention
+    writes into the v slot so linear2 reads the contiguous [attn | gelu(mlp)] columns: no torch.cat."""
+    D = H * hd
+    y = ws.y_single(D, R)
+    (shift, scale, gate), mbs = _mod_views(mod, col, 3, D)
+    r = ws.x
+    _C.ln_modulate(r, shift, scale, ws.xm, mbs)
+    _C.gemm(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
+    q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D: 3 * D]
+    _C.qknorm_rope(q, k, plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale, 0, rope.cos, rope.sin,
+                   rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0, H, hd, rope.mode)
+    _C.v_transpose(v, ws.vt, H, hd)
+    _C.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)
+    _C.gemm(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=r, gate=gate, gate_batch_stride=mbs)
+
+
+def _run_modulation(vec32: Tensor, layers, D: int) -> Tensor:
+    """Modulation.forward (layers.py:186-191) for a list of layers sharing vec: one GEMV launch."""
+    cols, col, task_layers = [], 0, []
+    for w, b in layers:
+        task_layers.append((w, b, col))
+        cols.append(col)
+        col += w.shape[0]
+    tasks = _C.GemvTasks(task_layers, vec32.device)
+    mod = torch.empty(vec32.shape[0], col, dtype=torch.float32, device=vec32.device)
+    _C.gemv_tasks(vec32, tasks, mod, act_in=1)
+    return mod, cols
+
+
+class HipDoubleStreamBlockProcessor:
+    """Drop-in for DoubleStreamBlockProcessor (layers.py:195-253): `(block, img, txt, vec, pe) -> (img, txt)`."""
+
+    def __call__(self, attn: nn.Module, img: Tensor, txt: Tensor, vec: Tensor, pe) -> tuple[Tensor, Tensor]:
+        H, hd = attn.num_heads, attn.head_dim
+        D = H * hd
+        plan = plan_double(attn)
+        B, Li, _ = img.shape
+        Lt = txt.shape[1]
+        R = plan.img_mlp[0].shape[0]
+        ws = _workspace(B, Lt, Li, D, R, H, hd, img.device)
+        cos, sin, mode = _pe_to_cos_sin(pe, hd)
+        mod, cols = _run_modulation(vec.float().contiguous(), plan.mod_layers, D)
+        ws.x[:, Lt:].copy_(img)
+        ws.x[:, :Lt].copy_(txt)
+        run_double_block(plan, ws, mod, cols[0], cols[1], _RopeTable(cos, sin, mode), H, hd)
+        return ws.x[:, Lt:].clone().to(img.dtype), ws.x[:, :Lt].clone().to(txt.dtype)
+
+
+class HipSingleStreamBlockProcessor:
+    """Drop-in for SingleStreamBlockProcessor (layers.py:309-334): `(block, x, vec, pe) -> x`."""
+
+    def __call__(self, attn: nn.Module, x: Tensor, vec: Tensor, pe) -> Tensor:
+        H, hd = attn.num_heads, attn.head_dim
+        D = H * hd
+        plan = plan_single(attn)
+        B, L, _ = x.shape
+        R = plan.w1.shape[0] - 3 * D
+        ws = _workspace(B, 0, L, D, R, H, hd, x.device)
+        cos, sin, mode = _pe_to_cos_sin(pe, hd)
+        mod, cols = _run_modulation(vec.float().contiguous(), plan.mod_layers, D)
+        ws.x.copy_(x)
+        run_single_block(plan, ws, mod, cols[0], _RopeTable(cos, sin, mode), H, hd, R)
+        return ws.x.clone().to(x.dtype)
+
+
+# =============================================================================================
+# the model
+# =============================================================================================
+class MMDiTModel(nn.Module):
+    """Reference MMDiTModel (model.py:69-233) with the arithmetic in gfx950 kernels."""
+
+    config_class = MMDiTConfig
+
+    def __init__(self, config: MMDiTConfig):
+        super().__init__()
+        self.config = config
+        self.in_channels = config.in_channels
+        self.out_channels = self.in_channels
+        self.patch_size = config.patch_size
+        if config.hidden_size % config.num_heads != 0:
+            raise ValueError(f"Hidden size {config.hidden_size} must be divisible by num_heads {config.num_heads}")
+        pe_dim = config.hidden_size // config.num_heads
+        if sum(config.axes_dim) != pe_dim:
+            raise ValueError(f"Got {config.axes_dim} but expected positional dim {pe_dim}")
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_heads
+        self.pe_embedder = HipEmbedND(pe_dim, config.theta, config.axes_dim, liger=config.use_liger_rope)
+        D = self.hidden_size
+        self.img_in = nn.Linear(self.in_channels, D, bias=True)
+        self.time_in = MLPEmbedder(256, D)
+        self.vector_in = MLPEmbedder(config.vec_in_dim, D)
+        self.guidance_in = MLPEmbedder(256, D) if config.guidance_embed else nn.Identity()
+        self.cond_in = nn.Linear(self.in_channels + self.patch_size ** 2, D, bias=True) if config.cond_embed else nn.Identity()
+        self.txt_in = nn.Linear(config.context_in_dim, D)
+        self.double_blocks = nn.ModuleList([
+            DoubleStreamBlock(D, self.num_heads, mlp_ratio=config.mlp_ratio, qkv_bias=config.qkv_bias, fused_qkv=config.fused_qkv)
+            for _ in range(config.depth)])
+        self.single_blocks = nn.ModuleList([
+            SingleStreamBlock(D, self.num_heads, mlp_ratio=config.mlp_ratio, fused_qkv=config.fused_qkv)
+            for _ in range(config.depth_single_blocks)])
+        self.final_layer = LastLayer(D, 1, self.out_channels)
+        if config.cond_embed:  # model.py:149-152
+            nn.init.zeros_(self.cond_in.weight)
+            nn.init.zeros_(self.cond_in.bias)
+        self._plan = None
+        self.forward = self.forward_ckpt  # instance attribute, as the reference does (model.py:143-146)
+
+    # ------------------------------------------------------------------ planning
+    def invalidate_plan(self):
+        self._plan = None
+        for b in list(self.double_blocks) + list(self.single_blocks):
+            if hasattr(b, "_osk_plan"):
+                object.__delattr__(b, "_osk_plan")
+
+    def _build_plan(self, device):
+        cfg = self.config
+        D = self.hidden_size
+        p = {}
+        p["double"] = [plan_double(b) for b in self.double_blocks]
+        p["single"] = [plan_single(b) for b in self.single_blocks]
+        # img_in (+ cond_in) as ONE GEMM over the concatenated, K-padded input
+        ws_in = [_w(self.img_in.weight)]
+        b_in = self.img_in.bias.detach().float()
+        if cfg.cond_embed:
+            ws_in.append(_w(self.cond_in.weight))
+            b_in = b_in + self.cond_in.bias.detach().float()
+        p["in_w"] = _pad_k(torch.cat(ws_in, 1).contiguous())
+        p["in_b"] = b_in.contiguous()
+        p["txt_w"] = _pad_k(_w(self.txt_in.weight))
+        p["txt_b"] = _b32(self.txt_in.bias)
+        p["final_w"] = _w(self.final_layer.linear.weight)
+        p["final_b"] = _b32(self.final_layer.linear.bias)
+        # all adaLN layers share vec: one task list, one launch per step
+        layers, col = [], 0
+        p["col_double"], p["col_single"] = [], []
+        for b in p["double"]:
+            c = []
+            for w, bias in b.mod_layers:
+                layers.append((w, bias, col))
+                c.append(col)
+                col += w.shape[0]
+            p["col_double"].append(c)
+        for b in p["single"]:
+            w, bias = b.mod_layers[0]
+            layers.append((w, bias, col))
+            p["col_single"].append(col)
+            col += w.shape[0]
+        fl = self.final_layer.adaLN_modulation[1]
+        layers.append((_w(fl.weight), _w(fl.bias), col))
+        p["col_final"] = col
+        col += fl.weight.shape[0]
+        p["mod_cols"] = col
+        p["mod_tasks"] = _C.GemvTasks(layers, device)
+
+        def emb(m):
+            return (_C.GemvTasks([(_w(m.in_layer.weight), _w(m.in_layer.bias), 0)], device),
+                    _C.GemvTasks([(_w(m.out_layer.weight), _w(m.out_layer.bias), 0)], device))
+
+        p["time_in"] = emb(self.time_in)
+        p["vector_in"] = emb(self.vector_in)
+        p["guidance_in"] = emb(self.guidance_in) if cfg.guidance_embed else None
+        self._plan = p
+        return p
+
+    # ------------------------------------------------------------------ forward
+    def prepare_block_inputs(self, img, img_ids, txt, txt_ids, timesteps, y_vec, cond=None, guidance=None):
+        """model.py:154-202.  Returns (ws, vec f32 [B, D], rope tables); img/txt land in ws.x."""
+        cfg = self.config
+        if img.ndim != 3 or txt.ndim != 3:
+            raise ValueError("Input img and txt tensors must have 3 dimensions.")
+        if cfg.cond_embed and cond is None:
+            raise ValueError("Didn't get conditional input for conditional model.")
+        if cfg.guidance_embed and guidance is None:
+            raise ValueError("Didn't get guidance strength for guidance distilled model.")
+        dev = img.device
+        p = self._plan or self._build_plan(dev)
+        D, H = self.hidden_size, self.num_heads
+        hd = D // H
+        R = int(D * cfg.mlp_ratio)
+        B, Li, _ = img.shape
+        Lt = txt.shape[1]
+        ws = _workspace(B, Lt, Li, D, R, H, hd, dev)
+        # --- img_in (+cond_in): concatenated K-padded A operand
+        Kp = p["in_w"].shape[1]
+        a_in = getattr(ws, "a_in", None)
+        if a_in is None or a_in.shape[2] != Kp:
+            a_in = ws.a_in = torch.zeros(B, Li, Kp, dtype=BF16, device=dev)
+        C_in = img.shape[2]
+        a_in[:, :, :C_in].copy_(img)
+        if cfg.cond_embed:
+            a_in[:, :, C_in: C_in + cond.shape[2]].copy_(cond)
+        _C.gemm(a_in, p["in_w"], p["in_b"], ws.x[:, Lt:])
+        # --- txt_in
+        Kt = p["txt_w"].shape[1]
+        if Kt == txt.shape[2] and txt.dtype == BF16 and txt.stride(2) == 1:
+            a_txt = txt
+        else:
+            a_txt = getattr(ws, "a_txt", None)
+            if a_txt is None or a_txt.shape[2] != Kt:
+                a_txt = ws.a_txt = torch.zeros(B, Lt, Kt, dtype=BF16, device=dev)
+            a_txt[:, :, : txt.shape[2]].copy_(txt)
+        _C.gemm(a_txt, p["txt_w"], p["txt_b"], ws.x[:, :Lt])
+        # --- vec = time_in(temb(t)) [+ guidance_in(temb(g))] + vector_in(y)   (f32 throughout)
+        temb = torch.empty(B, 256, dtype=torch.float32, device=dev)
+        hbuf = torch.empty(B, D, dtype=torch.float32, device=dev)
+        vec = torch.empty(B, D, dtype=torch.float32, device=dev)
+        _C.timestep_embedding(timesteps.float().contiguous(), temb)
+        _C.gemv_tasks(temb, p["time_in"][0], hbuf)
+        _C.gemv_tasks(hbuf, p["time_in"][1], vec, act_in=1)
+        if cfg.guidance_embed:
+            _C.timestep_embedding(guidance.float().contiguous(), temb)
+            _C.gemv_tasks(temb, p["guidance_in"][0], hbuf)
+            _C.gemv_tasks(hbuf, p["guidance_in"][1], vec, act_in=1, accumulate=True)
+        _C.gemv_tasks(y_vec.float().contiguous(), p["vector_in"][0], hbuf)
+        _C.gemv_tasks(hbuf, p["vector_in"][1], vec, act_in=1, accumulate=True)
+        # --- RoPE tables for the joint sequence
+        ids = torch.cat((txt_ids, img_ids), dim=1)
+        rope = self.pe_embedder(ids)
+        return ws, vec, rope
+
+    def forward_ckpt(self, img: Tensor, img_ids: Tensor, txt: Tensor, txt_ids: Tensor, timesteps: Tensor,
+                     y_vec: Tensor, cond: Tensor = None, guidance: Tensor | None = None, **kwargs) -> Tensor:
+        """MMDiTModel.forward_ckpt (model.py:208-233); inference only."""
+        ws, vec, rope = self.prepare_block_inputs(img, img_ids, txt, txt_ids, timesteps, y_vec, cond, guidance)
+        p = self._plan
+        D, H = self.hidden_size, self.num_heads
+        hd = D // H
+        R = int(D * self.config.mlp_ratio)
+        B = img.shape[0]
+        mod = torch.empty(B, p["mod_cols"], dtype=torch.float32, device=img.device)
+        _C.gemv_tasks(vec, p["mod_tasks"], mod, act_in=1)
+        for plan, (ci, ct) in zip(p["double"], p["col_double"]):
+            run_double_block(plan, ws, mod, ci, ct, rope, H, hd)
+        for plan, c in zip(p["single"], p["col_single"]):
+            run_single_block(plan, ws, mod, c, rope, H, hd, R)
+        # LastLayer (layers.py:398-402): (shift, scale) order
+        Lt = ws.L_txt
+        cf = p["col_final"]
+        shift, scale = mod[:, cf: cf + D], mod[:, cf + D: cf + 2 * D]
+        _C.ln_modulate(ws.x[:, Lt:], shift, scale, ws.xm[:, Lt:], mod.stride(0))
+        out = torch.empty(B, ws.L_img, p["final_w"].shape[0], dtype=BF16, device=img.device)
+        _C.gemm(ws.xm[:, Lt:], p["final_w"], p["final_b"], out)
+        return out.to(img.dtype) if img.dtype != BF16 else out
+
+
+def Flux(cache_dir: str = None, from_pretrained: str = None, device_map="cuda", torch_dtype: torch.dtype = BF16,
+         strict_load: bool = False, **kwargs) -> MMDiTModel:
+    """Factory with the reference signature (model.py:271-303); `from_pretrained` takes a safetensors path."""
+    config = MMDiTConfig(from_pretrained=from_pretrained, cache_dir=cache_dir, **kwargs)
+    with torch.device(device_map):
+        model = MMDiTModel(config)
+    model = model.to(torch_dtype)
+    if from_pretrained:
+        from safetensors.torch import load_file
+
+        sd = load_file(from_pretrained, device=str(device_map))
+        model.load_state_dict(sd, strict=strict_load)
+    return model
