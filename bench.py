@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py — denoise-step latency and latent-frames/s of the MMDiT sampler on MI355X.
+
+Workload (BASELINE.json configs[1]): XL-width MMDiT (hidden 1152, 16 heads x hd 72, 9 double + 19 single
+blocks — the reference denoiser at DiT-XL/2 geometry), bf16, latent 16x64x64 (= 16x512x512
+px through the 8x VAE) -> 16,384 image tokens + 512 text tokens, 30-step rectified-flow Euler sampling with
+the reference's CFG triple (batch 3 per video: cond / uncond / uncond_2).  Synthetic N(0,1) latents, random
+text embeddings, random-init weights (no checkpoints offline).
+
+One "step" = one denoise step of the sampler = MMDiT forward on the CFG triple + CFG combine + Euler update.
+`value` = latent frames per second for a 30-step sampling = T_lat / (30 * step_time), inputs resident in HBM.
+
+  python bench.py --gpus 1 --steps 30 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W          (sequence parallel over the token axis, RCCL)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+SAMPLING_STEPS = 30
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="XL", choices=["S", "XL", "11B"])
+    ap.add_argument("--frames", type=int, default=16, help="latent frames T_lat")
+    ap.add_argument("--latent-hw", type=int, default=64, help="latent height = width")
+    ap.add_argument("--cfg-batch", type=int, default=3, help="3 = reference CFG triple, 1 = pure step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=45.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, L_img, L_txt, cfg_batch, budget_s):
+    """The oracle (CPU restatement of the reference, fp32) timed on this host's cores on a bounded sample of
+    the same workload: ONE double block and ONE single block at the full token count, batch 1; the step time
+    is extrapolated (x depth, x CFG batch).  kind = "port": the real reference cannot travel to the GPU box."""
+    from oracle import mmdit_oracle as O
+    from oracle import synth
+
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    one = dict(cfg, depth=1, depth_single_blocks=1)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(synth.mmdit_param_shapes(one), 0).items()}
+    D = cfg["hidden_size"]
+    hd = D // cfg["num_heads"]
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(1, L_img, D, generator=g)
+    txt = torch.randn(1, L_txt, D, generator=g)
+    vec = torch.randn(1, D, generator=g)
+    ang = torch.rand(1, L_img + L_txt, hd // 2, generator=g).double()
+    t0 = time.perf_counter()
+    with torch.inference_mode():
+        img2, txt2 = O.double_block(sd, one, 0, img, txt, vec, ang, "interleaved")
+        t1 = time.perf_counter()
+        if t1 - t0 > budget_s:  # very slow host: skip the second half, assume single ~ double
+            t2 = t1 + (t1 - t0)
+        else:
+            O.single_block(sd, one, 0, torch.cat((txt2, img2), 1), vec, ang, "interleaved")
+            t2 = time.perf_counter()
+    t_double, t_single = t1 - t0, t2 - t1
+    step_s = cfg_batch * (cfg["depth"] * t_double + cfg["depth_single_blocks"] * t_single)
+    return t_double, t_single, step_s, ncores
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    from open_sora_amd import _C, configs, mmdit, sampling
+
+    cfg = dict(configs.MMDIT[args.model])
+    T, hw = args.frames, args.latent_hw
+    L_img, L_txt = T * (hw // 2) * (hw // 2), 512
+    L = L_img + L_txt
+    nb = args.cfg_batch
+    D, H = cfg["hidden_size"], cfg["num_heads"]
+    hd = D // H
+
+    torch.manual_seed(1234)
+    model = mmdit.Flux(device_map=dev, torch_dtype=torch.bfloat16, **cfg)
+    with torch.no_grad():  # random-init weights of the architecture (cond_in is zero-init in the reference)
+        for n_, p_ in model.named_parameters():
+            if n_.startswith("cond_in"):
+                p_.normal_(0, 0.02)
+    if world > 1:
+        from open_sora_amd import seqpar
+
+        seqpar.enable(model, dist.group.WORLD)
+
+    # synthetic inputs, resident in HBM before the timed region
+    g = torch.Generator(device=dev).manual_seed(42)
+    z = torch.randn(1, 16, T, hw, hw, device=dev, dtype=torch.bfloat16, generator=g)
+    x = sampling.pack(z).contiguous()                                        # [1, L_img, 64]
+    g2 = torch.Generator(device=dev).manual_seed(43)
+    txt = (torch.randn(nb, L_txt, cfg["context_in_dim"], device=dev, generator=g2) * 0.2).to(torch.bfloat16)
+    y_vec = torch.randn(nb, cfg["vec_in_dim"], device=dev, generator=g2).to(torch.bfloat16)
+    img_ids, txt_ids = sampling.prepare_ids(nb, T, hw, hw, L_txt, dev, torch.bfloat16)
+    cond = torch.zeros(nb, L_img, 68, device=dev, dtype=torch.bfloat16)      # t2v: masks = 0, masked_ref = 0
+    ts = sampling.get_schedule(SAMPLING_STEPS, (hw // 2) * (hw // 2), T)
+
+    x_next = torch.empty_like(x)
+    img3 = torch.empty(nb, L_img, 64, device=dev, dtype=torch.bfloat16)
+
+    def step(i, x, x_next):
+        t_curr, t_prev = ts[i % SAMPLING_STEPS], ts[i % SAMPLING_STEPS + 1]
+        t_vec = torch.full((nb,), t_curr, dtype=torch.bfloat16, device=dev)
+        img3.copy_(x.expand(nb, -1, -1))
+        pred = model(img=img3, img_ids=img_ids, txt=txt, txt_ids=txt_ids, timesteps=t_vec, y_vec=y_vec, cond=cond)
+        if nb == 3:
+            _C.cfg_euler(pred, x, x_next, 7.5, 3.0, float(t_prev - t_curr))
+        else:
+            _C.cfg_euler(pred.expand(3, -1, -1).contiguous(), x, x_next, 1.0, 1.0, float(t_prev - t_curr))
+        return x_next, x
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.inference_mode():
+        for i in range(args.warmup):
+            x, x_next = step(i, x, x_next)
+        _C.PROFILE_ATTENTION = [] if rank == 0 else None
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            x, x_next = step(i, x, x_next)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = _C.PROFILE_ATTENTION
+        _C.PROFILE_ATTENTION = None
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(x.float()).all(), "non-finite latents after the timed steps"
+    ms_per_step = elapsed / args.steps * 1e3
+    frames_per_s = T / (SAMPLING_STEPS * ms_per_step * 1e-3)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (attention): HIP events recorded around every launch in the timed region
+    roofline = None
+    if prof:
+        torch.cuda.synchronize()
+        durs = [s.elapsed_time(e) for s, e in prof]
+        avg_ms = sum(durs) / len(durs)
+        Lq = L // world
+        fl = configs.attention_flops(nb, H, Lq, L, hd)  # per launch on this rank
+        ach = fl / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": f"attn_fwd_kernel<{hd}>", "achieved": round(ach, 1),
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),
+                    "flops_per_launch": fl}
+    step_flops = configs.flops_per_forward(cfg, nb, L_img, L_txt)
+    out = {
+        "metric": "latent_frames_per_sec (30-step rectified-flow sampling; denoise-step ms in ms_per_step)",
+        "value": round(frames_per_s, 4), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"MMDiT-{args.model} (hidden {D}, {H}x{hd}, {cfg['depth']}+{cfg['depth_single_blocks']} blocks) "
+                               f"denoise step, latent {T}x{hw}x{hw} (16x512x512 px), L={L} tokens, CFG batch {nb}, "
+                               f"{SAMPLING_STEPS}-step Euler sampling",
+                   "tokens": L, "cfg_batch": nb, "parallelism": "single GPU" if world == 1 else f"sp{world} (token axis, all-gather K/V)"},
+        "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world, 1),
+        "step_mfma_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4),
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        td, tsg, cpu_step, ncores = cpu_baseline(cfg, L_img, L_txt, nb, args.cpu_budget_s)
+        out["cpu_baseline"] = {
+            "value": round(T / (SAMPLING_STEPS * cpu_step), 6), "unit": "latent frames/s", "cores": ncores,
+            "kind": "port",
+            "sample": f"oracle fp32 on {ncores} host threads: 1 double block ({td:.2f} s) + 1 single block ({tsg:.2f} s) "
+                      f"at B=1, L={L}; step extrapolated x({cfg['depth']},{cfg['depth_single_blocks']}) x CFG batch {nb} = {cpu_step:.1f} s",
+        }
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -171,6 +171,10 @@ def v_transpose(v: torch.Tensor, vt: torch.Tensor, H: int, hd: int):
            "osk_v_transpose_bf16")
 
 
+# bench.py sets this to a list to collect (start, end) HIP events around every attention launch
+PROFILE_ATTENTION = None
+
+
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, H: int, hd: int,
                   scale: float, *, lse=None, n_seg: int = 1, seg_len: int | None = None,
                   k_seg_stride: int = 0, vt_seg_stride: int = 0):
@@ -179,10 +183,17 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
     B, Lq, _ = q.shape
     if seg_len is None:
         seg_len = k.shape[1]
+    prof = PROFILE_ATTENTION
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _check(lib.osk_attention_fwd_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
                                       k.stride(0), k.stride(1), vt.data_ptr(), vt_seg_stride, out.data_ptr(),
                                       out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg, seg_len, hd,
                                       scale, _stream()), "osk_attention_fwd_bf16")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1))
     return out
 
 

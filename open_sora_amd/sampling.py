@@ -1,0 +1,141 @@
+"""Host side of the rectified-flow sampler around the denoiser (the caller of the hot path).
+
+Mirrors, by name and argument meaning, the pieces of /root/reference/opensora/utils/sampling.py that sit on
+either side of MMDiTModel.forward:
+    get_oscillation_gs :120-133    time_shift / get_res_lin_function / get_schedule :295-332
+    get_noise :335-372             pack / unpack :375-393         prepare_ids (from prepare :431-447)
+    I2VDenoiser.denoise :159-226   (CFG triple, oscillating guidance, Euler update)
+Schedules are Python floats; tensors stay on the device; the CFG combine + Euler update is one HIP kernel
+(osk_cfg_euler_bf16) instead of six bf16 elementwise launches.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import torch
+from torch import Tensor
+
+from . import _C
+
+
+def get_oscillation_gs(guidance_scale: float, i: int, force_num: int = 10) -> float:
+    """sampling.py:120-133: full guidance for the first `force_num` steps and on even steps, 1.0 otherwise."""
+    return guidance_scale if (i < force_num or i % 2 == 0) else 1.0
+
+
+def time_shift(alpha: float, t):
+    return alpha * t / (1 + (alpha - 1) * t)
+
+
+def get_res_lin_function(x1: float = 256, y1: float = 1, x2: float = 4096, y2: float = 3):
+    m = (y2 - y1) / (x2 - x1)
+    b = y1 - m * x1
+    return lambda x: m * x + b
+
+
+def get_schedule(num_steps: int, image_seq_len: int, num_frames: int, shift_alpha: float | None = None,
+                 base_shift: float = 1, max_shift: float = 3, shift: bool = True) -> list[float]:
+    """sampling.py:307-332: linspace(1, 0, N+1) in f32, optionally shifted by alpha(seq_len) * sqrt(frames)."""
+    ts = torch.linspace(1, 0, num_steps + 1)
+    if shift:
+        if shift_alpha is None:
+            shift_alpha = get_res_lin_function(y1=base_shift, y2=max_shift)(image_seq_len)
+            shift_alpha *= math.sqrt(num_frames)
+        ts = time_shift(shift_alpha, ts)
+    return ts.tolist()
+
+
+def _ae_compression() -> int:
+    return int(os.environ.get("AE_SPATIAL_COMPRESSION", 16))
+
+
+def get_noise(num_samples: int, height: int, width: int, num_frames: int, device, dtype, seed: int,
+              patch_size: int = 2, channel: int = 16) -> Tensor:
+    """sampling.py:335-372 (device generator seeded per call)."""
+    D = _ae_compression()
+    gen = torch.Generator(device=device).manual_seed(seed)
+    return torch.randn(num_samples, channel, num_frames, patch_size * math.ceil(height / D),
+                       patch_size * math.ceil(width / D), device=device, dtype=dtype, generator=gen)
+
+
+def pack(x: Tensor, patch_size: int = 2) -> Tensor:
+    """'b c t (h ph) (w pw) -> b (t h w) (c ph pw)' (sampling.py:375-378)."""
+    b, c, t, H, W = x.shape
+    p = patch_size
+    x = x.reshape(b, c, t, H // p, p, W // p, p)
+    return x.permute(0, 2, 3, 5, 1, 4, 6).reshape(b, t * (H // p) * (W // p), c * p * p)
+
+
+def unpack(x: Tensor, height: int, width: int, num_frames: int, patch_size: int = 2) -> Tensor:
+    """'b (t h w) (c ph pw) -> b c t (h ph) (w pw)' (sampling.py:381-393)."""
+    D = _ae_compression()
+    h, w, p = math.ceil(height / D), math.ceil(width / D), patch_size
+    b, _, cpp = x.shape
+    c = cpp // (p * p)
+    x = x.reshape(b, num_frames, h, w, c, p, p)
+    return x.permute(0, 4, 1, 2, 5, 3, 6).reshape(b, c, num_frames, h * p, w * p)
+
+
+def prepare_ids(bs: int, t: int, h: int, w: int, n_txt: int, device, dtype, patch_size: int = 2):
+    """img_ids[t,h,w] = (t,h,w) in patch units, txt_ids = 0 (sampling.py:437-447,455-457)."""
+    hp, wp = h // patch_size, w // patch_size
+    ids = torch.zeros(t, hp, wp, 3)
+    ids[..., 0] += torch.arange(t)[:, None, None]
+    ids[..., 1] += torch.arange(hp)[None, :, None]
+    ids[..., 2] += torch.arange(wp)[None, None, :]
+    img_ids = ids.reshape(1, t * hp * wp, 3).repeat(bs, 1, 1).to(device, dtype)
+    txt_ids = torch.zeros(bs, n_txt, 3, device=device, dtype=dtype)
+    return img_ids, txt_ids
+
+
+class I2VDenoiser:
+    """sampling.py:158-245.  `denoise(model, img=..., timesteps=[...], guidance=..., guidance_img=..., masks=...,
+    masked_ref=..., img_ids=..., txt=..., txt_ids=..., y_vec=..., [text_osci, image_osci, scale_temporal_osci,
+    patch_size, sigma_min])` with img/txt/... already tripled (cond | uncond | uncond_2)."""
+
+    def denoise(self, model, **kwargs) -> Tensor:
+        img = kwargs.pop("img")
+        timesteps = kwargs.pop("timesteps")
+        guidance = kwargs.pop("guidance")
+        guidance_img = kwargs.pop("guidance_img")
+        masks = kwargs.pop("masks")
+        masked_ref = kwargs.pop("masked_ref")
+        kwargs.pop("sigma_min", None)
+        text_osci = kwargs.pop("text_osci", False)
+        image_osci = kwargs.pop("image_osci", False)
+        scale_temporal_osci = kwargs.pop("scale_temporal_osci", False)
+        patch_size = kwargs.pop("patch_size", 2)
+
+        n3 = img.shape[0]
+        n = n3 // 3
+        dev, dt = img.device, img.dtype
+        guidance_vec = torch.full((n3,), guidance, device=dev, dtype=dt)
+        b, c, t, w_, h_ = masked_ref.size()
+        cond = pack(torch.cat((masks, masked_ref), dim=1), patch_size=patch_size)
+        cond3 = torch.cat([cond, cond, torch.zeros_like(cond)], dim=0)  # 3rd branch drops the image condition
+        x = img[:n].contiguous()
+        x_next = torch.empty_like(x)
+        img3 = torch.empty(n3, *x.shape[1:], device=dev, dtype=dt)
+        for i, (t_curr, t_prev) in enumerate(zip(timesteps[:-1], timesteps[1:])):
+            t_vec = torch.full((n3,), t_curr, dtype=dt, device=dev)
+            img3.view(3, *x.shape).copy_(x.unsqueeze(0).expand(3, *x.shape))
+            pred = model(img=img3, **kwargs, cond=cond3, timesteps=t_vec, guidance=guidance_vec)
+            text_gs = get_oscillation_gs(guidance, i) if text_osci else guidance
+            image_gs = get_oscillation_gs(guidance_img, i) if image_osci else guidance_img
+            gvec = None
+            if image_gs > 1.0 and scale_temporal_osci:
+                upper = torch.linspace(image_gs, 1.0, len(timesteps))[i]
+                ramp = torch.linspace(1.0, float(upper), t)[None, None, :, None, None].repeat(b, c, 1, h_, w_)
+                gvec = pack(ramp, patch_size=patch_size).to(dev, torch.float32).contiguous()
+                image_gs = 1.0
+            _C.cfg_euler(pred.contiguous(), x, x_next, float(text_gs), float(image_gs), float(t_prev - t_curr), gvec)
+            x, x_next = x_next, x
+        return x
+
+    def prepare_guidance(self, text: list, optional_models: dict, device, dtype, **kwargs):
+        ret = {"guidance_img": kwargs.pop("guidance_img")}
+        neg = kwargs.get("neg", None)
+        if neg is None:
+            neg = [""] * len(text)
+        return text + neg + neg, ret

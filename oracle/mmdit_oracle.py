@@ -100,9 +100,16 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
     """flash_attn_func semantics: softmax(q k^T hd^-1/2) v, non-causal.
     q,k,v [B,H,L,hd] -> [B,L,H*hd].  Softmax in fp32 regardless of the I/O dtype."""
     B, H, L, hd = q.shape
-    s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * (hd ** -0.5)
-    p = torch.softmax(s, dim=-1)
-    o = torch.matmul(p, v.float()).to(q.dtype)
+    if B * H * L * L > (1 << 28):  # bound the score matrix to one (b, h) at a time at large L
+        o = torch.empty(B, H, L, hd, dtype=q.dtype)
+        for b in range(B):
+            for h in range(H):
+                s = torch.matmul(q[b, h].float(), k[b, h].float().t()) * (hd ** -0.5)
+                o[b, h] = torch.matmul(torch.softmax(s, dim=-1), v[b, h].float()).to(q.dtype)
+    else:
+        s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * (hd ** -0.5)
+        p = torch.softmax(s, dim=-1)
+        o = torch.matmul(p, v.float()).to(q.dtype)
     return o.permute(0, 2, 1, 3).reshape(B, L, H * hd)
 
 

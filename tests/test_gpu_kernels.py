@@ -1,0 +1,300 @@
+"""GPU parity tests, kernel by kernel: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerances are stated per test; bf16 outputs are compared after the same final rounding."""
+import math
+
+import pytest
+import torch
+
+from oracle import mmdit_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rnd(name, shape, std=1.0, seed=7, dtype=BF):
+    return torch.from_numpy(synth.normal(name, seed, shape, std=std)).to(DEV).to(dtype)
+
+
+def bf16_ulp_close(a, b, rel=2 ** -7, abs_=1e-3):
+    """a, b float tensors; allow one bf16 rounding step of disagreement."""
+    d = (a.double() - b.double()).abs()
+    tol = abs_ + rel * b.double().abs()
+    bad = (d > tol).sum().item()
+    assert bad == 0, f"{bad} elements differ; max err {d.max().item():.4e}"
+
+
+# ----------------------------------------------------------------------------- LN + modulate
+@pytest.mark.parametrize("D", [128, 384, 1152, 3072])
+def test_ln_modulate(hip_lib, D):
+    B, L = 2, 37
+    x = rnd("x", (B, L, D), std=2.0)
+    mod = rnd("mod", (B, 2 * D + 8), std=0.5, dtype=torch.float32)
+    shift, scale = mod[:, :D], mod[:, D + 8: 2 * D + 8]
+    out = torch.empty_like(x)
+    hip_lib.ln_modulate(x, shift, scale, out, mod.stride(0))
+    xf = x.float().cpu()
+    ref = (1 + scale.cpu()[:, None]) * O._layer_norm(xf) + shift.cpu()[:, None]
+    bf16_ulp_close(out.float().cpu(), ref.bfloat16().float())
+
+
+def test_ln_modulate_strided_views(hip_lib):
+    B, Lt, Li, D = 2, 5, 11, 256
+    buf = rnd("x", (B, Lt + Li, D))
+    outb = torch.zeros_like(buf)
+    mod = rnd("mod", (B, 2 * D), std=0.3, dtype=torch.float32)
+    hip_lib.ln_modulate(buf[:, Lt:], mod[:, :D], mod[:, D:], outb[:, Lt:], mod.stride(0))
+    ref = (1 + mod.cpu()[:, None, D:]) * O._layer_norm(buf[:, Lt:].float().cpu()) + mod.cpu()[:, None, :D]
+    bf16_ulp_close(outb[:, Lt:].float().cpu(), ref.bfloat16().float())
+    assert outb[:, :Lt].abs().max().item() == 0.0  # nothing written outside the view
+
+
+# ----------------------------------------------------------------------------- GEMM
+def _gemm_ref(a, w, bias, gelu_from=None, res=None, gate=None):
+    v = a.double().cpu() @ w.double().cpu().T
+    if bias is not None:
+        v = v + bias.double().cpu()
+    if gelu_from is not None:
+        g = torch.nn.functional.gelu(v[..., gelu_from:].float(), approximate="tanh").double()
+        v = torch.cat([v[..., :gelu_from], g], -1)
+    if gate is not None:
+        v = res.double().cpu() + gate.double().cpu()[:, None] * v
+    return v
+
+
+@pytest.mark.parametrize("M_L,N,K", [((1, 128), 128, 64), ((2, 200), 384, 128), ((1, 77), 64, 192), ((3, 130), 1152, 1152), ((1, 513), 200, 256)])
+def test_gemm_plain_bias(hip_lib, M_L, N, K):
+    B, L = M_L
+    a = rnd("a", (B, L, K))
+    w = rnd("w", (N, K), std=K ** -0.5)
+    bias = rnd("b", (N,), std=0.1, dtype=torch.float32)
+    out = torch.empty(B, L, N, dtype=BF, device=DEV)
+    hip_lib.gemm(a, w, bias, out)
+    ref = _gemm_ref(a, w, bias)
+    bf16_ulp_close(out.float().cpu(), ref.float().bfloat16().float(), rel=2 ** -7, abs_=2e-3)
+    out32 = torch.empty(B, L, N, dtype=torch.float32, device=DEV)
+    hip_lib.gemm(a, w, None, out32)
+    ref32 = _gemm_ref(a, w, None)
+    assert (out32.cpu().double() - ref32).abs().max().item() <= 1e-3 * max(1.0, ref32.abs().max().item())
+
+
+def test_gemm_is_transpose_detecting(hip_lib):
+    """A = I block, asymmetric W: C must equal W^T rows exactly (guide: A=I-check with asymmetric B)."""
+    K = N = 128
+    a = torch.eye(K, dtype=BF, device=DEV)[None]
+    w = (torch.arange(N * K, device=DEV).reshape(N, K) % 251).to(BF)
+    out = torch.empty(1, K, N, dtype=torch.float32, device=DEV)
+    hip_lib.gemm(a, w, None, out)
+    assert torch.equal(out[0].cpu(), w.float().cpu().T)
+
+
+def test_gemm_gelu_gate_residual_views(hip_lib):
+    """single-block shaped: linear1 (GELU from col 3D) then linear2 reading [attn|gelu(mlp)] columns in place."""
+    B, L, D, R = 2, 150, 128, 512
+    x = rnd("x", (B, L, D))
+    w1 = rnd("w1", (3 * D + R, D), std=D ** -0.5)
+    b1 = rnd("b1", (3 * D + R,), std=0.1, dtype=torch.float32)
+    y = torch.empty(B, L, 3 * D + R, dtype=BF, device=DEV)
+    hip_lib.gemm(x, w1, b1, y, gelu_from=3 * D)
+    ref1 = _gemm_ref(x, w1, b1, gelu_from=3 * D)
+    bf16_ulp_close(y.float().cpu(), ref1.float().bfloat16().float(), abs_=3e-3)
+    w2 = rnd("w2", (D, D + R), std=(D + R) ** -0.5)
+    b2 = rnd("b2", (D,), std=0.1, dtype=torch.float32)
+    gate = rnd("g", (B, 3 * D), std=0.5, dtype=torch.float32)
+    res = x.clone()
+    hip_lib.gemm(y[:, :, 2 * D:], w2, b2, res, res=res, gate=gate[:, 2 * D:], gate_batch_stride=gate.stride(0))
+    ref2 = _gemm_ref(y[:, :, 2 * D:], w2, b2, res=x, gate=gate[:, 2 * D:])
+    bf16_ulp_close(res.float().cpu(), ref2.float().bfloat16().float(), abs_=3e-3)
+
+
+def test_gemm_joint_buffer_rows(hip_lib):
+    """double-block shaped: txt and img GEMMs write disjoint row ranges of one [B, L, 3D] buffer."""
+    B, Lt, Li, D = 2, 40, 90, 128
+    y = torch.zeros(B, Lt + Li, 3 * D, dtype=BF, device=DEV)
+    xi, xt = rnd("xi", (B, Li, D)), rnd("xt", (B, Lt, D))
+    wi, wt = rnd("wi", (3 * D, D), std=D ** -0.5), rnd("wt", (3 * D, D), std=D ** -0.5)
+    hip_lib.gemm(xi, wi, None, y[:, Lt:])
+    hip_lib.gemm(xt, wt, None, y[:, :Lt])
+    bf16_ulp_close(y[:, Lt:].float().cpu(), _gemm_ref(xi, wi, None).float().bfloat16().float(), abs_=3e-3)
+    bf16_ulp_close(y[:, :Lt].float().cpu(), _gemm_ref(xt, wt, None).float().bfloat16().float(), abs_=3e-3)
+
+
+# ----------------------------------------------------------------------------- QK norm + RoPE
+@pytest.mark.parametrize("hd,axes", [(64, [16, 24, 24]), (72, [8, 32, 32]), (128, [16, 56, 56])])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_qknorm_rope(hip_lib, hd, axes, mode):
+    B, Lt, Li, H = 2, 9, 70, 3
+    L, D = Lt + Li, H * hd
+    y = rnd("qkv", (B, L, 3 * D), std=1.5)
+    y0 = y.clone()
+    scales = [rnd(f"s{i}", (hd,), std=0.2).float().add(1.0).to(BF) for i in range(4)]
+    ids = torch.zeros(B, L, 3)
+    g = torch.stack(torch.meshgrid(torch.arange(2), torch.arange(5), torch.arange(7), indexing="ij"), -1).reshape(-1, 3).float()
+    ids[:, Lt:] = g[None]
+    ang = (O.rope_angles_liger if mode == 1 else O.rope_angles)(ids, axes, 10000)
+    cos = torch.empty(B, L, hd // 2, dtype=torch.float32, device=DEV)
+    sin = torch.empty_like(cos)
+    hip_lib.rope_table(ids.view(B * L, 3).to(DEV), axes, 10000, mode == 1, cos, sin)
+    assert (cos.cpu() - torch.cos(ang).float()).abs().max() < 2e-5
+    assert (sin.cpu() - torch.sin(ang).float()).abs().max() < 2e-5
+    q, k = y[:, :, :D], y[:, :, D: 2 * D]
+    hip_lib.qknorm_rope(q, k, scales[0], scales[1], scales[2], scales[3], Lt, cos, sin, cos.stride(0), H, hd, mode)
+    rope = O.apply_rope_half if mode == 1 else O.apply_rope_interleaved
+    for which, (st, sm) in enumerate([(scales[0], scales[2]), (scales[1], scales[3])]):
+        x0 = y0[:, :, which * D: (which + 1) * D].cpu().view(B, L, H, hd).permute(0, 2, 1, 3)
+        n_t = O.rms_norm(x0[:, :, :Lt], st.cpu())
+        n_i = O.rms_norm(x0[:, :, Lt:], sm.cpu())
+        ref = rope(torch.cat([n_t, n_i], 2), ang)  # bf16 tensors -> reference rounding points
+        got = y[:, :, which * D: (which + 1) * D].cpu().view(B, L, H, hd).permute(0, 2, 1, 3)
+        bf16_ulp_close(got.float(), ref.float(), rel=2 ** -7, abs_=2e-3)
+    assert torch.equal(y[:, :, 2 * D:], y0[:, :, 2 * D:])  # v untouched
+
+
+# ----------------------------------------------------------------------------- V transpose (bit exact)
+@pytest.mark.parametrize("hd", [64, 72, 128])
+def test_v_transpose_exact(hip_lib, hd):
+    B, L, H = 2, 150, 2
+    D = H * hd
+    y = rnd("v", (B, L, 3 * D))
+    v = y[:, :, 2 * D:]
+    Lp = (L + 63) // 64 * 64
+    vt = torch.full((B, H, hd, Lp), 7.0, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    pos2key = (torch.arange(Lp) // 16 * 16) + perm[torch.arange(Lp) % 16]
+    vpad = torch.zeros(B, Lp, H, hd, dtype=BF)
+    vpad[:, :L] = v.cpu().view(B, L, H, hd)
+    ref = vpad[:, pos2key].permute(0, 2, 3, 1)
+    assert torch.equal(vt.cpu(), ref)
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_case(hip_lib, B, H, hd, Lq, Lk, seed=3, spike=False):
+    D = H * hd
+    q = rnd("q", (B, Lq, D), seed=seed)
+    kv = rnd("kv", (B, Lk, 2 * D), seed=seed + 1)
+    if spike:  # force a large running-max jump late in the key sequence (online-softmax rescale path)
+        kv[:, Lk - 3, :D] = q[:, 0, :] * 4.0
+    k, v = kv[:, :, :D], kv[:, :, D:]
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.empty(B, H, hd, Lp, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+    out = torch.empty(B, Lq, D, dtype=BF, device=DEV)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=DEV)
+    hip_lib.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5, lse=lse)
+
+    def heads(t, L):
+        return t.float().cpu().view(B, L, H, hd).permute(0, 2, 1, 3)
+
+    qh, kh, vh = heads(q, Lq), heads(k, Lk), heads(v, Lk)
+    s = (qh.double() @ kh.double().transpose(-1, -2)) * hd ** -0.5
+    ref = (torch.softmax(s, -1) @ vh.double()).permute(0, 2, 1, 3).reshape(B, Lq, D)
+    ref_lse = torch.logsumexp(s, -1)
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    # P is rounded to bf16 inside the kernel (as flash-attn does): abs error ~ 2^-8 * |v| scale
+    assert err <= 2.5e-2, f"attention max err {err}"
+    rel = ((out.float().cpu().double() - ref).norm() / ref.norm()).item()
+    assert rel <= 6e-3, f"attention relL2 {rel}"
+    assert (lse.cpu().double() - ref_lse).abs().max().item() <= 2e-3
+    return out
+
+
+@pytest.mark.parametrize("hd", [64, 72, 128])
+@pytest.mark.parametrize("Lq,Lk", [(256, 256), (300, 1000), (64, 65), (33, 700)])
+def test_attention_vs_oracle(hip_lib, hd, Lq, Lk):
+    _attn_case(hip_lib, 2, 2, hd, Lq, Lk)
+
+
+@pytest.mark.parametrize("hd", [72, 128])
+def test_attention_rescale_branch(hip_lib, hd):
+    _attn_case(hip_lib, 1, 2, hd, 128, 900, spike=True)
+
+
+def test_attention_in_place_v_slot_and_segments(hip_lib):
+    """(1) output may overwrite the dead v slot of the projection buffer; (2) keys split in 2 segments
+    (sequence-parallel all-gather layout) give the same result as one segment."""
+    B, H, hd, L = 1, 2, 128, 384
+    D = H * hd
+    y = rnd("y", (B, L, 3 * D))
+    q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D:]
+    vt = torch.empty(B, H, hd, L, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+    ref = torch.empty(B, L, D, dtype=BF, device=DEV)
+    hip_lib.attention_fwd(q, k, vt, ref, H, hd, hd ** -0.5)
+    # two segments of 192 keys: K segments contiguous copies, VT per segment (192 -> padded 192)
+    seg = 192
+    kseg = torch.stack([k[:, :seg].contiguous(), k[:, seg:].contiguous()])          # [2, B, seg, D]
+    vts = torch.empty(2, B, H, hd, seg, dtype=BF, device=DEV)
+    for s in range(2):
+        hip_lib.v_transpose(v[:, s * seg: (s + 1) * seg], vts[s], H, hd)
+    out2 = torch.empty(B, L, D, dtype=BF, device=DEV)
+    hip_lib.attention_fwd(q, kseg[0], vts, out2, H, hd, hd ** -0.5, n_seg=2, seg_len=seg,
+                          k_seg_stride=kseg.stride(0), vt_seg_stride=vts.stride(0))
+    assert (out2.float() - ref.float()).abs().max().item() <= 8e-3
+    hip_lib.attention_fwd(q, k, vt, v, H, hd, hd ** -0.5)  # in place into the v slot
+    assert torch.equal(v, ref)
+
+
+def test_attention_constant_v_property(hip_lib):
+    """softmax rows sum to one: V == c per channel  =>  out == c exactly (up to bf16), at a large shape."""
+    B, H, hd, L = 1, 4, 72, 4096 + 37
+    D = H * hd
+    q, k = rnd("q", (B, L, D)), rnd("k", (B, L, D))
+    c = rnd("c", (D,))
+    v = c[None, None].expand(B, L, D).contiguous()
+    Lp = (L + 63) // 64 * 64
+    vt = torch.empty(B, H, hd, Lp, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+    out = torch.empty(B, L, D, dtype=BF, device=DEV)
+    hip_lib.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5)
+    assert (out.float() - c.float()[None, None]).abs().max().item() <= 2 ** -6 * c.float().abs().max().item() + 1e-3
+
+
+# ----------------------------------------------------------------------------- small kernels
+def test_gemv_tasks_and_timestep_embedding(hip_lib):
+    Bv, K = 3, 384
+    x = rnd("vec", (Bv, K), dtype=torch.float32)
+    layers, col = [], 0
+    refs = []
+    for i, n in enumerate([6 * K, 3 * K, 100]):
+        w = rnd(f"w{i}", (n, K), std=K ** -0.5)
+        b = rnd(f"b{i}", (n,), std=0.1) if i != 1 else None
+        layers.append((w, b, col))
+        r = torch.nn.functional.silu(x.cpu().double()) @ w.cpu().double().T
+        if b is not None:
+            r = r + b.cpu().double()
+        refs.append(r)
+        col += n
+    tasks = hip_lib.GemvTasks(layers, DEV)
+    out = torch.zeros(Bv, col, dtype=torch.float32, device=DEV)
+    hip_lib.gemv_tasks(x, tasks, out, act_in=1)
+    ref = torch.cat(refs, 1)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-4
+    hip_lib.gemv_tasks(x, tasks, out, act_in=1, accumulate=True)
+    assert (out.cpu().double() - 2 * ref).abs().max().item() <= 2e-4
+    t = torch.tensor([0.69921875, 0.0, 1.0], dtype=torch.float32, device=DEV)
+    emb = torch.empty(3, 256, dtype=torch.float32, device=DEV)
+    hip_lib.timestep_embedding(t, emb)
+    ref_e = O.timestep_embedding(t.cpu(), 256)
+    assert (emb.cpu() - ref_e).abs().max().item() <= 2e-4  # f32 trig of arguments up to 1e3
+
+
+def test_cfg_euler(hip_lib):
+    n = 8 * 1000
+    pred = rnd("p", (3, n))
+    x = rnd("x", (n,))
+    xo = torch.empty_like(x)
+    hip_lib.cfg_euler(pred, x, xo, 7.5, 3.0, -0.0321)
+    c, u, u2 = pred.float().cpu()
+    ref = x.float().cpu() + (-0.0321) * (u2 + 3.0 * (u - u2) + 7.5 * (c - u))
+    bf16_ulp_close(xo.float().cpu(), ref.bfloat16().float(), abs_=1e-3)
+
+
+def test_errors_raise(hip_lib):
+    a = torch.zeros(1, 8, 100, dtype=BF, device=DEV)
+    w = torch.zeros(16, 100, dtype=BF, device=DEV)
+    out = torch.zeros(1, 8, 16, dtype=BF, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip_lib.gemm(a, w, None, out)  # K % 64 != 0

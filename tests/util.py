@@ -1,0 +1,42 @@
+"""Shared helpers for the parity tests (tolerance policy of SURVEY.md §8(d))."""
+import numpy as np
+import torch
+
+from oracle import synth
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def max_abs(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a.double() - b.double()).abs().max())
+
+
+def assert_parity(ours: torch.Tensor, truth_fp32: torch.Tensor, ref_bf16: torch.Tensor, what: str,
+                  rel_factor: float = 1.5, floor: float = 2.0 ** -8, abs_factor: float = 4.0):
+    """ours (HIP path, bf16) vs truth (oracle fp32) judged against the reference-precision comparator
+    (oracle run with bf16 tensors):  e_ours <= max(1.5 e_ref, 2^-8)  and  max|err| <= 4 max|err_ref|."""
+    ours, truth_fp32, ref_bf16 = ours.float().cpu(), truth_fp32.float().cpu(), ref_bf16.float().cpu()
+    assert torch.isfinite(ours).all(), f"{what}: non-finite output"
+    e_ours, e_ref = rel_l2(ours, truth_fp32), rel_l2(ref_bf16, truth_fp32)
+    a_ours, a_ref = max_abs(ours, truth_fp32), max_abs(ref_bf16, truth_fp32)
+    msg = f"{what}: relL2 ours {e_ours:.3e} ref-bf16 {e_ref:.3e}; max-abs ours {a_ours:.3e} ref-bf16 {a_ref:.3e}"
+    print(msg)
+    assert e_ours <= max(rel_factor * e_ref, floor), msg
+    assert a_ours <= max(abs_factor * a_ref, floor * float(truth_fp32.abs().max())), msg
+
+
+def torch_params(cfg, seed=0, dtype=torch.float32, device="cpu"):
+    p = synth.make_params(synth.mmdit_param_shapes(cfg), seed)
+    return {k: torch.from_numpy(v).to(device=device, dtype=dtype) for k, v in p.items()}
+
+
+def torch_inputs(cfg, B, T, h, w, L_txt, dtype=torch.float32, device="cpu"):
+    d = synth.mmdit_inputs(cfg, B, T, h, w, L_txt)
+    out = {}
+    for k, v in d.items():
+        t = torch.from_numpy(v).to(device)
+        out[k] = t if k in ("img_ids", "txt_ids") else t.to(dtype)
+    return out
