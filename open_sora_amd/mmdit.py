@@ -28,6 +28,22 @@ from torch import Tensor, nn
 
 from . import _C
 
+# Kernel table used by the orchestration below.  The product binds it to the HIP library (_C) at import —
+# there is no other implementation in this package.  tests/ may swap in a CPU emulation of the kernels'
+# semantics (tests/cpu_ops.py) to exercise the host-side orchestration and the multi-process sequence-parallel
+# path under gloo without a GPU; that emulation is checker infrastructure and never ships.
+_OPS = _C
+
+
+def set_ops_for_testing(ops) -> None:
+    global _OPS
+    _OPS = ops
+    _WS_CACHE.clear()
+
+
+def ops():
+    return _OPS
+
 BF16 = torch.bfloat16
 
 
@@ -373,7 +389,7 @@ class HipEmbedND(nn.Module):
         half = sum(self.axes_dim) // 2
         cos = torch.empty(B, L, half, dtype=torch.float32, device=ids.device)
         sin = torch.empty_like(cos)
-        _C.rope_table(idf, self.axes_dim, self.theta, self.liger, cos, sin)
+        _OPS.rope_table(idf, self.axes_dim, self.theta, self.liger, cos, sin)
         return _RopeTable(cos, sin, 1 if self.liger else 0)
 
 
@@ -398,27 +414,27 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
     (t_sh1, t_sc1, t_g1, t_sh2, t_sc2, t_g2), _ = _mod_views(mod, col_txt, 6, D)
     r_img, r_txt = x_img, x_txt
 
-    _C.ln_modulate(r_img, i_sh1, i_sc1, xm_img, mbs)
-    _C.ln_modulate(r_txt, t_sh1, t_sc1, xm_txt, mbs)
-    _C.gemm(xm_img, plan.img.qkv_w, plan.img.qkv_b, y[:, Lt:])
-    _C.gemm(xm_txt, plan.txt.qkv_w, plan.txt.qkv_b, y[:, :Lt])
+    _OPS.ln_modulate(r_img, i_sh1, i_sc1, xm_img, mbs)
+    _OPS.ln_modulate(r_txt, t_sh1, t_sc1, xm_txt, mbs)
+    _OPS.gemm(xm_img, plan.img.qkv_w, plan.img.qkv_b, y[:, Lt:])
+    _OPS.gemm(xm_txt, plan.txt.qkv_w, plan.txt.qkv_b, y[:, :Lt])
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D:]
-    _C.qknorm_rope(q, k, plan.txt.q_scale, plan.txt.k_scale, plan.img.q_scale, plan.img.k_scale, Lt,
+    _OPS.qknorm_rope(q, k, plan.txt.q_scale, plan.txt.k_scale, plan.img.q_scale, plan.img.k_scale, Lt,
                    rope.cos, rope.sin, rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0, H, hd, rope.mode)
-    _C.v_transpose(v, ws.vt, H, hd)
-    _C.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)  # output overwrites the (dead) v slot
+    _OPS.v_transpose(v, ws.vt, H, hd)
+    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)  # output overwrites the (dead) v slot
     # img stream
-    _C.gemm(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=r_img, gate=i_g1, gate_batch_stride=mbs)
-    _C.ln_modulate(x_img, i_sh2, i_sc2, xm_img, mbs)
+    _OPS.gemm(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=r_img, gate=i_g1, gate_batch_stride=mbs)
+    _OPS.ln_modulate(x_img, i_sh2, i_sc2, xm_img, mbs)
     w0, b0, w2, b2 = plan.img_mlp
-    _C.gemm(xm_img, w0, b0, ws.h[:, Lt:], gelu_from=0)
-    _C.gemm(ws.h[:, Lt:], w2, b2, x_img, res=x_img, gate=i_g2, gate_batch_stride=mbs)
+    _OPS.gemm(xm_img, w0, b0, ws.h[:, Lt:], gelu_from=0)
+    _OPS.gemm(ws.h[:, Lt:], w2, b2, x_img, res=x_img, gate=i_g2, gate_batch_stride=mbs)
     # txt stream
-    _C.gemm(v[:, :Lt], plan.txt.proj_w, plan.txt.proj_b, x_txt, res=r_txt, gate=t_g1, gate_batch_stride=mbs)
-    _C.ln_modulate(x_txt, t_sh2, t_sc2, xm_txt, mbs)
+    _OPS.gemm(v[:, :Lt], plan.txt.proj_w, plan.txt.proj_b, x_txt, res=r_txt, gate=t_g1, gate_batch_stride=mbs)
+    _OPS.ln_modulate(x_txt, t_sh2, t_sc2, xm_txt, mbs)
     w0, b0, w2, b2 = plan.txt_mlp
-    _C.gemm(xm_txt, w0, b0, ws.h[:, :Lt], gelu_from=0)
-    _C.gemm(ws.h[:, :Lt], w2, b2, x_txt, res=x_txt, gate=t_g2, gate_batch_stride=mbs)
+    _OPS.gemm(xm_txt, w0, b0, ws.h[:, :Lt], gelu_from=0)
+    _OPS.gemm(ws.h[:, :Lt], w2, b2, x_txt, res=x_txt, gate=t_g2, gate_batch_stride=mbs)
 
 
 def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, rope: _RopeTable, H: int, hd: int,
@@ -429,14 +445,14 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
     y = ws.y_single(D, R)
     (shift, scale, gate), mbs = _mod_views(mod, col, 3, D)
     r = ws.x
-    _C.ln_modulate(r, shift, scale, ws.xm, mbs)
-    _C.gemm(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
+    _OPS.ln_modulate(r, shift, scale, ws.xm, mbs)
+    _OPS.gemm(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D: 3 * D]
-    _C.qknorm_rope(q, k, plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale, 0, rope.cos, rope.sin,
+    _OPS.qknorm_rope(q, k, plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale, 0, rope.cos, rope.sin,
                    rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0, H, hd, rope.mode)
-    _C.v_transpose(v, ws.vt, H, hd)
-    _C.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)
-    _C.gemm(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=r, gate=gate, gate_batch_stride=mbs)
+    _OPS.v_transpose(v, ws.vt, H, hd)
+    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)
+    _OPS.gemm(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=r, gate=gate, gate_batch_stride=mbs)
 
 
 def _run_modulation(vec32: Tensor, layers, D: int) -> Tensor:
@@ -446,9 +462,9 @@ def _run_modulation(vec32: Tensor, layers, D: int) -> Tensor:
         task_layers.append((w, b, col))
         cols.append(col)
         col += w.shape[0]
-    tasks = _C.GemvTasks(task_layers, vec32.device)
+    tasks = _OPS.GemvTasks(task_layers, vec32.device)
     mod = torch.empty(vec32.shape[0], col, dtype=torch.float32, device=vec32.device)
-    _C.gemv_tasks(vec32, tasks, mod, act_in=1)
+    _OPS.gemv_tasks(vec32, tasks, mod, act_in=1)
     return mod, cols
 
 
@@ -507,6 +523,10 @@ class MMDiTModel(nn.Module):
         pe_dim = config.hidden_size // config.num_heads
         if sum(config.axes_dim) != pe_dim:
             raise ValueError(f"Got {config.axes_dim} but expected positional dim {pe_dim}")
+        if config.hidden_size % 64 != 0 or pe_dim not in (64, 72, 128):
+            raise ValueError(
+                f"gfx950 kernels need hidden_size % 64 == 0 and head_dim in (64, 72, 128); got {config.hidden_size}, {pe_dim}"
+            )
         self.hidden_size = config.hidden_size
         self.num_heads = config.num_heads
         self.pe_embedder = HipEmbedND(pe_dim, config.theta, config.axes_dim, liger=config.use_liger_rope)
@@ -575,11 +595,11 @@ class MMDiTModel(nn.Module):
         p["col_final"] = col
         col += fl.weight.shape[0]
         p["mod_cols"] = col
-        p["mod_tasks"] = _C.GemvTasks(layers, device)
+        p["mod_tasks"] = _OPS.GemvTasks(layers, device)
 
         def emb(m):
-            return (_C.GemvTasks([(_w(m.in_layer.weight), _w(m.in_layer.bias), 0)], device),
-                    _C.GemvTasks([(_w(m.out_layer.weight), _w(m.out_layer.bias), 0)], device))
+            return (_OPS.GemvTasks([(_w(m.in_layer.weight), _w(m.in_layer.bias), 0)], device),
+                    _OPS.GemvTasks([(_w(m.out_layer.weight), _w(m.out_layer.bias), 0)], device))
 
         p["time_in"] = emb(self.time_in)
         p["vector_in"] = emb(self.vector_in)
@@ -614,7 +634,7 @@ class MMDiTModel(nn.Module):
         a_in[:, :, :C_in].copy_(img)
         if cfg.cond_embed:
             a_in[:, :, C_in: C_in + cond.shape[2]].copy_(cond)
-        _C.gemm(a_in, p["in_w"], p["in_b"], ws.x[:, Lt:])
+        _OPS.gemm(a_in, p["in_w"], p["in_b"], ws.x[:, Lt:])
         # --- txt_in
         Kt = p["txt_w"].shape[1]
         if Kt == txt.shape[2] and txt.dtype == BF16 and txt.stride(2) == 1:
@@ -624,20 +644,22 @@ class MMDiTModel(nn.Module):
             if a_txt is None or a_txt.shape[2] != Kt:
                 a_txt = ws.a_txt = torch.zeros(B, Lt, Kt, dtype=BF16, device=dev)
             a_txt[:, :, : txt.shape[2]].copy_(txt)
-        _C.gemm(a_txt, p["txt_w"], p["txt_b"], ws.x[:, :Lt])
+        _OPS.gemm(a_txt, p["txt_w"], p["txt_b"], ws.x[:, :Lt])
         # --- vec = time_in(temb(t)) [+ guidance_in(temb(g))] + vector_in(y)   (f32 throughout)
         temb = torch.empty(B, 256, dtype=torch.float32, device=dev)
         hbuf = torch.empty(B, D, dtype=torch.float32, device=dev)
         vec = torch.empty(B, D, dtype=torch.float32, device=dev)
-        _C.timestep_embedding(timesteps.float().contiguous(), temb)
-        _C.gemv_tasks(temb, p["time_in"][0], hbuf)
-        _C.gemv_tasks(hbuf, p["time_in"][1], vec, act_in=1)
+        # `t = time_factor * t` happens in the caller's dtype in the reference (layers.py:78): with the sampler's
+        # bf16 t_vec, 1000*t is rounded to bf16 BEFORE the f32 sinusoid.  Keep that rounding point (B scalars).
+        _OPS.timestep_embedding((1000.0 * timesteps).float().contiguous(), temb, time_factor=1.0)
+        _OPS.gemv_tasks(temb, p["time_in"][0], hbuf)
+        _OPS.gemv_tasks(hbuf, p["time_in"][1], vec, act_in=1)
         if cfg.guidance_embed:
-            _C.timestep_embedding(guidance.float().contiguous(), temb)
-            _C.gemv_tasks(temb, p["guidance_in"][0], hbuf)
-            _C.gemv_tasks(hbuf, p["guidance_in"][1], vec, act_in=1, accumulate=True)
-        _C.gemv_tasks(y_vec.float().contiguous(), p["vector_in"][0], hbuf)
-        _C.gemv_tasks(hbuf, p["vector_in"][1], vec, act_in=1, accumulate=True)
+            _OPS.timestep_embedding((1000.0 * guidance).float().contiguous(), temb, time_factor=1.0)
+            _OPS.gemv_tasks(temb, p["guidance_in"][0], hbuf)
+            _OPS.gemv_tasks(hbuf, p["guidance_in"][1], vec, act_in=1, accumulate=True)
+        _OPS.gemv_tasks(y_vec.float().contiguous(), p["vector_in"][0], hbuf)
+        _OPS.gemv_tasks(hbuf, p["vector_in"][1], vec, act_in=1, accumulate=True)
         # --- RoPE tables for the joint sequence
         ids = torch.cat((txt_ids, img_ids), dim=1)
         rope = self.pe_embedder(ids)
@@ -653,7 +675,7 @@ class MMDiTModel(nn.Module):
         R = int(D * self.config.mlp_ratio)
         B = img.shape[0]
         mod = torch.empty(B, p["mod_cols"], dtype=torch.float32, device=img.device)
-        _C.gemv_tasks(vec, p["mod_tasks"], mod, act_in=1)
+        _OPS.gemv_tasks(vec, p["mod_tasks"], mod, act_in=1)
         for plan, (ci, ct) in zip(p["double"], p["col_double"]):
             run_double_block(plan, ws, mod, ci, ct, rope, H, hd)
         for plan, c in zip(p["single"], p["col_single"]):
@@ -662,9 +684,9 @@ class MMDiTModel(nn.Module):
         Lt = ws.L_txt
         cf = p["col_final"]
         shift, scale = mod[:, cf: cf + D], mod[:, cf + D: cf + 2 * D]
-        _C.ln_modulate(ws.x[:, Lt:], shift, scale, ws.xm[:, Lt:], mod.stride(0))
+        _OPS.ln_modulate(ws.x[:, Lt:], shift, scale, ws.xm[:, Lt:], mod.stride(0))
         out = torch.empty(B, ws.L_img, p["final_w"].shape[0], dtype=BF16, device=img.device)
-        _C.gemm(ws.xm[:, Lt:], p["final_w"], p["final_b"], out)
+        _OPS.gemm(ws.xm[:, Lt:], p["final_w"], p["final_b"], out)
         return out.to(img.dtype) if img.dtype != BF16 else out
 
 

@@ -10,8 +10,9 @@ GOLDEN = {
     # name: (cfg, B, T, h, w, L_txt)
     "hd64_eager_fused": (dict(_TINY, hidden_size=128, num_heads=2, axes_dim=[16, 24, 24], fused_qkv=True, use_liger_rope=False), 2, 2, 5, 7, 40),
     "hd64_liger_split": (dict(_TINY, hidden_size=128, num_heads=2, axes_dim=[16, 24, 24], fused_qkv=False, use_liger_rope=True, guidance_embed=True), 1, 3, 4, 6, 24),
-    "hd72_eager_split": (dict(_TINY, hidden_size=144, num_heads=2, axes_dim=[8, 32, 32], fused_qkv=False, use_liger_rope=False), 2, 2, 6, 6, 32),
-    "hd72_liger_fused": (dict(_TINY, hidden_size=216, num_heads=3, axes_dim=[8, 32, 32], fused_qkv=True, use_liger_rope=True, qkv_bias=False), 1, 2, 7, 9, 16),
+    # hd 72 needs hidden % 64 == 0 for the MFMA GEMM K tiling -> 8 heads (hidden 576), fewer blocks
+    "hd72_eager_split": (dict(_TINY, hidden_size=576, num_heads=8, axes_dim=[8, 32, 32], fused_qkv=False, use_liger_rope=False, depth=1, depth_single_blocks=2), 2, 2, 6, 6, 32),
+    "hd72_liger_fused": (dict(_TINY, hidden_size=576, num_heads=8, axes_dim=[8, 32, 32], fused_qkv=True, use_liger_rope=True, qkv_bias=False, depth=1, depth_single_blocks=2), 1, 2, 7, 9, 16),
     "hd128_liger_split": (dict(_TINY, hidden_size=256, num_heads=2, axes_dim=[16, 56, 56], fused_qkv=False, use_liger_rope=True), 3, 2, 4, 5, 24),
     "hd128_eager_fused": (dict(_TINY, hidden_size=256, num_heads=2, axes_dim=[16, 56, 56], fused_qkv=True, use_liger_rope=False, cond_embed=False), 1, 1, 9, 11, 8),
 }

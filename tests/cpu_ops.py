@@ -1,0 +1,139 @@
+"""TEST INFRASTRUCTURE ONLY — a CPU emulation of the *semantics* of every kernel in include/osk.h, with the same
+Python call signatures as open_sora_amd/_C.py.  It lets the not-gpu suite run the host-side orchestration
+(open_sora_amd/mmdit.py, seqpar.py, sampling.py: buffer views, column offsets, token sharding, collectives under
+gloo) against the goldens without a GPU.  It is never imported by the product path and is not a fallback:
+open_sora_amd binds its kernel table to the HIP library at import.
+
+Math is fp32 on the bf16-stored operands, outputs rounded once (what the HIP kernels do)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from oracle import mmdit_oracle as O
+
+BF = torch.bfloat16
+PROFILE_ATTENTION = None
+_PERM = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+
+
+def _mod_rows(t: torch.Tensor, batch_stride: int, B: int, D: int) -> torch.Tensor:
+    """f32 view whose row b starts batch_stride elements after row b-1 (pointer-carrier convention of _C)."""
+    if B == 1:
+        return t.reshape(-1)[:D][None]
+    assert t.stride(0) == batch_stride or t.shape[0] == 1
+    return t[:, :D]
+
+
+def ln_modulate(x, shift, scale, out, mod_batch_stride, eps=1e-6):
+    B, L, D = x.shape
+    y = F.layer_norm(x.float(), (D,), eps=eps)
+    out.copy_(((1 + _mod_rows(scale, mod_batch_stride, B, D)[:, None]) * y + _mod_rows(shift, mod_batch_stride, B, D)[:, None]).to(out.dtype))
+    return out
+
+
+def gemm(a, w, bias, out, *, res=None, gate=None, gate_batch_stride=0, gelu_from=None):
+    B, L, K = a.shape
+    N = w.shape[0]
+    assert K % 64 == 0, "osk_gemm_bf16 requires K % 64 == 0"
+    v = a.float() @ w.float().T
+    if bias is not None:
+        v = v + bias.float()
+    if gelu_from is not None and gelu_from < N:
+        v = torch.cat([v[..., :gelu_from], F.gelu(v[..., gelu_from:], approximate="tanh")], -1)
+    if gate is not None:
+        v = res.float() + _mod_rows(gate, gate_batch_stride, B, N)[:, None] * v
+    out.copy_(v.to(out.dtype))
+    return out
+
+
+class GemvTasks:
+    def __init__(self, layers, device):
+        self.layers = layers
+
+
+def gemv_tasks(x, tasks, out, act_in=0, accumulate=False):
+    xx = F.silu(x.float()) if act_in == 1 else x.float()
+    for w, b, col in tasks.layers:
+        r = xx @ w.float().T
+        if b is not None:
+            r = r + b.float()
+        sl = out[:, col: col + w.shape[0]]
+        sl.copy_(sl + r if accumulate else r)
+    return out
+
+
+def timestep_embedding(t, out, max_period=10000.0, time_factor=1000.0):
+    out.copy_(O.timestep_embedding(t.float(), out.shape[1], max_period, time_factor))
+    return out
+
+
+def rope_table(ids, axes_dim, theta, f32_angles, cos, sin):
+    ang = (O.rope_angles_liger if f32_angles else O.rope_angles)(ids[None], axes_dim, theta)[0]
+    cos.view(-1, cos.shape[-1]).copy_(torch.cos(ang).float())
+    sin.view(-1, sin.shape[-1]).copy_(torch.sin(ang).float())
+
+
+def qknorm_rope(q, k, qs0, ks0, qs1, ks1, l_split, cos, sin, cs_batch_stride, H, hd, rope_mode, eps=1e-6):
+    B, L, _ = q.shape
+    c = cos if cs_batch_stride else cos[:1]
+    s = sin if cs_batch_stride else sin[:1]
+    for t, (s0, s1) in ((q, (qs0, qs1)), (k, (ks0, ks1))):
+        x = t.reshape(B, L, H, hd)
+        y = torch.cat([O.rms_norm(x[:, :l_split], s0), O.rms_norm(x[:, l_split:], s1)], 1)  # bf16 rounding points
+        yf = y.float()
+        cc, ss = c[:, :, None, :], s[:, :, None, :]
+        if rope_mode == 0:
+            p = yf.reshape(B, L, H, hd // 2, 2)
+            o = torch.stack([cc * p[..., 0] - ss * p[..., 1], ss * p[..., 0] + cc * p[..., 1]], -1).reshape(B, L, H, hd)
+        else:
+            x1, x2 = yf[..., : hd // 2], yf[..., hd // 2:]
+            o = torch.cat([x1 * cc - x2 * ss, x2 * cc + x1 * ss], -1)
+        t.copy_(o.reshape(B, L, H * hd).to(t.dtype))
+
+
+def v_transpose(v, vt, H, hd):
+    B, L, _ = v.shape
+    Lp = vt.shape[-1]
+    pad = torch.zeros(B, Lp, H, hd, dtype=v.dtype)
+    pad[:, :L] = v.reshape(B, L, H, hd)
+    pos2key = (torch.arange(Lp) // 16 * 16) + _PERM[torch.arange(Lp) % 16]
+    vt.copy_(pad[:, pos2key].permute(0, 2, 3, 1))
+
+
+def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=None, k_seg_stride=0, vt_seg_stride=0):
+    B, Lq, D = q.shape
+    if seg_len is None:
+        seg_len = k.shape[1]
+    seg_lp = (seg_len + 63) // 64 * 64
+    # rebuild the key-major K and V from the segment layout
+    ks, vs = [], []
+    key2pos = torch.empty(seg_lp, dtype=torch.long)
+    key2pos[(torch.arange(seg_lp) // 16 * 16) + _PERM[torch.arange(seg_lp) % 16]] = torch.arange(seg_lp)
+    for s in range(n_seg):
+        if n_seg == 1:
+            k_s, vt_s = k, vt
+        else:
+            k_s = torch.as_strided(k, (B, seg_len, D), k.stride(), k.storage_offset() + s * k_seg_stride)
+            vt_s = torch.as_strided(vt, (B, H, hd, seg_lp), (H * hd * seg_lp, hd * seg_lp, seg_lp, 1),
+                                    vt.storage_offset() + s * vt_seg_stride)
+        ks.append(k_s.float().reshape(B, seg_len, H, hd))
+        vs.append(vt_s.float().reshape(B, H, hd, seg_lp)[..., key2pos][..., :seg_len].permute(0, 3, 1, 2))
+    K = torch.cat(ks, 1).permute(0, 2, 1, 3)
+    V = torch.cat(vs, 1).permute(0, 2, 1, 3)
+    Q = q.float().reshape(B, Lq, H, hd).permute(0, 2, 1, 3)
+    s_ = (Q @ K.transpose(-1, -2)) * scale
+    o = torch.softmax(s_, -1) @ V
+    res = o.permute(0, 2, 1, 3).reshape(B, Lq, D).to(out.dtype)
+    out.copy_(res)
+    if lse is not None:
+        lse.copy_(torch.logsumexp(s_, -1))
+    return out
+
+
+def cfg_euler(pred, x, x_out, g_txt, g_img, dt, g_img_vec=None):
+    c, u, u2 = pred.float().reshape(3, -1)
+    gi = g_img if g_img_vec is None else g_img_vec.reshape(-1)
+    v = u2 + gi * (u - u2) + g_txt * (c - u)
+    x_out.copy_((x.float().reshape(-1) + dt * v).reshape(x.shape).to(x_out.dtype))
+    return x_out

@@ -1,0 +1,145 @@
+"""CPU: the host-side orchestration of open_sora_amd.mmdit (joint [txt;img] buffers, in-place v-slot reuse,
+batched adaLN columns, K padding of the embedders, processor plug-ins) driven through a CPU emulation of the
+kernels' semantics (tests/cpu_ops.py) and compared with the goldens made by the REAL reference.  This is host
+logic only — the kernels themselves are checked on the GPU by tests/test_gpu_*.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import configs, mmdit_oracle as O
+from tests import cpu_ops
+from tests.util import assert_parity, torch_inputs, torch_params
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BF = torch.bfloat16
+
+
+@pytest.fixture()
+def cpu_mmdit(hip_lib):
+    from open_sora_amd import mmdit
+
+    mmdit.set_ops_for_testing(cpu_ops)
+    yield mmdit
+    mmdit.set_ops_for_testing(hip_lib)
+
+
+def _build(mmdit, cfg):
+    model = mmdit.Flux(device_map="cpu", torch_dtype=BF, **cfg)
+    model.load_state_dict(torch_params(cfg, dtype=BF), strict=True)
+    return model
+
+
+@pytest.mark.parametrize("name", list(configs.GOLDEN))
+def test_engine_orchestration_vs_golden(cpu_mmdit, name):
+    cfg, B, T, h, w, L_txt = configs.GOLDEN[name]
+    truth = torch.from_numpy(np.load(os.path.join(GOLDEN_DIR, f"mmdit_{name}.npz"))["out"])
+    model = _build(cpu_mmdit, cfg)
+    inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF)
+    with torch.inference_mode():
+        out = model(**inp)
+        ref_bf16 = O.forward(torch_params(cfg, dtype=BF), cfg, **inp)
+    assert_parity(out, truth, ref_bf16, f"host orchestration [{name}]")
+
+
+def test_processors_on_reference_style_pe(cpu_mmdit):
+    cfg, B, T, h, w, L_txt = configs.GOLDEN["hd64_eager_fused"]
+    model = _build(cpu_mmdit, cfg)
+    sd32 = torch_params(cfg)
+    inp32 = torch_inputs(cfg, B, T, h, w, L_txt)
+    with torch.inference_mode():
+        img, txt, vec, ang = O.prepare_block_inputs(sd32, cfg, **inp32)
+        c, s = torch.cos(ang), torch.sin(ang)
+        pe = torch.stack([c, -s, s, c], dim=-1).reshape(*ang.shape, 2, 2).float().unsqueeze(1)
+        t_img, t_txt = O.double_block(sd32, cfg, 0, img, txt, vec, ang, "interleaved")
+        sdb = {k: v.bfloat16() for k, v in sd32.items()}
+        r_img, r_txt = O.double_block(sdb, cfg, 0, img.bfloat16(), txt.bfloat16(), vec.bfloat16(), ang, "interleaved")
+        o_img, o_txt = model.double_blocks[0](img.bfloat16(), txt.bfloat16(), vec.bfloat16(), pe)
+        assert_parity(o_img, t_img, r_img, "double processor img")
+        assert_parity(o_txt, t_txt, r_txt, "double processor txt")
+        x = torch.cat((t_txt, t_img), 1)
+        t_x = O.single_block(sd32, cfg, 0, x, vec, ang, "interleaved")
+        r_x = O.single_block(sdb, cfg, 0, x.bfloat16(), vec.bfloat16(), ang, "interleaved")
+        o_x = model.single_blocks[0](x.bfloat16(), vec.bfloat16(), pe)
+        assert_parity(o_x, t_x, r_x, "single processor")
+
+
+def test_processors_install_on_reference_blocks(cpu_mmdit):
+    """The plug-in point of the reference itself: block.set_processor(...) on the reference's own
+    DoubleStreamBlock / SingleStreamBlock (only where /root/reference is mounted)."""
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("/root/reference not mounted")
+    cfg, B, T, h, w, L_txt = configs.GOLDEN["hd64_liger_split"]
+    M, layers, _ = ref_loader.mmdit()
+    ref = M.Flux(device_map="cpu", torch_dtype=torch.float32, **cfg)
+    ref.load_state_dict(torch_params(cfg), strict=True)
+    inp = torch_inputs(cfg, B, T, h, w, L_txt)
+    with torch.inference_mode():
+        truth = ref(**inp)
+        refb = ref.to(BF)
+        inpb = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF)
+        ref_bf16 = refb(**inpb)
+        for blk in refb.double_blocks:
+            blk.set_processor(cpu_mmdit.HipDoubleStreamBlockProcessor())
+        for blk in refb.single_blocks:
+            blk.set_processor(cpu_mmdit.HipSingleStreamBlockProcessor())
+        out = refb(**inpb)
+    assert_parity(out, truth, ref_bf16, "reference model with our processors installed")
+
+
+def test_sampler_loop_matches_reference_formula(cpu_mmdit):
+    """I2VDenoiser.denoise against a direct transcription of sampling.py:181-222 around a stub model."""
+    from open_sora_amd import sampling
+
+    torch.manual_seed(0)
+    n, T, Hh, Ww = 1, 2, 4, 6
+    z = torch.randn(n, 16, T, Hh, Ww).to(BF)
+    img = sampling.pack(z).repeat(3, 1, 1)
+    masks = torch.zeros(n, 1, T, Hh, Ww, dtype=BF)
+    masks[:, :, 0] = 1
+    masked_ref = (torch.randn(n, 16, T, Hh, Ww) * masks).to(BF)
+    ts = sampling.get_schedule(4, (Hh // 2) * (Ww // 2), T)
+    W = torch.randn(64 + 68, 64) * 0.02
+
+    def model(img, cond, timesteps, guidance, **kw):
+        return (torch.cat([img.float(), cond.float()], -1) @ W * (1 + timesteps.float()[:, None, None])).to(BF)
+
+    out = sampling.I2VDenoiser().denoise(model, img=img, timesteps=ts, guidance=7.5, guidance_img=3.0, masks=masks,
+                                         masked_ref=masked_ref, sigma_min=1e-5, text_osci=True, image_osci=True,
+                                         scale_temporal_osci=True)
+    # transcription of the reference loop in fp32
+    x = img[:n].float()
+    cond = sampling.pack(torch.cat((masks, masked_ref), 1)).float()
+    cond3 = torch.cat([cond, cond, torch.zeros_like(cond)])
+    for i, (tc, tp) in enumerate(zip(ts[:-1], ts[1:])):
+        tv = torch.full((3 * n,), tc, dtype=BF)
+        pred = model(x.to(BF).repeat(3, 1, 1), cond3.to(BF), tv, None).float()
+        tg = sampling.get_oscillation_gs(7.5, i)
+        ig = sampling.get_oscillation_gs(3.0, i)
+        c, u, u2 = pred.chunk(3)
+        if ig > 1.0:
+            upper = torch.linspace(ig, 1.0, len(ts))[i]
+            ramp = torch.linspace(1.0, float(upper), T)[None, None, :, None, None].repeat(n, 16, 1, Hh, Ww)
+            ig = sampling.pack(ramp)
+        x = (x + (tp - tc) * (u2 + ig * (u - u2) + tg * (c - u))).to(BF).float()
+    assert (out.float() - x).abs().max().item() <= 2e-2 * max(1.0, x.abs().max().item())
+
+
+def test_pack_unpack_roundtrip_and_schedule(cpu_mmdit):
+    from open_sora_amd import sampling
+
+    z = torch.arange(2 * 16 * 3 * 8 * 12, dtype=torch.float32).reshape(2, 16, 3, 8, 12)
+    p = sampling.pack(z)
+    assert p.shape == (2, 3 * 4 * 6, 64)
+    assert torch.equal(sampling.unpack(p, 8 * 8, 12 * 8, 3), z)
+    # channel order (c ph pw), token order (t h w)  — sampling.py:375-378
+    assert p[0, 0, 0] == z[0, 0, 0, 0, 0] and p[0, 0, 1] == z[0, 0, 0, 0, 1] and p[0, 0, 2] == z[0, 0, 0, 1, 0]
+    assert p[0, 1, 0] == z[0, 0, 0, 0, 2] and p[0, 0, 4] == z[0, 1, 0, 0, 0]
+    ts = sampling.get_schedule(30, 1024, 16)
+    assert len(ts) == 31 and ts[0] == 1.0 and ts[-1] == 0.0 and all(a > b for a, b in zip(ts[:-1], ts[1:]))
+    alpha = (1 + 2 / 3840 * (1024 - 256)) * 4.0  # sampling.py:295-332
+    t1 = 1 - 1 / 30
+    assert abs(ts[1] - alpha * t1 / (1 + (alpha - 1) * t1)) < 1e-6

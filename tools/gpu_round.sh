@@ -14,7 +14,7 @@ echo "== smoke"; timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1
 echo "== microbench"; timeout 300 python tools/microbench.py ${MICRO_ARGS:-} > $O/microbench.jsonl 2> $O/microbench.err; cat $O/microbench.jsonl
 echo "== microbench gemm variant 1"; OSK_GEMM_VARIANT=1 timeout 200 python tools/microbench.py --quick --gemm-only > $O/microbench_v1.jsonl 2>> $O/microbench.err; grep gemm $O/microbench_v1.jsonl | head -8
 echo "== bench"; timeout 600 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 > $O/bench.json 2> $O/bench.err; cat $O/bench.json; tail -3 $O/bench.err
-echo "== rocprof"; rm -rf $O/prof; timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/rocprof_bench.json 2> $O/rocprof.err; tail -2 $O/rocprof.err
+echo "== rocprof"; rm -rf $O/prof; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/rocprof_bench.json 2> $O/rocprof.err; tail -2 $O/rocprof.err
 find $O/prof -name "*stats*" | head; 
 fi
 echo "== done"
