@@ -21,6 +21,7 @@
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 4 * B * H * Lq * Lk * hd (QK^T + PV, not halved).
 #include "osk_common.h"
 #include "../../include/osk.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -58,7 +59,7 @@ struct AttnParams {
 };
 
 template <int HD>
-__global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(512) attn_fwd_kernel_v1(const AttnParams p) {
   using C = Cfg<HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -270,20 +271,330 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
   }
 }
 
-template <int HD>
-int launch(const AttnParams& p, hipStream_t st) {
+
+#undef STAGE_ISSUE
+#undef STAGE_COMMIT
+
+// =====================================================================================================
+// v2: software-pipelined.  In iteration t a wave issues the QK^T MFMAs of tile t+1 BEFORE the softmax of
+// tile t, so the softmax VALU work (max / exp2 / pack) of one tile runs in the shadow of the next tile's
+// matrix work instead of both waves of a SIMD alternating "all-MFMA" and "all-VALU" phases in lockstep
+// behind the per-tile barrier (v1: MFMA pipe idle during every softmax).  K is therefore staged two tiles
+// ahead, V^T one tile ahead; still one barrier per tile, same LDS footprint.
+// Row max is exchanged with v_permlane32_swap (VALU) instead of ds_bpermute.  For head_dim 72 the row sum
+// comes out of the PV MFMA for free: padding row 72 of the V^T tile is set to 1.0, so accumulator row 72
+// of O^T is sum_k P[q][k] (of the bf16-rounded P, i.e. consistent with the numerator).
+// =====================================================================================================
+template <int HD, int HINTS>
+__global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
   using C = Cfg<HD>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<HD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+  constexpr bool ONES_ROW = (HD % 32) != 0;  // a free padding row exists -> row sum from the MFMA
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int nbh = p.B * p.H;
+  const int bh = blockIdx.x % nbh, qb = blockIdx.x / nbh;
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  for (int i = tid; i < C::SMEM / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  if constexpr (ONES_ROW) {
+    __syncthreads();
+    // V^T row HD (first padding row) = 1.0 in both buffers
+    if (tid < 64) {
+      const unsigned one2 = 0x3F803F80u;
+      reinterpret_cast<unsigned*>(smem + C::KTILE + HD * C::VROW)[tid & 31] = one2;
+      reinterpret_cast<unsigned*>(smem + C::BUF + C::KTILE + HD * C::VROW)[tid & 31] = one2;
+    }
+  }
+
+  const int qi = qb * 256 + wave * 32 + l31;
+  const int qc = qi < p.Lq ? qi : p.Lq - 1;
+  const unsigned short* qrow = p.q + b * p.qbs + (int64_t)qc * p.qrs + h * HD;
+  bf16x8_t qf[C::NKS];
+#pragma unroll
+  for (int ks = 0; ks < C::NKS; ++ks) {
+    const int e0 = ks * 16 + hi * 8;
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (e0 < HD) u = *reinterpret_cast<const uint4*>(qrow + e0);
+    qf[ks] = __builtin_bit_cast(bf16x8_t, u);
+  }
+
+  // staging slots (<= 2 chunks of K and of V^T per thread)
+  static_assert(C::KIT <= 2 && C::VIT <= 2, "staging assumes <= 1024 chunks per tile");
+  const int kr0 = tid / C::CPR, kc0 = tid - kr0 * C::CPR;
+  const int kr1 = (tid + 512) / C::CPR, kc1 = (tid + 512) - kr1 * C::CPR;
+  const int vd0 = tid >> 3, vc0 = tid & 7, vd1 = (tid + 512) >> 3;
+  constexpr bool K1_FULL = C::NKC >= 1024, V1_FULL = C::NVC >= 1024;
+  const bool k1_on = C::KIT > 1 && (K1_FULL || (tid + 512 < C::NKC));
+  const bool v1_on = C::VIT > 1 && (V1_FULL || (tid + 512 < C::NVC));
+  const unsigned short* kbase_b = p.k + b * p.kbs + h * HD;
+  const unsigned short* vbase_bh = p.vt + (int64_t)bh * HD * p.seg_lp;
+  uint4 rk0 = make_uint4(0, 0, 0, 0), rk1 = rk0, rv0 = rk0, rv1 = rk0;
+
+#define K_ISSUE(T)                                                                                  \
+  {                                                                                                 \
+    const int s_ = (T) / p.tps, tt_ = (T) - s_ * p.tps;                                             \
+    const int key0_ = tt_ * 64, last_ = p.seg_len - 1;                                              \
+    const unsigned short* kb_ = kbase_b + s_ * p.kss;                                               \
+    int ka_ = key0_ + kr0;                                                                          \
+    ka_ = ka_ < last_ ? ka_ : last_;                                                                \
+    rk0 = *reinterpret_cast<const uint4*>(kb_ + (int64_t)ka_ * p.krs + kc0 * 8);                    \
+    if (k1_on) {                                                                                    \
+      int kb2_ = key0_ + kr1;                                                                       \
+      kb2_ = kb2_ < last_ ? kb2_ : last_;                                                           \
+      rk1 = *reinterpret_cast<const uint4*>(kb_ + (int64_t)kb2_ * p.krs + kc1 * 8);                 \
+    }                                                                                               \
+  }
+#define V_ISSUE(T)                                                                                  \
+  {                                                                                                 \
+    const int s_ = (T) / p.tps, tt_ = (T) - s_ * p.tps;                                             \
+    const unsigned short* vb_ = vbase_bh + s_ * p.vtss + tt_ * 64;                                  \
+    rv0 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)vd0 * p.seg_lp + vc0 * 8);                 \
+    if (v1_on) rv1 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)vd1 * p.seg_lp + vc0 * 8);      \
+  }
+#define K_COMMIT(BUFI)                                                                              \
+  {                                                                                                 \
+    unsigned char* kb_ = smem + (BUFI) * C::BUF;                                                    \
+    *reinterpret_cast<uint4*>(kb_ + kr0 * C::KROW + kc0 * 16) = rk0;                                \
+    if (k1_on) *reinterpret_cast<uint4*>(kb_ + kr1 * C::KROW + kc1 * 16) = rk1;                     \
+  }
+#define V_COMMIT(BUFI)                                                                              \
+  {                                                                                                 \
+    unsigned char* vb_ = smem + (BUFI) * C::BUF + C::KTILE;                                         \
+    *reinterpret_cast<uint4*>(vb_ + vd0 * C::VROW + vc0 * 16) = rv0;                                \
+    if (v1_on) *reinterpret_cast<uint4*>(vb_ + vd1 * C::VROW + vc0 * 16) = rv1;                     \
+  }
+#define QK_TILE(SDST, BUFI)                                                                         \
+  {                                                                                                 \
+    const unsigned char* kb_ = smem + (BUFI) * C::BUF;                                              \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) { SDST[0][r] = 0.f; SDST[1][r] = 0.f; }          \
+    _Pragma("unroll") for (int ks = 0; ks < C::NKS; ++ks) {                                         \
+      _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                                            \
+        const bf16x8_t kf_ = *reinterpret_cast<const bf16x8_t*>(kb_ + (t2 * 32 + l31) * C::KROW +   \
+                                                                (ks * 2 + hi) * 16);                \
+        SDST[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_, qf[ks], SDST[t2], 0, 0, 0);         \
+      }                                                                                             \
+    }                                                                                               \
+  }
+
+  f32x16_t o[C::NDT];
+#pragma unroll
+  for (int d = 0; d < C::NDT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int nt = p.n_seg * p.tps;
+
+  __syncthreads();  // LDS init done
+  K_ISSUE(0);
+  V_ISSUE(0);
+  K_COMMIT(0);
+  V_COMMIT(0);
+  if (nt > 1) {
+    K_ISSUE(1);
+    K_COMMIT(1);
+  }
+  __syncthreads();
+
+  f32x16_t sc_[2], sn_[2];  // scores of the current / next tile
+  QK_TILE(sc_, 0);
+
+#define MASK_TILE(S, T)                                                                             \
+  {                                                                                                 \
+    const int sidx_ = (T) / p.tps, tt_ = (T) - sidx_ * p.tps;                                       \
+    const int valid_ = p.seg_len - tt_ * 64;                                                        \
+    if (valid_ < 64) {                                                                              \
+      _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) _Pragma("unroll") for (int r = 0; r < 16; ++r) { \
+        const int kl_ = t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                  \
+        if (kl_ >= valid_) S[t2][r] = -INFINITY;                                                    \
+      }                                                                                             \
+    }                                                                                               \
+  }
+  // row max of a score tile (own 32 values, then the other half-wave through v_permlane32_swap), the new running
+  // max, the rescale factor of the accumulators and whether any lane of the wave needs the rescale
+#define ROW_MAX(S)                                                                                  \
+  {                                                                                                 \
+    float mt_ = S[0][0];                                                                            \
+    _Pragma("unroll") for (int r = 1; r < 16; ++r) mt_ = fmaxf(mt_, S[0][r]);                       \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) mt_ = fmaxf(mt_, S[1][r]);                       \
+    const unsigned mu_ = __float_as_uint(mt_);                                                      \
+    auto sw_ = __builtin_amdgcn_permlane32_swap(mu_, mu_, false, false);                            \
+    mt_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                  \
+    m_new = fmaxf(m_run, mt_);                                                                      \
+    alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);                                         \
+    resc = !__all(m_new == m_run);                                                                  \
+  }
+
+  float m_new, alpha;
+  int resc;
+  MASK_TILE(sc_, 0);
+  ROW_MAX(sc_);
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    const bool has1 = t + 1 < nt, has2 = t + 2 < nt;
+    if (has2) K_ISSUE(t + 2);
+    if (has1) V_ISSUE(t + 1);
+    // ---- block 1: (rare) rescale of the accumulators for the new running max of tile t
+    if (resc) {
+#pragma unroll
+      for (int d = 0; d < C::NDT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+    if constexpr (!ONES_ROW) l_run *= alpha;
+    m_run = m_new;
+    // ---- block 2: next tile's QK^T (MFMA)  ||  exp2 + pack of this tile (VALU).  QK is unconditional: on the last
+    //      tile it multiplies stale-but-finite LDS data and the result is dropped; one basic block for the scheduler.
+    QK_TILE(sn_, cur ^ 1);
+    const float msc = m_run * p.sc;
+    float rs = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sc_[t2][r] * p.sc - msc);
+        sc_[t2][r] = e;
+        if constexpr (!ONES_ROW) rs += e;
+      }
+    if constexpr (!ONES_ROW) l_run += rs;
+    bf16x8_t pb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int t2 = g >> 1, r0 = (g & 1) * 8;
+      uint4 u;
+      u.x = pack_bf16x2(sc_[t2][r0 + 0], sc_[t2][r0 + 1]);
+      u.y = pack_bf16x2(sc_[t2][r0 + 2], sc_[t2][r0 + 3]);
+      u.z = pack_bf16x2(sc_[t2][r0 + 4], sc_[t2][r0 + 5]);
+      u.w = pack_bf16x2(sc_[t2][r0 + 6], sc_[t2][r0 + 7]);
+      pb[g] = __builtin_bit_cast(bf16x8_t, u);
+    }
+    if constexpr (HINTS >= 1) {
+      constexpr int NM = 2 * C::NKS;
+      constexpr int NV = ONES_ROW ? 80 : 112;  // fma + exp + cvt_pk (+ row-sum adds)
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 ds_read (K fragment)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, (NV + NM - 1) / NM, 0);  // a slice of the softmax VALU
+      }
+    }
+    {
+      // anchor: all 16 packed P words must exist HERE (before the mask branch), otherwise hipcc sinks the exp2 /
+      // pack work below the branch into block 3 and block 2 degenerates to bare MFMAs
+      const uint4 a0 = __builtin_bit_cast(uint4, pb[0]), a1 = __builtin_bit_cast(uint4, pb[1]);
+      const uint4 a2 = __builtin_bit_cast(uint4, pb[2]), a3 = __builtin_bit_cast(uint4, pb[3]);
+      asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w),
+                   "v"(a2.x), "v"(a2.y), "v"(a2.z), "v"(a2.w), "v"(a3.x), "v"(a3.y), "v"(a3.z), "v"(a3.w));
+    }
+    // ---- ragged tail of the NEXT tile, then block 3: O^T += V^T . P^T (MFMA)  ||  row max of the next tile (VALU)
+    if (has1) MASK_TILE(sn_, t + 1);
+    {
+      const unsigned char* vb = smem + cur * C::BUF + C::KTILE;
+#pragma unroll
+      for (int d = 0; d < C::NDT; ++d) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + (d * 32 + l31) * C::VROW + (g * 2 + hi) * 16);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[g], o[d], 0, 0, 0);
+        }
+      }
+    }
+    ROW_MAX(sn_);
+    if constexpr (HINTS >= 1) {
+      constexpr int NM = 4 * C::NDT;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x002, (40 + NM - 1) / NM, 1);
+      }
+    }
+    if (has2) K_COMMIT(cur);        // K_{t+2} -> the buffer K_t lived in (last read in iteration t-1)
+    if (has1) V_COMMIT(cur ^ 1);    // V_{t+1}
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc_[0][r] = sn_[0][r]; sc_[1][r] = sn_[1][r]; }
+  }
+#undef MASK_TILE
+#undef ROW_MAX
+
+  // ---- epilogue
+  if constexpr (ONES_ROW) {
+    // row HD of O^T = sum_k P: lives in lanes hi == 0, register (HD % 32) -> index of d = HD
+    constexpr int dloc = HD % 32;                 // 8 for hd 72
+    constexpr int rr = (dloc & 3) + 4 * (dloc >> 3);  // d_local = (r&3) + 8*(r>>2) + 4*hi, hi = 0
+    static_assert(((dloc >> 2) & 1) == 0, "ones row must sit in the hi == 0 half");
+    l_run = o[HD / 32][rr];
+    const unsigned lu = __float_as_uint(l_run);
+    auto sw = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
+    l_run = __uint_as_float(sw[0]);  // lanes 0-31 keep their own, lanes 32-63 receive lanes 0-31
+  }
+  float l_tot = l_run;
+  if constexpr (!ONES_ROW) {
+    const unsigned lu = __float_as_uint(l_run);
+    auto sw = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
+    l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  const float inv = 1.0f / l_tot;
+  if (qi < p.Lq) {
+    unsigned short* orow = p.out + b * p.obs + (int64_t)qi * p.ors + h * HD;
+#pragma unroll
+    for (int d = 0; d < C::NDT; ++d) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int d0 = d * 32 + qd * 8 + hi * 4;
+        if (d0 < HD) {
+          uint2 u;
+          u.x = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
+          u.y = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+          *reinterpret_cast<uint2*>(orow + d0) = u;
+        }
+      }
+    }
+    if (p.lse && hi == 0)
+      p.lse[(int64_t)bh * p.Lq + qi] = (m_run * p.sc + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+}
+#undef K_ISSUE
+#undef V_ISSUE
+#undef K_COMMIT
+#undef V_COMMIT
+#undef QK_TILE
+
+int attn_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OSK_ATTN_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <typename KernelT>
+int launch_kernel(KernelT kernel, int smem, const AttnParams& p, hipStream_t st, bool* attr_set) {
+  if (!*attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    *attr_set = true;
   }
   const int nqb = (p.Lq + 255) / 256;
   dim3 grid(nqb * p.B * p.H), block(512);
-  hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, block, C::SMEM, st, p);
+  hipLaunchKernelGGL(kernel, grid, block, smem, st, p);
   return (int)hipGetLastError();
+}
+
+template <int HD>
+int launch(const AttnParams& p, hipStream_t st) {
+  using C = Cfg<HD>;
+  static bool set0 = false, set1 = false, set9 = false;
+  switch (attn_variant()) {
+    case 9: return launch_kernel(attn_fwd_kernel_v1<HD>, C::SMEM, p, st, &set9);
+    case 1: return launch_kernel(attn_fwd_kernel<HD, 1>, C::SMEM, p, st, &set1);
+    default: return launch_kernel(attn_fwd_kernel<HD, 0>, C::SMEM, p, st, &set0);
+  }
 }
 
 }  // namespace

@@ -75,10 +75,11 @@ def bench_elementwise(B, L, D, H, hd):
 def main():
     quick = "--quick" in sys.argv
     gemm_only = "--gemm-only" in sys.argv
+    attn_only = "--attn-only" in sys.argv
     torch.manual_seed(0)
     L, D, B = 16896, 1152, 3
     M = B * L
-    for (N, K, tag) in [(3 * D, D, "xl.qkv"), (4 * D, D, "xl.mlp_up"), (D, 4 * D, "xl.mlp_down"), (D, D, "xl.proj"),
+    for (N, K, tag) in [] if attn_only else [(3 * D, D, "xl.qkv"), (4 * D, D, "xl.mlp_up"), (D, 4 * D, "xl.mlp_down"), (D, D, "xl.proj"),
                         (7 * D, D, "xl.linear1"), (D, 5 * D, "xl.linear2")]:
         bench_gemm(M, N, K, tag)
     if not quick:
@@ -89,10 +90,10 @@ def main():
         return
     bench_attn(3, 16, L, 72, "xl.cfg2.b3")
     bench_attn(1, 16, L, 72, "xl.cfg2.b1")
-    if not quick:
-        bench_attn(1, 24, 8828, 128, "11b.256px.b1")
-        bench_attn(1, 18, L, 64, "hd64")
-    bench_elementwise(B, L, D, 16, 72)
+    bench_attn(1, 24, 8828, 128, "11b.256px.b1")
+    bench_attn(1, 18, L, 64, "hd64")
+    if not attn_only:
+        bench_elementwise(B, L, D, 16, 72)
 
 
 if __name__ == "__main__":
