@@ -300,8 +300,7 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
   for (int i = tid; i < C::SMEM / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
   if constexpr (ONES_ROW) {
     __syncthreads();
-    // V^T row HD (first padding row) = 1.0 in both buffers
-    if (tid < 64) {
+    if (tid < 64) {  // V^T row HD (first padding row) = 1.0 in both buffers
       const unsigned one2 = 0x3F803F80u;
       reinterpret_cast<unsigned*>(smem + C::KTILE + HD * C::VROW)[tid & 31] = one2;
       reinterpret_cast<unsigned*>(smem + C::BUF + C::KTILE + HD * C::VROW)[tid & 31] = one2;
@@ -320,7 +319,7 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
     qf[ks] = __builtin_bit_cast(bf16x8_t, u);
   }
 
-  // staging slots (<= 2 chunks of K and of V^T per thread)
+  // ---- staging: <= 2 16-B chunks of K and of V^T per thread; running pointers, no per-tile index math
   static_assert(C::KIT <= 2 && C::VIT <= 2, "staging assumes <= 1024 chunks per tile");
   const int kr0 = tid / C::CPR, kc0 = tid - kr0 * C::CPR;
   const int kr1 = (tid + 512) / C::CPR, kc1 = (tid + 512) - kr1 * C::CPR;
@@ -328,42 +327,63 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
   constexpr bool K1_FULL = C::NKC >= 1024, V1_FULL = C::NVC >= 1024;
   const bool k1_on = C::KIT > 1 && (K1_FULL || (tid + 512 < C::NKC));
   const bool v1_on = C::VIT > 1 && (V1_FULL || (tid + 512 < C::NVC));
-  const unsigned short* kbase_b = p.k + b * p.kbs + h * HD;
-  const unsigned short* vbase_bh = p.vt + (int64_t)bh * HD * p.seg_lp;
+  const unsigned short* kseg = p.k + b * p.kbs + h * HD;           // segment base of the K loader
+  const unsigned short* kp0 = kseg + (int64_t)kr0 * p.krs + kc0 * 8;  // this thread's chunk in the loader's tile
+  const unsigned short* kp1 = kseg + (int64_t)kr1 * p.krs + kc1 * 8;
+  const unsigned short* vp0 = p.vt + ((int64_t)bh * HD + vd0) * p.seg_lp + vc0 * 8;
+  const unsigned short* vp1 = p.vt + ((int64_t)bh * HD + vd1) * p.seg_lp + vc0 * 8;
+  const int64_t k_tile_step = (int64_t)64 * p.krs;
+  const int64_t k_seg_jump = p.kss - (int64_t)p.tps * 64 * p.krs;  // from past-the-last tile of a segment to the next
+  const int64_t v_seg_jump = p.vtss - (int64_t)p.tps * 64;
+  const int last_valid = p.seg_len - (p.tps - 1) * 64;              // keys in the last tile of a segment (1..64)
+  int ktt = 0, vtt = 0;                                             // tile-in-segment counters of the two loaders
   uint4 rk0 = make_uint4(0, 0, 0, 0), rk1 = rk0, rv0 = rk0, rv1 = rk0;
+  const int kbyte0 = kr0 * C::KROW + kc0 * 16, kbyte1 = kr1 * C::KROW + kc1 * 16;
+  const int vbyte0 = vd0 * C::VROW + vc0 * 16, vbyte1 = vd1 * C::VROW + vc0 * 16;
 
-#define K_ISSUE(T)                                                                                  \
+  // load the K loader's current tile into registers and advance it (ragged last tile: clamp rows to the segment)
+#define K_ISSUE()                                                                                   \
   {                                                                                                 \
-    const int s_ = (T) / p.tps, tt_ = (T) - s_ * p.tps;                                             \
-    const int key0_ = tt_ * 64, last_ = p.seg_len - 1;                                              \
-    const unsigned short* kb_ = kbase_b + s_ * p.kss;                                               \
-    int ka_ = key0_ + kr0;                                                                          \
-    ka_ = ka_ < last_ ? ka_ : last_;                                                                \
-    rk0 = *reinterpret_cast<const uint4*>(kb_ + (int64_t)ka_ * p.krs + kc0 * 8);                    \
-    if (k1_on) {                                                                                    \
-      int kb2_ = key0_ + kr1;                                                                       \
-      kb2_ = kb2_ < last_ ? kb2_ : last_;                                                           \
-      rk1 = *reinterpret_cast<const uint4*>(kb_ + (int64_t)kb2_ * p.krs + kc1 * 8);                 \
+    if (ktt == p.tps - 1 && last_valid < 64) {                                                      \
+      const int64_t c0_ = kr0 < last_valid ? 0 : (int64_t)(last_valid - 1 - kr0) * p.krs;           \
+      const int64_t c1_ = kr1 < last_valid ? 0 : (int64_t)(last_valid - 1 - kr1) * p.krs;           \
+      rk0 = *reinterpret_cast<const uint4*>(kp0 + c0_);                                             \
+      if (k1_on) rk1 = *reinterpret_cast<const uint4*>(kp1 + c1_);                                  \
+    } else {                                                                                        \
+      rk0 = *reinterpret_cast<const uint4*>(kp0);                                                   \
+      if (k1_on) rk1 = *reinterpret_cast<const uint4*>(kp1);                                        \
+    }                                                                                               \
+    kp0 += k_tile_step;                                                                             \
+    kp1 += k_tile_step;                                                                             \
+    if (++ktt == p.tps) {                                                                           \
+      ktt = 0;                                                                                      \
+      kp0 += k_seg_jump;                                                                            \
+      kp1 += k_seg_jump;                                                                            \
     }                                                                                               \
   }
-#define V_ISSUE(T)                                                                                  \
+#define V_ISSUE()                                                                                   \
   {                                                                                                 \
-    const int s_ = (T) / p.tps, tt_ = (T) - s_ * p.tps;                                             \
-    const unsigned short* vb_ = vbase_bh + s_ * p.vtss + tt_ * 64;                                  \
-    rv0 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)vd0 * p.seg_lp + vc0 * 8);                 \
-    if (v1_on) rv1 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)vd1 * p.seg_lp + vc0 * 8);      \
+    rv0 = *reinterpret_cast<const uint4*>(vp0);                                                     \
+    if (v1_on) rv1 = *reinterpret_cast<const uint4*>(vp1);                                          \
+    vp0 += 64;                                                                                      \
+    vp1 += 64;                                                                                      \
+    if (++vtt == p.tps) {                                                                           \
+      vtt = 0;                                                                                      \
+      vp0 += v_seg_jump;                                                                            \
+      vp1 += v_seg_jump;                                                                            \
+    }                                                                                               \
   }
 #define K_COMMIT(BUFI)                                                                              \
   {                                                                                                 \
     unsigned char* kb_ = smem + (BUFI) * C::BUF;                                                    \
-    *reinterpret_cast<uint4*>(kb_ + kr0 * C::KROW + kc0 * 16) = rk0;                                \
-    if (k1_on) *reinterpret_cast<uint4*>(kb_ + kr1 * C::KROW + kc1 * 16) = rk1;                     \
+    *reinterpret_cast<uint4*>(kb_ + kbyte0) = rk0;                                                  \
+    if (k1_on) *reinterpret_cast<uint4*>(kb_ + kbyte1) = rk1;                                       \
   }
 #define V_COMMIT(BUFI)                                                                              \
   {                                                                                                 \
     unsigned char* vb_ = smem + (BUFI) * C::BUF + C::KTILE;                                         \
-    *reinterpret_cast<uint4*>(vb_ + vd0 * C::VROW + vc0 * 16) = rv0;                                \
-    if (v1_on) *reinterpret_cast<uint4*>(vb_ + vd1 * C::VROW + vc0 * 16) = rv1;                     \
+    *reinterpret_cast<uint4*>(vb_ + vbyte0) = rv0;                                                  \
+    if (v1_on) *reinterpret_cast<uint4*>(vb_ + vbyte1) = rv1;                                       \
   }
 #define QK_TILE(SDST, BUFI)                                                                         \
   {                                                                                                 \
@@ -377,6 +397,32 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
       }                                                                                             \
     }                                                                                               \
   }
+  // scores of keys >= VALID inside a ragged last tile -> -inf
+#define MASK_TILE(S, VALID)                                                                         \
+  {                                                                                                 \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) _Pragma("unroll") for (int r = 0; r < 16; ++r) { \
+      const int kl_ = t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                    \
+      if (kl_ >= (VALID)) S[t2][r] = -INFINITY;                                                     \
+    }                                                                                               \
+  }
+  // row max of a score tile (32 own values as max3 chains, then the other half-wave through v_permlane32_swap),
+  // the new running max, the accumulator rescale factor and whether any lane of the wave needs the rescale
+#define ROW_MAX(S)                                                                                  \
+  {                                                                                                 \
+    float m0_ = fmaxf(fmaxf(S[0][0], S[0][1]), S[0][2]);                                            \
+    float m1_ = fmaxf(fmaxf(S[1][0], S[1][1]), S[1][2]);                                            \
+    _Pragma("unroll") for (int r = 3; r < 15; r += 2) {                                             \
+      m0_ = fmaxf(fmaxf(m0_, S[0][r]), S[0][r + 1]);                                                \
+      m1_ = fmaxf(fmaxf(m1_, S[1][r]), S[1][r + 1]);                                                \
+    }                                                                                               \
+    float mt_ = fmaxf(fmaxf(m0_, m1_), fmaxf(S[0][15], S[1][15]));                                  \
+    const unsigned mu_ = __float_as_uint(mt_);                                                      \
+    auto sw_ = __builtin_amdgcn_permlane32_swap(mu_, mu_, false, false);                            \
+    mt_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                  \
+    m_new = fmaxf(m_run, mt_);                                                                      \
+    alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);                                         \
+    resc = !__all(m_new == m_run);                                                                  \
+  }
 
   f32x16_t o[C::NDT];
 #pragma unroll
@@ -387,136 +433,176 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
   const int nt = p.n_seg * p.tps;
 
   __syncthreads();  // LDS init done
-  K_ISSUE(0);
-  V_ISSUE(0);
+  K_ISSUE();
+  V_ISSUE();
   K_COMMIT(0);
   V_COMMIT(0);
   if (nt > 1) {
-    K_ISSUE(1);
+    K_ISSUE();
     K_COMMIT(1);
   }
   __syncthreads();
 
-  f32x16_t sc_[2], sn_[2];  // scores of the current / next tile
-  QK_TILE(sc_, 0);
-
-#define MASK_TILE(S, T)                                                                             \
-  {                                                                                                 \
-    const int sidx_ = (T) / p.tps, tt_ = (T) - sidx_ * p.tps;                                       \
-    const int valid_ = p.seg_len - tt_ * 64;                                                        \
-    if (valid_ < 64) {                                                                              \
-      _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) _Pragma("unroll") for (int r = 0; r < 16; ++r) { \
-        const int kl_ = t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                  \
-        if (kl_ >= valid_) S[t2][r] = -INFINITY;                                                    \
-      }                                                                                             \
-    }                                                                                               \
-  }
-  // row max of a score tile (own 32 values, then the other half-wave through v_permlane32_swap), the new running
-  // max, the rescale factor of the accumulators and whether any lane of the wave needs the rescale
-#define ROW_MAX(S)                                                                                  \
-  {                                                                                                 \
-    float mt_ = S[0][0];                                                                            \
-    _Pragma("unroll") for (int r = 1; r < 16; ++r) mt_ = fmaxf(mt_, S[0][r]);                       \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) mt_ = fmaxf(mt_, S[1][r]);                       \
-    const unsigned mu_ = __float_as_uint(mt_);                                                      \
-    auto sw_ = __builtin_amdgcn_permlane32_swap(mu_, mu_, false, false);                            \
-    mt_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                  \
-    m_new = fmaxf(m_run, mt_);                                                                      \
-    alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);                                         \
-    resc = !__all(m_new == m_run);                                                                  \
-  }
-
+  f32x16_t sa_[2], sb_[2];  // score tiles: roles (current / next) alternate every iteration, no copies
   float m_new, alpha;
   int resc;
-  MASK_TILE(sc_, 0);
-  ROW_MAX(sc_);
+  int ctt = 0;              // tile-in-segment counter of the tile whose scores are "current"
+  QK_TILE(sa_, 0);
+  if (p.tps == 1 && last_valid < 64) MASK_TILE(sa_, last_valid);
+  ROW_MAX(sa_);
 
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    const bool has1 = t + 1 < nt, has2 = t + 2 < nt;
-    if (has2) K_ISSUE(t + 2);
-    if (has1) V_ISSUE(t + 1);
-    // ---- block 1: (rare) rescale of the accumulators for the new running max of tile t
-    if (resc) {
-#pragma unroll
-      for (int d = 0; d < C::NDT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-    }
-    if constexpr (!ONES_ROW) l_run *= alpha;
-    m_run = m_new;
-    // ---- block 2: next tile's QK^T (MFMA)  ||  exp2 + pack of this tile (VALU).  QK is unconditional: on the last
-    //      tile it multiplies stale-but-finite LDS data and the result is dropped; one basic block for the scheduler.
-    QK_TILE(sn_, cur ^ 1);
-    const float msc = m_run * p.sc;
-    float rs = 0.f;
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sc_[t2][r] * p.sc - msc);
-        sc_[t2][r] = e;
-        if constexpr (!ONES_ROW) rs += e;
-      }
-    if constexpr (!ONES_ROW) l_run += rs;
-    bf16x8_t pb[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int t2 = g >> 1, r0 = (g & 1) * 8;
-      uint4 u;
-      u.x = pack_bf16x2(sc_[t2][r0 + 0], sc_[t2][r0 + 1]);
-      u.y = pack_bf16x2(sc_[t2][r0 + 2], sc_[t2][r0 + 3]);
-      u.z = pack_bf16x2(sc_[t2][r0 + 4], sc_[t2][r0 + 5]);
-      u.w = pack_bf16x2(sc_[t2][r0 + 6], sc_[t2][r0 + 7]);
-      pb[g] = __builtin_bit_cast(bf16x8_t, u);
-    }
-    if constexpr (HINTS >= 1) {
-      constexpr int NM = 2 * C::NKS;
-      constexpr int NV = ONES_ROW ? 80 : 112;  // fma + exp + cvt_pk (+ row-sum adds)
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 ds_read (K fragment)
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, (NV + NM - 1) / NM, 0);  // a slice of the softmax VALU
-      }
-    }
-    {
-      // anchor: all 16 packed P words must exist HERE (before the mask branch), otherwise hipcc sinks the exp2 /
-      // pack work below the branch into block 3 and block 2 degenerates to bare MFMAs
-      const uint4 a0 = __builtin_bit_cast(uint4, pb[0]), a1 = __builtin_bit_cast(uint4, pb[1]);
-      const uint4 a2 = __builtin_bit_cast(uint4, pb[2]), a3 = __builtin_bit_cast(uint4, pb[3]);
-      asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w),
-                   "v"(a2.x), "v"(a2.y), "v"(a2.z), "v"(a2.w), "v"(a3.x), "v"(a3.y), "v"(a3.z), "v"(a3.w));
-    }
-    // ---- ragged tail of the NEXT tile, then block 3: O^T += V^T . P^T (MFMA)  ||  row max of the next tile (VALU)
-    if (has1) MASK_TILE(sn_, t + 1);
-    {
-      const unsigned char* vb = smem + cur * C::BUF + C::KTILE;
-#pragma unroll
-      for (int d = 0; d < C::NDT; ++d) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + (d * 32 + l31) * C::VROW + (g * 2 + hi) * 16);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[g], o[d], 0, 0, 0);
-        }
-      }
-    }
-    ROW_MAX(sn_);
-    if constexpr (HINTS >= 1) {
-      constexpr int NM = 4 * C::NDT;
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x002, (40 + NM - 1) / NM, 1);
-      }
-    }
-    if (has2) K_COMMIT(cur);        // K_{t+2} -> the buffer K_t lived in (last read in iteration t-1)
-    if (has1) V_COMMIT(cur ^ 1);    // V_{t+1}
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sc_[0][r] = sn_[0][r]; sc_[1][r] = sn_[1][r]; }
+  // one iteration: SC = scores of tile t (masked, max known), SN receives tile t+1
+#define ITERATION(SC, SN, CUR)                                                                      \
+  {                                                                                                 \
+    const bool has1_ = t + 1 < nt, has2_ = t + 2 < nt;                                              \
+    if (has2_) K_ISSUE();                                                                           \
+    if (has1_) V_ISSUE();                                                                           \
+    /* block 1: (rare) rescale of the accumulators for the new running max of tile t */            \
+    if (resc) {                                                                                     \
+      _Pragma("unroll") for (int d = 0; d < C::NDT; ++d) _Pragma("unroll") for (int r = 0; r < 16; ++r) o[d][r] *= alpha; \
+    }                                                                                               \
+    if constexpr (!ONES_ROW) l_run *= alpha;                                                        \
+    m_run = m_new;                                                                                  \
+    /* block 2: next tile's QK^T (MFMA) || exp2 + pack of this tile (VALU).  QK is unconditional: on the   \
+       last tile it multiplies stale-but-finite LDS data and the result is dropped (one basic block). */   \
+    const float msc_ = m_run * p.sc;                                                                \
+    bf16x8_t pb_[4];                                                                                \
+    float rs_ = 0.f;                                                                                \
+    if constexpr (HINTS == 2) {                                                                     \
+      /* hand-ordered block 2: [K-fragment read two slots ahead] [MFMA] [a slice of exp2 + pack], pinned with     \
+         sched_barrier so the VALU work sits in the shadow of the 32-cycle MFMAs instead of behind all of them */ \
+      constexpr int NM_ = 2 * C::NKS;                                                               \
+      const unsigned char* kb_ = smem + ((CUR) ^ 1) * C::BUF;                                       \
+      bf16x8_t kfr_[NM_];                                                                           \
+      unsigned w_[16];                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+        kfr_[i] = *reinterpret_cast<const bf16x8_t*>(kb_ + ((i & 1) * 32 + l31) * C::KROW + ((i >> 1) * 2 + hi) * 16); \
+      _Pragma("unroll") for (int i = 0; i < NM_; ++i) {                                             \
+        if (i + 2 < NM_)                                                                            \
+          kfr_[i + 2] = *reinterpret_cast<const bf16x8_t*>(kb_ + (((i + 2) & 1) * 32 + l31) * C::KROW + (((i + 2) >> 1) * 2 + hi) * 16); \
+        if (i < 2) {                                                                                \
+          f32x16_t z_;                                                                              \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) z_[r] = 0.f;                               \
+          SN[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr_[i], qf[i >> 1], z_, 0, 0, 0);    \
+        } else {                                                                                    \
+          SN[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr_[i], qf[i >> 1], SN[i & 1], 0, 0, 0); \
+        }                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        _Pragma("unroll") for (int pp = (i * 16) / NM_; pp < ((i + 1) * 16) / NM_; ++pp) {          \
+          const int t2 = pp >> 3, r = (pp & 7) * 2;                                                 \
+          const float e0_ = __builtin_amdgcn_exp2f(SC[t2][r] * p.sc - msc_);                        \
+          const float e1_ = __builtin_amdgcn_exp2f(SC[t2][r + 1] * p.sc - msc_);                    \
+          if constexpr (!ONES_ROW) rs_ += e0_ + e1_;                                                \
+          w_[pp] = pack_bf16x2(e0_, e1_);                                                           \
+        }                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+      }                                                                                             \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
+        uint4 u_ = make_uint4(w_[4 * g], w_[4 * g + 1], w_[4 * g + 2], w_[4 * g + 3]);              \
+        pb_[g] = __builtin_bit_cast(bf16x8_t, u_);                                                  \
+      }                                                                                             \
+    } else {                                                                                        \
+    QK_TILE(SN, (CUR) ^ 1);                                                                         \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) _Pragma("unroll") for (int r = 0; r < 16; ++r) { \
+      const float e_ = __builtin_amdgcn_exp2f(SC[t2][r] * p.sc - msc_);                             \
+      SC[t2][r] = e_;                                                                               \
+      if constexpr (!ONES_ROW) rs_ += e_;                                                           \
+    }                                                                                               \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+      const int t2 = g >> 1, r0 = (g & 1) * 8;                                                      \
+      uint4 u_;                                                                                     \
+      u_.x = pack_bf16x2(SC[t2][r0 + 0], SC[t2][r0 + 1]);                                           \
+      u_.y = pack_bf16x2(SC[t2][r0 + 2], SC[t2][r0 + 3]);                                           \
+      u_.z = pack_bf16x2(SC[t2][r0 + 4], SC[t2][r0 + 5]);                                           \
+      u_.w = pack_bf16x2(SC[t2][r0 + 6], SC[t2][r0 + 7]);                                           \
+      pb_[g] = __builtin_bit_cast(bf16x8_t, u_);                                                    \
+    }                                                                                               \
+    }                                                                                               \
+    if constexpr (!ONES_ROW) l_run += rs_;                                                          \
+    {                                                                                               \
+      /* anchor: all 16 packed P words must exist HERE, otherwise hipcc sinks the exp2 / pack work below the \
+         mask branch into block 3 and block 2 degenerates to bare MFMAs */                           \
+      const uint4 a0 = __builtin_bit_cast(uint4, pb_[0]), a1 = __builtin_bit_cast(uint4, pb_[1]);   \
+      const uint4 a2 = __builtin_bit_cast(uint4, pb_[2]), a3 = __builtin_bit_cast(uint4, pb_[3]);   \
+      asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), \
+                   "v"(a1.w), "v"(a2.x), "v"(a2.y), "v"(a2.z), "v"(a2.w), "v"(a3.x), "v"(a3.y),     \
+                   "v"(a3.z), "v"(a3.w));                                                           \
+    }                                                                                               \
+    if constexpr (HINTS == 1) {                                                                     \
+      /* shape block 2: 1 K-fragment read : 1 MFMA : a slice of the exp2/pack VALU work, 2*NKS times */ \
+      constexpr int NM_ = 2 * C::NKS, NV_ = ONES_ROW ? 80 : 112;                                    \
+      _Pragma("unroll") for (int i = 0; i < NM_; ++i) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x002, (NV_ + NM_ - 1) / NM_, 0);                      \
+      }                                                                                             \
+    }                                                                                               \
+    /* ragged tail of the NEXT tile, then block 3: O^T += V^T . P^T (MFMA) || row max of the next tile (VALU) */ \
+    if (++ctt == p.tps) ctt = 0;                                                                    \
+    if (has1_ && ctt == p.tps - 1 && last_valid < 64) MASK_TILE(SN, last_valid);                    \
+    if constexpr (HINTS == 2) {                                                                     \
+      /* hand-ordered block 3: [V^T fragment read two slots ahead] [MFMA] [two max3 of the next tile's row max] */ \
+      constexpr int NM_ = 4 * C::NDT;                                                               \
+      const unsigned char* vb_ = smem + (CUR) * C::BUF + C::KTILE;                                  \
+      bf16x8_t vfr_[NM_];                                                                           \
+      float mx_[2] = {SN[0][0], SN[1][0]};                                                          \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+        vfr_[i] = *reinterpret_cast<const bf16x8_t*>(vb_ + ((i % C::NDT) * 32 + l31) * C::VROW + ((i / C::NDT) * 2 + hi) * 16); \
+      _Pragma("unroll") for (int i = 0; i < NM_; ++i) {                                             \
+        if (i + 2 < NM_)                                                                            \
+          vfr_[i + 2] = *reinterpret_cast<const bf16x8_t*>(vb_ + (((i + 2) % C::NDT) * 32 + l31) * C::VROW + (((i + 2) / C::NDT) * 2 + hi) * 16); \
+        o[i % C::NDT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr_[i], pb_[i / C::NDT], o[i % C::NDT], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        /* 30 remaining score values in max3 steps of 2, spread over the first MFMAs */            \
+        _Pragma("unroll") for (int j = (i * 16) / NM_; j < ((i + 1) * 16) / NM_; ++j) {             \
+          if (j < 15) {                                                                             \
+            const int t2 = j & 1, r = 1 + 2 * (j >> 1);                                             \
+            if (r + 1 < 16) mx_[t2] = fmaxf(fmaxf(mx_[t2], SN[t2][r]), SN[t2][r + 1]);              \
+            else mx_[t2] = fmaxf(mx_[t2], SN[t2][r]);                                               \
+          }                                                                                         \
+        }                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+      }                                                                                             \
+      {                                                                                             \
+        float mt_ = fmaxf(mx_[0], mx_[1]);                                                          \
+        mt_ = fmaxf(mt_, fmaxf(SN[0][15], SN[1][15]));                                              \
+        const unsigned mu_ = __float_as_uint(mt_);                                                  \
+        auto sw_ = __builtin_amdgcn_permlane32_swap(mu_, mu_, false, false);                        \
+        mt_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                              \
+        m_new = fmaxf(m_run, mt_);                                                                  \
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);                                     \
+        resc = !__all(m_new == m_run);                                                              \
+      }                                                                                             \
+    } else {                                                                                        \
+      const unsigned char* vb_ = smem + (CUR) * C::BUF + C::KTILE;                                  \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
+        _Pragma("unroll") for (int d = 0; d < C::NDT; ++d) {                                        \
+          const bf16x8_t vf_ = *reinterpret_cast<const bf16x8_t*>(vb_ + (d * 32 + l31) * C::VROW + (g * 2 + hi) * 16); \
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_, pb_[g], o[d], 0, 0, 0);               \
+        }                                                                                           \
+      }                                                                                             \
+      ROW_MAX(SN);                                                                                  \
+    }                                                                                               \
+    if constexpr (HINTS == 1) {                                                                     \
+      constexpr int NM_ = 4 * C::NDT;                                                               \
+      _Pragma("unroll") for (int i = 0; i < NM_; ++i) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 1);                                          \
+      }                                                                                             \
+    }                                                                                               \
+    if (has2_) K_COMMIT(CUR);        /* K_{t+2} -> the buffer K_t lived in (last read in iteration t-1) */ \
+    if (has1_) V_COMMIT((CUR) ^ 1);  /* V_{t+1} */                                                   \
+    __syncthreads();                                                                                \
   }
+
+  for (int t = 0; t < nt; t += 2) {
+    ITERATION(sa_, sb_, 0);
+    ++t;
+    if (t < nt) ITERATION(sb_, sa_, 1);
+    --t;
+  }
+#undef ITERATION
 #undef MASK_TILE
 #undef ROW_MAX
 
@@ -561,7 +647,6 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
 #undef V_ISSUE
 #undef K_COMMIT
 #undef V_COMMIT
-#undef QK_TILE
 
 int attn_variant() {
   static int v = -1;
@@ -589,10 +674,11 @@ int launch_kernel(KernelT kernel, int smem, const AttnParams& p, hipStream_t st,
 template <int HD>
 int launch(const AttnParams& p, hipStream_t st) {
   using C = Cfg<HD>;
-  static bool set0 = false, set1 = false, set9 = false;
+  static bool set0 = false, set1 = false, set2 = false, set9 = false;
   switch (attn_variant()) {
     case 9: return launch_kernel(attn_fwd_kernel_v1<HD>, C::SMEM, p, st, &set9);
     case 1: return launch_kernel(attn_fwd_kernel<HD, 1>, C::SMEM, p, st, &set1);
+    case 2: return launch_kernel(attn_fwd_kernel<HD, 2>, C::SMEM, p, st, &set2);
     default: return launch_kernel(attn_fwd_kernel<HD, 0>, C::SMEM, p, st, &set0);
   }
 }

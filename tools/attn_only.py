@@ -1,0 +1,17 @@
+#!/usr/bin/env python
+"""Launch only the attention kernel at the bench shape a few times (target of rocprofv3 --pmc passes)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from open_sora_amd import _C
+B, H, L, hd = (int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (3, 16, 16896, 72)))
+D = H * hd
+torch.manual_seed(0)
+y = torch.randn(B, L, 3 * D, device="cuda").to(torch.bfloat16)
+q, k, v = y[:, :, :D], y[:, :, D:2 * D], y[:, :, 2 * D:]
+vt = torch.empty(B, H, hd, (L + 63) // 64 * 64, dtype=torch.bfloat16, device="cuda")
+_C.v_transpose(v, vt, H, hd)
+out = torch.empty(B, L, D, dtype=torch.bfloat16, device="cuda")
+for _ in range(3):
+    _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5)
+torch.cuda.synchronize()
