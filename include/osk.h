@@ -85,7 +85,9 @@ int osk_rope_table(const float* ids, int64_t n_rows, int n_axes, const int32_t* 
  * q row (b,l) head h at q + b*batch_stride + l*row_stride + h*hd (same for k).  Rows l < l_split use
  * (q_scale0,k_scale0) (the txt stream's norm weights), rows >= l_split use (q_scale1,k_scale1).
  * Scales bf16 [hd].  cos/sin f32 [*, L, hd/2] with batch stride cs_batch_stride (0 = shared).
- * Rounding points follow the reference: bf16(x*rrms) * bf16 scale -> bf16, rotate in f32, -> bf16. */
+ * Rounding points follow the reference: bf16(x*rrms) * bf16 scale -> bf16, rotate in f32, -> bf16.
+ * Either q or k (not both) may be NULL: only the other one is processed (the sequence-parallel path norms
+ * K first so its all-gather can start while the Q / MLP projections run). */
 int osk_qknorm_rope_bf16(void* q, void* k, int64_t batch_stride, int64_t row_stride,
                          const void* q_scale0, const void* k_scale0,
                          const void* q_scale1, const void* k_scale1, int l_split,

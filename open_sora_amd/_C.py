@@ -155,10 +155,12 @@ def rope_table(ids: torch.Tensor, axes_dim, theta: float, f32_angles: bool, cos:
 
 def qknorm_rope(q: torch.Tensor, k: torch.Tensor, qs0, ks0, qs1, ks1, l_split: int, cos, sin,
                 cs_batch_stride: int, H: int, hd: int, rope_mode: int, eps: float = 1e-6):
-    """q, k: bf16 [B, L, H*hd] views (same strides, last dim contiguous) rewritten in place."""
-    B, L, _ = q.shape
-    assert q.stride() == k.stride()
-    _check(lib.osk_qknorm_rope_bf16(q.data_ptr(), k.data_ptr(), q.stride(0), q.stride(1), qs0.data_ptr(),
+    """q, k: bf16 [B, L, H*hd] views (same strides, last dim contiguous) rewritten in place; one of them may
+    be None (one-sided call)."""
+    t = q if q is not None else k
+    B, L, _ = t.shape
+    assert q is None or k is None or q.stride() == k.stride()
+    _check(lib.osk_qknorm_rope_bf16(_p(q), _p(k), t.stride(0), t.stride(1), qs0.data_ptr(),
                                     ks0.data_ptr(), qs1.data_ptr(), ks1.data_ptr(), l_split, cos.data_ptr(),
                                     sin.data_ptr(), cs_batch_stride, B, L, H, hd, rope_mode, eps, _stream()),
            "osk_qknorm_rope_bf16")

@@ -118,7 +118,9 @@ __global__ void __launch_bounds__(256) qknorm_rope_kernel(
   const float* sr = sin_t + b * csb + (int64_t)l * (HD / 2);
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
-    unsigned short* p = (which ? k : q) + b * bs + (int64_t)l * rs + h * HD + cc * CW;
+    unsigned short* tb = which ? k : q;
+    if (!tb) continue;  // one-sided call (sequence-parallel path norms K before Q); uniform over the grid
+    unsigned short* p = tb + b * bs + (int64_t)l * rs + h * HD + cc * CW;
     const unsigned short* sc = which ? (l < l_split ? ks0 : ks1) : (l < l_split ? qs0 : qs1);
     float v[CW];
     if constexpr (CW == 8) {
@@ -181,7 +183,7 @@ extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, co
                                     const void* ks0, const void* qs1, const void* ks1, int l_split,
                                     const float* cos_t, const float* sin_t, int64_t csb, int B, int L,
                                     int H, int hd, int rope_mode, float eps, void* stream) {
-  if (!q || !k || !qs0 || !ks0 || !qs1 || !ks1 || !cos_t || !sin_t) return OSK_EINVAL;
+  if ((!q && !k) || !qs0 || !ks0 || !qs1 || !ks1 || !cos_t || !sin_t) return OSK_EINVAL;
   if (B <= 0 || L <= 0 || H <= 0 || (bs & 7) || (rs & 7)) return OSK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)B * L * H;

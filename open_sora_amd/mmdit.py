@@ -401,58 +401,90 @@ def _mod_views(mod: Tensor, col: int, n: int, D: int):
     return [mod[:, col + i * D: col + (i + 1) * D] for i in range(n)], mod.stride(0)
 
 
+def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd: int):
+    """attention() of math.py:22-36 on the joint [txt;img] sequence; the output overwrites the (dead) v slot."""
+    _OPS.v_transpose(v, ws.vt, H, hd)
+    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)
+
+
 def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: int, col_txt: int, rope: _RopeTable,
-                     H: int, hd: int):
+                     H: int, hd: int, sp=None):
     """DoubleStreamBlockProcessor.__call__ (layers.py:195-253) on the workspace's joint buffers.
-    Residual streams live in ws.x ([:, :L_txt] txt, [:, L_txt:] img) and are updated in place."""
+    Residual streams live in ws.x ([:, :L_txt] txt, [:, L_txt:] img) and are updated in place.
+    sp: a seqpar.SeqPar when the token axis is sharded (ws then holds this rank's rows; either stream may be
+    empty on a rank) — K/V are projected first and all-gathered while the Q projection runs."""
     D = H * hd
-    Lt = ws.L_txt
+    Lt, Li = ws.L_txt, ws.L_img
     x_txt, x_img = ws.x[:, :Lt], ws.x[:, Lt:]
     xm_txt, xm_img = ws.xm[:, :Lt], ws.xm[:, Lt:]
     y = ws.y_double(D)
     (i_sh1, i_sc1, i_g1, i_sh2, i_sc2, i_g2), mbs = _mod_views(mod, col_img, 6, D)
     (t_sh1, t_sc1, t_g1, t_sh2, t_sc2, t_g2), _ = _mod_views(mod, col_txt, 6, D)
-    r_img, r_txt = x_img, x_txt
+    csb = rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0
+    streams = []
+    if Li:
+        streams.append((plan.img, x_img, xm_img, y[:, Lt:], i_sh1, i_sc1))
+    if Lt:
+        streams.append((plan.txt, x_txt, xm_txt, y[:, :Lt], t_sh1, t_sc1))
 
-    _OPS.ln_modulate(r_img, i_sh1, i_sc1, xm_img, mbs)
-    _OPS.ln_modulate(r_txt, t_sh1, t_sc1, xm_txt, mbs)
-    _OPS.gemm(xm_img, plan.img.qkv_w, plan.img.qkv_b, y[:, Lt:])
-    _OPS.gemm(xm_txt, plan.txt.qkv_w, plan.txt.qkv_b, y[:, :Lt])
+    for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
+        _OPS.ln_modulate(x_s, sh1, sc1, xm_s, mbs)
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D:]
-    _OPS.qknorm_rope(q, k, plan.txt.q_scale, plan.txt.k_scale, plan.img.q_scale, plan.img.k_scale, Lt,
-                   rope.cos, rope.sin, rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0, H, hd, rope.mode)
-    _OPS.v_transpose(v, ws.vt, H, hd)
-    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)  # output overwrites the (dead) v slot
-    # img stream
-    _OPS.gemm(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=r_img, gate=i_g1, gate_batch_stride=mbs)
-    _OPS.ln_modulate(x_img, i_sh2, i_sc2, xm_img, mbs)
-    w0, b0, w2, b2 = plan.img_mlp
-    _OPS.gemm(xm_img, w0, b0, ws.h[:, Lt:], gelu_from=0)
-    _OPS.gemm(ws.h[:, Lt:], w2, b2, x_img, res=x_img, gate=i_g2, gate_batch_stride=mbs)
-    # txt stream
-    _OPS.gemm(v[:, :Lt], plan.txt.proj_w, plan.txt.proj_b, x_txt, res=r_txt, gate=t_g1, gate_batch_stride=mbs)
-    _OPS.ln_modulate(x_txt, t_sh2, t_sc2, xm_txt, mbs)
-    w0, b0, w2, b2 = plan.txt_mlp
-    _OPS.gemm(xm_txt, w0, b0, ws.h[:, :Lt], gelu_from=0)
-    _OPS.gemm(ws.h[:, :Lt], w2, b2, x_txt, res=x_txt, gate=t_g2, gate_batch_stride=mbs)
+    scales = (plan.txt.q_scale, plan.txt.k_scale, plan.img.q_scale, plan.img.k_scale)
+    if sp is None:
+        for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
+            _OPS.gemm(xm_s, aw.qkv_w, aw.qkv_b, y_s)
+        _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        _joint_attention(ws, q, k, v, H, hd)
+    else:
+        for aw, x_s, xm_s, y_s, sh1, sc1 in streams:  # K, V first: their all-gather overlaps the Q projection
+            _OPS.gemm(xm_s, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
+        _OPS.qknorm_rope(None, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        pending = sp.gather_kv_start(ws, k, v, H, hd)
+        for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
+            _OPS.gemm(xm_s, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
+        _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        sp.attention(ws, pending, q, v, H, hd)
+    if Li:  # img stream
+        _OPS.gemm(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=x_img, gate=i_g1, gate_batch_stride=mbs)
+        _OPS.ln_modulate(x_img, i_sh2, i_sc2, xm_img, mbs)
+        w0, b0, w2, b2 = plan.img_mlp
+        _OPS.gemm(xm_img, w0, b0, ws.h[:, Lt:], gelu_from=0)
+        _OPS.gemm(ws.h[:, Lt:], w2, b2, x_img, res=x_img, gate=i_g2, gate_batch_stride=mbs)
+    if Lt:  # txt stream
+        _OPS.gemm(v[:, :Lt], plan.txt.proj_w, plan.txt.proj_b, x_txt, res=x_txt, gate=t_g1, gate_batch_stride=mbs)
+        _OPS.ln_modulate(x_txt, t_sh2, t_sc2, xm_txt, mbs)
+        w0, b0, w2, b2 = plan.txt_mlp
+        _OPS.gemm(xm_txt, w0, b0, ws.h[:, :Lt], gelu_from=0)
+        _OPS.gemm(ws.h[:, :Lt], w2, b2, x_txt, res=x_txt, gate=t_g2, gate_batch_stride=mbs)
 
 
 def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, rope: _RopeTable, H: int, hd: int,
-                     R: int):
+                     R: int, sp=None):
     """SingleStreamBlockProcessor.__call__ (layers.py:309-334).  linear1's output row is [q|k|v|mlp]; attention
-    writes into the v slot so linear2 reads the contiguous [attn | gelu(mlp)] columns: no torch.cat."""
+    writes into the v slot so linear2 reads the contiguous [attn | gelu(mlp)] columns: no torch.cat.
+    sp: see run_double_block — the K/V all-gather overlaps the Q and MLP-up projections."""
     D = H * hd
     y = ws.y_single(D, R)
     (shift, scale, gate), mbs = _mod_views(mod, col, 3, D)
-    r = ws.x
-    _OPS.ln_modulate(r, shift, scale, ws.xm, mbs)
-    _OPS.gemm(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
+    csb = rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0
+    _OPS.ln_modulate(ws.x, shift, scale, ws.xm, mbs)
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D: 3 * D]
-    _OPS.qknorm_rope(q, k, plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale, 0, rope.cos, rope.sin,
-                   rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0, H, hd, rope.mode)
-    _OPS.v_transpose(v, ws.vt, H, hd)
-    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)
-    _OPS.gemm(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=r, gate=gate, gate_batch_stride=mbs)
+    scales = (plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale)
+    if sp is None:
+        _OPS.gemm(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
+        _OPS.qknorm_rope(q, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        _joint_attention(ws, q, k, v, H, hd)
+    else:
+        b1 = plan.b1
+        _OPS.gemm(ws.xm, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])
+        _OPS.qknorm_rope(None, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        pending = sp.gather_kv_start(ws, k, v, H, hd)
+        _OPS.gemm(ws.xm, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
+        _OPS.gemm(ws.xm, plan.w1[:D], None if b1 is None else b1[:D], q)
+        _OPS.qknorm_rope(q, None, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        sp.attention(ws, pending, q, v, H, hd)
+    _OPS.gemm(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=ws.x, gate=gate, gate_batch_stride=mbs)
 
 
 def _run_modulation(vec32: Tensor, layers, D: int) -> Tensor:
@@ -548,6 +580,7 @@ class MMDiTModel(nn.Module):
             nn.init.zeros_(self.cond_in.weight)
             nn.init.zeros_(self.cond_in.bias)
         self._plan = None
+        self._sp = None  # set by open_sora_amd.seqpar.enable
         self.forward = self.forward_ckpt  # instance attribute, as the reference does (model.py:143-146)
 
     # ------------------------------------------------------------------ planning
@@ -608,8 +641,11 @@ class MMDiTModel(nn.Module):
         return p
 
     # ------------------------------------------------------------------ forward
-    def prepare_block_inputs(self, img, img_ids, txt, txt_ids, timesteps, y_vec, cond=None, guidance=None):
-        """model.py:154-202.  Returns (ws, vec f32 [B, D], rope tables); img/txt land in ws.x."""
+    def prepare_block_inputs(self, img, img_ids, txt, txt_ids, timesteps, y_vec, cond=None, guidance=None,
+                             _shard=None):
+        """model.py:154-202.  Returns (ws, vec f32 [B, D], rope tables); img/txt land in ws.x.
+        _shard = (lo, hi): embed only tokens [lo, hi) of the joint [txt;img] sequence (sequence parallelism,
+        the contiguous split of distributed.py:609-624); positions stay global."""
         cfg = self.config
         if img.ndim != 3 or txt.ndim != 3:
             raise ValueError("Input img and txt tensors must have 3 dimensions.")
@@ -622,29 +658,40 @@ class MMDiTModel(nn.Module):
         D, H = self.hidden_size, self.num_heads
         hd = D // H
         R = int(D * cfg.mlp_ratio)
-        B, Li, _ = img.shape
-        Lt = txt.shape[1]
+        B = img.shape[0]
+        ids = torch.cat((txt_ids, img_ids), dim=1)
+        if _shard is not None:
+            lo, hi = _shard
+            Lt_full = txt.shape[1]
+            t0, t1 = min(lo, Lt_full), min(hi, Lt_full)
+            i0, i1 = max(lo, Lt_full) - Lt_full, max(hi, Lt_full) - Lt_full
+            img, txt, ids = img[:, i0:i1], txt[:, t0:t1], ids[:, lo:hi]
+            if cond is not None:
+                cond = cond[:, i0:i1]
+        Li, Lt = img.shape[1], txt.shape[1]
         ws = _workspace(B, Lt, Li, D, R, H, hd, dev)
         # --- img_in (+cond_in): concatenated K-padded A operand
-        Kp = p["in_w"].shape[1]
-        a_in = getattr(ws, "a_in", None)
-        if a_in is None or a_in.shape[2] != Kp:
-            a_in = ws.a_in = torch.zeros(B, Li, Kp, dtype=BF16, device=dev)
-        C_in = img.shape[2]
-        a_in[:, :, :C_in].copy_(img)
-        if cfg.cond_embed:
-            a_in[:, :, C_in: C_in + cond.shape[2]].copy_(cond)
-        _OPS.gemm(a_in, p["in_w"], p["in_b"], ws.x[:, Lt:])
+        if Li:
+            Kp = p["in_w"].shape[1]
+            a_in = getattr(ws, "a_in", None)
+            if a_in is None or a_in.shape[2] != Kp:
+                a_in = ws.a_in = torch.zeros(B, Li, Kp, dtype=BF16, device=dev)
+            C_in = img.shape[2]
+            a_in[:, :, :C_in].copy_(img)
+            if cfg.cond_embed:
+                a_in[:, :, C_in: C_in + cond.shape[2]].copy_(cond)
+            _OPS.gemm(a_in, p["in_w"], p["in_b"], ws.x[:, Lt:])
         # --- txt_in
-        Kt = p["txt_w"].shape[1]
-        if Kt == txt.shape[2] and txt.dtype == BF16 and txt.stride(2) == 1:
-            a_txt = txt
-        else:
-            a_txt = getattr(ws, "a_txt", None)
-            if a_txt is None or a_txt.shape[2] != Kt:
-                a_txt = ws.a_txt = torch.zeros(B, Lt, Kt, dtype=BF16, device=dev)
-            a_txt[:, :, : txt.shape[2]].copy_(txt)
-        _OPS.gemm(a_txt, p["txt_w"], p["txt_b"], ws.x[:, :Lt])
+        if Lt:
+            Kt = p["txt_w"].shape[1]
+            if Kt == txt.shape[2] and txt.dtype == BF16 and txt.stride(2) == 1:
+                a_txt = txt
+            else:
+                a_txt = getattr(ws, "a_txt", None)
+                if a_txt is None or a_txt.shape[2] != Kt:
+                    a_txt = ws.a_txt = torch.zeros(B, Lt, Kt, dtype=BF16, device=dev)
+                a_txt[:, :, : txt.shape[2]].copy_(txt)
+            _OPS.gemm(a_txt, p["txt_w"], p["txt_b"], ws.x[:, :Lt])
         # --- vec = time_in(temb(t)) [+ guidance_in(temb(g))] + vector_in(y)   (f32 throughout)
         temb = torch.empty(B, 256, dtype=torch.float32, device=dev)
         hbuf = torch.empty(B, D, dtype=torch.float32, device=dev)
@@ -660,15 +707,24 @@ class MMDiTModel(nn.Module):
             _OPS.gemv_tasks(hbuf, p["guidance_in"][1], vec, act_in=1, accumulate=True)
         _OPS.gemv_tasks(y_vec.float().contiguous(), p["vector_in"][0], hbuf)
         _OPS.gemv_tasks(hbuf, p["vector_in"][1], vec, act_in=1, accumulate=True)
-        # --- RoPE tables for the joint sequence
-        ids = torch.cat((txt_ids, img_ids), dim=1)
+        # --- RoPE tables for the (local part of the) joint sequence
         rope = self.pe_embedder(ids)
         return ws, vec, rope
 
     def forward_ckpt(self, img: Tensor, img_ids: Tensor, txt: Tensor, txt_ids: Tensor, timesteps: Tensor,
                      y_vec: Tensor, cond: Tensor = None, guidance: Tensor | None = None, **kwargs) -> Tensor:
-        """MMDiTModel.forward_ckpt (model.py:208-233); inference only."""
-        ws, vec, rope = self.prepare_block_inputs(img, img_ids, txt, txt_ids, timesteps, y_vec, cond, guidance)
+        """MMDiTModel.forward_ckpt (model.py:208-233); inference only.  With sequence parallelism enabled
+        (open_sora_amd.seqpar.enable) this is mmdit_model_forward (distributed.py:580-683): every rank gets the
+        full inputs, works on its contiguous token chunk and returns the full [B, L_img, C] prediction."""
+        sp = getattr(self, "_sp", None)
+        L_img, L_txt = img.shape[1], txt.shape[1]
+        shard = None
+        if sp is not None:
+            shard = sp.shard_range(L_txt + L_img, L_txt)  # None when a rank would hold no image tokens
+            if shard is None:
+                sp = None
+        ws, vec, rope = self.prepare_block_inputs(img, img_ids, txt, txt_ids, timesteps, y_vec, cond, guidance,
+                                                  _shard=shard)
         p = self._plan
         D, H = self.hidden_size, self.num_heads
         hd = D // H
@@ -677,16 +733,22 @@ class MMDiTModel(nn.Module):
         mod = torch.empty(B, p["mod_cols"], dtype=torch.float32, device=img.device)
         _OPS.gemv_tasks(vec, p["mod_tasks"], mod, act_in=1)
         for plan, (ci, ct) in zip(p["double"], p["col_double"]):
-            run_double_block(plan, ws, mod, ci, ct, rope, H, hd)
+            run_double_block(plan, ws, mod, ci, ct, rope, H, hd, sp)
         for plan, c in zip(p["single"], p["col_single"]):
-            run_single_block(plan, ws, mod, c, rope, H, hd, R)
+            run_single_block(plan, ws, mod, c, rope, H, hd, R, sp)
         # LastLayer (layers.py:398-402): (shift, scale) order
         Lt = ws.L_txt
         cf = p["col_final"]
         shift, scale = mod[:, cf: cf + D], mod[:, cf + D: cf + 2 * D]
-        _OPS.ln_modulate(ws.x[:, Lt:], shift, scale, ws.xm[:, Lt:], mod.stride(0))
-        out = torch.empty(B, ws.L_img, p["final_w"].shape[0], dtype=BF16, device=img.device)
-        _OPS.gemm(ws.xm[:, Lt:], p["final_w"], p["final_b"], out)
+        C_out = p["final_w"].shape[0]
+        if sp is None:
+            _OPS.ln_modulate(ws.x[:, Lt:], shift, scale, ws.xm[:, Lt:], mod.stride(0))
+            out = torch.empty(B, ws.L_img, C_out, dtype=BF16, device=img.device)
+            _OPS.gemm(ws.xm[:, Lt:], p["final_w"], p["final_b"], out)
+        else:
+            # equal-size gather: every rank projects ALL its rows (rank 0's few txt rows are discarded after)
+            _OPS.ln_modulate(ws.x, shift, scale, ws.xm, mod.stride(0))
+            out = sp.gather_output(ws, lambda dst: _OPS.gemm(ws.xm, p["final_w"], p["final_b"], dst), C_out, L_txt)
         return out.to(img.dtype) if img.dtype != BF16 else out
 
 

@@ -75,10 +75,12 @@ def rope_table(ids, axes_dim, theta, f32_angles, cos, sin):
 
 
 def qknorm_rope(q, k, qs0, ks0, qs1, ks1, l_split, cos, sin, cs_batch_stride, H, hd, rope_mode, eps=1e-6):
-    B, L, _ = q.shape
+    B, L, _ = (q if q is not None else k).shape
     c = cos if cs_batch_stride else cos[:1]
     s = sin if cs_batch_stride else sin[:1]
     for t, (s0, s1) in ((q, (qs0, qs1)), (k, (ks0, ks1))):
+        if t is None:
+            continue
         x = t.reshape(B, L, H, hd)
         y = torch.cat([O.rms_norm(x[:, :l_split], s0), O.rms_norm(x[:, l_split:], s1)], 1)  # bf16 rounding points
         yf = y.float()
