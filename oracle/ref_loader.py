@@ -176,6 +176,35 @@ def install() -> None:
     du.logging = lg
     du.BaseOutput = BaseOutput
     _mod("diffusers.utils.torch_utils", randn_tensor=randn_tensor)
+
+    # ---- diffusers scaffolding of AutoencoderKLCausal3D (autoencoder_kl_causal_3d.py:28-49): plain nn.Module,
+    # no config registry / hub loading / forward hooks.  Arithmetic-free, so the wrapper's own encode/decode/
+    # tiling/blending code runs unmodified.
+    class ConfigMixin:
+        pass
+
+    class FromOriginalVAEMixin:
+        pass
+
+    class ModelMixin(nn.Module):
+        pass
+
+    class AttnProcessor:
+        pass
+
+    class AttnAddedKVProcessor:
+        pass
+
+    _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=lambda f: f)
+    _mod("diffusers.loaders", FromOriginalVAEMixin=FromOriginalVAEMixin)
+    ap = sys.modules["diffusers.models.attention_processor"]
+    ap.ADDED_KV_ATTENTION_PROCESSORS = (AttnAddedKVProcessor,)
+    ap.CROSS_ATTENTION_PROCESSORS = (AttnProcessor,)
+    ap.AttentionProcessor = AttnProcessor
+    ap.AttnAddedKVProcessor = AttnAddedKVProcessor
+    ap.AttnProcessor = AttnProcessor
+    _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
+    _mod("diffusers.utils.accelerate_utils", apply_forward_hook=lambda f: f)
     _installed = True
 
 
@@ -187,6 +216,12 @@ def mmdit():
         importlib.import_module("opensora.models.mmdit.layers"),
         importlib.import_module("opensora.models.mmdit.math"),
     )
+
+
+def hunyuan_ae():
+    """-> the reference's autoencoder_kl_causal_3d module (AutoencoderKLCausal3D, AutoEncoder3DConfig)."""
+    install()
+    return importlib.import_module("opensora.models.hunyuan_vae.autoencoder_kl_causal_3d")
 
 
 def hunyuan_vae():

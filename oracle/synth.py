@@ -151,3 +151,82 @@ def mmdit_inputs(cfg: dict, B: int, T: int, h: int, w: int, L_txt: int, seed: in
     if cfg.get("guidance_embed", False):
         d["guidance"] = np.full((B,), 4.0, np.float32)
     return d
+
+
+# --------------------------------------------------------------------------- Hunyuan causal 3-D VAE weights
+def vae_param_shapes(cfg: dict) -> dict:
+    """Parameter name -> shape of the reference AutoencoderKLCausal3D state dict
+    (opensora/models/hunyuan_vae/autoencoder_kl_causal_3d.py:99-133; vae.py:58-119,158-231;
+    unet_causal_3d_blocks.py:92,216-245,312-341).  cfg keys: in_channels, out_channels, latent_channels,
+    block_out_channels, layers_per_block (AutoEncoder3DConfig field names)."""
+    ch = list(cfg["block_out_channels"])
+    lpb = cfg.get("layers_per_block", 2)
+    zc = cfg.get("latent_channels", 16)
+    cin, cout = cfg.get("in_channels", 3), cfg.get("out_channels", 3)
+    s: dict = {}
+
+    def conv(name, co, ci, k):
+        s[name + ".weight"] = (co, ci, k, k, k)
+        s[name + ".bias"] = (co,)
+
+    def norm(name, c):
+        s[name + ".weight"] = (c,)
+        s[name + ".bias"] = (c,)
+
+    def resnet(name, ci, co):
+        norm(name + ".norm1", ci)
+        conv(name + ".conv1.conv", co, ci, 3)
+        norm(name + ".norm2", co)
+        conv(name + ".conv2.conv", co, co, 3)
+        if ci != co:
+            conv(name + ".conv_shortcut.conv", co, ci, 1)
+
+    def mid(name, c):
+        a = name + ".attentions.0"
+        norm(a + ".group_norm", c)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            s[f"{a}.{n}.weight"] = (c, c)
+            s[f"{a}.{n}.bias"] = (c,)
+        resnet(name + ".resnets.0", c, c)
+        resnet(name + ".resnets.1", c, c)
+
+    # encoder (vae.py:58-119)
+    conv("encoder.conv_in.conv", ch[0], cin, 3)
+    prev = ch[0]
+    for i, c in enumerate(ch):
+        for j in range(lpb):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
+        if i < len(ch) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv.conv", c, c, 3)
+        prev = c
+    mid("encoder.mid_block", ch[-1])
+    norm("encoder.conv_norm_out", ch[-1])
+    conv("encoder.conv_out.conv", 2 * zc, ch[-1], 3)
+    # decoder (vae.py:158-231)
+    conv("decoder.conv_in.conv", ch[-1], zc, 3)
+    rev = ch[::-1]
+    prev = rev[0]
+    for i, c in enumerate(rev):
+        for j in range(lpb + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
+        if i < len(ch) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv.conv", c, c, 3)
+        prev = c
+    mid("decoder.mid_block", ch[-1])
+    norm("decoder.conv_norm_out", ch[0])
+    conv("decoder.conv_out.conv", cout, ch[0], 3)
+    s["quant_conv.weight"] = (2 * zc, 2 * zc, 1, 1, 1)
+    s["quant_conv.bias"] = (2 * zc,)
+    s["post_quant_conv.weight"] = (zc, zc, 1, 1, 1)
+    s["post_quant_conv.bias"] = (zc,)
+    return s
+
+
+def vae_video(B: int, T: int, H: int, W: int, seed: int = 7, C: int = 3) -> np.ndarray:
+    """Synthetic pixel video in [-1, 1]-ish range, NCTHW, bf16-representable."""
+    return bf16_round(np.clip(normal("in.video", seed, (B, C, T, H, W), std=0.5), -1.0, 1.0))
+
+
+def vae_latent(B: int, T: int, h: int, w: int, seed: int = 8, C: int = 16) -> np.ndarray:
+    """Synthetic (already scaled) latent, NCTHW, bf16-representable."""
+    return bf16_round(normal("in.latent", seed, (B, C, T, h, w), std=0.5))
