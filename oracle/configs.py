@@ -16,3 +16,18 @@ GOLDEN = {
     "hd128_liger_split": (dict(_TINY, hidden_size=256, num_heads=2, axes_dim=[16, 56, 56], fused_qkv=False, use_liger_rope=True), 3, 2, 4, 5, 24),
     "hd128_eager_fused": (dict(_TINY, hidden_size=256, num_heads=2, axes_dim=[16, 56, 56], fused_qkv=True, use_liger_rope=False, cond_embed=False), 1, 1, 9, 11, 8),
 }
+
+# ---- Hunyuan causal 3-D VAE: tiny geometries for goldens (AutoEncoder3DConfig field names)
+_VAE = dict(in_channels=3, out_channels=3, latent_channels=16, norm_num_groups=32, time_compression_ratio=4,
+            spatial_compression_ratio=8)
+VAE_GOLDEN = {
+    # name: (cfg, B, T, H, W)   video [B, 3, T, H, W]; latent [B, 16, (T-1)//4+1, H/8, W/8]
+    "c32_lpb1": (dict(_VAE, block_out_channels=(32, 64, 128, 128), layers_per_block=1), 1, 9, 32, 32),
+    "c64_lpb2_rect": (dict(_VAE, block_out_channels=(64, 64, 128, 128), layers_per_block=2), 2, 5, 32, 48),
+    "c32_single_frame": (dict(_VAE, block_out_channels=(32, 64, 64, 128), layers_per_block=1), 1, 1, 48, 32),
+}
+# spatial / temporal tiling (autoencoder_kl_causal_3d.py:384-552): tile 32 px / 8 frames on a 48 x 56 x 17 video
+VAE_TILED_GOLDEN = {
+    "c32_tiled": (dict(_VAE, block_out_channels=(32, 64, 128, 128), layers_per_block=1, sample_size=32,
+                       sample_tsize=8, tile_overlap_factor=0.25), 1, 17, 48, 56),
+}

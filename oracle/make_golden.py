@@ -40,8 +40,40 @@ def reference_mmdit_outputs(cfg, B, T, h, w, L_txt, seed=0):
     return taps
 
 
+def reference_vae(cfg):
+    """The reference's own AutoencoderKLCausal3D (fp32, CPU) with the synthetic weights of oracle/synth.py."""
+    ae = ref_loader.hunyuan_ae()
+    model = ae.AutoencoderKLCausal3D(ae.AutoEncoder3DConfig(from_pretrained=None, **cfg))
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(synth.vae_param_shapes(cfg), 0).items()}
+    model.load_state_dict(sd, strict=True)
+    return model.eval()
+
+
+def reference_vae_outputs(cfg, B, T, H, W, tiled=False):
+    model = reference_vae(cfg)
+    if tiled:
+        model.enable_tiling()
+    x = torch.from_numpy(synth.vae_video(B, T, H, W))
+    taps = {}
+    with torch.inference_mode():
+        z, post = model.encode(x, sample_posterior=False, return_posterior=True)
+        taps["z"] = z.numpy().copy()
+        taps["logvar"] = post.logvar.numpy().copy()
+        zin = torch.from_numpy(synth.vae_latent(B, z.shape[2], z.shape[3], z.shape[4]))
+        taps["dec"] = model.decode(zin).numpy().copy()
+    return taps
+
+
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
+    for table, tiled in ((configs.VAE_GOLDEN, False), (configs.VAE_TILED_GOLDEN, True)):
+        for name, (cfg, B, T, H, W) in table.items():
+            taps = reference_vae_outputs(cfg, B, T, H, W, tiled)
+            path = os.path.join(OUT_DIR, f"vae_{name}.npz")
+            np.savez_compressed(path, **{k: v.astype(np.float32) for k, v in taps.items()})
+            print(f"{path}: z {taps['z'].shape} dec {taps['dec'].shape} ({os.path.getsize(path)} B)")
+    if "--vae-only" in sys.argv:
+        return
     for name, (cfg, B, T, h, w, L_txt) in configs.GOLDEN.items():
         taps = reference_mmdit_outputs(cfg, B, T, h, w, L_txt)
         path = os.path.join(OUT_DIR, f"mmdit_{name}.npz")

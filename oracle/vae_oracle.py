@@ -177,20 +177,128 @@ def tile_params(cfg):
                 tlatent=st // cfg.get("time_compression_ratio", 4), overlap=cfg.get("tile_overlap_factor", 0.25))
 
 
-def spatial_tiled(fn, x, tile, stride, blend_extent, row_limit):
-    """The common loop of spatial_tiled_encode / spatial_tiled_decode (autoencoder_kl_causal_3d.py:384-489)."""
+def _spatial_tiled(fn, x, tile, stride, blend_extent, row_limit):
+    """The common loop of spatial_tiled_encode / spatial_tiled_decode (autoencoder_kl_causal_3d.py:384-489).
+    blend_v / blend_h write into tile b in place (:360-374), so a tile blended from above is what its right
+    neighbour blends against; `rows` therefore holds the updated tiles."""
     rows = []
     for i in range(0, x.shape[-2], stride):
         rows.append([fn(x[..., i: i + tile, j: j + tile]) for j in range(0, x.shape[-1], stride)])
     out_rows = []
     for i, row in enumerate(rows):
         out_row = []
-        for j, t in enumerate(row):
+        for j in range(len(row)):
+            t = row[j]
             if i > 0:
                 t = _blend(rows[i - 1][j], t, blend_extent, -2)
             if j > 0:
                 t = _blend(row[j - 1], t, blend_extent, -1)
-            row[j] = t  # the reference blends in place: later tiles see the blended neighbour
+            row[j] = t
             out_row.append(t[..., :row_limit, :row_limit])
         out_rows.append(torch.cat(out_row, -1))
     return torch.cat(out_rows, -2)
+
+
+def _temporal_tiled(fn, x, tile, stride, blend_extent, t_limit):
+    """temporal_tiled_encode / temporal_tiled_decode (autoencoder_kl_causal_3d.py:491-552): tiles of tile+1 frames,
+    the first output frame of every later tile dropped, cross-fade over blend_extent frames."""
+    row = []
+    for i in range(0, x.shape[2], stride):
+        t = fn(x[:, :, i: i + tile + 1])
+        row.append(t[:, :, 1:] if i > 0 else t)
+    out = []
+    for i in range(len(row)):
+        if i > 0:
+            row[i] = _blend(row[i - 1], row[i], blend_extent, 2)
+            out.append(row[i][:, :, :t_limit])
+        else:
+            out.append(row[i][:, :, : t_limit + 1])
+    return torch.cat(out, 2)
+
+
+def encode_moments_tiled(sd, cfg, x, spatial=True, temporal=True):
+    """AutoencoderKLCausal3D.encode dispatch (autoencoder_kl_causal_3d.py:291-306) up to the moments."""
+    tp = tile_params(cfg)
+    ov = tp["overlap"]
+
+    def plain(t):
+        return encode_moments(sd, cfg, t)
+
+    def sp(t):
+        if spatial and (t.shape[-1] > tp["sample"] or t.shape[-2] > tp["sample"]):
+            be = int(tp["latent"] * ov)
+            return _spatial_tiled(plain, t, tp["sample"], int(tp["sample"] * (1 - ov)), be, tp["latent"] - be)
+        return plain(t)
+
+    if temporal and x.shape[2] > tp["tsample"]:
+        be = int(tp["tlatent"] * ov)
+        return _temporal_tiled(sp, x, tp["tsample"], int(tp["tsample"] * (1 - ov)), be, tp["tlatent"] - be)
+    return sp(x)
+
+
+def encode_tiled(sd, cfg, x, spatial=True, temporal=True):
+    mean, _ = encode_moments_tiled(sd, cfg, x, spatial, temporal).chunk(2, 1)
+    return SCALE_FACTOR * (mean - SHIFT_FACTOR)
+
+
+def decode_tiled(sd, cfg, z, spatial=True, temporal=True):
+    """AutoencoderKLCausal3D.decode/_decode dispatch (autoencoder_kl_causal_3d.py:319-358)."""
+    tp = tile_params(cfg)
+    ov = tp["overlap"]
+    z = z / SCALE_FACTOR + SHIFT_FACTOR
+
+    def plain(t):
+        return decoder(sd, cfg, F.conv3d(t, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"]))
+
+    def sp(t):
+        if spatial and (t.shape[-1] > tp["latent"] or t.shape[-2] > tp["latent"]):
+            be = int(tp["sample"] * ov)
+            return _spatial_tiled(plain, t, tp["latent"], int(tp["latent"] * (1 - ov)), be, tp["sample"] - be)
+        return plain(t)
+
+    if temporal and z.shape[2] > tp["tlatent"]:
+        be = int(tp["tsample"] * ov)
+        return _temporal_tiled(sp, z, tp["tlatent"], int(tp["tlatent"] * (1 - ov)), be, tp["tsample"] - be)
+    return sp(z)
+
+
+def conv_flops(cfg, T, H, W):
+    """SURVEY.md §8(d) VAE unit of work: 2*Cin*Cout*k^3*To*Ho*Wo over every conv + 8*S*C^2 + 4*S^2*C for the
+    mid-block attention, for one encode of [1,3,T,H,W] and one decode of its latent.  Returns (enc, dec)."""
+    ch = list(cfg["block_out_channels"])
+    lpb = cfg.get("layers_per_block", 2)
+    zc = cfg.get("latent_channels", 16)
+
+    def conv(ci, co, k, t, h, w):
+        return 2.0 * ci * co * k ** 3 * t * h * w
+
+    def res(ci, co, t, h, w):
+        return conv(ci, co, 3, t, h, w) + conv(co, co, 3, t, h, w) + (conv(ci, co, 1, t, h, w) if ci != co else 0.0)
+
+    def mid(c, t, h, w):
+        s = t * h * w
+        return 2 * res(c, c, t, h, w) + 8.0 * s * c * c + 4.0 * s * s * c
+
+    t, h, w = T, H, W
+    enc = conv(cfg.get("in_channels", 3), ch[0], 3, t, h, w)
+    prev = ch[0]
+    for i, st in enumerate(block_strides(len(ch))):
+        for j in range(lpb):
+            enc += res(prev if j == 0 else ch[i], ch[i], t, h, w)
+        prev = ch[i]
+        if st is not None:
+            t, h, w = (t - 1) // st[0] + 1, (h - 1) // st[1] + 1, (w - 1) // st[2] + 1
+            enc += conv(ch[i], ch[i], 3, t, h, w)
+    enc += mid(ch[-1], t, h, w) + conv(ch[-1], 2 * zc, 3, t, h, w) + conv(2 * zc, 2 * zc, 1, t, h, w)
+    dec = conv(zc, zc, 1, t, h, w) + conv(zc, ch[-1], 3, t, h, w) + mid(ch[-1], t, h, w)
+    rev = ch[::-1]
+    prev = rev[0]
+    for i, st in enumerate(block_strides(len(ch))):
+        for j in range(lpb + 1):
+            dec += res(prev if j == 0 else rev[i], rev[i], t, h, w)
+        prev = rev[i]
+        if st is not None:
+            t, h, w = 1 + st[0] * (t - 1), h * st[1], w * st[2]
+            dec += conv(rev[i], rev[i], 3, t, h, w)
+    dec += conv(ch[0], cfg.get("out_channels", 3), 3, t, h, w)
+    return enc, dec
