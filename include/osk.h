@@ -129,6 +129,48 @@ int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_
 int osk_cfg_euler_bf16(const void* pred, int64_t n, const void* x, void* x_out,
                        float g_txt, float g_img, const float* g_img_vec, float dt, void* stream);
 
+/* =====================================================================================================
+ * Causal 3-D VAE (HunyuanVideo VAE, /root/reference/opensora/models/hunyuan_vae).  Activations are channels-last
+ * NDHWC bf16 ([B, T, H, W, C] contiguous); the NCTHW <-> NDHWC conversion happens once at the module boundary.
+ * ===================================================================================================== */
+
+/* ---- CausalConv3d (+ optional fused nearest upsample in front, + optional fused residual add behind).
+ * replaces CausalConv3d.forward = F.pad(x, (k/2,k/2,k/2,k/2,k-1,0), "replicate") + ChannelChunkConv3d
+ * (hunyuan_vae/unet_causal_3d_blocks.py:82-96; vae/utils.py:153-190 — the channel chunking is unnecessary here:
+ * 64-bit addressing), the interpolation of UpsampleCausal3D.forward (unet_causal_3d_blocks.py:136-150: frame 0
+ * upsampled in H,W only, later frames in T,H,W) when up_t/up_hw != 0, the strided DownsampleCausal3D conv
+ * (:175), the 1x1x1 conv_shortcut / quant_conv / post_quant_conv (ksize 1), and the `input + hidden` of
+ * ResnetBlockCausal3D.forward (:257) when res != NULL.
+ *   x   bf16 [B, T, H, W, Cin]   source grid BEFORE the virtual upsample; Cin = 8 * 2^j (pad 3 -> 8 channels)
+ *   w   bf16 [Cout, w_row_stride], element [co][((dt*3 + dh)*3 + dw)*Cin + ci] = weight[co][ci][dt][dh][dw];
+ *       rows zero-padded to w_row_stride >= round_up(ksize^3 * Cin, 64)
+ *   bias f32 [Cout] or NULL;  res bf16 [B, To, Ho, Wo, Cout] or NULL;  out bf16 [B, To, Ho, Wo, Cout]
+ *   To = (Tu-1)/stride_t + 1 with Tu = up_t ? 1 + 2(T-1) : T;  Ho = (Hu-1)/stride_h + 1 with Hu = up_hw ? 2H : H
+ * f32 accumulate, one rounding (bias and residual added in f32). */
+int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, int W, int Cin,
+                                 const void* w, int64_t w_row_stride, const float* bias, int Cout, int ksize,
+                                 int stride_t, int stride_h, int stride_w, int up_t, int up_hw,
+                                 const void* res, void* out, int To, int Ho, int Wo, void* stream);
+
+/* ---- GroupNorm statistics: sums[b][g] = (sum, sum of squares) in f64 over S voxels x C/G channels.
+ * first half of nn.GroupNorm(32, C, eps=1e-6) (unet_causal_3d_blocks.py:216,218; vae.py:115,229; diffusers
+ * Attention.group_norm).  x bf16 [B, S, C]; sums f64 [B, G, 2] (zeroed inside, on the stream).  C in
+ * {32..512} power of two, C/G <= 16. */
+int osk_groupnorm_stats_ndhwc_bf16(const void* x, int B, int64_t S, int C, int G, double* sums, void* stream);
+
+/* ---- GroupNorm apply (+ SiLU): y = bf16((x - mean_g) * rstd_g * gamma_c + beta_c); out = silu ? bf16(y*sigmoid(y)) : y
+ * second half of nn.GroupNorm + nonlinearity (unet_causal_3d_blocks.py:250-254).  gamma/beta f32 [C]. */
+int osk_groupnorm_apply_ndhwc_bf16(const void* x, const double* sums, const float* gamma, const float* beta,
+                                   void* out, int B, int64_t S, int C, int G, float eps, int silu, void* stream);
+
+/* ---- frame-causal masked softmax over attention score rows (mid-block attention, one head of dim C):
+ *   probs[i][j] = softmax_j(scale * scores[i][j])  over keys j < (i / keys_per_frame + 1) * keys_per_frame,
+ *   0 elsewhere (columns up to ld_probs are written, so probs is a K-padded GEMM operand).
+ * replaces prepare_causal_attention_mask + the softmax inside diffusers Attention / SDPA
+ * (unet_causal_3d_blocks.py:52-60,345-351).  keys_per_frame = 0: no mask.  scores f32, probs bf16. */
+int osk_masked_softmax_f32_bf16(const float* scores, int64_t ld_scores, void* probs, int64_t ld_probs,
+                                int Sq, int Sk, int keys_per_frame, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

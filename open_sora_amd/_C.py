@@ -32,6 +32,11 @@ SIGNATURES = {
     "osk_attention_fwd_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
                                _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
+    "osk_causal_conv3d_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
+                                     _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
+    "osk_groupnorm_stats_ndhwc_bf16": [_vp, _i32, _i64, _i32, _i32, _vp, _vp],
+    "osk_groupnorm_apply_ndhwc_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _vp],
+    "osk_masked_softmax_f32_bf16": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
 }
 
 
@@ -207,3 +212,54 @@ def cfg_euler(pred: torch.Tensor, x: torch.Tensor, x_out: torch.Tensor, g_txt: f
     _check(lib.osk_cfg_euler_bf16(pred.data_ptr(), n, x.data_ptr(), x_out.data_ptr(), g_txt, g_img,
                                   _p(g_img_vec), dt, _stream()), "osk_cfg_euler_bf16")
     return x_out
+
+
+# ----------------------------------------------------------------------------------------------
+# causal 3-D VAE kernels (NDHWC bf16)
+# ----------------------------------------------------------------------------------------------
+def conv_out_dims(T: int, H: int, W: int, stride=(1, 1, 1), up=(False, False)):
+    Tu = 1 + 2 * (T - 1) if up[0] else T
+    Hu, Wu = (2 * H, 2 * W) if up[1] else (H, W)
+    return (Tu - 1) // stride[0] + 1, (Hu - 1) // stride[1] + 1, (Wu - 1) // stride[2] + 1
+
+
+def causal_conv3d(x: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, ksize: int, stride=(1, 1, 1),
+                  up=(False, False), res=None) -> torch.Tensor:
+    """x bf16 [B, T, H, W, Cin] contiguous; w bf16 [Cout, Kpad] (tap-major, channel-minor, zero padded);
+    bias f32 [Cout] | None; out bf16 [B, To, Ho, Wo, Cout] contiguous; res like out | None."""
+    B, T, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    To, Ho, Wo = conv_out_dims(T, H, W, stride, up)
+    assert x.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (B, To, Ho, Wo, Cout), (out.shape, (B, To, Ho, Wo, Cout))
+    assert res is None or (res.is_contiguous() and res.shape == out.shape)
+    _check(lib.osk_causal_conv3d_ndhwc_bf16(x.data_ptr(), B, T, H, W, Cin, w.data_ptr(), w.stride(0), _p(bias), Cout,
+                                            ksize, stride[0], stride[1], stride[2], int(up[0]), int(up[1]), _p(res),
+                                            out.data_ptr(), To, Ho, Wo, _stream()), "osk_causal_conv3d_ndhwc_bf16")
+    return out
+
+
+def groupnorm_stats(x: torch.Tensor, G: int, sums: torch.Tensor) -> torch.Tensor:
+    """x bf16 [B, ..., C] contiguous -> sums f64 [B, G, 2]."""
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    _check(lib.osk_groupnorm_stats_ndhwc_bf16(x.data_ptr(), B, S, C, G, sums.data_ptr(), _stream()),
+           "osk_groupnorm_stats_ndhwc_bf16")
+    return sums
+
+
+def groupnorm_apply(x: torch.Tensor, sums: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor,
+                    G: int, eps: float = 1e-6, silu: bool = True) -> torch.Tensor:
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    _check(lib.osk_groupnorm_apply_ndhwc_bf16(x.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                              out.data_ptr(), B, S, C, G, eps, 1 if silu else 0, _stream()),
+           "osk_groupnorm_apply_ndhwc_bf16")
+    return out
+
+
+def masked_softmax(scores: torch.Tensor, probs: torch.Tensor, Sk: int, keys_per_frame: int, scale: float):
+    """scores f32 [Sq, >=Sk] (row stride arbitrary), probs bf16 [Sq, ldp] contiguous rows, ldp >= Sk."""
+    Sq = scores.shape[0]
+    _check(lib.osk_masked_softmax_f32_bf16(scores.data_ptr(), scores.stride(0), probs.data_ptr(), probs.stride(0), Sq,
+                                           Sk, keys_per_frame, scale, _stream()), "osk_masked_softmax_f32_bf16")
+    return probs

@@ -1,0 +1,180 @@
+// HBM-bound kernels of the causal 3-D VAE for gfx950, channels-last (NDHWC) bf16 activations:
+//   GroupNorm statistics (one streaming read), GroupNorm apply + SiLU (one read, one write),
+//   frame-causal masked row softmax of the mid-block attention scores.
+// All accesses are 16 B per lane (8 bf16 channels of one voxel).
+#include "osk_common.h"
+#include "../../include/osk.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// statistics: sums[b][g] = (sum x, sum x^2) over the S voxels x (C/G) channels of group g, in f64.
+// A block walks a contiguous slab of voxels; thread = (row-in-pass, 16-B channel chunk); per-thread f32
+// partials over <= a few hundred values, block reduction through LDS, one f64 atomic pair per (block, group).
+// Algorithmic bytes: 2 * S * C per batch item (read once).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_stats_kernel(const unsigned short* __restrict__ x, int64_t S, int C, int G,
+                                                      int rows_per_block, double* __restrict__ sums) {
+  __shared__ float red[2][256][8];
+  const int b = blockIdx.y;
+  const int cpr = C >> 3;            // 16-B chunks per voxel row (4..64, power of two)
+  const int rpp = 256 / cpr;         // voxel rows per pass
+  const int c = threadIdx.x % cpr, r = threadIdx.x / cpr;
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t row1 = row0 + rows_per_block;
+  row1 = row1 < S ? row1 : S;
+  const unsigned short* xb = x + (int64_t)b * S * C;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  for (int64_t row = row0 + r; row < row1; row += rpp) {
+    const uint4 u = *reinterpret_cast<const uint4*>(xb + row * C + c * 8);
+    float v[8];
+    unpack8(u, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][threadIdx.x][j] = s[j]; red[1][threadIdx.x][j] = q[j]; }
+  __syncthreads();
+  // thread t < C handles channel t: sum over the rpp row slots
+  for (int ch = threadIdx.x; ch < C; ch += 256) {
+    const int cc = ch >> 3, j = ch & 7;
+    float a = 0.f, a2 = 0.f;
+    for (int rr = 0; rr < rpp; ++rr) {
+      a += red[0][rr * cpr + cc][j];
+      a2 += red[1][rr * cpr + cc][j];
+    }
+    // channels of one group are adjacent lanes: reduce cpg = C/G lanes (power of two <= 16) by shuffles
+    const int cpg = C / G;
+    for (int o = cpg >> 1; o >= 1; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      a2 += __shfl_xor(a2, o, 64);
+    }
+    if ((ch & (cpg - 1)) == 0) {
+      double* dst = sums + ((int64_t)b * G + ch / cpg) * 2;
+      atomicAdd(dst, (double)a);
+      atomicAdd(dst + 1, (double)a2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply: y = bf16((x - mean_g) * rstd_g * gamma_c + beta_c);  out = silu ? bf16(y * sigmoid(y)) : y
+// (two roundings, as torch's bf16 GroupNorm followed by bf16 SiLU: unet_causal_3d_blocks.py:250-254).
+// Algorithmic bytes: 4 * S * C per batch item.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_apply_kernel(const unsigned short* __restrict__ x, const double* __restrict__ sums,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      unsigned short* __restrict__ out, int64_t S, int C, int G,
+                                                      float eps, int do_silu, int rows_per_block) {
+  __shared__ float sc[512], sh[512];
+  const int b = blockIdx.y;
+  const int cpg = C / G;
+  const double cnt = (double)S * cpg;
+  for (int ch = threadIdx.x; ch < C; ch += 256) {
+    const double* sg = sums + ((int64_t)b * G + ch / cpg) * 2;
+    const double mean = sg[0] / cnt;
+    double var = sg[1] / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = rsqrtf((float)var + eps);
+    const float a = rstd * gamma[ch];
+    sc[ch] = a;
+    sh[ch] = beta[ch] - (float)mean * a;
+  }
+  __syncthreads();
+  const int cpr = C >> 3, rpp = 256 / cpr;
+  const int c = threadIdx.x % cpr, r = threadIdx.x / cpr;
+  float a[8], d[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = sc[c * 8 + j]; d[j] = sh[c * 8 + j]; }
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t row1 = row0 + rows_per_block;
+  row1 = row1 < S ? row1 : S;
+  const unsigned short* xb = x + (int64_t)b * S * C;
+  unsigned short* ob = out + (int64_t)b * S * C;
+  for (int64_t row = row0 + r; row < row1; row += rpp) {
+    const uint4 u = *reinterpret_cast<const uint4*>(xb + row * C + c * 8);
+    float v[8];
+    unpack8(u, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = bf16_bits_to_f32(f32_to_bf16_bits(v[j] * a[j] + d[j]));
+      if (do_silu) y = silu(y);
+      v[j] = y;
+    }
+    *reinterpret_cast<uint4*>(ob + row * C + c * 8) = pack8(v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// P[i, j] = softmax_j(scale * s[i, j] + (frame(j) <= frame(i) ? 0 : -inf)), bf16 out, columns >= S_k zero-filled
+// up to ldp.  One wave per row, two passes over the f32 scores (max, then exp-sum-write).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) masked_softmax_kernel(const float* __restrict__ s, int64_t lds_,
+                                                            unsigned short* __restrict__ pr, int64_t ldp, int Sq,
+                                                            int Sk, int n_hw, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= Sq) return;
+  const int kmax = n_hw > 0 ? ((row / n_hw + 1) * n_hw < Sk ? (row / n_hw + 1) * n_hw : Sk) : Sk;  // keys allowed
+  const float* sr = s + (int64_t)row * lds_;
+  unsigned short* po = pr + (int64_t)row * ldp;
+  float mx = -INFINITY;
+  for (int j = lane; j < kmax; j += 64) mx = fmaxf(mx, sr[j]);
+  mx = wave_max(mx) * scale;
+  float sum = 0.f;
+  for (int j = lane; j < kmax; j += 64) sum += __expf(sr[j] * scale - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < (int)ldp; j += 64) {
+    const float e = j < kmax ? __expf(sr[j] * scale - mx) * inv : 0.f;
+    po[j] = f32_to_bf16_bits(e);
+  }
+}
+
+}  // namespace
+
+extern "C" int osk_groupnorm_stats_ndhwc_bf16(const void* x, int B, int64_t S, int C, int G, double* sums,
+                                              void* stream) {
+  if (!x || !sums || B <= 0 || S <= 0 || C < 32 || C > 512 || G <= 0) return OSK_EINVAL;
+  if ((C & (C - 1)) || C % G || ((C / G) & (C / G - 1)) || C / G > 16 || ((uintptr_t)x & 15)) return OSK_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, st);
+  if (e != hipSuccess) return (int)e;
+  const int rpp = 256 / (C >> 3);
+  int64_t nblk = (S + 2047) / 2048;           // >= 2048 voxels per block ...
+  if (nblk > 2048) nblk = 2048;               // ... and at most 2048 blocks per batch item
+  int64_t rows = (S + nblk - 1) / nblk;
+  rows = (rows + rpp - 1) / rpp * rpp;
+  nblk = (S + rows - 1) / rows;
+  dim3 grid((unsigned)nblk, B), block(256);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, (const unsigned short*)x, S, C, G, (int)rows, sums);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osk_groupnorm_apply_ndhwc_bf16(const void* x, const double* sums, const float* gamma,
+                                              const float* beta, void* out, int B, int64_t S, int C, int G,
+                                              float eps, int silu, void* stream) {
+  if (!x || !sums || !gamma || !beta || !out || B <= 0 || S <= 0 || C < 32 || C > 512 || G <= 0) return OSK_EINVAL;
+  if ((C & (C - 1)) || C % G || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return OSK_EUNSUPPORTED;
+  const int rpp = 256 / (C >> 3);
+  int64_t nblk = (S + 1023) / 1024;
+  if (nblk > 4096) nblk = 4096;
+  int64_t rows = (S + nblk - 1) / nblk;
+  rows = (rows + rpp - 1) / rpp * rpp;
+  nblk = (S + rows - 1) / rows;
+  dim3 grid((unsigned)nblk, B), block(256);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, (const unsigned short*)x, sums, gamma, beta,
+                     (unsigned short*)out, S, C, G, eps, silu, (int)rows);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osk_masked_softmax_f32_bf16(const float* scores, int64_t ld_scores, void* probs, int64_t ld_probs,
+                                           int Sq, int Sk, int keys_per_frame, float scale, void* stream) {
+  if (!scores || !probs || Sq <= 0 || Sk <= 0 || ld_scores < Sk || ld_probs < Sk || keys_per_frame < 0) return OSK_EINVAL;
+  dim3 grid((Sq + 3) / 4), block(256);
+  hipLaunchKernelGGL(masked_softmax_kernel, grid, block, 0, (hipStream_t)stream, scores, ld_scores,
+                     (unsigned short*)probs, ld_probs, Sq, Sk, keys_per_frame, scale);
+  return (int)hipGetLastError();
+}

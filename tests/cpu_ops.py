@@ -139,3 +139,68 @@ def cfg_euler(pred, x, x_out, g_txt, g_img, dt, g_img_vec=None):
     v = u2 + gi * (u - u2) + g_txt * (c - u)
     x_out.copy_((x.float().reshape(-1) + dt * v).reshape(x.shape).to(x_out.dtype))
     return x_out
+
+
+# ----------------------------------------------------------------------------------------------
+# causal 3-D VAE kernels (NDHWC bf16): semantics of include/osk.h, fp32 math, one rounding
+# ----------------------------------------------------------------------------------------------
+def conv_out_dims(T, H, W, stride=(1, 1, 1), up=(False, False)):
+    Tu = 1 + 2 * (T - 1) if up[0] else T
+    Hu, Wu = (2 * H, 2 * W) if up[1] else (H, W)
+    return (Tu - 1) // stride[0] + 1, (Hu - 1) // stride[1] + 1, (Wu - 1) // stride[2] + 1
+
+
+def causal_conv3d(x, w, bias, out, ksize, stride=(1, 1, 1), up=(False, False), res=None):
+    B, T, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    taps = ksize ** 3
+    wk = w[:, : taps * Cin].float().reshape(Cout, ksize, ksize, ksize, Cin).permute(0, 4, 1, 2, 3)
+    assert float(w[:, taps * Cin:].float().abs().sum()) == 0.0, "weight K padding must be zero"
+    xs = x.float().permute(0, 4, 1, 2, 3)
+    if up[1]:
+        xs = xs.repeat_interleave(2, 3).repeat_interleave(2, 4)
+    if up[0]:
+        xs = torch.cat((xs[:, :, :1], xs[:, :, 1:].repeat_interleave(2, 2)), 2)
+    if ksize > 1:
+        xs = F.pad(xs, (ksize // 2, ksize // 2, ksize // 2, ksize // 2, ksize - 1, 0), mode="replicate")
+    y = F.conv3d(xs, wk, None if bias is None else bias.float(), stride=stride).permute(0, 2, 3, 4, 1)
+    if res is not None:
+        y = y + res.float()
+    out.copy_(y.to(out.dtype))
+    return out
+
+
+def groupnorm_stats(x, G, sums):
+    B, C = x.shape[0], x.shape[-1]
+    xf = x.double().reshape(B, -1, G, C // G)
+    sums[:, :, 0] = xf.sum((1, 3))
+    sums[:, :, 1] = (xf * xf).sum((1, 3))
+    return sums
+
+
+def groupnorm_apply(x, sums, gamma, beta, out, G, eps=1e-6, silu=True):
+    B, C = x.shape[0], x.shape[-1]
+    n = x.numel() // (B * G)
+    mean = sums[:, :, 0] / n
+    var = (sums[:, :, 1] / n - mean * mean).clamp_min(0)
+    rstd = torch.rsqrt(var.float() + eps)
+    shp = [B] + [1] * (x.ndim - 2) + [C]
+    mean_c = mean.float().repeat_interleave(C // G, 1).reshape(shp)
+    rstd_c = rstd.repeat_interleave(C // G, 1).reshape(shp)
+    y = ((x.float() - mean_c) * rstd_c * gamma.float() + beta.float()).to(BF).float()
+    if silu:
+        y = F.silu(y)
+    out.copy_(y.to(out.dtype))
+    return out
+
+
+def masked_softmax(scores, probs, Sk, keys_per_frame, scale):
+    Sq = scores.shape[0]
+    s = scores[:, :Sk].float() * scale
+    if keys_per_frame > 0:
+        fq = torch.arange(Sq) // keys_per_frame
+        fk = torch.arange(Sk) // keys_per_frame
+        s = s.masked_fill(fk[None, :] > fq[:, None], float("-inf"))
+    probs.zero_()
+    probs[:, :Sk] = torch.softmax(s, -1).to(probs.dtype)
+    return probs

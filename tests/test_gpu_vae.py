@@ -1,0 +1,237 @@
+"""GPU parity tests of the causal 3-D VAE path: kernels (through the C ABI) against the CPU oracle, then the whole
+encode / decode against the goldens produced by the real reference, then size-independent properties at the
+BASELINE config-3 size (33 x 256 x 256)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import configs, synth, vae_oracle as V
+from tests.util import assert_parity
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rnd(name, shape, std=1.0, seed=11):
+    return torch.from_numpy(synth.bf16_round(synth.normal(name, seed, shape, std=std)))
+
+
+def _pack_w(w, cin_p):
+    """[Cout, Cin, k, k, k] fp32 (bf16-representable) -> the kernel's [Cout, Kpad] bf16 layout."""
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    wk = torch.zeros(co, k, k, k, cin_p)
+    wk[..., :ci] = w.permute(0, 2, 3, 4, 1)
+    K = k ** 3 * cin_p
+    out = torch.zeros(co, (K + 63) // 64 * 64)
+    out[:, :K] = wk.reshape(co, K)
+    return out.to(DEV).to(BF)
+
+
+def _conv_ref(x, w, b, stride, up, res):
+    """x NCTHW fp32 -> NCTHW fp64 reference of upsample -> replicate/causal pad -> conv (+res)."""
+    k = w.shape[-1]
+    xs = x.double()
+    if up[0] or up[1]:
+        xs = V.upsample_nearest_causal(xs, (2 if up[0] else 1, 2 if up[1] else 1, 2 if up[1] else 1))
+    if k > 1:
+        xs = F.pad(xs, (k // 2, k // 2, k // 2, k // 2, k - 1, 0), mode="replicate")
+    y = F.conv3d(xs, w.double(), b.double(), stride=stride)
+    return y if res is None else y + res.double()
+
+
+CONV_CASES = [
+    # Cin, Cout, k, stride, up(t, hw), B, T, H, W, residual
+    (3, 32, 3, (1, 1, 1), (False, False), 1, 5, 12, 10, False),      # encoder conv_in (3 -> 8 padded channels)
+    (32, 64, 3, (1, 1, 1), (False, False), 2, 3, 9, 7, True),        # Cin < 64 path, ragged M, residual
+    (64, 64, 3, (1, 2, 2), (False, False), 1, 4, 11, 13, False),     # spatial downsample, odd H/W
+    (64, 128, 3, (2, 2, 2), (False, False), 1, 5, 8, 8, False),      # spatio-temporal downsample
+    (128, 128, 3, (1, 1, 1), (True, True), 1, 3, 6, 5, False),       # upsample T,H,W folded into the gather
+    (64, 64, 3, (1, 1, 1), (False, True), 2, 2, 5, 6, False),        # upsample H,W only
+    (128, 128, 3, (1, 1, 1), (True, True), 1, 1, 4, 4, False),       # single frame: T_out = 1
+    (128, 3, 3, (1, 1, 1), (False, False), 1, 3, 10, 9, False),      # decoder conv_out (3 channels, scalar stores)
+    (16, 128, 3, (1, 1, 1), (False, False), 1, 3, 6, 6, False),      # decoder conv_in
+    (32, 32, 1, (1, 1, 1), (False, False), 1, 3, 5, 7, False),       # quant_conv (K = 32 padded to 64)
+    (64, 128, 1, (1, 1, 1), (False, False), 1, 2, 9, 9, False),      # conv_shortcut
+    (256, 160, 3, (1, 1, 1), (False, False), 1, 2, 6, 7, True),      # two N tiles, ragged N
+    (512, 512, 3, (1, 1, 1), (False, False), 1, 2, 4, 4, True),      # widest layer
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[0]}to{c[1]}k{c[2]}s{''.join(map(str, c[3]))}u{int(c[4][0])}{int(c[4][1])}")
+def test_causal_conv3d(hip_lib, case):
+    ci, co, k, stride, up, B, T, H, W, with_res = case
+    x = rnd("x", (B, ci, T, H, W))
+    w = rnd("w", (co, ci, k, k, k), std=(ci * k ** 3) ** -0.5)
+    b = rnd("b", (co,), std=0.1)
+    cip = 8
+    while cip < ci:
+        cip *= 2
+    xn = torch.zeros(B, T, H, W, cip)
+    xn[..., :ci] = x.permute(0, 2, 3, 4, 1)
+    To, Ho, Wo = hip_lib.conv_out_dims(T, H, W, stride, up)
+    res = rnd("res", (B, co, To, Ho, Wo)) if with_res else None
+    ref = _conv_ref(x, w, b, stride, up, res)
+    assert tuple(ref.shape[2:]) == (To, Ho, Wo)
+    out = torch.full((B, To, Ho, Wo, co), float("nan"), dtype=BF, device=DEV)
+    hip_lib.causal_conv3d(xn.to(DEV).to(BF), _pack_w(w, cip), b.to(DEV).float(), out, k, stride, up,
+                          None if res is None else res.permute(0, 2, 3, 4, 1).contiguous().to(DEV).to(BF))
+    got = out.float().cpu().permute(0, 4, 1, 2, 3).double()
+    # f32 accumulation of exact bf16 products + one bf16 rounding
+    err = (got - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-3 * float(ref.abs().max())
+    assert torch.isfinite(got).all() and (err <= tol).all(), f"max err {err.max():.3e} (ref max {ref.abs().max():.3e})"
+
+
+def test_conv3d_rejects_bad_arguments(hip_lib):
+    x = torch.zeros(1, 2, 4, 4, 24, dtype=BF, device=DEV)
+    w = torch.zeros(8, 27 * 24 + 8, dtype=BF, device=DEV)
+    out = torch.zeros(1, 2, 4, 4, 8, dtype=BF, device=DEV)
+    with pytest.raises(RuntimeError):  # Cin not 8 * 2^j
+        hip_lib.causal_conv3d(x, w, None, out, 3)
+    x = torch.zeros(1, 2, 4, 4, 32, dtype=BF, device=DEV)
+    with pytest.raises(RuntimeError):  # weight rows not padded to a multiple of 64 of K = 27 * 32
+        hip_lib.causal_conv3d(x, torch.zeros(8, 27 * 32, dtype=BF, device=DEV)[:, :800], None, out, 3)
+
+
+@pytest.mark.parametrize("C,S,B,silu", [(32, 1000, 2, True), (64, 777, 1, True), (128, 4096, 1, False),
+                                        (256, 513, 2, True), (512, 2048, 1, True)])
+def test_groupnorm_silu(hip_lib, C, S, B, silu):
+    x = rnd("x", (B, S, C), std=1.5) + 0.7
+    x = torch.from_numpy(synth.bf16_round(x.numpy()))
+    gamma, beta = rnd("g", (C,), std=0.2) + 1.0, rnd("b", (C,), std=0.2)
+    xd = x.to(DEV).to(BF)
+    sums = torch.empty(B, 32, 2, dtype=torch.float64, device=DEV)
+    hip_lib.groupnorm_stats(xd, 32, sums)
+    xg = x.double().reshape(B, S, 32, C // 32)
+    assert torch.allclose(sums[:, :, 0].cpu(), xg.sum((1, 3)), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(sums[:, :, 1].cpu(), (xg * xg).sum((1, 3)), rtol=1e-6, atol=1e-3)
+    out = torch.empty_like(xd)
+    hip_lib.groupnorm_apply(xd, sums, gamma.to(DEV), beta.to(DEV), out, 32, 1e-6, silu)
+    y = F.group_norm(x.transpose(1, 2), 32, gamma, beta, 1e-6).transpose(1, 2).to(BF).float()
+    ref = (F.silu(y) if silu else y).to(BF).float()
+    d = (out.float().cpu() - ref).abs()
+    assert (d <= 2.0 ** -6 * ref.abs() + 2e-3).all(), f"max err {d.max():.3e}"
+
+
+@pytest.mark.parametrize("S,n_hw", [(48, 16), (300, 100), (257, 0)])
+def test_masked_softmax(hip_lib, S, n_hw):
+    s = torch.from_numpy(synth.normal("s", 3, (S, S), std=20.0))
+    Sp = (S + 63) // 64 * 64
+    S4 = (S + 3) // 4 * 4
+    sd = torch.zeros(S, S4, device=DEV)
+    sd[:, :S] = s.to(DEV)
+    probs = torch.full((S, Sp), 7.0, dtype=BF, device=DEV)
+    hip_lib.masked_softmax(sd, probs, S, n_hw, 0.125)
+    z = s * 0.125
+    if n_hw:
+        f = torch.arange(S) // n_hw
+        z = z.masked_fill(f[None, :] > f[:, None], float("-inf"))
+    ref = torch.softmax(z, -1)
+    got = probs.float().cpu()
+    assert (got[:, S:] == 0).all()
+    assert (got[:, :S] - ref).abs().max() <= 2.0 ** -8
+
+
+def _sd(cfg, dtype=torch.float32, device="cpu"):
+    return {k: torch.from_numpy(v).to(device=device, dtype=dtype) for k, v in synth.make_params(synth.vae_param_shapes(cfg), 0).items()}
+
+
+def _model(cfg):
+    from open_sora_amd import hunyuan_vae
+
+    m = hunyuan_vae.CausalVAE3D_HUNYUAN(device_map=DEV, torch_dtype=BF, **cfg)
+    m.load_state_dict(_sd(cfg, BF, DEV), strict=True)
+    return m
+
+
+@pytest.mark.parametrize("name", list(configs.VAE_GOLDEN))
+def test_vae_encode_decode_vs_reference_golden(hip_lib, name):
+    cfg, B, T, H, W = configs.VAE_GOLDEN[name]
+    g = np.load(os.path.join(GOLDEN_DIR, f"vae_{name}.npz"))
+    m = _model(cfg)
+    x = torch.from_numpy(synth.vae_video(B, T, H, W))
+    zin = torch.from_numpy(synth.vae_latent(B, *g["z"].shape[2:]))
+    sdb = _sd(cfg, BF)
+    with torch.inference_mode():
+        z = m.encode(x.to(DEV).to(BF), sample_posterior=False)
+        dec = m.decode(zin.to(DEV).to(BF))
+        torch.cuda.synchronize()
+        z_ref = V.encode(sdb, cfg, x.to(BF))     # reference-precision comparator: the oracle run in bf16
+        d_ref = V.decode(sdb, cfg, zin.to(BF))
+    assert_parity(z, torch.from_numpy(g["z"]), z_ref, f"vae encode [{name}]")
+    assert_parity(dec, torch.from_numpy(g["dec"]), d_ref, f"vae decode [{name}]")
+
+
+def test_vae_tiled_vs_reference_golden(hip_lib):
+    name = "c32_tiled"
+    cfg, B, T, H, W = configs.VAE_TILED_GOLDEN[name]
+    g = np.load(os.path.join(GOLDEN_DIR, f"vae_{name}.npz"))
+    m = _model(cfg)
+    m.enable_tiling()
+    x = torch.from_numpy(synth.vae_video(B, T, H, W))
+    zin = torch.from_numpy(synth.vae_latent(B, *g["z"].shape[2:]))
+    sdb = _sd(cfg, BF)
+    with torch.inference_mode():
+        z = m.encode(x.to(DEV).to(BF), sample_posterior=False)
+        dec = m.decode(zin.to(DEV).to(BF))
+        z_ref = V.encode_tiled(sdb, cfg, x.to(BF))
+        d_ref = V.decode_tiled(sdb, cfg, zin.to(BF))
+    assert_parity(z, torch.from_numpy(g["z"]), z_ref, "vae tiled encode")
+    assert_parity(dec, torch.from_numpy(g["dec"]), d_ref, "vae tiled decode")
+
+
+def test_full_size_conv_spot_check(hip_lib):
+    """BASELINE config 3 size: the single largest conv of the decoder (dec.up2 upsampler: 256 -> 256 channels,
+    17 x 128 x 128 -> 33 x 256 x 256 with the upsample folded in) checked voxel-by-voxel on a random sample
+    (borders included) against a direct fp64 evaluation of pad(upsample(x)) * w."""
+    ci = co = 256
+    T, H, W = 17, 128, 128
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(1, T, H, W, ci, device=DEV, generator=g).to(BF)
+    w = (torch.randn(co, 3, 3, 3, ci, device=DEV, generator=g) * (27 * ci) ** -0.5).to(BF)
+    b = torch.randn(co, device=DEV, generator=g) * 0.1
+    To, Ho, Wo = hip_lib.conv_out_dims(T, H, W, (1, 1, 1), (True, True))
+    assert (To, Ho, Wo) == (33, 256, 256)
+    out = torch.empty(1, To, Ho, Wo, co, dtype=BF, device=DEV)
+    hip_lib.causal_conv3d(x, w.reshape(co, -1).contiguous(), b, out, 3, (1, 1, 1), (True, True))
+    torch.cuda.synchronize()
+    rs = np.random.RandomState(0)
+    pts = [(0, 0, 0), (To - 1, Ho - 1, Wo - 1), (1, 0, Wo - 1), (2, Ho - 1, 0)] + \
+          [(rs.randint(To), rs.randint(Ho), rs.randint(Wo)) for _ in range(60)]
+    xc, wc, bc = x[0].double(), w.double(), b.double()
+    for (t, h, ww) in pts:
+        acc = bc.clone()
+        for dt in range(3):
+            tu = min(max(t + dt - 2, 0), To - 1)
+            ts = 0 if tu == 0 else 1 + (tu - 1) // 2
+            for dh in range(3):
+                hs = min(max(h + dh - 1, 0), Ho - 1) // 2
+                for dw in range(3):
+                    ws = min(max(ww + dw - 1, 0), Wo - 1) // 2
+                    acc += wc[:, dt, dh, dw, :] @ xc[ts, hs, ws]
+        got = out[0, t, h, ww].double()
+        assert (got - acc).abs().max() <= 2.0 ** -7 * acc.abs().max() + 1e-3, (t, h, ww)
+
+
+def test_full_size_encode_decode_properties(hip_lib):
+    """BASELINE config 3: [1,3,33,256,256] through the shipped architecture (128/256/512/512, 2 layers per block).
+    Size-independent properties: shapes, finiteness, and batch independence (every kernel treats the batch items
+    separately; only the f64 GroupNorm atomics may reorder)."""
+    cfg = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2)
+    m = _model(cfg)
+    x = torch.from_numpy(synth.vae_video(1, 33, 256, 256)).to(DEV).to(BF)
+    with torch.inference_mode():
+        z = m.encode(x, sample_posterior=False)
+        assert list(z.shape) == [1, 16, 9, 32, 32] and torch.isfinite(z.float()).all()
+        dec = m.decode(z)
+        assert list(dec.shape) == [1, 3, 33, 256, 256] and torch.isfinite(dec.float()).all()
+        x2 = torch.cat((x[:, :, :5, :64, :64], x[:, :, 5:10, :64, :64]), 0)
+        z2 = m.encode(x2, sample_posterior=False)
+        za = m.encode(x2[:1], sample_posterior=False)
+        zb = m.encode(x2[1:], sample_posterior=False)
+        assert (z2 - torch.cat((za, zb))).abs().max() <= 2.0 ** -6 * z2.abs().max()
