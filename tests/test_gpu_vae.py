@@ -108,8 +108,8 @@ def test_groupnorm_silu(hip_lib, C, S, B, silu):
     sums = torch.empty(B, 32, 2, dtype=torch.float64, device=DEV)
     hip_lib.groupnorm_stats(xd, 32, sums)
     xg = x.double().reshape(B, S, 32, C // 32)
-    assert torch.allclose(sums[:, :, 0].cpu(), xg.sum((1, 3)), rtol=1e-6, atol=1e-3)
-    assert torch.allclose(sums[:, :, 1].cpu(), (xg * xg).sum((1, 3)), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(sums[:, :, 0].cpu(), xg.sum((1, 3)), rtol=1e-5, atol=1e-3)  # f32 per-thread partials, f64 across blocks
+    assert torch.allclose(sums[:, :, 1].cpu(), (xg * xg).sum((1, 3)), rtol=1e-5, atol=1e-3)  # f32 per-thread partials, f64 across blocks
     out = torch.empty_like(xd)
     hip_lib.groupnorm_apply(xd, sums, gamma.to(DEV), beta.to(DEV), out, 32, 1e-6, silu)
     y = F.group_norm(x.transpose(1, 2), 32, gamma, beta, 1e-6).transpose(1, 2).to(BF).float()
