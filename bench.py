@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=16, help="latent frames T_lat")
     ap.add_argument("--latent-hw", type=int, default=64, help="latent height = width")
     ap.add_argument("--cfg-batch", type=int, default=3, help="3 = reference CFG triple, 1 = pure step")
+    ap.add_argument("--workload", default="dit", choices=["dit", "vae"],
+                    help="dit = BASELINE configs[1] (default, the headline metric); vae = configs[2]")
+    ap.add_argument("--vae-frames", type=int, default=33)
+    ap.add_argument("--vae-size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
     return ap.parse_args()
@@ -78,6 +82,84 @@ def cpu_baseline(cfg, L_img, L_txt, cfg_batch, budget_s):
     return t_double, t_single, step_s, ncores
 
 
+def vae_cpu_baseline(budget_s):
+    """The oracle's CausalConv3d (fp32, all host cores) on a bounded sample: ONE 128->128 3x3x3 conv at
+    9 x 128 x 128 (a slice of the encoder's first ResNet stage), scaled to the whole encode+decode by FLOPs."""
+    import torch.nn.functional as F
+    from oracle import vae_oracle as V
+
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 128, 9, 128, 128, generator=g)
+    sd = {"c.conv.weight": torch.randn(128, 128, 3, 3, 3, generator=g) * 0.02, "c.conv.bias": torch.zeros(128)}
+    with torch.inference_mode():
+        V.causal_conv3d(sd, "c", x[:, :, :2])  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            V.causal_conv3d(sd, "c", x)
+            n += 1
+            if time.perf_counter() - t0 > min(budget_s, 20.0) or n >= 8:
+                break
+        dt = (time.perf_counter() - t0) / n
+    fl = 2.0 * 128 * 128 * 27 * 9 * 128 * 128
+    return fl / dt, ncores, dt
+
+
+def bench_vae(args, dev):
+    """BASELINE configs[2]: 3D-VAE (CausalConv3d) encode + decode of a [1,3,T,256,256] video, 1x MI355X."""
+    from open_sora_amd import _C, configs, hunyuan_vae
+
+    cfg = dict(configs.VAE["hunyuan"])
+    T, S = args.vae_frames, args.vae_size
+    torch.manual_seed(1234)
+    model = hunyuan_vae.CausalVAE3D_HUNYUAN(device_map=dev, torch_dtype=torch.bfloat16, **cfg)
+    g = torch.Generator(device=dev).manual_seed(42)
+    x = (torch.randn(1, 3, T, S, S, device=dev, generator=g) * 0.5).clamp(-1, 1).to(torch.bfloat16)
+
+    def step():
+        z = model.encode(x, sample_posterior=False)
+        return model.decode(z)
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            out = step()
+        _C.PROFILE_CONV = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof, _C.PROFILE_CONV = _C.PROFILE_CONV, None
+    assert torch.isfinite(out.float()).all() and list(out.shape) == [1, 3, 1 + 4 * ((T - 1) // 4), S, S]
+    ms = elapsed / args.steps * 1e3
+    enc_f, dec_f = configs.vae_flops(cfg, T, S, S)
+    conv_ms = sum(s.elapsed_time(e) for s, e, _ in prof) / args.steps
+    ach = (enc_f + dec_f) / (conv_ms * 1e-3) / 1e12
+    res = {
+        "metric": "vae_video_frames_per_sec (encode + decode; ms per encode+decode in ms_per_step)",
+        "value": round(T / (ms * 1e-3), 3), "unit": "video frames/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Hunyuan causal 3-D VAE (128/256/512/512, 16 latent ch) encode + decode of [1,3,{T},{S},{S}], no tiling",
+                   "flops_encode": enc_f, "flops_decode": dec_f},
+        "step_tflops": round((enc_f + dec_f) / (ms * 1e-3) / 1e12, 1),
+        "step_mfma_frac": round((enc_f + dec_f) / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+        "roofline": {"bound": "mfma", "kernel": "conv3d_kernel", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches": len(prof) // args.steps, "total_conv_ms_per_step": round(conv_ms, 3)},
+    }
+    if not args.no_cpu_baseline:
+        fps, ncores, dt = vae_cpu_baseline(args.cpu_budget_s)
+        cpu_s = (enc_f + dec_f) / fps
+        res["cpu_baseline"] = {"value": round(T / cpu_s, 5), "unit": "video frames/s", "cores": ncores, "kind": "port",
+                               "sample": f"oracle CausalConv3d fp32 on {ncores} host threads: one 128->128 3x3x3 conv at 9x128x128 "
+                                         f"({dt:.2f} s, {fps / 1e12:.3f} TFLOP/s), encode+decode extrapolated by FLOPs = {cpu_s:.1f} s"}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -93,6 +175,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if args.workload == "vae":
+        assert world == 1, "the VAE workload is single-GPU (BASELINE configs[2])"
+        return bench_vae(args, dev)
 
     from open_sora_amd import _C, configs, mmdit, sampling
 

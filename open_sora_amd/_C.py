@@ -217,6 +217,10 @@ def cfg_euler(pred: torch.Tensor, x: torch.Tensor, x_out: torch.Tensor, g_txt: f
 # ----------------------------------------------------------------------------------------------
 # causal 3-D VAE kernels (NDHWC bf16)
 # ----------------------------------------------------------------------------------------------
+# bench.py sets this to a list to collect (start, end, padded-channel FLOPs) around every conv launch
+PROFILE_CONV = None
+
+
 def conv_out_dims(T: int, H: int, W: int, stride=(1, 1, 1), up=(False, False)):
     Tu = 1 + 2 * (T - 1) if up[0] else T
     Hu, Wu = (2 * H, 2 * W) if up[1] else (H, W)
@@ -232,9 +236,16 @@ def causal_conv3d(x: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, ksi
     To, Ho, Wo = conv_out_dims(T, H, W, stride, up)
     assert x.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (B, To, Ho, Wo, Cout), (out.shape, (B, To, Ho, Wo, Cout))
     assert res is None or (res.is_contiguous() and res.shape == out.shape)
+    prof = PROFILE_CONV
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _check(lib.osk_causal_conv3d_ndhwc_bf16(x.data_ptr(), B, T, H, W, Cin, w.data_ptr(), w.stride(0), _p(bias), Cout,
                                             ksize, stride[0], stride[1], stride[2], int(up[0]), int(up[1]), _p(res),
                                             out.data_ptr(), To, Ho, Wo, _stream()), "osk_causal_conv3d_ndhwc_bf16")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * Cin * Cout * ksize ** 3 * B * To * Ho * Wo))
     return out
 
 

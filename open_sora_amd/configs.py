@@ -34,3 +34,59 @@ def flops_per_forward(cfg: dict, B: int, L_img: int, L_txt: int) -> float:
 
 def attention_flops(B: int, H: int, Lq: int, Lk: int, hd: int) -> float:
     return 4.0 * B * H * float(Lq) * float(Lk) * hd
+
+
+# ---- Hunyuan causal 3-D VAE (the shipped architecture, /root/reference/configs/diffusion/inference/256px.py:57-66)
+VAE = {
+    "hunyuan": dict(in_channels=3, out_channels=3, latent_channels=16, block_out_channels=(128, 256, 512, 512),
+                    layers_per_block=2, norm_num_groups=32, time_compression_ratio=4, spatial_compression_ratio=8),
+}
+
+
+def vae_flops(cfg: dict, T: int, H: int, W: int):
+    """SURVEY.md §8(d) VAE unit of work: 2*Cin*Cout*k^3*To*Ho*Wo over every conv plus 8*S*C^2 + 4*S^2*C for the
+    mid-block attention, for one encode of [1,3,T,H,W] and one decode of its latent -> (encode, decode) FLOPs."""
+    import math
+
+    ch = list(cfg["block_out_channels"])
+    lpb, zc = cfg.get("layers_per_block", 2), cfg.get("latent_channels", 16)
+    ns, nt = int(math.log2(cfg.get("spatial_compression_ratio", 8))), int(math.log2(cfg.get("time_compression_ratio", 4)))
+    n = len(ch)
+    strides = []
+    for i in range(n):
+        sp, tm = i < ns, (i >= n - 1 - nt) and i != n - 1
+        strides.append(((2 if tm else 1), (2 if sp else 1), (2 if sp else 1)) if (sp or tm) else None)
+
+    def conv(ci, co, k, t, h, w):
+        return 2.0 * ci * co * k ** 3 * t * h * w
+
+    def res(ci, co, t, h, w):
+        return conv(ci, co, 3, t, h, w) + conv(co, co, 3, t, h, w) + (conv(ci, co, 1, t, h, w) if ci != co else 0.0)
+
+    def mid(c, t, h, w):
+        s = t * h * w
+        return 2 * res(c, c, t, h, w) + 8.0 * s * c * c + 4.0 * s * s * c
+
+    t, h, w = T, H, W
+    enc = conv(cfg.get("in_channels", 3), ch[0], 3, t, h, w)
+    prev = ch[0]
+    for i, st in enumerate(strides):
+        for j in range(lpb):
+            enc += res(prev if j == 0 else ch[i], ch[i], t, h, w)
+        prev = ch[i]
+        if st is not None:
+            t, h, w = (t - 1) // st[0] + 1, (h - 1) // st[1] + 1, (w - 1) // st[2] + 1
+            enc += conv(ch[i], ch[i], 3, t, h, w)
+    enc += mid(ch[-1], t, h, w) + conv(ch[-1], 2 * zc, 3, t, h, w) + conv(2 * zc, 2 * zc, 1, t, h, w)
+    dec = conv(zc, zc, 1, t, h, w) + conv(zc, ch[-1], 3, t, h, w) + mid(ch[-1], t, h, w)
+    rev = ch[::-1]
+    prev = rev[0]
+    for i, st in enumerate(strides):
+        for j in range(lpb + 1):
+            dec += res(prev if j == 0 else rev[i], rev[i], t, h, w)
+        prev = rev[i]
+        if st is not None:
+            t, h, w = 1 + st[0] * (t - 1), h * st[1], w * st[2]
+            dec += conv(rev[i], rev[i], 3, t, h, w)
+    dec += conv(ch[0], cfg.get("out_channels", 3), 3, t, h, w)
+    return enc, dec
