@@ -1,0 +1,218 @@
+// Flash-attention forward for head_dim 72 (DiT-XL geometry), gfx950: hand-scheduled main loop.
+//
+// Structure = attention_w64.hip (4 waves x 64 query rows, one wave per SIMD, LDS-DMA staged 64-key tiles,
+// swapped-operand v_mfma_f32_32x32x16_bf16), but the whole K/V loop is ONE asm statement emitted by
+// tools/gen_attn_asm.py (attention_asm72_body.inc): explicit register file (O^T and Q in AGPRs, two score tiles,
+// P and two 4-slot fragment rings in VGPRs), every MFMA shadow filled by hand with ~5 issue slots of LDS reads /
+// exp2 / pack / max work, counted lgkmcnt waits, one barrier per tile.  See the generator's header for the
+// dataflow; this file is the wrapper: LDS init, Q pre-scale, the asm operands, the epilogue.
+//
+// Numerics vs attention_w64.hip / attention_fwd.hip:
+//  * Q is multiplied by scale*log2(e) and re-rounded to bf16 once per workgroup (one extra bf16 rounding of q);
+//  * the online-softmax reference max M is kept bf16-exact inside the contraction (Q padding dim 72 = -M, K
+//    padding dim 72 = 1.0), so P = exp2(S') with S' straight out of the MFMA; M moves only when a row max exceeds
+//    it by more than 8 (log2 units): P <= 2^8, O and the row sum (ones row of V^T) carry the same factor.
+// Requires seg_len % 64 == 0 (no ragged key tile); the dispatcher falls back to attention_fwd.hip otherwise.
+#include "attention_params.h"
+#include "attention_asm72_regs.inc"
+
+namespace osk_attn {
+namespace {
+
+constexpr int HD = 72, NKS = 5, NDT = 3;
+
+OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+OSK_DEV uint64_t rfl64(uint64_t v) {
+  return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
+}
+
+template <bool SAFE>
+__global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  int bh, qb;
+  block_to_work(p, (p.Lq + 255) / 256, bh, qb);
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  // ---- LDS: zero (a tile slot that is never filled must hold finite data), ones row of both V^T slots,
+  //      constant chunk {1.0, 0 x 7} = K's padding dims 72..79
+  for (int i = tid; i < OSK72_SMEM / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (tid < 64) {
+    const int slot = tid >> 5;
+    reinterpret_cast<unsigned*>(smem + OSK72_VOFF0 + slot * OSK72_VTILE + HD * 128)[tid & 31] = 0x3F803F80u;
+  }
+  if (tid == 64) *reinterpret_cast<unsigned*>(smem + OSK72_CONST_OFF) = 0x00003F80u;
+  __syncthreads();
+
+  // ---- Q fragments, pre-scaled by scale*log2(e), -> AGPRs a[OSK72_AQ0 ...] (u-major, k-step, 4 words)
+  int qi[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    qi[u] = qb * 256 + wave * 64 + u * 32 + l31;
+    const int qc = qi[u] < p.Lq ? qi[u] : p.Lq - 1;
+    const unsigned short* qrow = p.q + b * p.qbs + (int64_t)qc * p.qrs + h * HD;
+    unsigned w[NKS * 4];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int e0 = ks * 16 + hi * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e0 < HD) v = *reinterpret_cast<const uint4*>(qrow + e0);
+      float f[8];
+      unpack8(v, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] *= p.sc;
+      const uint4 s = pack8(f);
+      w[ks * 4 + 0] = s.x; w[ks * 4 + 1] = s.y; w[ks * 4 + 2] = s.z; w[ks * 4 + 3] = s.w;
+    }
+#define OSK_QIN                                                                                              \
+  "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),    \
+      "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]), "v"(w[16]), "v"(w[17]), "v"(w[18]), \
+      "v"(w[19])
+    if (u == 0) {
+      asm volatile(OSK72_QW0 ::OSK_QIN : OSK72_A_CLOBBERS);
+    } else {
+      asm volatile(OSK72_QW1 ::OSK_QIN : OSK72_A_CLOBBERS);
+    }
+  }
+
+  // ---- per-lane LDS-DMA source offsets (bytes from the loader's tile base) of this wave's instruction slots:
+  //      K instruction j = wave + 4 i (j = 8: the 8-dim column image), V^T instruction j = (3 - wave) + 4 i
+  const int srow8 = lane >> 3, spos = lane & 7;
+  unsigned koff[3], voff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = wave + 4 * i;
+    unsigned o = 0;
+    if (j < 8) {
+      const int row = j * 8 + srow8;
+      o = (unsigned)(((int64_t)row * p.krs + ((spos ^ ((row >> 1) & 7)) << 3)) * 2);
+    } else if (j == 8) {
+      o = (unsigned)(((int64_t)lane * p.krs + 64) * 2);
+    }
+    koff[i] = o;
+    const int jv = (3 - wave) + 4 * i;
+    unsigned ov = 0;
+    if (jv < HD / 8) {
+      const int d = jv * 8 + srow8;
+      ov = (unsigned)(((int64_t)d * p.seg_lp + ((spos ^ ((d >> 1) & 7)) << 3)) * 2);
+    }
+    voff[i] = ov;
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int sw = (l31 >> 1) & 7;
+  unsigned fo[4], kc[2][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fo[j] = lds_base + l31 * 128 + (((2 * j + hi) ^ sw) << 4);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+      kc[s][t2] = hi ? lds_base + OSK72_CONST_OFF : lds_base + s * OSK72_KTILE + 8192 + t2 * 512 + l31 * 16;
+
+  const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + b * p.kbs + h * HD));
+  const uint64_t vbase = rfl64((uint64_t)(uintptr_t)(p.vt + (int64_t)bh * HD * p.seg_lp));
+  const unsigned kstep = rfl((unsigned)(128 * p.krs));
+  const uint64_t kjump = rfl64((uint64_t)((p.kss - (int64_t)p.tps * 64 * p.krs) * 2));
+  const uint64_t vjump = rfl64((uint64_t)((p.vtss - (int64_t)p.tps * 64) * 2));
+  const unsigned tps = rfl((unsigned)p.tps), nt = rfl((unsigned)(p.n_seg * p.tps));
+  const unsigned kdst = rfl(lds_base + wave * 1024), vdst = rfl(lds_base + OSK72_VOFF0 + (3 - wave) * 1024);
+  const unsigned nkw = rfl(wave == 0 ? 3u : 2u), nvw = rfl(wave == 3 ? 3u : 2u);
+
+  float m_ref[2];
+  if constexpr (SAFE) {
+    asm volatile(
+#include "attention_asm72_body_safe.inc"
+        : "=&v"(m_ref[0]), "=&v"(m_ref[1])
+        : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(fo[0]), "v"(fo[1]),
+          "v"(fo[2]), "v"(fo[3]), "v"(kc[0][0]), "v"(kc[0][1]), "v"(kc[1][0]), "v"(kc[1][1]), "s"(kbase), "s"(vbase),
+          "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
+        : OSK72_CLOBBERS);
+  } else {
+    asm volatile(
+#include "attention_asm72_body.inc"
+        : "=&v"(m_ref[0]), "=&v"(m_ref[1])
+        : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(fo[0]), "v"(fo[1]),
+          "v"(fo[2]), "v"(fo[3]), "v"(kc[0][0]), "v"(kc[0][1]), "v"(kc[1][0]), "v"(kc[1][1]), "s"(kbase), "s"(vbase),
+          "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
+        : OSK72_CLOBBERS);
+  }
+
+  // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 72 (sum of P), store
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float o[NDT][16];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+#define OSK_OOUT                                                                                             \
+  "=v"(o[d][0]), "=v"(o[d][1]), "=v"(o[d][2]), "=v"(o[d][3]), "=v"(o[d][4]), "=v"(o[d][5]), "=v"(o[d][6]),          \
+      "=v"(o[d][7]), "=v"(o[d][8]), "=v"(o[d][9]), "=v"(o[d][10]), "=v"(o[d][11]), "=v"(o[d][12]), "=v"(o[d][13]), \
+      "=v"(o[d][14]), "=v"(o[d][15])
+      if (u == 0 && d == 0) {
+        asm volatile(OSK72_OR0 : OSK_OOUT);
+      } else if (u == 0 && d == 1) {
+        asm volatile(OSK72_OR1 : OSK_OOUT);
+      } else if (u == 0 && d == 2) {
+        asm volatile(OSK72_OR2 : OSK_OOUT);
+      } else if (u == 1 && d == 0) {
+        asm volatile(OSK72_OR3 : OSK_OOUT);
+      } else if (u == 1 && d == 1) {
+        asm volatile(OSK72_OR4 : OSK_OOUT);
+      } else {
+        asm volatile(OSK72_OR5 : OSK_OOUT);
+      }
+    }
+    // row 72 of O^T = sum_k P: lanes hi == 0, register (8 & 3) + 4 (8 >> 3) = 4 of row tile 2
+    const unsigned lu = __float_as_uint(o[2][4]);
+    auto sw2 = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
+    const float l_tot = __uint_as_float(sw2[0]);
+    const float inv = 1.0f / l_tot;
+    if (qi[u] < p.Lq) {
+      unsigned short* orow = p.out + b * p.obs + (int64_t)qi[u] * p.ors + h * HD;
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int d0 = d * 32 + qd * 8 + hi * 4;
+          if (d0 < HD) {
+            uint2 w2;
+            w2.x = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
+            w2.y = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+            *reinterpret_cast<uint2*>(orow + d0) = w2;
+          }
+        }
+      }
+      if (p.lse && hi == 0)
+        p.lse[(int64_t)bh * p.Lq + qi[u]] = (m_ref[u] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+    }
+  }
+}
+
+template <bool SAFE>
+int launch_one(const AttnParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  auto kernel = attn_asm72_kernel<SAFE>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, OSK72_SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int nqb = (p.Lq + 255) / 256;
+  dim3 grid(nqb * p.B * p.H), block(256);
+  hipLaunchKernelGGL(kernel, grid, block, OSK72_SMEM, st, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool asm72_supported(const AttnParams& p, int hd) { return hd == 72 && (p.seg_len % 64) == 0; }
+
+int launch_asm72(const AttnParams& p, int safe, hipStream_t st) {
+  return safe ? launch_one<true>(p, st) : launch_one<false>(p, st);
+}
+
+}  // namespace osk_attn

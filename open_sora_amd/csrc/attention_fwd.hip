@@ -19,11 +19,12 @@
 // output rows for PV (3 MFMA row tiles).
 //
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 4 * B * H * Lq * Lk * hd (QK^T + PV, not halved).
-#include "osk_common.h"
+#include "attention_params.h"
 #include "../../include/osk.h"
 #include <stdlib.h>
 
 namespace {
+using osk_attn::AttnParams;
 
 template <int HD>
 struct Cfg {
@@ -44,20 +45,6 @@ struct Cfg {
   static constexpr int VIT = (NVC + 511) / 512;
 };
 
-struct AttnParams {
-  const unsigned short* q;
-  int64_t qbs, qrs;
-  const unsigned short* k;
-  int64_t kss, kbs, krs;
-  const unsigned short* vt;
-  int64_t vtss;
-  unsigned short* out;
-  int64_t obs, ors;
-  float* lse;
-  int B, H, Lq, n_seg, seg_len, seg_lp, tps;
-  float sc;  // softmax scale * log2(e)
-};
-
 template <int HD>
 __global__ void __launch_bounds__(512) attn_fwd_kernel_v1(const AttnParams p) {
   using C = Cfg<HD>;
@@ -65,8 +52,8 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel_v1(const AttnParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int nbh = p.B * p.H;
-  const int bh = blockIdx.x % nbh, qb = blockIdx.x / nbh;
+  int bh, qb;
+  osk_attn::block_to_work(p, (p.Lq + 255) / 256, bh, qb);
   const int b = bh / p.H, h = bh - b * p.H;
 
   // zero the whole LDS once: pad chunks / pad rows are never overwritten by the staging below
@@ -293,8 +280,8 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int nbh = p.B * p.H;
-  const int bh = blockIdx.x % nbh, qb = blockIdx.x / nbh;
+  int bh, qb;
+  osk_attn::block_to_work(p, (p.Lq + 255) / 256, bh, qb);
   const int b = bh / p.H, h = bh - b * p.H;
 
   for (int i = tid; i < C::SMEM / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
@@ -648,12 +635,20 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
 #undef K_COMMIT
 #undef V_COMMIT
 
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+// kernel structure (A/B knob, read once): -1 (default) = best available: the hand-scheduled head_dim-72 kernel
+// (attention_asm72.hip) when it applies, else 0;  0 = 8 waves x 32 rows (this file), 1 / 2 = the same with
+// scheduling hints, 9 = v1, 3 / 4 = 4 waves x 64 rows compiler-scheduled (attention_w64.hip) without / with
+// sched_group_barrier pipelines, 5 / 6 = attention_asm72.hip production / hazard-padded schedule
 int attn_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OSK_ATTN_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
+  static const int v = env_int("OSK_ATTN_VARIANT", -1);
+  return v;
+}
+int attn_map() {
+  static const int v = env_int("OSK_ATTN_MAP", 1);
   return v;
 }
 
@@ -676,11 +671,19 @@ int launch(const AttnParams& p, hipStream_t st) {
   using C = Cfg<HD>;
   static bool set0 = false, set1 = false, set2 = false, set9 = false;
   switch (attn_variant()) {
+    case -1:
+    case 5:
+    case 6:
+      if (osk_attn::asm72_supported(p, HD)) return osk_attn::launch_asm72(p, attn_variant() == 6, st);
+      break;
+    case 3: return osk_attn::launch_w64(p, HD, 0, st);
+    case 4: return osk_attn::launch_w64(p, HD, 1, st);
     case 9: return launch_kernel(attn_fwd_kernel_v1<HD>, C::SMEM, p, st, &set9);
     case 1: return launch_kernel(attn_fwd_kernel<HD, 1>, C::SMEM, p, st, &set1);
     case 2: return launch_kernel(attn_fwd_kernel<HD, 2>, C::SMEM, p, st, &set2);
-    default: return launch_kernel(attn_fwd_kernel<HD, 0>, C::SMEM, p, st, &set0);
+    default: break;
   }
+  return launch_kernel(attn_fwd_kernel<HD, 0>, C::SMEM, p, st, &set0);
 }
 
 }  // namespace
@@ -705,6 +708,7 @@ extern "C" int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int
   p.seg_lp = (seg_len + 63) / 64 * 64;
   p.tps = p.seg_lp / 64;
   p.sc = scale * 1.4426950408889634f;
+  p.map = attn_map();
   hipStream_t st = (hipStream_t)stream;
   switch (hd) {
     case 64: return launch<64>(p, st);
