@@ -26,7 +26,7 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
-template <bool SAFE>
+template <int VAR>
 __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -123,22 +123,28 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   const unsigned nkw = rfl(wave == 0 ? 3u : 2u), nvw = rfl(wave == 3 ? 3u : 2u);
 
   float m_ref[2];
-  if constexpr (SAFE) {
+#define OSK72_OPERANDS                                                                                              \
+  : "=&v"(m_ref[0]), "=&v"(m_ref[1])                                                                                 \
+  : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(fo[0]), "v"(fo[1]),     \
+    "v"(fo[2]), "v"(fo[3]), "v"(kc[0][0]), "v"(kc[0][1]), "v"(kc[1][0]), "v"(kc[1][1]), "s"(kbase), "s"(vbase),     \
+    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)                 \
+  : OSK72_CLOBBERS
+  if constexpr (VAR == 0) {
     asm volatile(
-#include "attention_asm72_body_safe.inc"
-        : "=&v"(m_ref[0]), "=&v"(m_ref[1])
-        : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(fo[0]), "v"(fo[1]),
-          "v"(fo[2]), "v"(fo[3]), "v"(kc[0][0]), "v"(kc[0][1]), "v"(kc[1][0]), "v"(kc[1][1]), "s"(kbase), "s"(vbase),
-          "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
-        : OSK72_CLOBBERS);
+#include "attention_asm72_body_v0.inc"
+        OSK72_OPERANDS);
+  } else if constexpr (VAR == 1) {
+    asm volatile(
+#include "attention_asm72_body_v1.inc"
+        OSK72_OPERANDS);
+  } else if constexpr (VAR == 2) {
+    asm volatile(
+#include "attention_asm72_body_v2.inc"
+        OSK72_OPERANDS);
   } else {
     asm volatile(
-#include "attention_asm72_body.inc"
-        : "=&v"(m_ref[0]), "=&v"(m_ref[1])
-        : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(fo[0]), "v"(fo[1]),
-          "v"(fo[2]), "v"(fo[3]), "v"(kc[0][0]), "v"(kc[0][1]), "v"(kc[1][0]), "v"(kc[1][1]), "s"(kbase), "s"(vbase),
-          "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
-        : OSK72_CLOBBERS);
+#include "attention_asm72_body_v3.inc"
+        OSK72_OPERANDS);
   }
 
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 72 (sum of P), store
@@ -191,10 +197,10 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   }
 }
 
-template <bool SAFE>
+template <int VAR>
 int launch_one(const AttnParams& p, hipStream_t st) {
   static bool attr_set = false;
-  auto kernel = attn_asm72_kernel<SAFE>;
+  auto kernel = attn_asm72_kernel<VAR>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, OSK72_SMEM);
@@ -211,8 +217,15 @@ int launch_one(const AttnParams& p, hipStream_t st) {
 
 bool asm72_supported(const AttnParams& p, int hd) { return hd == 72 && (p.seg_len % 64) == 0; }
 
-int launch_asm72(const AttnParams& p, int safe, hipStream_t st) {
-  return safe ? launch_one<true>(p, st) : launch_one<false>(p, st);
+// var 0 = production schedule; 1..3 = experimental bodies emitted by tools/gen_attn_asm.py --exp (default: the
+// hazard-padded debug schedule in all three)
+int launch_asm72(const AttnParams& p, int var, hipStream_t st) {
+  switch (var) {
+    case 1: return launch_one<1>(p, st);
+    case 2: return launch_one<2>(p, st);
+    case 3: return launch_one<3>(p, st);
+    default: return launch_one<0>(p, st);
+  }
 }
 
 }  // namespace osk_attn

@@ -642,7 +642,7 @@ int env_int(const char* name, int dflt) {
 // kernel structure (A/B knob, read once): -1 (default) = best available: the hand-scheduled head_dim-72 kernel
 // (attention_asm72.hip) when it applies, else 0;  0 = 8 waves x 32 rows (this file), 1 / 2 = the same with
 // scheduling hints, 9 = v1, 3 / 4 = 4 waves x 64 rows compiler-scheduled (attention_w64.hip) without / with
-// sched_group_barrier pipelines, 5 / 6 = attention_asm72.hip production / hazard-padded schedule
+// sched_group_barrier pipelines, 5 = attention_asm72.hip production schedule, 6..8 = its experimental bodies (hazard-padded debug schedule by default)
 int attn_variant() {
   static const int v = env_int("OSK_ATTN_VARIANT", -1);
   return v;
@@ -674,7 +674,10 @@ int launch(const AttnParams& p, hipStream_t st) {
     case -1:
     case 5:
     case 6:
-      if (osk_attn::asm72_supported(p, HD)) return osk_attn::launch_asm72(p, attn_variant() == 6, st);
+    case 7:
+    case 8:
+      if (osk_attn::asm72_supported(p, HD))
+        return osk_attn::launch_asm72(p, attn_variant() >= 5 ? attn_variant() - 5 : 0, st);
       break;
     case 3: return osk_attn::launch_w64(p, HD, 0, st);
     case 4: return osk_attn::launch_w64(p, HD, 1, st);

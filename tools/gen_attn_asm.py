@@ -30,6 +30,7 @@ KOFF = [0, KTILE]
 VOFF = [2 * KTILE, 2 * KTILE + VTILE]
 CONST_OFF = 2 * KTILE + 2 * VTILE          # 16-byte chunk {1.0bf16, 0...}: K's padding dims 72..79
 SMEM = CONST_OFF + 16
+WINDOWS = [4, 25, 24, 40, 26, 43]          # first / last shadow of filler classes A, B, C (see body())
 THR_BITS = "0x41000000"                    # 8.0: rescale when a row max exceeds the reference by > 2^8
 
 # ---- physical registers owned by the asm (declared as clobbers by the wrapper)
@@ -87,6 +88,15 @@ class Stream:
         self.table = []     # (kind, text) for --table
 
     def emit(self, text, kind="x"):
+        ab = getattr(self, "ablate", frozenset()) if getattr(self, "in_body", False) else frozenset()
+        if ("noexp" in ab and text.startswith("v_exp")) or ("nobar" in ab and text.startswith("s_barrier")) or \
+           ("nodma" in ab and text.startswith("global_load_lds")) or \
+           ("nolds" in ab and (text.startswith("ds_read") or "lgkmcnt" in text)) or \
+           ("novalu" in ab and kind in ("e", "v") and not text.startswith("v_mfma") and not text.startswith("v_cmp")) or \
+           ("nomfma" in ab and text.startswith("v_mfma")) or ("norare" in ab and text.startswith("s_cbranch_vccnz")) or \
+           ("nocvt" in ab and text.startswith("v_cvt_pk")) or ("nomax" in ab and (text.startswith("v_max") or text.startswith("v_cmp"))) or \
+           ("nowait" in ab and text.startswith("s_waitcnt lgkmcnt")) or ("nosalu" in ab and kind == "s" and not text.startswith("s_add_u32 m0") and "s%d, s%d, 1" % (S_T, S_T) not in text and "s_cmp_lt_u32 s%d, s%d" % (S_T, S_NT) not in text and "_exit" not in text and "_body0" not in text):
+            return
         self.lines.append("  " + text)
         self.table.append((kind, text))
 
@@ -165,25 +175,46 @@ def rowmax_chain(sn, u, t2, tmp):
     return ops
 
 
-def rowmax_final(u, ta, tb):
-    return [("v", "v_max_f32 %s, %s, %s" % (vr(ta), vr(ta), vr(tb))),
-            ("v", "v_mov_b32 %s, %s" % (vr(tb), vr(ta))),
-            ("n", "s_nop 1"),
-            ("v", "v_permlane32_swap_b32 %s, %s" % (vr(ta), vr(tb))),
-            ("v", "v_max_f32 %s, %s, %s" % (vr(MT[u]), vr(ta), vr(tb)))]
+def lanemax_final():
+    """common path: ONE number per lane = max of its 64 pending scores (both query blocks); the exact per-row max
+    (other half-wave included) is only formed in the rare path"""
+    return [("v", "v_max3_f32 %s, %s, %s, %s" % (vr(MT[0]), vr(TMP0), vr(TMP0 + 1), vr(TMP0 + 2))),
+            ("v", "v_max_f32 %s, %s, %s" % (vr(MT[0]), vr(MT[0]), vr(TMP0 + 3))),
+            # the compare already here: VCC is old news when the next body's s_cbranch_vccnz reads it
+            ("v", "v_cmp_lt_f32 vcc, %s, %s" % (THR_BITS, vr(MT[0])))]
 
 
-def k_dma(st, slot, i):
-    """K loader slot i of this wave -> ring slot `slot` (instruction j = wave + 4 i)"""
-    st.emit("s_add_u32 m0, s%d, %d" % (S_KDST, KOFF[slot] + 4096 * i), "s")
-    st.emit("s_nop 0", "n")
-    st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["koff%d" % i], S_KB, S_KB + 1), "g")
+def rowmax_from_chains(st):
+    """rare path / prologue: per query block, combine the two chain maxima (TMP0+u: keys 0..31, TMP0+2+u: keys
+    32..63 of this lane's half) and the other half-wave's -> MT[u]"""
+    for u in range(2):
+        ta, tb = TMP0 + u, TMP0 + 2 + u
+        st.emit("v_max_f32 %s, %s, %s" % (vr(ta), vr(ta), vr(tb)))
+        st.emit("v_mov_b32 %s, %s" % (vr(tb), vr(ta)))
+        st.emit("s_nop 1", "n")
+        st.emit("v_permlane32_swap_b32 %s, %s" % (vr(ta), vr(tb)))
+        st.emit("s_nop 1", "n")
+        st.emit("v_max_f32 %s, %s, %s" % (vr(MT[u]), vr(ta), vr(tb)))
 
 
-def v_dma(st, slot, i):
-    st.emit("s_add_u32 m0, s%d, %d" % (S_VDST, (VOFF[slot] - VOFF[0]) + 4096 * i), "s")
-    st.emit("s_nop 0", "n")
-    st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["voff%d" % i], S_VB, S_VB + 1), "g")
+def k_dma(st, slot, i, part=3):
+    """K loader slot i of this wave -> ring slot `slot` (instruction j = wave + 4 i).  part 1 = M0 write only,
+    2 = the DMA only (one other instruction must sit between them), 3 = both with an s_nop"""
+    if part & 1:
+        st.emit("s_add_u32 m0, s%d, %d" % (S_KDST, KOFF[slot] + 4096 * i), "s")
+    if part == 3:
+        st.emit("s_nop 0", "n")
+    if part & 2:
+        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["koff%d" % i], S_KB, S_KB + 1), "g")
+
+
+def v_dma(st, slot, i, part=3):
+    if part & 1:
+        st.emit("s_add_u32 m0, s%d, %d" % (S_VDST, (VOFF[slot] - VOFF[0]) + 4096 * i), "s")
+    if part == 3:
+        st.emit("s_nop 0", "n")
+    if part & 2:
+        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["voff%d" % i], S_VB, S_VB + 1), "g")
 
 
 def k_advance(st, uid):
@@ -258,8 +289,9 @@ def fixup(st, sx, uid, init):
     if not init:
         st.emit("s_nop 15", "n")
         st.emit("s_nop 15", "n")  # trailing P.V MFMAs -> v_accvgpr_read of O
+    rowmax_from_chains(st)
     for u in range(2):
-        d, n, pk, f, de, al, t = TX[0], TX[1], TX[2], TX[3], TMP0, TMP0 + 1, TMP0 + 2
+        d, n, pk, f, de, al, t = TX[0], TX[1], TX[2], TX[3], TMP0 + 4, TMP0 + 5, TMP0 + 6
         if init:
             st.emit("v_mov_b32 %s, %s" % (vr(n), vr(MT[u])))
         else:
@@ -286,19 +318,19 @@ def fixup(st, sx, uid, init):
             for dd in range(NDT):
                 for r0 in range(0, 16, 4):
                     for r in range(r0, r0 + 4):
-                        st.emit("v_accvgpr_read_b32 %s, %s" % (vr(TMP0 + 3 + (r - r0)), ar(AO(u, dd) + r)))
+                        st.emit("v_accvgpr_read_b32 %s, %s" % (vr(TMP0 + (r - r0)), ar(AO(u, dd) + r)))
                     st.emit("s_nop 0", "n")
                     for r in range(r0, r0 + 4):
-                        tt = vr(TMP0 + 3 + (r - r0))
+                        tt = vr(TMP0 + (r - r0))
                         st.emit("v_mul_f32 %s, %s, %s" % (tt, tt, vr(al)))
                     st.emit("s_nop 0", "n")
                     for r in range(r0, r0 + 4):
-                        st.emit("v_accvgpr_write_b32 %s, %s" % (ar(AO(u, dd) + r), vr(TMP0 + 3 + (r - r0))))
+                        st.emit("v_accvgpr_write_b32 %s, %s" % (ar(AO(u, dd) + r), vr(TMP0 + (r - r0))))
     st.emit("s_nop 7", "n")  # v_accvgpr_write -> MFMA operand
 
 
 # ------------------------------------------------------------------------------------------ body
-def body(st, k, safe):
+def body(st, k, safe, ablate=frozenset()):
     """iteration with ring slot parity k: SC = scores of tile t (k == 0: set A), SN receives tile t+1"""
     sc, sn = (SA0, SB0) if k == 0 else (SB0, SA0)
     cur = k
@@ -308,89 +340,97 @@ def body(st, k, safe):
     for p in range(4):
         k_read(st, cur ^ 1, p, ("k", p))
     # -- 4 trailing P.V MFMAs of tile t-1 (fragments read before the barrier) + the K loader's LDS-DMA
-    pv_mfma(st, 20)
-    k_dma(st, cur, 0)                    # K(t+2) -> slot cur, one LDS-DMA piece per MFMA shadow
+    k_dma(st, cur, 0, 1)                 # K(t+2) -> slot cur and V(t+1) -> slot cur^1: one LDS-DMA piece per shadow
+    pv_mfma(st, 20)                      # (the M0 write sits before the MFMA: no s_nop needed)
+    k_dma(st, cur, 0, 2)
+    k_dma(st, cur, 1, 1)
     pv_mfma(st, 21)
-    k_dma(st, cur, 1)
+    k_dma(st, cur, 1, 2)
+    v_dma(st, cur ^ 1, 0, 1)
     pv_mfma(st, 22)
-    k_dma2(st, cur, uid)
+    v_dma(st, cur ^ 1, 0, 2)
+    v_dma(st, cur ^ 1, 1, 1)
     pv_mfma(st, 23)
-    k_advance(st, uid)
+    v_dma(st, cur ^ 1, 1, 2)
     # -- decision: does any row max of tile t exceed the reference by more than 2^THR?
-    st.emit("v_max_f32 %s, %s, %s" % (vr(TX[0]), vr(MT[0]), vr(MT[1])))
-    st.emit("v_cmp_lt_f32 vcc, %s, %s" % (THR_BITS, vr(TX[0])))
     st.emit("s_cbranch_vccnz .L@@_rare%d" % k)
     st.label(".L@@_entry%d" % k)
 
-    # -- fillers of the 40 gaps behind the QK^T (global MFMA index i = 4..23) and P.V (i = 24..43) MFMAs.
-    # items: (weight, release gap, deadline gap, kind, text); a gap = the instructions emitted after MFMA i.
-    items = []
+    # -- fillers of the 40 shadows behind the QK^T (global MFMA index i = 4..23) and P.V (i = 24..43) MFMAs,
+    # paced in CYCLES (v_exp 8, other VALU 4, per-shadow budget ~26 of the MFMA's 32): three classes, each spread
+    # uniformly over its window of shadows
+    #   A: exp2 + pack of key groups 0..2   shadows  4..25   (P.V of group g starts at i = 24 + 6 g)
+    #   B: exp2 + pack of key group 3       shadows 24..40
+    #   C: row max of tile t+1              shadows 26..43   (its last QK^T MFMAs are i = 20..23)
+    cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
+    clsA, clsB, clsC = [], [], []
     for g in range(4):
         for u in range(2):
-            # complete one full gap before the first P.V MFMA of key group g (i = 24 + 6 g)
-            for kind_, text in exp_group(sc, u, g):
-                items.append([1.5 if kind_ == "e" else 1.0, 4, 24 + 6 * g - 2, kind_, text])
+            (clsA if g < 3 else clsB).extend(exp_group(sc, u, g))
     ca = [rowmax_chain(sn, 0, 0, TMP0), rowmax_chain(sn, 1, 0, TMP0 + 1)]     # t2 = 0: last MFMAs at i = 20, 21
     cb = [rowmax_chain(sn, 0, 1, TMP0 + 2), rowmax_chain(sn, 1, 1, TMP0 + 3)]  # t2 = 1: last MFMAs at i = 22, 23
-    for op in [o for pair in zip(*ca) for o in pair]:
-        items.append([1.0, 26, 99, op[0], op[1]])
-    for op in [o for pair in zip(*cb) for o in pair]:
-        items.append([1.0, 28, 99, op[0], op[1]])
-    for op in rowmax_final(0, TMP0, TMP0 + 2) + rowmax_final(1, TMP0 + 1, TMP0 + 3):
-        items.append([0.5 if op[0] == "n" else 1.0, 28, 99, op[0], op[1]])
-    nxt = 0                      # items are emitted strictly in list order (dependencies are positional)
+    clsC.extend([o for pair in zip(*ca) for o in pair])
+    n_first_b = len(clsC)                # chain-B ops (t2 = 1) must not start before shadow 28
+    clsC.extend([o for pair in zip(*cb) for o in pair])
+    clsC.extend(lanemax_final())
+    W = WINDOWS
+    classes = [[clsA, W[0], W[1], 0, 0.0], [clsB, W[2], W[3], 0, 0.0], [clsC, W[4], W[5], 0, 0.0]]  # items, first, last, next, emitted
+    totals = [sum(cost(o[0]) for o in c[0]) for c in classes]
     mf = [("qk", a) for a in range(20)] + [("pv", b) for b in range(20)]
-    last_gap = 4 + len(mf) - 1
     for n, (kind, idx) in enumerate(mf):
         i = 4 + n
         if kind == "qk":
-            if idx % 2 == 0:
-                st.need(("k", idx // 2))
+            if idx % 4 == 0:             # pairs 2m and 2m+1 with one wait (both were issued >= 3 pairs ago)
+                st.need(("k", idx // 2 + 1))
             qk_mfma(st, sn, idx)
         else:
-            if idx % 2 == 0:
-                st.need(("v", idx // 2))
+            if idx % 4 == 0:
+                st.need(("v", idx // 2 + 1))
             pv_mfma(st, idx)
         if safe:
             st.emit("s_nop 7", "n")
-        cap = 5.0
+        used = 0.0
         # ring reads: after the 2nd MFMA of pair x its ring slot is free -> read pair x + 4
         if kind == "qk" and idx % 2 == 1:
             p = idx // 2
             if p + 4 < 10:
-                k_read(st, cur ^ 1, p + 4, ("k", p + 4)); cap -= 1
+                k_read(st, cur ^ 1, p + 4, ("k", p + 4))
             else:
-                v_read(st, cur, p + 4 - 10, ("v", p + 4 - 10)); cap -= 1   # V pairs 0..3 behind the last K pairs
+                v_read(st, cur, p + 4 - 10, ("v", p + 4 - 10))   # V pairs 0..3 behind the last K pairs
+            used += 4
         if kind == "pv" and idx % 2 == 1:
             r = idx // 2
             if r + 4 < 12:
-                v_read(st, cur, r + 4, ("v", r + 4)); cap -= 1
-        if i in (5, 7, 9, 11):                                # V(t+1) -> slot cur^1, one piece per shadow
-            if i == 5:
-                v_dma(st, cur ^ 1, 0)
-            elif i == 7:
-                v_dma(st, cur ^ 1, 1)
-            elif i == 9:
-                v_dma2(st, cur ^ 1, uid)
-            else:
-                v_advance(st, uid)
-            cap -= 3.5
-        # even spreading: remaining weight over remaining gaps (counting only released items), never below the
-        # hard deadlines
-        rem_w = sum(it[0] for it in items[nxt:])
-        target = min(cap, rem_w / (last_gap - i + 1) + 0.75)
-        used = 0.0
-        while nxt < len(items):
-            w, rel, dl, kind_, text = items[nxt]
-            if rel > i:
-                break
-            if used >= target and dl > i:
-                break
-            st.emit(text, kind_)
-            used += w
-            nxt += 1
-    while nxt < len(items):      # whatever did not fit (tail of the row max)
-        st.emit(items[nxt][4], items[nxt][3]); nxt += 1
+                v_read(st, cur, r + 4, ("v", r + 4))
+                used += 4
+        if i == 4:
+            k_dma2(st, cur, uid); used += 12
+        elif i == 5:
+            v_dma2(st, cur ^ 1, uid); used += 12
+        elif i == 6:
+            k_advance(st, uid); used += 28
+        elif i == 7:
+            v_advance(st, uid); used += 28
+        for ci, c in enumerate(classes):
+            items, first, last, nx, em = c
+            if i < first:
+                continue
+            frac = min(1.0, (i - first + 1) / float(last - first + 1))
+            while c[3] < len(items):
+                kind_, text = items[c[3]]
+                if ci == 2 and c[3] >= n_first_b and i < max(28, W[4]):
+                    break
+                behind = totals[ci] * frac - c[4]
+                if behind <= 0 and i < last:
+                    break
+                if used >= 30 and i < last:
+                    break
+                st.emit(text, kind_)
+                used += cost(kind_)
+                c[4] += cost(kind_)
+                c[3] += 1
+    for c in classes:
+        assert c[3] == len(c[0]), "unscheduled filler work"
     # -- end of body: DMA landed + every fragment read retired, then the tile barrier
     st.emit("s_waitcnt vmcnt(0) lgkmcnt(0)", "w")
     st.drain()
@@ -402,8 +442,9 @@ def body(st, k, safe):
         st.emit("s_branch .L@@_body0", "s")
 
 
-def generate(safe=False):
+def generate(safe=False, ablate=frozenset()):
     st = Stream()
+    st.ablate = ablate
     e = st.emit
     # ---- copy the mutable scalars into asm-owned SGPRs
     e("s_mov_b64 s[%d:%d], %s" % (S_KB, S_KB + 1, OP["kbase"]))
@@ -443,21 +484,27 @@ def generate(safe=False):
     e("s_barrier")                      # every wave has read K0: slot 0 may be refilled
     e("s_nop 15")
     e("s_nop 15")
-    for op in (rowmax_chain(SA0, 0, 0, TMP0) + rowmax_chain(SA0, 0, 1, TMP0 + 2) + rowmax_final(0, TMP0, TMP0 + 2)
-               + rowmax_chain(SA0, 1, 0, TMP0 + 1) + rowmax_chain(SA0, 1, 1, TMP0 + 3) + rowmax_final(1, TMP0 + 1, TMP0 + 3)):
+    for op in (rowmax_chain(SA0, 0, 0, TMP0) + rowmax_chain(SA0, 1, 0, TMP0 + 1) + rowmax_chain(SA0, 0, 1, TMP0 + 2)
+               + rowmax_chain(SA0, 1, 1, TMP0 + 3)):
         e(op[1])
     fixup(st, SA0, "init", init=True)
-    # what body 0 does before its entry point: K(2) -> slot 0, first K fragment reads of tile 1
-    dma_group(st, "k", 0, "p3")
+    # what body 0 does before its entry point: first LDS-DMA pieces of K(2) -> slot 0 and V(1) -> slot 1, first K
+    # fragment reads of tile 1
+    k_dma(st, 0, 0)
+    k_dma(st, 0, 1)
+    v_dma(st, 1, 0)
+    v_dma(st, 1, 1)
     for p in range(4):
         k_read(st, 1, p, ("k", p))
     e("s_branch .L@@_entry0")
     pend = list(st.pending)
     # ---- the two loop bodies
     st.pending = []
-    body(st, 0, safe)
+    st.in_body = True
+    body(st, 0, safe, ablate)
     st.pending = []
-    body(st, 1, safe)
+    body(st, 1, safe, ablate)
+    st.in_body = False
     # ---- rare paths
     for k in range(2):
         st.label(".L@@_rare%d" % k)
@@ -477,11 +524,15 @@ def generate(safe=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--table", action="store_true")
+    ap.add_argument("--exp", nargs="*", default=["safe"], help="experimental variants 1..3: safe | ablations joined by + (noexp nobar nodma nolds novalu nomfma): timing only, wrong results")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
     args = ap.parse_args()
-    for safe, name in ((False, "attention_asm72_body.inc"), (True, "attention_asm72_body_safe.inc")):
-        st = generate(safe)
-        if args.table and not safe:
+    variants = [(False, frozenset())] + [(x == "safe", frozenset(x.split("+")) - {"safe"}) for x in args.exp]
+    while len(variants) < 4:
+        variants.append((True, frozenset()))
+    for vi, (safe, ablate) in enumerate(variants[:4]):
+        st = generate(safe, ablate)
+        if args.table and vi == 0:
             gap = []
             for kind, text in st.table:
                 if kind == "M":
@@ -491,10 +542,11 @@ def main():
                 else:
                     gap.append({"x": "v", "w": "w"}.get(kind, kind))
             print("".join(gap))
-        with open(os.path.join(args.out, name), "w") as f:
-            f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  %s schedule.\n" % ("padded (debug)" if safe else "production"))
+        with open(os.path.join(args.out, "attention_asm72_body_v%d.inc" % vi), "w") as f:
+            f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  variant %d: %s\n" %
+                    (vi, "production" if vi == 0 else ("hazard-padded (debug)" if safe else "timing ablation " + "+".join(sorted(ablate)))))
             for ln in st.lines:
-                f.write('"%s\\n"\n' % ln.replace("@@", "osk72s" if safe else "osk72"))
+                f.write('"%s\\n"\n' % ln.replace("@@", "osk72v%d" % vi))
     # register / operand contract for the wrapper
     with open(os.path.join(args.out, "attention_asm72_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.\n")
