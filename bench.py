@@ -265,10 +265,20 @@ def main():
         Lq = L // world
         fl = configs.attention_flops(nb, H, Lq, L, hd)  # per launch on this rank
         ach = fl / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": f"attn_fwd_kernel<{hd}>", "achieved": round(ach, 1),
+        kname = _C.lib.osk_attention_kernel_name(hd, L // world).decode()
+        # HBM bytes per launch: PMC passes (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE) of the same
+        # kernel at the same shape, collected by tools/gpu_attn_round.sh and committed under profiles/
+        traffic, traffic_src = None, None
+        rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "attn_traffic.json")
+        if os.path.exists(rec_path):
+            for rec in json.load(open(rec_path)):
+                if rec["kernel"] == kname and rec["shape"] == [nb, H, L, hd] and world == 1:
+                    traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),
-                    "flops_per_launch": fl}
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": 4 * nb * Lq * H * hd * 2 if world == 1 else None,
+                    "launches": len(durs), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": fl}
     step_flops = configs.flops_per_forward(cfg, nb, L_img, L_txt)
     out = {
         "metric": "latent_frames_per_sec (30-step rectified-flow sampling; denoise-step ms in ms_per_step)",

@@ -121,6 +121,10 @@ int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_
                            float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
                            float scale, void* stream);
 
+/* name of the device kernel osk_attention_fwd_bf16 dispatches to for (hd, seg_len) under the current
+ * OSK_ATTN_VARIANT (reporting only: bench.py labels its roofline line and the rocprof stats with it). */
+const char* osk_attention_kernel_name(int hd, int seg_len);
+
 /* ---- classifier-free-guidance combine + Euler step of the rectified-flow sampler (f32 math):
  *   v = u2 + g_img*(u - u2) + g_txt*(c - u);  x_out = x + dt * v
  * replaces opensora/utils/sampling.py:217-222.  pred bf16 [3, n] = (cond, uncond, uncond_2) chunks,

@@ -20,6 +20,7 @@ _i64, _i32, _f32, _f64, _vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_v
 SIGNATURES = {
     "osk_abi_version": [],
     "osk_arch": [],
+    "osk_attention_kernel_name": [_i32, _i32],
     "osk_ln_modulate_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_gemm_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
                       _i32, _i32, _i32, _i32, _i32, _vp],
@@ -50,7 +51,7 @@ def _load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "osk_arch" else _i32
+        fn.restype = C.c_char_p if name in ("osk_arch", "osk_attention_kernel_name") else _i32
     if lib.osk_abi_version() != 1:
         raise ImportError("libosk_hip.so ABI version mismatch")
     return lib

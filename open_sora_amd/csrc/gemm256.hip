@@ -1,0 +1,239 @@
+// Large-tile bf16 GEMM for gfx950 with a hand-scheduled K loop:  C = epi(A[M,K] @ W[N,K]^T + bias)
+//
+// Tile 256 (M) x BN (N, 256 or 128) x 64 (K), 512 threads = 8 waves (two per SIMD).  The K loop is ONE asm
+// statement emitted by tools/gen_gemm_asm.py (gemm256_body_n*.inc): two LDS stages filled by LDS-DMA one K step
+// ahead, fragment sets double-buffered in registers, the last k-sub-step of a K step issued AFTER the tile barrier
+// so that the first LDS reads of the next stage and its DMA sit in MFMA shadows, accumulators in AGPRs.
+// Operand convention, LDS image (128-byte rows, source-side XOR swizzle) and the fused epilogue (bias / GELU-tanh /
+// gate*x+residual / f32 out; a lane owns one output row and 4 consecutive columns per quad) are those of
+// gemm_bf16.hip, which remains the kernel for small or odd shapes (the dispatcher is in gemm_bf16.hip).
+//
+// Roofline: MFMA bf16.  Algorithmic FLOPs = 2*M*N*K.
+#include "gemm_params.h"
+#include "gemm256_regs_n256.inc"
+#include "gemm256_regs_n128.inc"
+
+namespace osk_gemm {
+namespace {
+
+OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v); }
+
+#define OSKG_OUT16                                                                                               \
+  "=v"(v16[0]), "=v"(v16[1]), "=v"(v16[2]), "=v"(v16[3]), "=v"(v16[4]), "=v"(v16[5]), "=v"(v16[6]), "=v"(v16[7]),    \
+      "=v"(v16[8]), "=v"(v16[9]), "=v"(v16[10]), "=v"(v16[11]), "=v"(v16[12]), "=v"(v16[13]), "=v"(v16[14]),          \
+      "=v"(v16[15])
+
+template <int BN, int T>
+OSK_DEV void read_acc(float* v16) {
+  if constexpr (BN == 256) {
+    if constexpr (T == 0) asm volatile(OSKG256_AR0 : OSKG_OUT16);
+    else if constexpr (T == 1) asm volatile(OSKG256_AR1 : OSKG_OUT16);
+    else if constexpr (T == 2) asm volatile(OSKG256_AR2 : OSKG_OUT16);
+    else if constexpr (T == 3) asm volatile(OSKG256_AR3 : OSKG_OUT16);
+    else if constexpr (T == 4) asm volatile(OSKG256_AR4 : OSKG_OUT16);
+    else if constexpr (T == 5) asm volatile(OSKG256_AR5 : OSKG_OUT16);
+    else if constexpr (T == 6) asm volatile(OSKG256_AR6 : OSKG_OUT16);
+    else asm volatile(OSKG256_AR7 : OSKG_OUT16);
+  } else {
+    if constexpr (T == 0) asm volatile(OSKG128_AR0 : OSKG_OUT16);
+    else if constexpr (T == 1) asm volatile(OSKG128_AR1 : OSKG_OUT16);
+    else if constexpr (T == 2) asm volatile(OSKG128_AR2 : OSKG_OUT16);
+    else asm volatile(OSKG128_AR3 : OSKG_OUT16);
+  }
+}
+
+// one 32 x 32 accumulator tile T = tn * TM + tm.  INTERIOR: the wave's whole tile lies inside C (wave-uniform), so
+// there is no per-element bounds check and the column vectors (bias, gate) were loaded once per tn by the caller.
+template <int BN, bool OUT_F32, bool INTERIOR, int T>
+OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int hi, const float4* bq, const float4* gq) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int tn = T / TM, tm = T % TM;
+  const int m = m0w + tm * 32 + l31;
+  const int mc = m < p.M ? m : p.M - 1;
+  const int b = mc / p.crpb, l = mc - b * p.crpb;
+  const int64_t roff = b * p.cbs + (int64_t)l * p.crs;
+  if constexpr (INTERIOR) {
+    uint2 rv[4];
+    if (p.gate) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        rv[qd] = *reinterpret_cast<const uint2*>(p.res + roff + n0w + tn * 32 + qd * 8 + hi * 4);
+    }
+    float acc[16];
+    read_acc<BN, T>(acc);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int n = n0w + tn * 32 + qd * 8 + hi * 4;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[qd * 4 + j];
+      if (p.bias) { v[0] += bq[qd].x; v[1] += bq[qd].y; v[2] += bq[qd].z; v[3] += bq[qd].w; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j >= p.gelu_from) v[j] = gelu_tanh(v[j]);
+      if (p.gate) {
+        v[0] = bf16_lo(rv[qd].x) + gq[qd].x * v[0];
+        v[1] = bf16_hi(rv[qd].x) + gq[qd].y * v[1];
+        v[2] = bf16_lo(rv[qd].y) + gq[qd].z * v[2];
+        v[3] = bf16_hi(rv[qd].y) + gq[qd].w * v[3];
+      }
+      if constexpr (OUT_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + roff + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + roff + n) = o;
+      }
+    }
+  } else {
+    float acc[16];
+    read_acc<BN, T>(acc);
+    if (m >= p.M) return;
+    const float* grow = p.gate ? p.gate + b * p.gbs : nullptr;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int n = n0w + tn * 32 + qd * 8 + hi * 4;
+      for (int j = 0; j < 4 && n + j < p.N; ++j) {
+        float t = acc[qd * 4 + j] + (p.bias ? p.bias[n + j] : 0.f);
+        if (n + j >= p.gelu_from) t = gelu_tanh(t);
+        if (grow) t = bf16_bits_to_f32(p.res[roff + n + j]) + grow[n + j] * t;
+        if constexpr (OUT_F32) reinterpret_cast<float*>(p.C)[roff + n + j] = t;
+        else reinterpret_cast<unsigned short*>(p.C)[roff + n + j] = f32_to_bf16_bits(t);
+      }
+    }
+  }
+}
+
+template <int BN, bool OUT_F32, bool INTERIOR, int... Ts>
+OSK_DEV void epilogue_tn(const GemmParams& p, int m0w, int n0w, int l31, int hi, std::integer_sequence<int, Ts...>) {
+  // Ts = the TM tiles of one tn: column vectors once, then the row tiles
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int tn = ((Ts, ...)) / TM;  // all Ts share tn
+  float4 bq[4], gq[4];
+  if constexpr (INTERIOR) {
+    // the gate vector belongs to the batch of the tile's rows; a 256-row tile may straddle two batches only when
+    // c_rows_per_batch is not a multiple of 256 -- then INTERIOR is refused by the caller
+    const int b = m0w / p.crpb;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int n = n0w + tn * 32 + qd * 8 + hi * 4;
+      if (p.bias) bq[qd] = *reinterpret_cast<const float4*>(p.bias + n);
+      if (p.gate) gq[qd] = *reinterpret_cast<const float4*>(p.gate + b * p.gbs + n);
+    }
+  }
+  (epilogue_tile<BN, OUT_F32, INTERIOR, Ts>(p, m0w, n0w, l31, hi, bq, gq), ...);
+}
+
+template <int BN, bool OUT_F32, bool INTERIOR>
+OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l31, int hi) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  if constexpr (TM == 4) {
+    epilogue_tn<BN, OUT_F32, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1, 2, 3>{});
+    epilogue_tn<BN, OUT_F32, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 4, 5, 6, 7>{});
+  } else {
+    epilogue_tn<BN, OUT_F32, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1>{});
+    epilogue_tn<BN, OUT_F32, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 2, 3>{});
+  }
+}
+
+template <int BN, bool OUT_F32>
+__global__ void __launch_bounds__(512, 2) gemm256_kernel(const GemmParams p) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
+  constexpr int WN = BN / (TN * 32);           // waves along N (4 or 2); waves along M = 8 / WN
+  constexpr int W_BASE = BN == 256 ? OSKG256_W_BASE : OSKG128_W_BASE;
+  constexpr int NWD = BN / 64;                 // weight LDS-DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int nbm = (p.M + 255) / 256, nbn = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * 256, n0 = bn * BN;
+
+  // ---- LDS-DMA sources: instruction j = wave + 8 i covers tile rows [8 j, 8 j + 8); byte offsets from the tensor base
+  const int srow8 = lane >> 3, spos = lane & 7;
+  unsigned aoff[4], woff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 8 * i) * 8 + srow8;
+    const int c = spos ^ ((r >> 1) & 7);
+    int m = m0 + r;
+    m = m < p.M ? m : p.M - 1;
+    const int b = m / p.arpb, l = m - b * p.arpb;
+    aoff[i] = (unsigned)((b * p.abs_ + (int64_t)l * p.ars + c * 8) * 2);
+    int n = n0 + (r < BN ? r : 0);
+    n = n < p.N ? n : p.N - 1;
+    woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int sw = (l31 >> 1) & 7;
+  unsigned faA[4], faW[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const unsigned sz = (unsigned)((((ks << 1) | hi) ^ sw) << 4);
+    faA[ks] = lds_base + (wm * TM * 32 + l31) * 128 + sz;
+    faW[ks] = lds_base + W_BASE + (wn * TN * 32 + l31) * 128 + sz;
+  }
+  const uint64_t abase = rfl64((uint64_t)(uintptr_t)p.A), wbase = rfl64((uint64_t)(uintptr_t)p.W);
+  const unsigned nk = rfl((unsigned)(p.K / 64));
+  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + W_BASE + wave * 1024);
+
+#define OSKG_OPERANDS                                                                                              \
+  ::"v"(faA[0]), "v"(faA[1]), "v"(faA[2]), "v"(faA[3]), "v"(faW[0]), "v"(faW[1]), "v"(faW[2]), "v"(faW[3]),         \
+      "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), \
+      "s"(abase), "s"(wbase), "s"(nk), "s"(adst), "s"(wdst)
+  if constexpr (BN == 256) {
+    asm volatile(
+#include "gemm256_body_n256.inc"
+        OSKG_OPERANDS : OSKG256_CLOBBERS);
+  } else {
+    asm volatile(
+#include "gemm256_body_n128.inc"
+        OSKG_OPERANDS : OSKG128_CLOBBERS);
+  }
+  (void)NWD;
+
+  // ---- epilogue: lane owns row m = ... + l31, columns n = quad*8 + hi*4 + {0..3} of every 32 x 32 tile
+  const int m0w = m0 + wm * TM * 32, n0w = n0 + wn * TN * 32;
+  const int b_first = m0w / p.crpb, b_last = (m0w + TM * 32 - 1) / p.crpb;
+  const bool interior = m0w + TM * 32 <= p.M && n0w + TN * 32 <= p.N && b_first == b_last;  // wave-uniform
+  if (interior) epilogue_all<BN, OUT_F32, true>(p, m0w, n0w, l31, hi);
+  else epilogue_all<BN, OUT_F32, false>(p, m0w, n0w, l31, hi);
+}
+
+template <int BN, bool OUT_F32>
+int launch_one(const GemmParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int SMEM = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;
+  auto kernel = gemm256_kernel<BN, OUT_F32>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int nblk = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kernel, dim3(nblk), dim3(512), SMEM, st, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// the 32-bit per-lane source offsets require both operand tensors to span < 4 GiB from their base pointers
+bool gemm256_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems) {
+  return p.K % 64 == 0 && p.M >= 256 && p.N >= 128 && a_span_elems * 2 < (int64_t)0xFFFFFFFF &&
+         w_span_elems * 2 < (int64_t)0xFFFFFFFF;
+}
+
+int launch_gemm256(const GemmParams& p, int bn, int out_f32, hipStream_t st) {
+  if (bn == 256) return out_f32 ? launch_one<256, true>(p, st) : launch_one<256, false>(p, st);
+  return out_f32 ? launch_one<128, true>(p, st) : launch_one<128, false>(p, st);
+}
+
+}  // namespace osk_gemm

@@ -13,7 +13,7 @@
 // A register-staged variant (same LDS image) is kept for A/B testing (OSK_GEMM_VARIANT=1).
 //
 // Roofline: MFMA bf16 (2.5 PFLOP/s dense).  Algorithmic FLOPs = 2*M*N*K.
-#include "osk_common.h"
+#include "gemm_params.h"
 #include "../../include/osk.h"
 #include <stdlib.h>
 
@@ -23,21 +23,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
 constexpr int SMEM_BYTES = 2 * 2 * TILE_BYTES;
 
-struct GemmParams {
-  const unsigned short* A;
-  int64_t abs_, ars;
-  int arpb;
-  const unsigned short* W;
-  int64_t wrs;
-  const float* bias;
-  void* C;
-  int64_t cbs, crs;
-  int crpb;
-  const unsigned short* res;
-  const float* gate;
-  int64_t gbs;
-  int M, N, K, gelu_from;
-};
+using osk_gemm::GemmParams;
 
 OSK_DEV void glds16(const unsigned short* g, unsigned char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -217,11 +203,14 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(const GemmParams p) {
   }
 }
 
+// A/B knob (read once): -1 (default) = the large-tile hand-scheduled kernel (gemm256.hip) whenever it applies,
+// else this file's kernel; 0 = always this file (LDS-DMA staging), 1 = this file, register staging;
+// 2 / 3 = gemm256.hip with BN forced to 256 / 128
 int gemm_variant() {
-  static int v = -1;
-  if (v < 0) {
+  static int v = -2;
+  if (v == -2) {
     const char* e = getenv("OSK_GEMM_VARIANT");
-    v = e ? atoi(e) : 0;
+    v = e ? atoi(e) : -1;
   }
   return v;
 }
@@ -247,10 +236,22 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
   p.C = C; p.cbs = c_batch_stride; p.crs = c_row_stride; p.crpb = c_rows_per_batch;
   p.res = (const unsigned short*)res; p.gate = gate; p.gbs = gate_batch_stride;
   p.M = M; p.N = N; p.K = K; p.gelu_from = gelu_from;
+  hipStream_t st = (hipStream_t)stream;
+  const int gv = gemm_variant();
+  if (gv == -1 || gv >= 2) {
+    const int nb = (M + a_rows_per_batch - 1) / a_rows_per_batch;
+    const int64_t a_span = (int64_t)(nb - 1) * a_batch_stride + (int64_t)(a_rows_per_batch - 1) * a_row_stride + K;
+    const int64_t w_span = (int64_t)(N - 1) * w_row_stride + K;
+    if (osk_gemm::gemm256_supported(p, a_span, w_span)) {
+      int bn = N >= 256 ? 256 : 128;   // measured: the 256-wide tile wins even at N = 1152 (4.5 tiles, 10 % padding)
+      if (gv == 2) bn = 256;
+      if (gv == 3) bn = 128;
+      return osk_gemm::launch_gemm256(p, bn, out_f32, st);
+    }
+  }
   const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   dim3 grid(nblk), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  const bool glds = gemm_variant() == 0;
+  const bool glds = gv != 1;
   if (glds) {
     if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, SMEM_BYTES, st, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, SMEM_BYTES, st, p);

@@ -1,0 +1,28 @@
+// Launch parameters shared by the bf16 GEMM kernels (gemm_bf16.hip, gemm256.hip).
+#pragma once
+#include "osk_common.h"
+#include <utility>
+
+namespace osk_gemm {
+
+struct GemmParams {
+  const unsigned short* A;
+  int64_t abs_, ars;
+  int arpb;
+  const unsigned short* W;
+  int64_t wrs;
+  const float* bias;
+  void* C;
+  int64_t cbs, crs;
+  int crpb;
+  const unsigned short* res;
+  const float* gate;
+  int64_t gbs;
+  int M, N, K, gelu_from;
+};
+
+// gemm256.hip: 256 x {256,128} x 64 tiles, 8 waves, hand-scheduled (generated) K loop
+bool gemm256_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
+int launch_gemm256(const GemmParams& p, int bn, int out_f32, hipStream_t st);
+
+}  // namespace osk_gemm

@@ -80,6 +80,51 @@ def test_gemm_plain_bias(hip_lib, M_L, N, K):
     assert (out32.cpu().double() - ref32).abs().max().item() <= 1e-3 * max(1.0, ref32.abs().max().item())
 
 
+# shapes that dispatch to the large-tile hand-scheduled kernel (gemm256.hip: M >= 256, N >= 128): exact tiles, ragged M
+# and N tails, tiles straddling a batch boundary, one K step (K = 64), both tile widths (N % 256 == 0 -> BN 256, else 128)
+@pytest.mark.parametrize("M_L,N,K", [((1, 256), 256, 64), ((1, 512), 512, 128), ((2, 300), 384, 192), ((3, 700), 1152, 1152),
+                                     ((1, 1000), 520, 256), ((2, 1024), 2304, 576), ((1, 257), 132, 64), ((1, 300), 200, 128)])
+def test_gemm_large_tile(hip_lib, M_L, N, K):
+    B, L = M_L
+    a = rnd("a", (B, L, K))
+    w = rnd("w", (N, K), std=K ** -0.5)
+    bias = rnd("b", (N,), std=0.1, dtype=torch.float32)
+    out = torch.empty(B, L, N, dtype=BF, device=DEV)
+    hip_lib.gemm(a, w, bias, out)
+    bf16_ulp_close(out.float().cpu(), _gemm_ref(a, w, bias).float().bfloat16().float(), rel=2 ** -7, abs_=2e-3)
+    out32 = torch.empty(B, L, N, dtype=torch.float32, device=DEV)
+    hip_lib.gemm(a, w, None, out32)
+    ref32 = _gemm_ref(a, w, None)
+    assert (out32.cpu().double() - ref32).abs().max().item() <= 1e-3 * max(1.0, ref32.abs().max().item())
+
+
+def test_gemm_large_tile_epilogues_and_views(hip_lib):
+    """single-block shaped at large-tile sizes: linear1 (GELU from col 3D) into a wide buffer, then linear2 reading the
+    [attn | gelu(mlp)] column view with gate * x + residual written in place (batch rows = 2 tiles + a tail)."""
+    B, L, D, R = 2, 600, 256, 1024
+    x = rnd("x", (B, L, D))
+    w1 = rnd("w1", (3 * D + R, D), std=D ** -0.5)
+    b1 = rnd("b1", (3 * D + R,), std=0.1, dtype=torch.float32)
+    y = torch.empty(B, L, 3 * D + R, dtype=BF, device=DEV)
+    hip_lib.gemm(x, w1, b1, y, gelu_from=3 * D)
+    bf16_ulp_close(y.float().cpu(), _gemm_ref(x, w1, b1, gelu_from=3 * D).float().bfloat16().float(), abs_=3e-3)
+    w2 = rnd("w2", (D, D + R), std=(D + R) ** -0.5)
+    b2 = rnd("b2", (D,), std=0.1, dtype=torch.float32)
+    gate = rnd("g", (B, 3 * D), std=0.5, dtype=torch.float32)
+    res = x.clone()
+    hip_lib.gemm(y[:, :, 2 * D:], w2, b2, res, res=res, gate=gate[:, 2 * D:], gate_batch_stride=gate.stride(0))
+    ref2 = _gemm_ref(y[:, :, 2 * D:], w2, b2, res=x, gate=gate[:, 2 * D:])
+    bf16_ulp_close(res.float().cpu(), ref2.float().bfloat16().float(), abs_=3e-3)
+    # joint-buffer rows: two GEMMs write disjoint row ranges of one buffer
+    Lt = 280
+    yj = torch.zeros(B, L, 3 * D, dtype=BF, device=DEV)
+    wi, wt = rnd("wi", (3 * D, D), std=D ** -0.5), rnd("wt", (3 * D, D), std=D ** -0.5)
+    hip_lib.gemm(x[:, Lt:], wi, None, yj[:, Lt:])
+    hip_lib.gemm(x[:, :Lt], wt, None, yj[:, :Lt])
+    bf16_ulp_close(yj[:, Lt:].float().cpu(), _gemm_ref(x[:, Lt:], wi, None).float().bfloat16().float(), abs_=3e-3)
+    bf16_ulp_close(yj[:, :Lt].float().cpu(), _gemm_ref(x[:, :Lt], wt, None).float().bfloat16().float(), abs_=3e-3)
+
+
 def test_gemm_is_transpose_detecting(hip_lib):
     """A = I block, asymmetric W: C must equal W^T rows exactly (guide: A=I-check with asymmetric B)."""
     K = N = 128

@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Generator of the hand-scheduled gfx950 K-loop of the large-tile bf16 GEMM (open_sora_amd/csrc/gemm256.hip).
+
+Tile 256 (M, activation rows) x BN (N, weight rows) x 64 (K); 8 waves = 512 threads (two per SIMD) in a WM x WN
+grid, each wave TM x TN v_mfma_f32_32x32x16_bf16 tiles with the operands swapped as in gemm_bf16.hip (A operand =
+weight fragment, B operand = activation fragment: a lane of the accumulator owns one output row m).
+  BN = 256: waves 2 x 4, wave tile 128 x 64  (TM 4, TN 2, 128 accumulator AGPRs)
+  BN = 128: waves 4 x 2, wave tile  64 x 64  (TM 2, TN 2,  64 accumulator AGPRs)
+LDS: two stages of [256][64] activations + [BN][64] weights, 128-byte rows, source-side XOR swizzle, filled by
+LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, 8 / 6 instructions per wave and K step).
+One K step of a wave (after the barrier that published stage `cur`):
+  fragment reads of k-sub-step 0 | the LAST k-sub-step of the previous K step (fragments already in registers)
+  with the LDS-DMA of stage cur^1 in its shadows | k-sub-steps 0..2, each prefetching the fragments of the next
+  into the other fragment set | vmcnt(0) lgkmcnt(0), barrier.
+Accumulators live in AGPRs a[0 : 16 TM TN); the wrapper reads them out for the fused epilogue.
+"""
+import argparse
+import os
+
+S_AB, S_WB, S_NK, S_ADST, S_WDST, S_T, S_KL, S_TMP, S_STEP = 40, 42, 44, 45, 46, 47, 48, 49, 50
+S_FIRST, S_LAST = 40, 51
+OPERANDS = ["faA0", "faA1", "faA2", "faA3", "faW0", "faW1", "faW2", "faW3", "aoff0", "aoff1", "aoff2", "aoff3",
+            "woff0", "woff1", "woff2", "woff3", "abase", "wbase", "nk", "adst", "wdst"]
+OP = {n: "%%%d" % i for i, n in enumerate(OPERANDS)}
+
+
+class Cfg:
+    def __init__(self, bn):
+        self.BN = bn
+        self.TM, self.TN = (4, 2) if bn == 256 else (2, 2)
+        self.NA, self.NW = 4, bn // 64           # LDS-DMA instructions per wave and stage (A: 32 / 8, W: BN/8 / 8)
+        self.A_STAGE, self.W_STAGE = 32768, bn * 128
+        self.W_BASE = 65536
+        self.SMEM = self.W_BASE + 2 * self.W_STAGE
+        self.NACC = 16 * self.TM * self.TN
+        self.NFRAG = self.TM + self.TN
+        self.V0 = 64                             # first asm-owned VGPR: two fragment sets
+        self.VN = 2 * self.NFRAG * 4
+        self.tag = "g%d" % bn
+
+    def frag(self, fset, idx):                   # idx: 0..TM-1 activation fragments, TM.. weight fragments
+        return self.V0 + (fset * self.NFRAG + idx) * 4
+
+
+def vr(b, n=1):
+    return "v%d" % b if n == 1 else "v[%d:%d]" % (b, b + n - 1)
+
+
+def ar(b, n=1):
+    return "a%d" % b if n == 1 else "a[%d:%d]" % (b, b + n - 1)
+
+
+def gen(c):
+    L = []
+    e = lambda t: L.append("  " + t)
+    lab = lambda n: L.append(".L%s_%s_%%=:" % (c.tag, n))   # %= : unique per emitted copy of the asm statement
+
+    def reads(stage, ks, fset):
+        out = []
+        for tm in range(c.TM):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, tm), 4), OP["faA%d" % ks], stage * c.A_STAGE + tm * 4096))
+        for tn in range(c.TN):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, c.TM + tn), 4), OP["faW%d" % ks], stage * c.W_STAGE + tn * 4096))
+        return out
+
+    def mfmas(fset):
+        out = []
+        for tn in range(c.TN):
+            for tm in range(c.TM):
+                acc = ar((tn * c.TM + tm) * 16, 16)
+                out.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, c.TM + tn), 4), vr(c.frag(fset, tm), 4), acc))
+        return out
+
+    def dma(stage):
+        """(m0 write, dma) pairs of this wave for one stage"""
+        out = []
+        for i in range(c.NA):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["aoff%d" % i], S_AB, S_AB + 1)))
+        for i in range(c.NW):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["woff%d" % i], S_WB, S_WB + 1)))
+        return out
+
+    def advance():
+        # point both loaders at the next K step; past the last one they stay (harmless re-fetch)
+        return ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
+                "s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK),
+                "s_cselect_b32 s%d, 128, 0" % S_STEP,
+                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL),
+                "s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1),
+                "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1)]
+
+    def interleave(mf, fill):
+        """after MFMA i emit fill[i] (a list of instructions)"""
+        for i, m in enumerate(mf):
+            e(m)
+            for f in (fill[i] if i < len(fill) else []):
+                e(f)
+
+    # ---- setup
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, OP["abase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, OP["wbase"]))
+    e("s_mov_b32 s%d, %s" % (S_NK, OP["nk"]))
+    e("s_mov_b32 s%d, %s" % (S_ADST, OP["adst"]))
+    e("s_mov_b32 s%d, %s" % (S_WDST, OP["wdst"]))
+    e("s_mov_b32 s%d, 0" % S_T)
+    e("s_mov_b32 s%d, 0" % S_KL)
+    for r in range(c.NACC):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    # ---- prologue: stage 0, then what step 0 does before its entry point (DMA of stage 1, reads of k-sub-step 0)
+    for m0w, d in dma(0):
+        e(m0w); e("s_nop 0"); e(d)
+    for a in advance():
+        e(a)
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    for m0w, d in dma(1):
+        e(m0w); e("s_nop 0"); e(d)
+    for a in advance():
+        e(a)
+    for r in reads(0, 0, 0):
+        e(r)
+    e("s_branch .L%s_entry0_%%=" % c.tag)
+
+    for k in range(2):
+        cur = k
+        lab("step%d" % k)
+        for r in reads(cur, 0, 0):
+            e(r)
+        # trailing k-sub-step 3 of the previous K step (fragment set 1) with the LDS-DMA of stage cur^1 in its shadows
+        mf = mfmas(1)
+        pieces = dma(cur ^ 1)
+        fill = [[] for _ in mf]
+        # M0 write before MFMA i, DMA after it: realised by putting the M0 write at the end of shadow i-1
+        e(pieces[0][0])
+        for i in range(len(mf)):
+            if i < len(pieces):
+                fill[i].append(pieces[i][1])
+                if i + 1 < len(pieces):
+                    fill[i].append(pieces[i + 1][0])
+        rest = pieces[len(mf):]
+        interleave(mf, fill)
+        for m0w, d in rest:
+            e(m0w); e("s_nop 0"); e(d)
+        for a in advance():
+            e(a)
+        lab("entry%d" % k)
+        for ks in range(3):
+            fset = ks % 2
+            e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(fset)
+            rd = reads(cur, ks + 1, fset ^ 1)
+            fill = [[] for _ in mf]
+            for i, r in enumerate(rd):
+                fill[i].append(r)
+            interleave(mf, fill)
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_barrier")
+        e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
+        e("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NK))
+        e("s_cbranch_scc0 .L%s_exit_%%=" % c.tag)
+        if k == 1:
+            e("s_branch .L%s_step0_%%=" % c.tag)
+    lab("exit")
+    for m in mfmas(1):
+        e(m)
+    e("s_nop 15")
+    e("s_nop 15")
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
+    args = ap.parse_args()
+    for bn in (256, 128):
+        c = Cfg(bn)
+        with open(os.path.join(args.out, "gemm256_body_n%d.inc" % bn), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile K loop.\n" % bn)
+            for ln in gen(c):
+                f.write('"%s\\n"\n' % ln)
+        with open(os.path.join(args.out, "gemm256_regs_n%d.inc" % bn), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
+            P = "OSKG%d_" % bn
+            f.write("#define %sSMEM %d\n#define %sW_BASE %d\n#define %sTM %d\n#define %sTN %d\n" % (P, c.SMEM, P, c.W_BASE, P, c.TM, P, c.TN))
+            clob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                   ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+            f.write("#define %sCLOBBERS %s\n" % (P, ", ".join(clob)))
+            for t in range(c.TM * c.TN):
+                f.write("#define %sAR%d %s\n" % (P, t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
+
+
+if __name__ == "__main__":
+    main()
