@@ -1,8 +1,8 @@
 // Flash-attention forward for head_dim 72 (DiT-XL geometry), gfx950: hand-scheduled main loop.
 //
-// Structure = attention_w64.hip (4 waves x 64 query rows, one wave per SIMD, LDS-DMA staged 64-key tiles,
-// swapped-operand v_mfma_f32_32x32x16_bf16), but the whole K/V loop is ONE asm statement emitted by
-// tools/gen_attn_asm.py (attention_asm72_body.inc): explicit register file (O^T and Q in AGPRs, two score tiles,
+// Structure = attention_w64.hip (4 waves x 64 query rows, one wave per SIMD -- or 8 waves x 32 rows, two per SIMD --
+// LDS-DMA staged 64-key tiles, swapped-operand v_mfma_f32_32x32x16_bf16), but the whole K/V loop is ONE asm
+// statement emitted by tools/gen_attn_asm.py (attention_asm72_n{NU}_v{VAR}.inc): explicit register file (O^T and Q in AGPRs, two score tiles,
 // P and two 4-slot fragment rings in VGPRs), every MFMA shadow filled by hand with ~5 issue slots of LDS reads /
 // exp2 / pack / max work, counted lgkmcnt waits, one barrier per tile.  See the generator's header for the
 // dataflow; this file is the wrapper: LDS init, Q pre-scale, the asm operands, the epilogue.
@@ -26,8 +26,10 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
-template <int VAR>
-__global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) {
+template <int NU, int VAR>
+__global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm72_kernel(const AttnParams p) {
+  constexpr int NW = 8 / NU;                                   // waves per workgroup
+  constexpr int NSLOT = NU == 2 ? OSK72N2_NSLOT : OSK72N1_NSLOT;  // LDS-DMA slots per wave and tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -39,7 +41,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
 
   // ---- LDS: zero (a tile slot that is never filled must hold finite data), ones row of both V^T slots,
   //      constant chunk {1.0, 0 x 7} = K's padding dims 72..79
-  for (int i = tid; i < OSK72_SMEM / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < OSK72_SMEM / 16; i += 64 * NW) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (tid < 64) {
     const int slot = tid >> 5;
@@ -48,11 +50,11 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   if (tid == 64) *reinterpret_cast<unsigned*>(smem + OSK72_CONST_OFF) = 0x00003F80u;
   __syncthreads();
 
-  // ---- Q fragments, pre-scaled by scale*log2(e), -> AGPRs a[OSK72_AQ0 ...] (u-major, k-step, 4 words)
-  int qi[2];
+  // ---- Q fragments, pre-scaled by scale*log2(e), -> AGPRs (u-major, k-step, 4 words)
+  int qi[NU];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    qi[u] = qb * 256 + wave * 64 + u * 32 + l31;
+  for (int u = 0; u < NU; ++u) {
+    qi[u] = qb * 256 + wave * (32 * NU) + u * 32 + l31;
     const int qc = qi[u] < p.Lq ? qi[u] : p.Lq - 1;
     const unsigned short* qrow = p.q + b * p.qbs + (int64_t)qc * p.qrs + h * HD;
     unsigned w[NKS * 4];
@@ -72,20 +74,24 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),    \
       "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]), "v"(w[16]), "v"(w[17]), "v"(w[18]), \
       "v"(w[19])
-    if (u == 0) {
-      asm volatile(OSK72_QW0 ::OSK_QIN : OSK72_A_CLOBBERS);
+    if constexpr (NU == 2) {
+      if (u == 0) {
+        asm volatile(OSK72N2_QW0 ::OSK_QIN : OSK72N2_A_CLOBBERS);
+      } else {
+        asm volatile(OSK72N2_QW1 ::OSK_QIN : OSK72N2_A_CLOBBERS);
+      }
     } else {
-      asm volatile(OSK72_QW1 ::OSK_QIN : OSK72_A_CLOBBERS);
+      asm volatile(OSK72N1_QW0 ::OSK_QIN : OSK72N1_A_CLOBBERS);
     }
   }
 
   // ---- per-lane LDS-DMA source offsets (bytes from the loader's tile base) of this wave's instruction slots:
-  //      K instruction j = wave + 4 i (j = 8: the 8-dim column image), V^T instruction j = (3 - wave) + 4 i
+  //      K instruction j = wave + NW i (j = 8: the 8-dim column image), V^T instruction j = (NW - 1 - wave) + NW i
   const int srow8 = lane >> 3, spos = lane & 7;
-  unsigned koff[3], voff[3];
+  unsigned koff[3] = {0, 0, 0}, voff[3] = {0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int j = wave + 4 * i;
+  for (int i = 0; i < NSLOT; ++i) {
+    const int j = wave + NW * i;
     unsigned o = 0;
     if (j < 8) {
       const int row = j * 8 + srow8;
@@ -94,7 +100,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
       o = (unsigned)(((int64_t)lane * p.krs + 64) * 2);
     }
     koff[i] = o;
-    const int jv = (3 - wave) + 4 * i;
+    const int jv = (NW - 1 - wave) + NW * i;
     unsigned ov = 0;
     if (jv < HD / 8) {
       const int d = jv * 8 + srow8;
@@ -119,37 +125,38 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   const uint64_t kjump = rfl64((uint64_t)((p.kss - (int64_t)p.tps * 64 * p.krs) * 2));
   const uint64_t vjump = rfl64((uint64_t)((p.vtss - (int64_t)p.tps * 64) * 2));
   const unsigned tps = rfl((unsigned)p.tps), nt = rfl((unsigned)(p.n_seg * p.tps));
-  const unsigned kdst = rfl(lds_base + wave * 1024), vdst = rfl(lds_base + OSK72_VOFF0 + (3 - wave) * 1024);
-  const unsigned nkw = rfl(wave == 0 ? 3u : 2u), nvw = rfl(wave == 3 ? 3u : 2u);
+  const unsigned kdst = rfl(lds_base + wave * 1024), vdst = rfl(lds_base + OSK72_VOFF0 + (NW - 1 - wave) * 1024);
+  // valid loader slots of this wave: the last one only where its instruction index is < 9
+  const unsigned nkw = rfl(wave + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1));
+  const unsigned nvw = rfl((NW - 1 - wave) + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1));
 
   float m_ref[2];
 #define OSK72_OPERANDS                                                                                              \
   : "=&v"(m_ref[0]), "=&v"(m_ref[1])                                                                                 \
   : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(fo[0]), "v"(fo[1]),     \
     "v"(fo[2]), "v"(fo[3]), "v"(kc[0][0]), "v"(kc[0][1]), "v"(kc[1][0]), "v"(kc[1][1]), "s"(kbase), "s"(vbase),     \
-    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)                 \
-  : OSK72_CLOBBERS
-  if constexpr (VAR == 0) {
+    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
+  if constexpr (NU == 2 && VAR == 0) {
     asm volatile(
-#include "attention_asm72_body_v0.inc"
-        OSK72_OPERANDS);
-  } else if constexpr (VAR == 1) {
+#include "attention_asm72_n2_v0.inc"
+        OSK72_OPERANDS : OSK72N2_CLOBBERS);
+  } else if constexpr (NU == 2) {
     asm volatile(
-#include "attention_asm72_body_v1.inc"
-        OSK72_OPERANDS);
-  } else if constexpr (VAR == 2) {
+#include "attention_asm72_n2_v1.inc"
+        OSK72_OPERANDS : OSK72N2_CLOBBERS);
+  } else if constexpr (VAR == 0) {
     asm volatile(
-#include "attention_asm72_body_v2.inc"
-        OSK72_OPERANDS);
+#include "attention_asm72_n1_v0.inc"
+        OSK72_OPERANDS : OSK72N1_CLOBBERS);
   } else {
     asm volatile(
-#include "attention_asm72_body_v3.inc"
-        OSK72_OPERANDS);
+#include "attention_asm72_n1_v1.inc"
+        OSK72_OPERANDS : OSK72N1_CLOBBERS);
   }
 
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 72 (sum of P), store
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NU; ++u) {
     float o[NDT][16];
 #pragma unroll
     for (int d = 0; d < NDT; ++d) {
@@ -157,18 +164,28 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   "=v"(o[d][0]), "=v"(o[d][1]), "=v"(o[d][2]), "=v"(o[d][3]), "=v"(o[d][4]), "=v"(o[d][5]), "=v"(o[d][6]),          \
       "=v"(o[d][7]), "=v"(o[d][8]), "=v"(o[d][9]), "=v"(o[d][10]), "=v"(o[d][11]), "=v"(o[d][12]), "=v"(o[d][13]), \
       "=v"(o[d][14]), "=v"(o[d][15])
-      if (u == 0 && d == 0) {
-        asm volatile(OSK72_OR0 : OSK_OOUT);
-      } else if (u == 0 && d == 1) {
-        asm volatile(OSK72_OR1 : OSK_OOUT);
-      } else if (u == 0 && d == 2) {
-        asm volatile(OSK72_OR2 : OSK_OOUT);
-      } else if (u == 1 && d == 0) {
-        asm volatile(OSK72_OR3 : OSK_OOUT);
-      } else if (u == 1 && d == 1) {
-        asm volatile(OSK72_OR4 : OSK_OOUT);
+      if constexpr (NU == 2) {
+        if (u == 0 && d == 0) {
+          asm volatile(OSK72N2_OR0 : OSK_OOUT);
+        } else if (u == 0 && d == 1) {
+          asm volatile(OSK72N2_OR1 : OSK_OOUT);
+        } else if (u == 0 && d == 2) {
+          asm volatile(OSK72N2_OR2 : OSK_OOUT);
+        } else if (u == 1 && d == 0) {
+          asm volatile(OSK72N2_OR3 : OSK_OOUT);
+        } else if (u == 1 && d == 1) {
+          asm volatile(OSK72N2_OR4 : OSK_OOUT);
+        } else {
+          asm volatile(OSK72N2_OR5 : OSK_OOUT);
+        }
       } else {
-        asm volatile(OSK72_OR5 : OSK_OOUT);
+        if (d == 0) {
+          asm volatile(OSK72N1_OR0 : OSK_OOUT);
+        } else if (d == 1) {
+          asm volatile(OSK72N1_OR1 : OSK_OOUT);
+        } else {
+          asm volatile(OSK72N1_OR2 : OSK_OOUT);
+        }
       }
     }
     // row 72 of O^T = sum_k P: lanes hi == 0, register (8 & 3) + 4 (8 >> 3) = 4 of row tile 2
@@ -197,10 +214,10 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   }
 }
 
-template <int VAR>
+template <int NU, int VAR>
 int launch_one(const AttnParams& p, hipStream_t st) {
   static bool attr_set = false;
-  auto kernel = attn_asm72_kernel<VAR>;
+  auto kernel = attn_asm72_kernel<NU, VAR>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, OSK72_SMEM);
@@ -208,7 +225,7 @@ int launch_one(const AttnParams& p, hipStream_t st) {
     attr_set = true;
   }
   const int nqb = (p.Lq + 255) / 256;
-  dim3 grid(nqb * p.B * p.H), block(256);
+  dim3 grid(nqb * p.B * p.H), block(64 * (8 / NU));
   hipLaunchKernelGGL(kernel, grid, block, OSK72_SMEM, st, p);
   return (int)hipGetLastError();
 }
@@ -217,15 +234,11 @@ int launch_one(const AttnParams& p, hipStream_t st) {
 
 bool asm72_supported(const AttnParams& p, int hd) { return hd == 72 && (p.seg_len % 64) == 0; }
 
-// var 0 = production schedule; 1..3 = experimental bodies emitted by tools/gen_attn_asm.py --exp (default: the
-// hazard-padded debug schedule in all three)
-int launch_asm72(const AttnParams& p, int var, hipStream_t st) {
-  switch (var) {
-    case 1: return launch_one<1>(p, st);
-    case 2: return launch_one<2>(p, st);
-    case 3: return launch_one<3>(p, st);
-    default: return launch_one<0>(p, st);
-  }
+// nu = query blocks per wave (2: 4 waves x 64 rows, 1: 8 waves x 32 rows); var 0 = production schedule, 1 = the
+// experimental body emitted by tools/gen_attn_asm.py --exp (default: the hazard-padded debug schedule)
+int launch_asm72(const AttnParams& p, int nu, int var, hipStream_t st) {
+  if (nu == 2) return var ? launch_one<2, 1>(p, st) : launch_one<2, 0>(p, st);
+  return var ? launch_one<1, 1>(p, st) : launch_one<1, 0>(p, st);
 }
 
 }  // namespace osk_attn

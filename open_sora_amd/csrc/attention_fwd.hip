@@ -25,6 +25,7 @@
 
 namespace {
 using osk_attn::AttnParams;
+#define OSK_ATTN_DEFAULT_NU 2
 
 template <int HD>
 struct Cfg {
@@ -642,7 +643,8 @@ int env_int(const char* name, int dflt) {
 // kernel structure (A/B knob, read once): -1 (default) = best available: the hand-scheduled head_dim-72 kernel
 // (attention_asm72.hip) when it applies, else 0;  0 = 8 waves x 32 rows (this file), 1 / 2 = the same with
 // scheduling hints, 9 = v1, 3 / 4 = 4 waves x 64 rows compiler-scheduled (attention_w64.hip) without / with
-// sched_group_barrier pipelines, 5 = attention_asm72.hip production schedule, 6..8 = its experimental bodies (hazard-padded debug schedule by default)
+// sched_group_barrier pipelines, 5 / 6 = attention_asm72.hip, 4 waves x 64 rows: production / experimental body (hazard-padded debug schedule by
+// default), 7 / 8 = the same for its 8 waves x 32 rows layout
 int attn_variant() {
   static const int v = env_int("OSK_ATTN_VARIANT", -1);
   return v;
@@ -676,8 +678,12 @@ int launch(const AttnParams& p, hipStream_t st) {
     case 6:
     case 7:
     case 8:
-      if (osk_attn::asm72_supported(p, HD))
-        return osk_attn::launch_asm72(p, attn_variant() >= 5 ? attn_variant() - 5 : 0, st);
+      if (osk_attn::asm72_supported(p, HD)) {
+        const int v = attn_variant();
+        // 5 / 6: 4 waves x 64 rows production / experimental body; 7 / 8: 8 waves x 32 rows production / experimental
+        const int nu = (v == 7 || v == 8) ? 1 : 2, var = (v == 6 || v == 8) ? 1 : 0;
+        return osk_attn::launch_asm72(p, v == -1 ? OSK_ATTN_DEFAULT_NU : nu, var, st);
+      }
       break;
     case 3: return osk_attn::launch_w64(p, HD, 0, st);
     case 4: return osk_attn::launch_w64(p, HD, 1, st);

@@ -38,6 +38,6 @@ OSK_DEV void block_to_work(const AttnParams& p, int nqb, int& bh, int& qb) {
 int launch_w64(const AttnParams& p, int hd, int hints, hipStream_t st);
 // attention_asm72.hip: the same structure for head_dim 72 with a hand-scheduled (generated) main loop
 bool asm72_supported(const AttnParams& p, int hd);
-int launch_asm72(const AttnParams& p, int var, hipStream_t st);
+int launch_asm72(const AttnParams& p, int nu, int var, hipStream_t st);
 
 }  // namespace osk_attn

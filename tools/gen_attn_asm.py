@@ -1,47 +1,41 @@
 #!/usr/bin/env python
-"""Generator of the hand-scheduled gfx950 main loop of the head_dim-72 flash-attention kernel
-(open_sora_amd/csrc/attention_asm72.hip includes the emitted attention_asm72_body.inc).
+"""Generator of the hand-scheduled gfx950 main loop of the head_dim-72 flash-attention kernels
+(open_sora_amd/csrc/attention_asm72.hip includes the emitted attention_asm72_n{NU}_v{VAR}.inc).
 
-Why a generator: one wave per SIMD owns the whole 512-register file, so every MFMA shadow (32 cycles, ~5 issue
-slots) has to be filled by hand; hipcc's scheduler clusters the softmax VALU work behind the MFMAs and shuffles
-accumulators between the VGPR and AGPR halves (tools/isa_stream.py on attention_w64.hip shows it).  The
-schedule below is explicit and reproducible; `python tools/gen_attn_asm.py --table` prints it gap by gap.
+Why a generator: the MFMA shadow (32 cycles, ~5 issue slots) has to be filled by hand; hipcc's scheduler clusters
+the softmax VALU work behind the MFMAs and shuffles accumulators between the VGPR and AGPR halves
+(tools/isa_stream.py on attention_w64.hip shows it).  The schedule below is explicit and reproducible;
+`python tools/gen_attn_asm.py --table NU` prints it shadow by shadow.
 
-Dataflow (same operand conventions as attention_w64.hip, which is the compiler-scheduled twin used to validate
-the LDS images and the pipeline on the GPU):
-  wave = 64 query rows = 2 query blocks u; KV tile = 64 keys; S^T = K . Q^T and O^T += V^T . P^T on
-  v_mfma_f32_32x32x16_bf16 with swapped operands (a lane owns one query).
-  Q is pre-multiplied by scale*log2(e); the running max M (bf16-exact, log2 units) sits, negated, in Q's padding
-  dim 72 and K's padding dim 72 reads 1.0 from a constant LDS chunk, so the MFMA delivers S' = q.k - M and
-  P = exp2(S') needs ONE v_exp per score; row sums come out of the P.V MFMA (ones row of V^T, accumulator row 72).
-  M only moves when a row max exceeds it by more than 2^THR (rare path: rescale O, shift the pending scores,
-  rewrite the padding dim).
-Body t (starts right after barrier t-1):  4 trailing P.V MFMAs of tile t-1 | QK^T of tile t+1 (20) | P.V of
-tile t (20 of 24); beside them: K / V^T fragment reads (4-deep rings), LDS-DMA of K(t+2), V(t+1), exp2 + pack
-of tile t, row max of tile t+1.
+Two layouts of the same dataflow, workgroup = 256 query rows, KV tile = 64 keys:
+  NU = 2: 4 waves x 64 rows (two 32-row query blocks u per wave share every K / V^T fragment), one wave per SIMD,
+          392 registers per wave;
+  NU = 1: 8 waves x 32 rows, two waves per SIMD (<= 256 registers each): twice the LDS fragment traffic, but each
+          wave's fillers also sit in the shadow of its partner's MFMAs.
+Dataflow (operand conventions of attention_w64.hip, the compiler-scheduled twin that validated the LDS images and
+the pipeline on the GPU): S^T = K . Q^T and O^T += V^T . P^T on v_mfma_f32_32x32x16_bf16 with swapped operands (a
+lane owns one query).  Q is pre-multiplied by scale*log2(e); the reference max M (bf16-exact, log2 units) sits,
+negated, in Q's padding dim 72 and K's padding dim 72 reads 1.0 from a constant LDS chunk, so the MFMA delivers
+S' = q.k - M and P = exp2(S') needs ONE v_exp per score; row sums come out of the P.V MFMA (ones row of V^T,
+accumulator row 72).  M only moves when some score exceeds it by more than 2^THR (rare path: rescale O, shift the
+pending scores, rewrite the padding dim).
+Body t (starts right after barrier t-1): the last 2 fragment pairs' P.V MFMAs of tile t-1 | QK^T of tile t+1 |
+P.V of tile t (first 10 of 12 fragment pairs); beside them: K / V^T fragment reads (4-deep rings), LDS-DMA of
+K(t+2), V(t+1), exp2 + pack of tile t, max of tile t+1.
 """
 import argparse
 import os
 
-HD = 72
-NKS, NDT = 5, 3
+HD, NKS, NDT = 72, 5, 3
 KTILE, VTILE = 9216, 12288
 KOFF = [0, KTILE]
 VOFF = [2 * KTILE, 2 * KTILE + VTILE]
 CONST_OFF = 2 * KTILE + 2 * VTILE          # 16-byte chunk {1.0bf16, 0...}: K's padding dims 72..79
 SMEM = CONST_OFF + 16
-WINDOWS = [4, 25, 24, 40, 26, 43]          # first / last shadow of filler classes A, B, C (see body())
-THR_BITS = "0x41000000"                    # 8.0: rescale when a row max exceeds the reference by > 2^8
+THR_BITS = "0x41000000"                    # 8.0: move M when a score exceeds the reference by > 2^8
+NKD = NVD = 9                              # LDS-DMA wave instructions per K / V^T tile
 
-# ---- physical registers owned by the asm (declared as clobbers by the wrapper)
-V_FIRST = 48
-SA0, SB0, PB0 = 48, 112, 176
-KR0, VR0 = 208, 224                        # fragment rings, 4 slots x 4 registers each
-TMP0 = 240                                 # 8 temporaries
-MT = [248, 249]                            # row max of the pending score tile, per query block
-MM = [250, 251]                            # running reference max M (bf16-exact f32), per query block
-TX = [252, 253, 254, 255]
-A_O0, A_Q0, A_LAST = 0, 96, 135
+# ---- asm-owned SGPRs
 S_FIRST, S_LAST = 36, 63
 S_KB, S_VB, S_KSTEP, S_KJ, S_VJ = 40, 42, 44, 46, 48
 S_TPS, S_NT, S_KDST, S_VDST, S_NKW, S_NVW = 50, 51, 52, 53, 54, 55
@@ -63,39 +57,63 @@ def ar(base, n=1):
     return "a%d" % base if n == 1 else "a[%d:%d]" % (base, base + n - 1)
 
 
-def S(setbase, u, t2, r=0):
-    return setbase + (u * 2 + t2) * 16 + r
+class Layout:
+    """register file and schedule geometry for NU query blocks per wave"""
 
+    def __init__(self, nu):
+        self.NU = nu
+        self.NW = 8 // nu                      # waves per workgroup
+        self.NSLOT = (NKD + self.NW - 1) // self.NW   # LDS-DMA slots per wave and tile (last one conditional)
+        self.V_FIRST = 48
+        self.SA0 = 48
+        self.SB0 = self.SA0 + 32 * nu
+        self.PB0 = self.SB0 + 32 * nu
+        self.KR0 = self.PB0 + 16 * nu          # fragment rings, 4 slots x 4 registers each
+        self.VR0 = self.KR0 + 16
+        self.TMP0 = self.VR0 + 16              # 8 temporaries
+        self.MT = [self.TMP0 + 8, self.TMP0 + 9]
+        self.MM = [self.TMP0 + 10, self.TMP0 + 11]
+        self.TX = [self.TMP0 + 12 + i for i in range(4)]
+        self.V_END = self.TMP0 + 16
+        self.A_O0 = 0
+        self.A_Q0 = 16 * NDT * nu
+        self.A_END = self.A_Q0 + 4 * NKS * nu
+        self.NTRAIL = 2 * nu                   # MFMAs of the 2 trailing fragment pairs
+        self.NQK = 10 * nu
+        self.NPVB = 10 * nu                    # P.V MFMAs inside the body
+        self.I_QK0 = self.NTRAIL               # global shadow index of the first QK^T MFMA
+        # first / last shadow of filler classes A (exp2+pack of key groups 0..2), B (group 3), C (max of tile t+1)
+        self.WINDOWS = [4, 25, 24, 40, 26, 43] if nu == 2 else [2, 13, 12, 19, 14, 21]
+        self.C_T2_RELEASE = 28 if nu == 2 else 15   # chains over keys 32..63: their last QK^T MFMAs come last
 
-def PB(u, g, w=0):
-    return PB0 + (u * 4 + g) * 4 + w
+    def S(self, setbase, u, t2, r=0):
+        return setbase + (u * 2 + t2) * 16 + r
 
+    def PB(self, u, g, w=0):
+        return self.PB0 + (u * 4 + g) * 4 + w
 
-def AO(u, d):
-    return A_O0 + (u * NDT + d) * 16
+    def AO(self, u, d):
+        return self.A_O0 + (u * NDT + d) * 16
 
-
-def AQ(u, ks):
-    return A_Q0 + (u * NKS + ks) * 4
+    def AQ(self, u, ks):
+        return self.A_Q0 + (u * NKS + ks) * 4
 
 
 class Stream:
-    """instruction list with in-order LDS-read bookkeeping (lgkmcnt) and simple hazard assertions"""
+    """instruction list with in-order LDS-read bookkeeping (lgkmcnt)"""
 
-    def __init__(self):
-        self.lines = []
-        self.pending = []   # tags of outstanding ds_reads, program order
-        self.table = []     # (kind, text) for --table
+    def __init__(self, ablate=frozenset()):
+        self.lines, self.pending, self.table = [], [], []
+        self.ablate, self.in_body = ablate, False
 
     def emit(self, text, kind="x"):
-        ab = getattr(self, "ablate", frozenset()) if getattr(self, "in_body", False) else frozenset()
+        ab = self.ablate if self.in_body else frozenset()
         if ("noexp" in ab and text.startswith("v_exp")) or ("nobar" in ab and text.startswith("s_barrier")) or \
            ("nodma" in ab and text.startswith("global_load_lds")) or \
            ("nolds" in ab and (text.startswith("ds_read") or "lgkmcnt" in text)) or \
            ("novalu" in ab and kind in ("e", "v") and not text.startswith("v_mfma") and not text.startswith("v_cmp")) or \
            ("nomfma" in ab and text.startswith("v_mfma")) or ("norare" in ab and text.startswith("s_cbranch_vccnz")) or \
-           ("nocvt" in ab and text.startswith("v_cvt_pk")) or ("nomax" in ab and (text.startswith("v_max") or text.startswith("v_cmp"))) or \
-           ("nowait" in ab and text.startswith("s_waitcnt lgkmcnt")) or ("nosalu" in ab and kind == "s" and not text.startswith("s_add_u32 m0") and "s%d, s%d, 1" % (S_T, S_T) not in text and "s_cmp_lt_u32 s%d, s%d" % (S_T, S_NT) not in text and "_exit" not in text and "_body0" not in text):
+           ("nocvt" in ab and text.startswith("v_cvt_pk")) or ("nomax" in ab and (text.startswith("v_max") or text.startswith("v_cmp"))):
             return
         self.lines.append("  " + text)
         self.table.append((kind, text))
@@ -112,62 +130,56 @@ class Stream:
         """wait until the read `tag` has landed (reads return in order)"""
         if tag in self.pending:
             idx = self.pending.index(tag)
-            after = len(self.pending) - 1 - idx
-            self.emit("s_waitcnt lgkmcnt(%d)" % after, "w")
+            self.emit("s_waitcnt lgkmcnt(%d)" % (len(self.pending) - 1 - idx), "w")
             self.pending = self.pending[idx + 1:]
-
-    def drain(self):
-        self.pending = []
 
 
 # ------------------------------------------------------------------------------------------ pieces
-def k_read(st, slot, p, tag):
+def k_read(st, L, slot, p, tag):
     """K fragment of pair p = (ks, t2) of the tile in ring slot `slot` -> K ring"""
     ks, t2 = p // 2, p % 2
-    dst = KR0 + (p % 4) * 4
+    dst = L.KR0 + (p % 4) * 4
     if ks < 4:
         st.ds_read(dst, OP["fo%d" % ks], KOFF[slot] + t2 * 4096, tag)
     else:
         st.ds_read(dst, OP["kc%d%d" % (slot, t2)], 0, tag)
 
 
-def v_read(st, slot, r, tag):
+def v_read(st, L, slot, r, tag):
     g, d = r // NDT, r % NDT
-    dst = VR0 + (r % 4) * 4
-    st.ds_read(dst, OP["fo%d" % g], VOFF[slot] + d * 4096, tag)
+    st.ds_read(L.VR0 + (r % 4) * 4, OP["fo%d" % g], VOFF[slot] + d * 4096, tag)
 
 
-def qk_mfma(st, sn, a):
-    ks, t2, u = a // 4, (a // 2) % 2, a % 2
-    p = a // 2
-    frag = KR0 + (p % 4) * 4
-    dst = vr(S(sn, u, t2), 16)
-    st.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, vr(frag, 4), ar(AQ(u, ks), 4), "0" if ks == 0 else dst), "M")
+def qk_mfma(st, L, sn, a):
+    p, u = a // L.NU, a % L.NU
+    ks, t2 = p // 2, p % 2
+    dst = vr(L.S(sn, u, t2), 16)
+    st.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, vr(L.KR0 + (p % 4) * 4, 4), ar(L.AQ(u, ks), 4),
+                                                       "0" if ks == 0 else dst), "M")
 
 
-def pv_mfma(st, b):
-    g, d, u = b // (2 * NDT), (b // 2) % NDT, b % 2
-    r = b // 2
-    frag = VR0 + (r % 4) * 4
-    dst = ar(AO(u, d), 16)
-    st.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, vr(frag, 4), vr(PB(u, g), 4), dst), "M")
+def pv_mfma(st, L, b):
+    r, u = b // L.NU, b % L.NU
+    g, d = r // NDT, r % NDT
+    dst = ar(L.AO(u, d), 16)
+    st.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, vr(L.VR0 + (r % 4) * 4, 4), vr(L.PB(u, g), 4), dst), "M")
 
 
-def exp_group(sc, u, g):
+def exp_group(L, sc, u, g):
     """exp2 + pack of 8 scores (16 keys of one query block) -> one B-operand fragment of P"""
     t2, r0 = g >> 1, (g & 1) * 8
     ops = []
     for r in range(8):
-        x = vr(S(sc, u, t2, r0 + r))
+        x = vr(L.S(sc, u, t2, r0 + r))
         ops.append(("e", "v_exp_f32 %s, %s" % (x, x)))
     for w in range(4):
-        ops.append(("v", "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(PB(u, g, w)), vr(S(sc, u, t2, r0 + 2 * w)),
-                                                           vr(S(sc, u, t2, r0 + 2 * w + 1)))))
+        ops.append(("v", "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(L.PB(u, g, w)), vr(L.S(sc, u, t2, r0 + 2 * w)),
+                                                           vr(L.S(sc, u, t2, r0 + 2 * w + 1)))))
     return ops
 
 
-def rowmax_chain(sn, u, t2, tmp):
-    x = lambda r: vr(S(sn, u, t2, r))
+def max_chain(L, sn, u, t2, tmp):
+    x = lambda r: vr(L.S(sn, u, t2, r))
     ops = [("v", "v_max3_f32 %s, %s, %s, %s" % (vr(tmp), x(0), x(1), x(2)))]
     for k in range(6):
         ops.append(("v", "v_max3_f32 %s, %s, %s, %s" % (vr(tmp), vr(tmp), x(3 + 2 * k), x(4 + 2 * k))))
@@ -175,253 +187,233 @@ def rowmax_chain(sn, u, t2, tmp):
     return ops
 
 
-def lanemax_final():
-    """common path: ONE number per lane = max of its 64 pending scores (both query blocks); the exact per-row max
-    (other half-wave included) is only formed in the rare path"""
-    return [("v", "v_max3_f32 %s, %s, %s, %s" % (vr(MT[0]), vr(TMP0), vr(TMP0 + 1), vr(TMP0 + 2))),
-            ("v", "v_max_f32 %s, %s, %s" % (vr(MT[0]), vr(MT[0]), vr(TMP0 + 3))),
-            # the compare already here: VCC is old news when the next body's s_cbranch_vccnz reads it
-            ("v", "v_cmp_lt_f32 vcc, %s, %s" % (THR_BITS, vr(MT[0])))]
+def chain_tmp(L, u, t2):
+    return L.TMP0 + t2 * L.NU + u
 
 
-def rowmax_from_chains(st):
-    """rare path / prologue: per query block, combine the two chain maxima (TMP0+u: keys 0..31, TMP0+2+u: keys
-    32..63 of this lane's half) and the other half-wave's -> MT[u]"""
-    for u in range(2):
-        ta, tb = TMP0 + u, TMP0 + 2 + u
+def lanemax_final(L):
+    """common path: ONE number per lane = max of its pending scores; the exact per-row max (other half-wave included)
+    is only formed in the rare path.  The compare sits here so that VCC is old news at the next body's branch."""
+    t = [vr(L.TMP0 + i) for i in range(2 * L.NU)]
+    if L.NU == 2:
+        ops = [("v", "v_max3_f32 %s, %s, %s, %s" % (vr(L.MT[0]), t[0], t[1], t[2])),
+               ("v", "v_max_f32 %s, %s, %s" % (vr(L.MT[0]), vr(L.MT[0]), t[3]))]
+    else:
+        ops = [("v", "v_max_f32 %s, %s, %s" % (vr(L.MT[0]), t[0], t[1]))]
+    return ops + [("v", "v_cmp_lt_f32 vcc, %s, %s" % (THR_BITS, vr(L.MT[0])))]
+
+
+def rowmax_from_chains(st, L):
+    """rare path / prologue: per query block, combine the two chain maxima and the other half-wave's -> MT[u]"""
+    for u in range(L.NU):
+        ta, tb = chain_tmp(L, u, 0), chain_tmp(L, u, 1)
         st.emit("v_max_f32 %s, %s, %s" % (vr(ta), vr(ta), vr(tb)))
         st.emit("v_mov_b32 %s, %s" % (vr(tb), vr(ta)))
         st.emit("s_nop 1", "n")
         st.emit("v_permlane32_swap_b32 %s, %s" % (vr(ta), vr(tb)))
         st.emit("s_nop 1", "n")
-        st.emit("v_max_f32 %s, %s, %s" % (vr(MT[u]), vr(ta), vr(tb)))
+        st.emit("v_max_f32 %s, %s, %s" % (vr(L.MT[u]), vr(ta), vr(tb)))
 
 
-def k_dma(st, slot, i, part=3):
-    """K loader slot i of this wave -> ring slot `slot` (instruction j = wave + 4 i).  part 1 = M0 write only,
+def k_dma(st, L, slot, i, part=3):
+    """K loader slot i of this wave -> ring slot `slot` (instruction j = wave + NW i).  part 1 = M0 write only,
     2 = the DMA only (one other instruction must sit between them), 3 = both with an s_nop"""
     if part & 1:
-        st.emit("s_add_u32 m0, s%d, %d" % (S_KDST, KOFF[slot] + 4096 * i), "s")
+        st.emit("s_add_u32 m0, s%d, %d" % (S_KDST, KOFF[slot] + 1024 * L.NW * i), "s")
     if part == 3:
         st.emit("s_nop 0", "n")
     if part & 2:
         st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["koff%d" % i], S_KB, S_KB + 1), "g")
 
 
-def v_dma(st, slot, i, part=3):
+def v_dma(st, L, slot, i, part=3):
     if part & 1:
-        st.emit("s_add_u32 m0, s%d, %d" % (S_VDST, (VOFF[slot] - VOFF[0]) + 4096 * i), "s")
+        st.emit("s_add_u32 m0, s%d, %d" % (S_VDST, (VOFF[slot] - VOFF[0]) + 1024 * L.NW * i), "s")
     if part == 3:
         st.emit("s_nop 0", "n")
     if part & 2:
         st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["voff%d" % i], S_VB, S_VB + 1), "g")
 
 
-def k_advance(st, uid):
-    """point the K loader at its next tile; past the last tile it stays (harmless re-fetch of the last tile)"""
-    L = ".L@@_ka%s" % uid
-    st.emit("s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL), "s")
+def dma_last(st, L, which, slot, uid):
+    """last loader slot: only the wave(s) whose instruction index is < 9"""
+    lab = ".L@@_%s2%s" % (which, uid)
+    st.emit("s_cmp_lt_u32 s%d, %d" % (S_NKW if which == "k" else S_NVW, L.NSLOT), "s")
+    st.emit("s_cbranch_scc1 %s" % lab, "s")
+    (k_dma if which == "k" else v_dma)(st, L, slot, L.NSLOT - 1)
+    st.label(lab)
+
+
+def advance(st, which, uid):
+    """point the loader at its next tile; past the last tile it stays (harmless re-fetch of the last tile)"""
+    lab = ".L@@_%sa%s" % (which, uid)
+    sl, sb, stt, sj = (S_KL, S_KB, S_KTT, S_KJ) if which == "k" else (S_VL, S_VB, S_VTT, S_VJ)
+    st.emit("s_add_u32 s%d, s%d, 1" % (S_TMP, sl), "s")
     st.emit("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NT), "s")
-    st.emit("s_cbranch_scc0 %s" % L, "s")
-    st.emit("s_mov_b32 s%d, s%d" % (S_KL, S_TMP), "s")
-    st.emit("s_add_u32 s%d, s%d, s%d" % (S_KB, S_KB, S_KSTEP), "s")
-    st.emit("s_addc_u32 s%d, s%d, 0" % (S_KB + 1, S_KB + 1), "s")
-    st.emit("s_add_u32 s%d, s%d, 1" % (S_KTT, S_KTT), "s")
-    st.emit("s_cmp_lg_u32 s%d, s%d" % (S_KTT, S_TPS), "s")
-    st.emit("s_cbranch_scc1 %s" % L, "s")
-    st.emit("s_mov_b32 s%d, 0" % S_KTT, "s")
-    st.emit("s_add_u32 s%d, s%d, s%d" % (S_KB, S_KB, S_KJ), "s")
-    st.emit("s_addc_u32 s%d, s%d, s%d" % (S_KB + 1, S_KB + 1, S_KJ + 1), "s")
-    st.label(L)
-
-
-def v_advance(st, uid):
-    L = ".L@@_va%s" % uid
-    st.emit("s_add_u32 s%d, s%d, 1" % (S_TMP, S_VL), "s")
-    st.emit("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NT), "s")
-    st.emit("s_cbranch_scc0 %s" % L, "s")
-    st.emit("s_mov_b32 s%d, s%d" % (S_VL, S_TMP), "s")
-    st.emit("s_add_u32 s%d, s%d, 128" % (S_VB, S_VB), "s")
-    st.emit("s_addc_u32 s%d, s%d, 0" % (S_VB + 1, S_VB + 1), "s")
-    st.emit("s_add_u32 s%d, s%d, 1" % (S_VTT, S_VTT), "s")
-    st.emit("s_cmp_lg_u32 s%d, s%d" % (S_VTT, S_TPS), "s")
-    st.emit("s_cbranch_scc1 %s" % L, "s")
-    st.emit("s_mov_b32 s%d, 0" % S_VTT, "s")
-    st.emit("s_add_u32 s%d, s%d, s%d" % (S_VB, S_VB, S_VJ), "s")
-    st.emit("s_addc_u32 s%d, s%d, s%d" % (S_VB + 1, S_VB + 1, S_VJ + 1), "s")
-    st.label(L)
-
-
-def k_dma2(st, slot, uid):
-    """third K loader slot: only the wave that owns instruction 8 (the 8-dim column image)"""
-    L = ".L@@_k2%s" % uid
-    st.emit("s_cmp_lt_u32 s%d, 3" % S_NKW, "s")
-    st.emit("s_cbranch_scc1 %s" % L, "s")
-    k_dma(st, slot, 2)
-    st.label(L)
-
-
-def v_dma2(st, slot, uid):
-    L = ".L@@_v2%s" % uid
-    st.emit("s_cmp_lt_u32 s%d, 3" % S_NVW, "s")
-    st.emit("s_cbranch_scc1 %s" % L, "s")
-    v_dma(st, slot, 2)
-    st.label(L)
-
-
-def dma_group(st, which, slot, uid):
-    """all LDS-DMA instructions of this wave for one K (or V^T) tile + loader advance (prologue form)"""
+    st.emit("s_cbranch_scc0 %s" % lab, "s")
+    st.emit("s_mov_b32 s%d, s%d" % (sl, S_TMP), "s")
     if which == "k":
-        k_dma(st, slot, 0)
-        k_dma(st, slot, 1)
-        k_dma2(st, slot, uid)
-        k_advance(st, uid)
+        st.emit("s_add_u32 s%d, s%d, s%d" % (sb, sb, S_KSTEP), "s")
     else:
-        v_dma(st, slot, 0)
-        v_dma(st, slot, 1)
-        v_dma2(st, slot, uid)
-        v_advance(st, uid)
+        st.emit("s_add_u32 s%d, s%d, 128" % (sb, sb), "s")
+    st.emit("s_addc_u32 s%d, s%d, 0" % (sb + 1, sb + 1), "s")
+    st.emit("s_add_u32 s%d, s%d, 1" % (stt, stt), "s")
+    st.emit("s_cmp_lg_u32 s%d, s%d" % (stt, S_TPS), "s")
+    st.emit("s_cbranch_scc1 %s" % lab, "s")
+    st.emit("s_mov_b32 s%d, 0" % stt, "s")
+    st.emit("s_add_u32 s%d, s%d, s%d" % (sb, sb, sj), "s")
+    st.emit("s_addc_u32 s%d, s%d, s%d" % (sb + 1, sb + 1, sj + 1), "s")
+    st.label(lab)
 
 
-def fixup(st, sx, uid, init):
+def dma_group(st, L, which, slot, uid):
+    """all LDS-DMA instructions of this wave for one K (or V^T) tile + loader advance (prologue form)"""
+    for i in range(L.NSLOT - 1):
+        (k_dma if which == "k" else v_dma)(st, L, slot, i)
+    dma_last(st, L, which, slot, uid)
+    advance(st, which, uid)
+
+
+def fixup(st, L, sx, init):
     """move the reference max M to (M + max(mt, 0)) [init: to mt], rounded to bf16: shift the pending scores,
     rescale O (not at init: O == 0), rewrite Q's padding dim 72 with -M."""
     if not init:
         st.emit("s_nop 15", "n")
         st.emit("s_nop 15", "n")  # trailing P.V MFMAs -> v_accvgpr_read of O
-    rowmax_from_chains(st)
-    for u in range(2):
-        d, n, pk, f, de, al, t = TX[0], TX[1], TX[2], TX[3], TMP0 + 4, TMP0 + 5, TMP0 + 6
+    rowmax_from_chains(st, L)
+    T = L.TMP0
+    for u in range(L.NU):
+        d, n, pk, f, de, al, t = L.TX[0], L.TX[1], L.TX[2], L.TX[3], T + 4, T + 5, T + 6
         if init:
-            st.emit("v_mov_b32 %s, %s" % (vr(n), vr(MT[u])))
+            st.emit("v_mov_b32 %s, %s" % (vr(n), vr(L.MT[u])))
         else:
-            st.emit("v_max_f32 %s, 0, %s" % (vr(d), vr(MT[u])))
-            st.emit("v_add_f32 %s, %s, %s" % (vr(n), vr(MM[u]), vr(d)))
+            st.emit("v_max_f32 %s, 0, %s" % (vr(d), vr(L.MT[u])))
+            st.emit("v_add_f32 %s, %s, %s" % (vr(n), vr(L.MM[u]), vr(d)))
         st.emit("v_xor_b32 %s, 0x80000000, %s" % (vr(n), vr(n)))              # -(M + mt')
         st.emit("v_cvt_pk_bf16_f32 %s, %s, 0" % (vr(pk), vr(n)))                # lo16 = bf16(-M_new), hi16 = 0
         st.emit("v_lshlrev_b32 %s, 16, %s" % (vr(f), vr(pk)))                   # f32(-M_new)
-        st.emit("v_add_f32 %s, %s, %s" % (vr(de), vr(MM[u]), vr(f)))            # M_old - M_new (<= 0 in the loop)
-        st.emit("v_xor_b32 %s, 0x80000000, %s" % (vr(MM[u]), vr(f)))            # M = M_new
+        st.emit("v_add_f32 %s, %s, %s" % (vr(de), vr(L.MM[u]), vr(f)))          # M_old - M_new (<= 0 in the loop)
+        st.emit("v_xor_b32 %s, 0x80000000, %s" % (vr(L.MM[u]), vr(f)))          # M = M_new
         if not init:
             st.emit("v_exp_f32 %s, %s" % (vr(al), vr(de)))                      # alpha = 2^(M_old - M_new)
         # Q padding dim 72 lives in lanes 32..63 of word 0 of the k-step-4 fragment
-        st.emit("v_accvgpr_read_b32 %s, %s" % (vr(t), ar(AQ(u, 4))))
+        st.emit("v_accvgpr_read_b32 %s, %s" % (vr(t), ar(L.AQ(u, 4))))
         st.emit("s_nop 0", "n")
         st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(t), vr(t), vr(pk), S_HIM, S_HIM + 1))
         st.emit("s_nop 0", "n")
-        st.emit("v_accvgpr_write_b32 %s, %s" % (ar(AQ(u, 4)), vr(t)))
+        st.emit("v_accvgpr_write_b32 %s, %s" % (ar(L.AQ(u, 4)), vr(t)))
         for t2 in range(2):
             for r in range(16):
-                x = vr(S(sx, u, t2, r))
+                x = vr(L.S(sx, u, t2, r))
                 st.emit("v_add_f32 %s, %s, %s" % (x, x, vr(de)))
         if not init:
             for dd in range(NDT):
                 for r0 in range(0, 16, 4):
                     for r in range(r0, r0 + 4):
-                        st.emit("v_accvgpr_read_b32 %s, %s" % (vr(TMP0 + (r - r0)), ar(AO(u, dd) + r)))
+                        st.emit("v_accvgpr_read_b32 %s, %s" % (vr(T + (r - r0)), ar(L.AO(u, dd) + r)))
                     st.emit("s_nop 0", "n")
                     for r in range(r0, r0 + 4):
-                        tt = vr(TMP0 + (r - r0))
-                        st.emit("v_mul_f32 %s, %s, %s" % (tt, tt, vr(al)))
+                        st.emit("v_mul_f32 %s, %s, %s" % (vr(T + (r - r0)), vr(T + (r - r0)), vr(al)))
                     st.emit("s_nop 0", "n")
                     for r in range(r0, r0 + 4):
-                        st.emit("v_accvgpr_write_b32 %s, %s" % (ar(AO(u, dd) + r), vr(TMP0 + (r - r0))))
+                        st.emit("v_accvgpr_write_b32 %s, %s" % (ar(L.AO(u, dd) + r), vr(T + (r - r0))))
     st.emit("s_nop 7", "n")  # v_accvgpr_write -> MFMA operand
 
 
 # ------------------------------------------------------------------------------------------ body
-def body(st, k, safe, ablate=frozenset()):
+def body(st, L, k, safe):
     """iteration with ring slot parity k: SC = scores of tile t (k == 0: set A), SN receives tile t+1"""
-    sc, sn = (SA0, SB0) if k == 0 else (SB0, SA0)
+    NU = L.NU
+    sc, sn = (L.SA0, L.SB0) if k == 0 else (L.SB0, L.SA0)
     cur = k
     uid = "b%d" % k
     st.label(".L@@_body%d" % k)
     # -- top: K fragment reads of pairs 0..3 (tile t+1 sits in ring slot cur^1)
     for p in range(4):
-        k_read(st, cur ^ 1, p, ("k", p))
-    # -- 4 trailing P.V MFMAs of tile t-1 (fragments read before the barrier) + the K loader's LDS-DMA
-    k_dma(st, cur, 0, 1)                 # K(t+2) -> slot cur and V(t+1) -> slot cur^1: one LDS-DMA piece per shadow
-    pv_mfma(st, 20)                      # (the M0 write sits before the MFMA: no s_nop needed)
-    k_dma(st, cur, 0, 2)
-    k_dma(st, cur, 1, 1)
-    pv_mfma(st, 21)
-    k_dma(st, cur, 1, 2)
-    v_dma(st, cur ^ 1, 0, 1)
-    pv_mfma(st, 22)
-    v_dma(st, cur ^ 1, 0, 2)
-    v_dma(st, cur ^ 1, 1, 1)
-    pv_mfma(st, 23)
-    v_dma(st, cur ^ 1, 1, 2)
-    # -- decision: does any row max of tile t exceed the reference by more than 2^THR?
+        k_read(st, L, cur ^ 1, p, ("k", p))
+    # -- trailing P.V MFMAs of tile t-1 (fragment pairs 10, 11 were read before the barrier); in their shadows the
+    #    first LDS-DMA pieces of K(t+2) -> slot cur and V(t+1) -> slot cur^1 (M0 write BEFORE the MFMA: no s_nop)
+    pieces = [("k", i) for i in range(L.NSLOT - 1)] + [("v", i) for i in range(L.NSLOT - 1)]
+    pieces = pieces[:L.NTRAIL]
+    done = {"k": sum(1 for w, _ in pieces if w == "k"), "v": sum(1 for w, _ in pieces if w == "v")}
+
+    def piece(pc, part):
+        (k_dma if pc[0] == "k" else v_dma)(st, L, cur if pc[0] == "k" else cur ^ 1, pc[1], part)
+
+    for n in range(L.NTRAIL):
+        if n < len(pieces):
+            piece(pieces[n], 1)
+        pv_mfma(st, L, 10 * NU + n)
+        if n < len(pieces):
+            piece(pieces[n], 2)
+    # -- decision: did some score of tile t exceed the reference by more than 2^THR (VCC from the previous body)?
     st.emit("s_cbranch_vccnz .L@@_rare%d" % k)
     st.label(".L@@_entry%d" % k)
 
-    # -- fillers of the 40 shadows behind the QK^T (global MFMA index i = 4..23) and P.V (i = 24..43) MFMAs,
-    # paced in CYCLES (v_exp 8, other VALU 4, per-shadow budget ~26 of the MFMA's 32): three classes, each spread
-    # uniformly over its window of shadows
-    #   A: exp2 + pack of key groups 0..2   shadows  4..25   (P.V of group g starts at i = 24 + 6 g)
-    #   B: exp2 + pack of key group 3       shadows 24..40
-    #   C: row max of tile t+1              shadows 26..43   (its last QK^T MFMAs are i = 20..23)
+    # -- remaining LDS-DMA work, one item per shadow right after the entry point: (emitter, cycles)
+    later = []
+    for i in range(done["k"], L.NSLOT - 1):
+        later.append((lambda i=i: k_dma(st, L, cur, i), 12))
+    later.append((lambda: dma_last(st, L, "k", cur, uid), 12))
+    for i in range(done["v"], L.NSLOT - 1):
+        later.append((lambda i=i: v_dma(st, L, cur ^ 1, i), 12))
+    later.append((lambda: dma_last(st, L, "v", cur ^ 1, uid), 12))
+    later.append((lambda: advance(st, "k", uid), 28))
+    later.append((lambda: advance(st, "v", uid), 28))
+
+    # -- fillers paced in CYCLES (v_exp 8, other VALU 4): three classes, each spread uniformly over its window
     cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
     clsA, clsB, clsC = [], [], []
     for g in range(4):
-        for u in range(2):
-            (clsA if g < 3 else clsB).extend(exp_group(sc, u, g))
-    ca = [rowmax_chain(sn, 0, 0, TMP0), rowmax_chain(sn, 1, 0, TMP0 + 1)]     # t2 = 0: last MFMAs at i = 20, 21
-    cb = [rowmax_chain(sn, 0, 1, TMP0 + 2), rowmax_chain(sn, 1, 1, TMP0 + 3)]  # t2 = 1: last MFMAs at i = 22, 23
-    clsC.extend([o for pair in zip(*ca) for o in pair])
-    n_first_b = len(clsC)                # chain-B ops (t2 = 1) must not start before shadow 28
-    clsC.extend([o for pair in zip(*cb) for o in pair])
-    clsC.extend(lanemax_final())
-    W = WINDOWS
-    classes = [[clsA, W[0], W[1], 0, 0.0], [clsB, W[2], W[3], 0, 0.0], [clsC, W[4], W[5], 0, 0.0]]  # items, first, last, next, emitted
+        for u in range(NU):
+            (clsA if g < 3 else clsB).extend(exp_group(L, sc, u, g))
+    ca = [max_chain(L, sn, u, 0, chain_tmp(L, u, 0)) for u in range(NU)]
+    cb = [max_chain(L, sn, u, 1, chain_tmp(L, u, 1)) for u in range(NU)]
+    clsC.extend([o for grp in zip(*ca) for o in grp])
+    n_first_b = len(clsC)
+    clsC.extend([o for grp in zip(*cb) for o in grp])
+    clsC.extend(lanemax_final(L))
+    W = L.WINDOWS
+    classes = [[clsA, W[0], W[1], 0, 0.0], [clsB, W[2], W[3], 0, 0.0], [clsC, W[4], W[5], 0, 0.0]]
     totals = [sum(cost(o[0]) for o in c[0]) for c in classes]
-    mf = [("qk", a) for a in range(20)] + [("pv", b) for b in range(20)]
+    mf = [("qk", a) for a in range(L.NQK)] + [("pv", b) for b in range(L.NPVB)]
     for n, (kind, idx) in enumerate(mf):
-        i = 4 + n
+        i = L.I_QK0 + n
+        pair, u = idx // NU, idx % NU
+        if u == 0 and pair % 2 == 0:     # pairs 2m and 2m+1 with one wait (both were issued >= 3 pairs ago)
+            st.need(("k" if kind == "qk" else "v", pair + 1))
         if kind == "qk":
-            if idx % 4 == 0:             # pairs 2m and 2m+1 with one wait (both were issued >= 3 pairs ago)
-                st.need(("k", idx // 2 + 1))
-            qk_mfma(st, sn, idx)
+            qk_mfma(st, L, sn, idx)
         else:
-            if idx % 4 == 0:
-                st.need(("v", idx // 2 + 1))
-            pv_mfma(st, idx)
+            pv_mfma(st, L, idx)
         if safe:
             st.emit("s_nop 7", "n")
         used = 0.0
-        # ring reads: after the 2nd MFMA of pair x its ring slot is free -> read pair x + 4
-        if kind == "qk" and idx % 2 == 1:
-            p = idx // 2
-            if p + 4 < 10:
-                k_read(st, cur ^ 1, p + 4, ("k", p + 4))
-            else:
-                v_read(st, cur, p + 4 - 10, ("v", p + 4 - 10))   # V pairs 0..3 behind the last K pairs
-            used += 4
-        if kind == "pv" and idx % 2 == 1:
-            r = idx // 2
-            if r + 4 < 12:
-                v_read(st, cur, r + 4, ("v", r + 4))
+        # ring reads: after the last MFMA of pair x its ring slot is free -> read pair x + 4
+        if u == NU - 1:
+            if kind == "qk":
+                if pair + 4 < 10:
+                    k_read(st, L, cur ^ 1, pair + 4, ("k", pair + 4))
+                else:
+                    v_read(st, L, cur, pair + 4 - 10, ("v", pair + 4 - 10))   # V pairs 0..3 behind the last K pairs
                 used += 4
-        if i == 4:
-            k_dma2(st, cur, uid); used += 12
-        elif i == 5:
-            v_dma2(st, cur ^ 1, uid); used += 12
-        elif i == 6:
-            k_advance(st, uid); used += 28
-        elif i == 7:
-            v_advance(st, uid); used += 28
+            elif pair + 4 < 12:
+                v_read(st, L, cur, pair + 4, ("v", pair + 4))
+                used += 4
+        if later:
+            fn, cyc = later.pop(0)
+            fn()
+            used += cyc
         for ci, c in enumerate(classes):
-            items, first, last, nx, em = c
+            items, first, last = c[0], c[1], c[2]
             if i < first:
                 continue
             frac = min(1.0, (i - first + 1) / float(last - first + 1))
             while c[3] < len(items):
                 kind_, text = items[c[3]]
-                if ci == 2 and c[3] >= n_first_b and i < max(28, W[4]):
+                if ci == 2 and c[3] >= n_first_b and i < L.C_T2_RELEASE:
                     break
-                behind = totals[ci] * frac - c[4]
-                if behind <= 0 and i < last:
+                if totals[ci] * frac - c[4] <= 0 and i < last:
                     break
                 if used >= 30 and i < last:
                     break
@@ -431,20 +423,21 @@ def body(st, k, safe, ablate=frozenset()):
                 c[3] += 1
     for c in classes:
         assert c[3] == len(c[0]), "unscheduled filler work"
+    assert not later
     # -- end of body: DMA landed + every fragment read retired, then the tile barrier
     st.emit("s_waitcnt vmcnt(0) lgkmcnt(0)", "w")
-    st.drain()
+    st.pending = []
     st.emit("s_barrier", "B")
     st.emit("s_add_u32 s%d, s%d, 1" % (S_T, S_T), "s")
     st.emit("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NT), "s")
     st.emit("s_cbranch_scc0 .L@@_exit", "s")
     if k == 1:
         st.emit("s_branch .L@@_body0", "s")
+    return pieces
 
 
-def generate(safe=False, ablate=frozenset()):
-    st = Stream()
-    st.ablate = ablate
+def generate(L, safe=False, ablate=frozenset()):
+    st = Stream(ablate)
     e = st.emit
     # ---- copy the mutable scalars into asm-owned SGPRs
     e("s_mov_b64 s[%d:%d], %s" % (S_KB, S_KB + 1, OP["kbase"]))
@@ -452,116 +445,111 @@ def generate(safe=False, ablate=frozenset()):
     e("s_mov_b32 s%d, %s" % (S_KSTEP, OP["kstep"]))
     e("s_mov_b64 s[%d:%d], %s" % (S_KJ, S_KJ + 1, OP["kjump"]))
     e("s_mov_b64 s[%d:%d], %s" % (S_VJ, S_VJ + 1, OP["vjump"]))
-    e("s_mov_b32 s%d, %s" % (S_TPS, OP["tps"]))
-    e("s_mov_b32 s%d, %s" % (S_NT, OP["nt"]))
-    e("s_mov_b32 s%d, %s" % (S_KDST, OP["kdst"]))
-    e("s_mov_b32 s%d, %s" % (S_VDST, OP["vdst"]))
-    e("s_mov_b32 s%d, %s" % (S_NKW, OP["nkw"]))
-    e("s_mov_b32 s%d, %s" % (S_NVW, OP["nvw"]))
-    e("s_mov_b32 s%d, 0" % S_T)
-    e("s_mov_b32 s%d, 0" % S_KTT)
-    e("s_mov_b32 s%d, 0" % S_VTT)
-    e("s_mov_b32 s%d, 0" % S_KL)
-    e("s_mov_b32 s%d, 0" % S_VL)
-    e("s_mov_b32 s%d, 0" % S_HIM)
+    for sreg, name in ((S_TPS, "tps"), (S_NT, "nt"), (S_KDST, "kdst"), (S_VDST, "vdst"), (S_NKW, "nkw"), (S_NVW, "nvw")):
+        e("s_mov_b32 s%d, %s" % (sreg, OP[name]))
+    for sreg in (S_T, S_KTT, S_VTT, S_KL, S_VL, S_HIM):
+        e("s_mov_b32 s%d, 0" % sreg)
     e("s_mov_b32 s%d, -1" % (S_HIM + 1))
     for u in range(2):
-        e("v_mov_b32 %s, 0" % vr(MM[u]))
-    for r in range(A_O0, A_Q0):
+        e("v_mov_b32 %s, 0" % vr(L.MM[u]))
+    for r in range(L.A_O0, L.A_Q0):
         e("v_accvgpr_write_b32 %s, 0" % ar(r))
     # ---- prologue: K0, V0 -> slot 0, K1 -> slot 1
-    dma_group(st, "k", 0, "p0")
-    dma_group(st, "v", 0, "p1")
-    dma_group(st, "k", 1, "p2")
+    dma_group(st, L, "k", 0, "p0")
+    dma_group(st, L, "v", 0, "p1")
+    dma_group(st, L, "k", 1, "p2")
     e("s_waitcnt vmcnt(0)")
     e("s_barrier")
     # scores of tile 0 -> set A (Q's padding dim is 0: raw scores)
     for p in range(10):
-        k_read(st, 0, p, ("k", p))
+        k_read(st, L, 0, p, ("k", p))
         st.need(("k", p))
-        qk_mfma(st, SA0, 2 * p)
-        qk_mfma(st, SA0, 2 * p + 1)
+        for u in range(L.NU):
+            qk_mfma(st, L, L.SA0, p * L.NU + u)
     e("s_barrier")                      # every wave has read K0: slot 0 may be refilled
     e("s_nop 15")
     e("s_nop 15")
-    for op in (rowmax_chain(SA0, 0, 0, TMP0) + rowmax_chain(SA0, 1, 0, TMP0 + 1) + rowmax_chain(SA0, 0, 1, TMP0 + 2)
-               + rowmax_chain(SA0, 1, 1, TMP0 + 3)):
-        e(op[1])
-    fixup(st, SA0, "init", init=True)
-    # what body 0 does before its entry point: first LDS-DMA pieces of K(2) -> slot 0 and V(1) -> slot 1, first K
-    # fragment reads of tile 1
-    k_dma(st, 0, 0)
-    k_dma(st, 0, 1)
-    v_dma(st, 1, 0)
-    v_dma(st, 1, 1)
+    for t2 in range(2):
+        for u in range(L.NU):
+            for op in max_chain(L, L.SA0, u, t2, chain_tmp(L, u, t2)):
+                e(op[1])
+    fixup(st, L, L.SA0, init=True)
+    # what body 0 does before its entry point: the first LDS-DMA pieces of K(2) -> slot 0 and V(1) -> slot 1 (the
+    # same ones body() puts into the trailing shadows), the first K fragment reads of tile 1
+    pieces = body(Stream(), L, 0, False)
+    for w, i in pieces:
+        (k_dma if w == "k" else v_dma)(st, L, 0 if w == "k" else 1, i)
     for p in range(4):
-        k_read(st, 1, p, ("k", p))
+        k_read(st, L, 1, p, ("k", p))
     e("s_branch .L@@_entry0")
-    pend = list(st.pending)
     # ---- the two loop bodies
-    st.pending = []
     st.in_body = True
-    body(st, 0, safe, ablate)
-    st.pending = []
-    body(st, 1, safe, ablate)
+    for k in range(2):
+        st.pending = []
+        body(st, L, k, safe)
     st.in_body = False
     # ---- rare paths
     for k in range(2):
         st.label(".L@@_rare%d" % k)
-        fixup(st, SA0 if k == 0 else SB0, "r%d" % k, init=False)
+        fixup(st, L, L.SA0 if k == 0 else L.SB0, init=False)
         e("s_branch .L@@_entry%d" % k)
-    # ---- exit: the 4 trailing P.V MFMAs of the last tile
+    # ---- exit: the trailing P.V MFMAs of the last tile
     st.label(".L@@_exit")
-    for b in range(20, 24):
-        pv_mfma(st, b)
+    for n in range(L.NTRAIL):
+        pv_mfma(st, L, 10 * L.NU + n)
     e("s_nop 15")
     e("s_nop 15")
-    e("v_mov_b32 %s, %s" % (OP["m0out"], vr(MM[0])))
-    e("v_mov_b32 %s, %s" % (OP["m1out"], vr(MM[1])))
+    e("v_mov_b32 %s, %s" % (OP["m0out"], vr(L.MM[0])))
+    e("v_mov_b32 %s, %s" % (OP["m1out"], vr(L.MM[1])))
     return st
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--table", action="store_true")
-    ap.add_argument("--exp", nargs="*", default=["safe"], help="experimental variants 1..3: safe | ablations joined by + (noexp nobar nodma nolds novalu nomfma): timing only, wrong results")
+    ap.add_argument("--table", type=int, default=0, help="print the production schedule of layout NU (1 or 2)")
+    ap.add_argument("--exp", default="safe", help="experimental variant 1: safe | ablations joined by + (noexp nobar "
+                    "nodma nolds novalu nomfma norare nocvt nomax): timing only, wrong results")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
     args = ap.parse_args()
-    variants = [(False, frozenset())] + [(x == "safe", frozenset(x.split("+")) - {"safe"}) for x in args.exp]
-    while len(variants) < 4:
-        variants.append((True, frozenset()))
-    for vi, (safe, ablate) in enumerate(variants[:4]):
-        st = generate(safe, ablate)
-        if args.table and vi == 0:
-            gap = []
-            for kind, text in st.table:
-                if kind == "M":
-                    print("".join(gap)); gap = ["M "]
-                elif kind == "L":
-                    print("".join(gap)); gap = []; print(text + ":")
-                else:
-                    gap.append({"x": "v", "w": "w"}.get(kind, kind))
-            print("".join(gap))
-        with open(os.path.join(args.out, "attention_asm72_body_v%d.inc" % vi), "w") as f:
-            f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  variant %d: %s\n" %
-                    (vi, "production" if vi == 0 else ("hazard-padded (debug)" if safe else "timing ablation " + "+".join(sorted(ablate)))))
-            for ln in st.lines:
-                f.write('"%s\\n"\n' % ln.replace("@@", "osk72v%d" % vi))
+    for nu in (2, 1):
+        L = Layout(nu)
+        exp_safe = args.exp == "safe"
+        exp_ab = frozenset() if exp_safe else frozenset(args.exp.split("+"))
+        for vi, (safe, ablate) in enumerate([(False, frozenset()), (exp_safe, exp_ab)]):
+            st = generate(L, safe, ablate)
+            if args.table == nu and vi == 0:
+                gap = []
+                for kind, text in st.table:
+                    if kind == "M":
+                        print("".join(gap)); gap = ["M "]
+                    elif kind == "L":
+                        print("".join(gap)); gap = []; print(text + ":")
+                    else:
+                        gap.append({"x": "v"}.get(kind, kind))
+                print("".join(gap))
+            with open(os.path.join(args.out, "attention_asm72_n%d_v%d.inc" % (nu, vi)), "w") as f:
+                f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  layout NU=%d, variant %d: %s\n" %
+                        (nu, vi, "production" if vi == 0 else ("hazard-padded (debug)" if safe else "timing ablation " + "+".join(sorted(ablate)))))
+                for ln in st.lines:
+                    f.write('"%s\\n"\n' % ln.replace("@@", "osk72n%dv%d" % (nu, vi)))
     # register / operand contract for the wrapper
     with open(os.path.join(args.out, "attention_asm72_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.\n")
         f.write("#define OSK72_SMEM %d\n#define OSK72_CONST_OFF %d\n" % (SMEM, CONST_OFF))
         f.write("#define OSK72_KTILE %d\n#define OSK72_VTILE %d\n#define OSK72_VOFF0 %d\n" % (KTILE, VTILE, VOFF[0]))
-        f.write("#define OSK72_AQ0 %d\n" % A_Q0)
-        clob = ['"v%d"' % i for i in range(V_FIRST, 256)] + ['"a%d"' % i for i in range(0, A_LAST + 1)] + \
-               ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
-        f.write("#define OSK72_CLOBBERS %s\n" % ", ".join(clob))
-        f.write("#define OSK72_A_CLOBBERS %s\n" % ", ".join('"a%d"' % i for i in range(0, A_LAST + 1)))
-        for u in range(2):   # Q fragment words of query block u (operands %0..%19) -> AGPRs
-            f.write("#define OSK72_QW%d %s\n" % (u, " ".join('"v_accvgpr_write_b32 a%d, %%%d\\n"' % (AQ(u, 0) + i, i) for i in range(NKS * 4))))
-        for u in range(2):   # O^T row tile (u, d) -> operands %0..%15
-            for d in range(NDT):
-                f.write("#define OSK72_OR%d %s\n" % (u * NDT + d, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, AO(u, d) + i) for i in range(16))))
+        for nu in (2, 1):
+            L = Layout(nu)
+            P = "OSK72N%d_" % nu
+            clob = ['"v%d"' % i for i in range(L.V_FIRST, L.V_END)] + ['"a%d"' % i for i in range(0, L.A_END)] + \
+                   ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+            f.write("#define %sCLOBBERS %s\n" % (P, ", ".join(clob)))
+            f.write("#define %sA_CLOBBERS %s\n" % (P, ", ".join('"a%d"' % i for i in range(0, L.A_END))))
+            f.write("#define %sNSLOT %d\n" % (P, L.NSLOT))
+            for u in range(nu):   # Q fragment words of query block u (operands %0..%19) -> AGPRs
+                f.write("#define %sQW%d %s\n" % (P, u, " ".join('"v_accvgpr_write_b32 a%d, %%%d\\n"' % (L.AQ(u, 0) + i, i) for i in range(NKS * 4))))
+            for u in range(nu):   # O^T row tile (u, d) -> operands %0..%15
+                for d in range(NDT):
+                    f.write("#define %sOR%d %s\n" % (P, u * NDT + d, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, L.AO(u, d) + i) for i in range(16))))
 
 
 if __name__ == "__main__":
