@@ -87,12 +87,16 @@ int osk_rope_table(const float* ids, int64_t n_rows, int n_axes, const int32_t* 
  * Scales bf16 [hd].  cos/sin f32 [*, L, hd/2] with batch stride cs_batch_stride (0 = shared).
  * Rounding points follow the reference: bf16(x*rrms) * bf16 scale -> bf16, rotate in f32, -> bf16.
  * Either q or k (not both) may be NULL: only the other one is processed (the sequence-parallel path norms
- * K first so its all-gather can start while the Q / MLP projections run). */
+ * K first so its all-gather can start while the Q / MLP projections run).
+ * q_mult multiplies the rotated q (not k) in f32 BEFORE its final rounding to bf16: pass 1.0 for the reference's
+ * values, or softmax_scale * log2(e) together with q_prescaled = 1 in osk_attention_fwd_bf16 (the reference
+ * multiplies the f32 scores by the scale after q.k; folding it into q's single rounding keeps the same
+ * one-rounding error on q and lets the attention kernel exponentiate the MFMA output directly). */
 int osk_qknorm_rope_bf16(void* q, void* k, int64_t batch_stride, int64_t row_stride,
                          const void* q_scale0, const void* k_scale0,
                          const void* q_scale1, const void* k_scale1, int l_split,
                          const float* cos_t, const float* sin_t, int64_t cs_batch_stride,
-                         int B, int L, int H, int hd, int rope_mode, float eps, void* stream);
+                         int B, int L, int H, int hd, int rope_mode, float eps, float q_mult, void* stream);
 
 /* ---- V -> key-major transposed copy for the attention kernel's PV operand.
  * (internal layout, no reference counterpart: flash-attn does this transpose in shared memory.)
@@ -113,13 +117,16 @@ int osk_v_transpose_bf16(const void* v, int64_t batch_stride, int64_t row_stride
  *    with seg_lp = round_up(seg_len, 64).
  * out row (b,i) head h at out + b*o_batch_stride + i*o_row_stride + h*hd (may alias the dead v slot).
  * lse f32 [B, H, Lq] (natural log of the softmax denominator incl. scale) or NULL.
+ * q_prescaled != 0: q already carries scale * log2(e) (osk_qknorm_rope_bf16's q_mult) and `scale` is ignored;
+ * q_prescaled == 0: the kernel applies `scale` itself (the head_dim-72 hand-scheduled kernel then re-rounds
+ * scale*log2(e)*q to bf16 once per workgroup: one extra bf16 rounding of q).
  * hd in {64, 72, 128}. */
 int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
                            const void* k, int64_t k_seg_stride, int64_t k_batch_stride, int64_t k_row_stride,
                            const void* vt, int64_t vt_seg_stride,
                            void* out, int64_t o_batch_stride, int64_t o_row_stride,
                            float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
-                           float scale, void* stream);
+                           float scale, int q_prescaled, void* stream);
 
 /* name of the device kernel osk_attention_fwd_bf16 dispatches to for (hd, seg_len) under the current
  * OSK_ATTN_VARIANT (reporting only: bench.py labels its roofline line and the rocprof stats with it). */

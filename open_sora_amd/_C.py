@@ -28,10 +28,10 @@ SIGNATURES = {
     "osk_timestep_embedding": [_vp, _i32, _i32, _f32, _f32, _vp, _vp],
     "osk_rope_table": [_vp, _i64, _i32, C.POINTER(_i32), _f64, _i32, _vp, _vp, _vp],
     "osk_qknorm_rope_bf16": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64,
-                             _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+                             _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
     "osk_v_transpose_bf16": [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "osk_attention_fwd_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
-                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
     "osk_causal_conv3d_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                      _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
@@ -160,15 +160,15 @@ def rope_table(ids: torch.Tensor, axes_dim, theta: float, f32_angles: bool, cos:
 
 
 def qknorm_rope(q: torch.Tensor, k: torch.Tensor, qs0, ks0, qs1, ks1, l_split: int, cos, sin,
-                cs_batch_stride: int, H: int, hd: int, rope_mode: int, eps: float = 1e-6):
+                cs_batch_stride: int, H: int, hd: int, rope_mode: int, eps: float = 1e-6, q_mult: float = 1.0):
     """q, k: bf16 [B, L, H*hd] views (same strides, last dim contiguous) rewritten in place; one of them may
-    be None (one-sided call)."""
+    be None (one-sided call).  q_mult: factor folded into q before its final rounding (attention_fwd q_prescaled)."""
     t = q if q is not None else k
     B, L, _ = t.shape
     assert q is None or k is None or q.stride() == k.stride()
     _check(lib.osk_qknorm_rope_bf16(_p(q), _p(k), t.stride(0), t.stride(1), qs0.data_ptr(),
                                     ks0.data_ptr(), qs1.data_ptr(), ks1.data_ptr(), l_split, cos.data_ptr(),
-                                    sin.data_ptr(), cs_batch_stride, B, L, H, hd, rope_mode, eps, _stream()),
+                                    sin.data_ptr(), cs_batch_stride, B, L, H, hd, rope_mode, eps, q_mult, _stream()),
            "osk_qknorm_rope_bf16")
 
 
@@ -185,7 +185,7 @@ PROFILE_ATTENTION = None
 
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, H: int, hd: int,
                   scale: float, *, lse=None, n_seg: int = 1, seg_len: int | None = None,
-                  k_seg_stride: int = 0, vt_seg_stride: int = 0):
+                  k_seg_stride: int = 0, vt_seg_stride: int = 0, q_prescaled: bool = False):
     """q bf16 [B, Lq, H*hd] view; k bf16 [B, seg_len, H*hd] view of segment 0 (further segments k_seg_stride
     elements apart); vt from v_transpose (per segment); out bf16 [B, Lq, H*hd] view."""
     B, Lq, _ = q.shape
@@ -198,7 +198,7 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
     _check(lib.osk_attention_fwd_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
                                       k.stride(0), k.stride(1), vt.data_ptr(), vt_seg_stride, out.data_ptr(),
                                       out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg, seg_len, hd,
-                                      scale, _stream()), "osk_attention_fwd_bf16")
+                                      scale, int(q_prescaled), _stream()), "osk_attention_fwd_bf16")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))

@@ -8,7 +8,8 @@
 // dataflow; this file is the wrapper: LDS init, Q pre-scale, the asm operands, the epilogue.
 //
 // Numerics vs attention_w64.hip / attention_fwd.hip:
-//  * Q is multiplied by scale*log2(e) and re-rounded to bf16 once per workgroup (one extra bf16 rounding of q);
+//  * Q carries scale*log2(e): folded into q's single rounding by osk_qknorm_rope_bf16 (q_prescaled, the model path),
+//    or applied here with one extra bf16 rounding of q (stand-alone calls);
 //  * the online-softmax reference max M is kept bf16-exact inside the contraction (Q padding dim 72 = -M, K
 //    padding dim 72 = 1.0), so P = exp2(S') with S' straight out of the MFMA; M moves only when a row max exceeds
 //    it by more than 8 (log2 units): P <= 2^8, O and the row sum (ones row of V^T) carry the same factor.
@@ -63,11 +64,14 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
       const int e0 = ks * 16 + hi * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (e0 < HD) v = *reinterpret_cast<const uint4*>(qrow + e0);
-      float f[8];
-      unpack8(v, f);
+      uint4 s = v;
+      if (!p.q_prescaled) {  // fold scale*log2(e) in here (one extra bf16 rounding of q); see osk.h
+        float f[8];
+        unpack8(v, f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] *= p.sc;
-      const uint4 s = pack8(f);
+        for (int j = 0; j < 8; ++j) f[j] *= p.sc;
+        s = pack8(f);
+      }
       w[ks * 4 + 0] = s.x; w[ks * 4 + 1] = s.y; w[ks * 4 + 2] = s.z; w[ks * 4 + 3] = s.w;
     }
 #define OSK_QIN                                                                                              \

@@ -702,7 +702,7 @@ extern "C" int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int
                                       int64_t k_row_stride, const void* vt, int64_t vt_seg_stride,
                                       void* out, int64_t o_batch_stride, int64_t o_row_stride,
                                       float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
-                                      float scale, void* stream) {
+                                      float scale, int q_prescaled, void* stream) {
   if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Lq <= 0 || n_seg <= 0 || seg_len <= 0) return OSK_EINVAL;
   if ((q_batch_stride & 7) || (q_row_stride & 7) || (k_seg_stride & 7) || (k_batch_stride & 7) ||
       (k_row_stride & 7) || (vt_seg_stride & 7) || (o_batch_stride & 3) || (o_row_stride & 3))
@@ -716,7 +716,8 @@ extern "C" int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int
   p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.n_seg = n_seg; p.seg_len = seg_len;
   p.seg_lp = (seg_len + 63) / 64 * 64;
   p.tps = p.seg_lp / 64;
-  p.sc = scale * 1.4426950408889634f;
+  p.sc = q_prescaled ? 1.0f : scale * 1.4426950408889634f;  // log2 units; 1: q already carries it
+  p.q_prescaled = q_prescaled;
   p.map = attn_map();
   hipStream_t st = (hipStream_t)stream;
   switch (hd) {

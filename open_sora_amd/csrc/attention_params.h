@@ -15,7 +15,8 @@ struct AttnParams {
   int64_t obs, ors;
   float* lse;
   int B, H, Lq, n_seg, seg_len, seg_lp, tps;
-  float sc;   // softmax scale * log2(e)
+  float sc;   // softmax scale * log2(e); 1.0 when q_prescaled
+  int q_prescaled;
   int map;    // block -> (head, query block) order: 0 = heads fastest, 1 = XCD-contiguous, query blocks fastest
 };
 

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) qknorm_rope_kernel(
     const unsigned short* __restrict__ qs0, const unsigned short* __restrict__ ks0,
     const unsigned short* __restrict__ qs1, const unsigned short* __restrict__ ks1, int l_split,
     const float* __restrict__ cos_t, const float* __restrict__ sin_t, int64_t csb, int B, int L, int H,
-    float eps) {
+    float eps, float q_mult) {
   constexpr int NCH = HD / CW;  // active lanes per row
   constexpr int LPR = NCH <= 8 ? 8 : (NCH <= 16 ? 16 : 32);
   constexpr int RPB = 256 / LPR;  // rows per block
@@ -166,6 +166,10 @@ __global__ void __launch_bounds__(256) qknorm_rope_kernel(
         o[j] = first ? (y[j] * cs - other * sn) : (y[j] * cs + other * sn);
       }
     }
+    if (which == 0) {  // softmax scale * log2(e) folded into q BEFORE its one rounding to bf16 (see osk.h)
+#pragma unroll
+      for (int j = 0; j < CW; ++j) o[j] *= q_mult;
+    }
     if (act && rvalid) {
       if constexpr (CW == 8) {
         *reinterpret_cast<uint4*>(p) = pack8(o);
@@ -182,7 +186,7 @@ __global__ void __launch_bounds__(256) qknorm_rope_kernel(
 extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, const void* qs0,
                                     const void* ks0, const void* qs1, const void* ks1, int l_split,
                                     const float* cos_t, const float* sin_t, int64_t csb, int B, int L,
-                                    int H, int hd, int rope_mode, float eps, void* stream) {
+                                    int H, int hd, int rope_mode, float eps, float q_mult, void* stream) {
   if ((!q && !k) || !qs0 || !ks0 || !qs1 || !ks1 || !cos_t || !sin_t) return OSK_EINVAL;
   if (B <= 0 || L <= 0 || H <= 0 || (bs & 7) || (rs & 7)) return OSK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -196,7 +200,7 @@ extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, co
     hipLaunchKernelGGL((qknorm_rope_kernel<HD, CW, MODE>), grid, block, 0, st, (unsigned short*)q,    \
                        (unsigned short*)k, bs, rs, (const unsigned short*)qs0,                        \
                        (const unsigned short*)ks0, (const unsigned short*)qs1,                        \
-                       (const unsigned short*)ks1, l_split, cos_t, sin_t, csb, B, L, H, eps);         \
+                       (const unsigned short*)ks1, l_split, cos_t, sin_t, csb, B, L, H, eps, q_mult); \
   }
   if (rope_mode == 0) {
     if (hd == 64) LAUNCH(64, 8, 0)

@@ -401,10 +401,16 @@ def _mod_views(mod: Tensor, col: int, n: int, D: int):
     return [mod[:, col + i * D: col + (i + 1) * D] for i in range(n)], mod.stride(0)
 
 
+def q_mult(hd: int) -> float:
+    """softmax scale * log2(e): folded into q by the QK-norm + RoPE kernel before q's single rounding to bf16, so the
+    attention kernels exponentiate (in base 2) what the MFMA hands them (include/osk.h, q_prescaled)."""
+    return hd ** -0.5 * 1.4426950408889634
+
+
 def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd: int):
     """attention() of math.py:22-36 on the joint [txt;img] sequence; the output overwrites the (dead) v slot."""
     _OPS.v_transpose(v, ws.vt, H, hd)
-    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5)
+    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5, q_prescaled=True)
 
 
 def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: int, col_txt: int, rope: _RopeTable,
@@ -434,7 +440,7 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
     if sp is None:
         for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
             _OPS.gemm(xm_s, aw.qkv_w, aw.qkv_b, y_s)
-        _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         _joint_attention(ws, q, k, v, H, hd)
     else:
         for aw, x_s, xm_s, y_s, sh1, sc1 in streams:  # K, V first: their all-gather overlaps the Q projection
@@ -443,7 +449,7 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
         pending = sp.gather_kv_start(ws, k, v, H, hd)
         for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
             _OPS.gemm(xm_s, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
-        _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         sp.attention(ws, pending, q, v, H, hd)
     if Li:  # img stream
         _OPS.gemm(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=x_img, gate=i_g1, gate_batch_stride=mbs)
@@ -473,7 +479,7 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
     scales = (plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale)
     if sp is None:
         _OPS.gemm(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
-        _OPS.qknorm_rope(q, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        _OPS.qknorm_rope(q, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         _joint_attention(ws, q, k, v, H, hd)
     else:
         b1 = plan.b1
@@ -482,7 +488,7 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
         pending = sp.gather_kv_start(ws, k, v, H, hd)
         _OPS.gemm(ws.xm, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
         _OPS.gemm(ws.xm, plan.w1[:D], None if b1 is None else b1[:D], q)
-        _OPS.qknorm_rope(q, None, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
+        _OPS.qknorm_rope(q, None, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         sp.attention(ws, pending, q, v, H, hd)
     _OPS.gemm(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=ws.x, gate=gate, gate_batch_stride=mbs)
 

@@ -85,7 +85,7 @@ class SeqPar:
         wv.wait()
         B, Lloc, D = q.shape
         mmdit.ops().attention_fwd(q, k_all[0], vt_all, out, H, hd, hd ** -0.5, n_seg=self.P, seg_len=Lloc,
-                                  k_seg_stride=k_all.stride(0), vt_seg_stride=vt_all.stride(0))
+                                  k_seg_stride=k_all.stride(0), vt_seg_stride=vt_all.stride(0), q_prescaled=True)
 
     # ------------------------------------------------------------------ output
     def gather_output(self, ws, project, C_out: int, L_txt: int) -> Tensor:

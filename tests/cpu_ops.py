@@ -74,7 +74,7 @@ def rope_table(ids, axes_dim, theta, f32_angles, cos, sin):
     sin.view(-1, sin.shape[-1]).copy_(torch.sin(ang).float())
 
 
-def qknorm_rope(q, k, qs0, ks0, qs1, ks1, l_split, cos, sin, cs_batch_stride, H, hd, rope_mode, eps=1e-6):
+def qknorm_rope(q, k, qs0, ks0, qs1, ks1, l_split, cos, sin, cs_batch_stride, H, hd, rope_mode, eps=1e-6, q_mult=1.0):
     B, L, _ = (q if q is not None else k).shape
     c = cos if cs_batch_stride else cos[:1]
     s = sin if cs_batch_stride else sin[:1]
@@ -91,6 +91,8 @@ def qknorm_rope(q, k, qs0, ks0, qs1, ks1, l_split, cos, sin, cs_batch_stride, H,
         else:
             x1, x2 = yf[..., : hd // 2], yf[..., hd // 2:]
             o = torch.cat([x1 * cc - x2 * ss, x2 * cc + x1 * ss], -1)
+        if t is q:
+            o = o * q_mult  # folded into q before its single rounding (kernel semantics)
         t.copy_(o.reshape(B, L, H * hd).to(t.dtype))
 
 
@@ -103,7 +105,8 @@ def v_transpose(v, vt, H, hd):
     vt.copy_(pad[:, pos2key].permute(0, 2, 3, 1))
 
 
-def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=None, k_seg_stride=0, vt_seg_stride=0):
+def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=None, k_seg_stride=0, vt_seg_stride=0,
+                  q_prescaled=False):
     B, Lq, D = q.shape
     if seg_len is None:
         seg_len = k.shape[1]
@@ -124,7 +127,7 @@ def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=Non
     K = torch.cat(ks, 1).permute(0, 2, 1, 3)
     V = torch.cat(vs, 1).permute(0, 2, 1, 3)
     Q = q.float().reshape(B, Lq, H, hd).permute(0, 2, 1, 3)
-    s_ = (Q @ K.transpose(-1, -2)) * scale
+    s_ = (Q @ K.transpose(-1, -2)) * (0.6931471805599453 if q_prescaled else scale)  # prescaled q: log2 units
     o = torch.softmax(s_, -1) @ V
     res = o.permute(0, 2, 1, 3).reshape(B, Lq, D).to(out.dtype)
     out.copy_(res)

@@ -195,6 +195,17 @@ def test_qknorm_rope(hip_lib, hd, axes, mode):
         got = y[:, :, which * D: (which + 1) * D].cpu().view(B, L, H, hd).permute(0, 2, 1, 3)
         bf16_ulp_close(got.float(), ref.float(), rel=2 ** -7, abs_=2e-3)
     assert torch.equal(y[:, :, 2 * D:], y0[:, :, 2 * D:])  # v untouched
+    # q_mult: the softmax scale folded into q before q's single rounding; k is unaffected
+    c = hd ** -0.5 * 1.4426950408889634
+    y2 = y0.clone()
+    hip_lib.qknorm_rope(y2[:, :, :D], y2[:, :, D: 2 * D], scales[0], scales[1], scales[2], scales[3], Lt, cos, sin,
+                        cos.stride(0), H, hd, mode, q_mult=c)
+    assert torch.equal(y2[:, :, D:], y[:, :, D:])
+    x0 = y0[:, :, :D].cpu().view(B, L, H, hd).permute(0, 2, 1, 3)
+    nq = torch.cat([O.rms_norm(x0[:, :, :Lt], scales[0].cpu()), O.rms_norm(x0[:, :, Lt:], scales[2].cpu())], 2)
+    ref32 = rope(nq.float(), ang) * c          # rotate in f32, scale in f32, ONE rounding
+    got = y2[:, :, :D].cpu().view(B, L, H, hd).permute(0, 2, 1, 3)
+    bf16_ulp_close(got.float(), ref32.bfloat16().float(), rel=2 ** -7, abs_=1e-3)
 
 
 # ----------------------------------------------------------------------------- V transpose (bit exact)
@@ -216,25 +227,29 @@ def test_v_transpose_exact(hip_lib, hd):
 
 
 # ----------------------------------------------------------------------------- attention
-def _attn_case(hip_lib, B, H, hd, Lq, Lk, seed=3, spike=False, lse_tol=2e-3):
+def _attn_case(hip_lib, B, H, hd, Lq, Lk, seed=3, spike=False, lse_tol=2e-3, prescaled=False):
+    """prescaled: q already carries scale*log2(e) (what osk_qknorm_rope_bf16's q_mult produces for the model path);
+    the fp64 reference is then taken on exactly those bf16 values, in base 2."""
     D = H * hd
     q = rnd("q", (B, Lq, D), seed=seed)
     kv = rnd("kv", (B, Lk, 2 * D), seed=seed + 1)
     if spike:  # force a large running-max jump late in the key sequence (online-softmax rescale path)
         kv[:, Lk - 3, :D] = q[:, 0, :] * 4.0
+    if prescaled:
+        q = (q.float() * (hd ** -0.5 * 1.4426950408889634)).to(BF)
     k, v = kv[:, :, :D], kv[:, :, D:]
     Lp = (Lk + 63) // 64 * 64
     vt = torch.empty(B, H, hd, Lp, dtype=BF, device=DEV)
     hip_lib.v_transpose(v, vt, H, hd)
     out = torch.empty(B, Lq, D, dtype=BF, device=DEV)
     lse = torch.empty(B, H, Lq, dtype=torch.float32, device=DEV)
-    hip_lib.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5, lse=lse)
+    hip_lib.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5, lse=lse, q_prescaled=prescaled)
 
     def heads(t, L):
         return t.float().cpu().view(B, L, H, hd).permute(0, 2, 1, 3)
 
     qh, kh, vh = heads(q, Lq), heads(k, Lk), heads(v, Lk)
-    s = (qh.double() @ kh.double().transpose(-1, -2)) * hd ** -0.5
+    s = (qh.double() @ kh.double().transpose(-1, -2)) * (0.6931471805599453 if prescaled else hd ** -0.5)
     ref = (torch.softmax(s, -1) @ vh.double()).permute(0, 2, 1, 3).reshape(B, Lq, D)
     ref_lse = torch.logsumexp(s, -1)
     err = (out.float().cpu().double() - ref).abs().max().item()
@@ -264,6 +279,13 @@ def test_attention_hd72_whole_tiles(hip_lib, Lq, Lk):
     # the kernel folds scale*log2(e) into Q and re-rounds it to bf16 (2^-9 relative on the logits): LSE tolerance
     # 4e-3 instead of 2e-3; the output bounds are the common ones
     _attn_case(hip_lib, 2, 3, 72, Lq, Lk, seed=11, lse_tol=4e-3)
+    # the model path: scale*log2(e) folded into q upstream -> no extra rounding, the common LSE bound holds
+    _attn_case(hip_lib, 2, 3, 72, Lq, Lk, seed=12, prescaled=True)
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+def test_attention_prescaled_q_other_head_dims(hip_lib, hd):
+    _attn_case(hip_lib, 1, 2, hd, 200, 333, seed=5, prescaled=True)
 
 
 @pytest.mark.parametrize("spike_key", [5, 64 + 7, 128 + 63, 448 + 1, 959])
