@@ -45,6 +45,8 @@ def bench_gemm(M, N, K, tag):
 def bench_attn(B, H, L, hd, tag):
     D = H * hd
     y = torch.randn(B, L, 3 * D, device=DEV).to(BF)
+    if os.environ.get("OSK_BENCH_ZERO"):  # DVFS probe: zero operands draw less power -> higher clocks (never a result)
+        y.zero_()
     q, k, v = y[:, :, :D], y[:, :, D:2 * D], y[:, :, 2 * D:]
     Lp = (L + 63) // 64 * 64
     vt = torch.empty(B, H, hd, Lp, dtype=BF, device=DEV)
