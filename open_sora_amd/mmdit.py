@@ -760,14 +760,14 @@ class MMDiTModel(nn.Module):
 
 def Flux(cache_dir: str = None, from_pretrained: str = None, device_map="cuda", torch_dtype: torch.dtype = BF16,
          strict_load: bool = False, **kwargs) -> MMDiTModel:
-    """Factory with the reference signature (model.py:271-303); `from_pretrained` takes a safetensors path."""
+    """Factory with the reference signature (model.py:271-303); `from_pretrained` takes a local safetensors / .pt path
+    (open_sora_amd/ckpt.py::load_checkpoint)."""
     config = MMDiTConfig(from_pretrained=from_pretrained, cache_dir=cache_dir, **kwargs)
     with torch.device(device_map):
         model = MMDiTModel(config)
     model = model.to(torch_dtype)
-    if from_pretrained:
-        from safetensors.torch import load_file
+    if from_pretrained:  # model.py:296-302
+        from .ckpt import load_checkpoint
 
-        sd = load_file(from_pretrained, device=str(device_map))
-        model.load_state_dict(sd, strict=strict_load)
+        model = load_checkpoint(model, from_pretrained, cache_dir=cache_dir, device_map=device_map, strict=strict_load)
     return model
