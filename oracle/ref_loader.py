@@ -231,3 +231,31 @@ def hunyuan_vae():
         importlib.import_module("opensora.models.hunyuan_vae.vae"),
         importlib.import_module("opensora.models.hunyuan_vae.unet_causal_3d_blocks"),
     )
+
+
+def extract_defs(rel_path: str, names: list[str], namespace: dict) -> dict:
+    """TEST INFRASTRUCTURE.  Executes ONLY the named top-level function / class / assignment statements of a reference
+    source file inside `namespace` (which supplies their free names: torch, einops, ...).  Used for the reference
+    files whose module-level imports (mmengine, peft, colossalai, ...) are absent here: the code that
+    runs is the reference's own text, nothing is copied into this repository."""
+    import ast
+
+    path = os.path.join(REF_ROOT, rel_path)
+    src = open(path).read()
+    tree = ast.parse(src)
+    want = set(names)
+    found = set()
+    for node in tree.body:
+        tgt = None
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            tgt = node.name
+        elif isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name):
+            tgt = node.targets[0].id
+        if tgt in want:
+            code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
+            exec(code, namespace)
+            found.add(tgt)
+    missing = want - found
+    if missing:
+        raise KeyError(f"{rel_path}: not found: {sorted(missing)}")
+    return namespace
