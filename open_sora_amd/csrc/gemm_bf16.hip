@@ -243,10 +243,19 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
     const int64_t a_span = (int64_t)(nb - 1) * a_batch_stride + (int64_t)(a_rows_per_batch - 1) * a_row_stride + K;
     const int64_t w_span = (int64_t)(N - 1) * w_row_stride + K;
     if (osk_gemm::gemm256_supported(p, a_span, w_span)) {
-      int bn = N >= 256 ? 256 : 128;   // measured: the 256-wide tile wins even at N = 1152 (4.5 tiles, 10 % padding)
-      if (gv == 2) bn = 256;
-      if (gv == 3) bn = 128;
-      return osk_gemm::launch_gemm256(p, bn, out_f32, st);
+      // tile choice by estimated time = rounds of the grid over the chip x time of one tile.  Per-tile throughput
+      // measured at the XL shapes (MI355X, random data): 256x256 ~1.0, 256x128 ~0.78, 128x128 (this file) ~0.72 of the
+      // large tile's rate; one 512-thread workgroup per CU for gemm256, two 256-thread ones for this file's kernel.
+      auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
+      const int64_t m256 = (M + 255) / 256, m128 = (M + 127) / 128;
+      const double c256 = rounds(m256 * ((N + 255) / 256), 256) * 4.0 / 1.00;
+      const double c128 = rounds(m256 * ((N + 127) / 128), 256) * 2.0 / 0.78;
+      const double cold = rounds(m128 * ((N + 127) / 128), 512) * 1.0 / (0.5 * 0.72);  // 2 co-resident tiles share a CU
+      int bn = (N >= 256 && c256 <= c128) ? 256 : 128;
+      bool use_old = cold < (bn == 256 ? c256 : c128);
+      if (gv == 2) { bn = 256; use_old = false; }
+      if (gv == 3) { bn = 128; use_old = false; }
+      if (!use_old) return osk_gemm::launch_gemm256(p, bn, out_f32, st);
     }
   }
   const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
