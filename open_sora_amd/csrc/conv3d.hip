@@ -18,8 +18,9 @@
 // add, bf16 pack) is lane-local and stores 8 B pieces of the NDHWC row.
 //
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 2 * Cin * Cout * k^3 * B*To*Ho*Wo  (SURVEY.md §8(d)).
-#include "osk_common.h"
+#include "conv_params.h"
 #include "../../include/osk.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,21 +28,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;
 constexpr int SMEM_BYTES = 2 * 2 * TILE_BYTES;
 
-struct ConvParams {
-  const unsigned short* x;
-  const unsigned short* w;
-  const float* bias;
-  const unsigned short* res;
-  unsigned short* out;
-  int B, T, H, W;     // source (pre-upsample) dims
-  int Tu, Hu, Wu;     // dims the conv sees (after the virtual nearest upsample)
-  int To, Ho, Wo;
-  int Cin, Cout;
-  int ks, st, sh, sw, up_t, up_hw;
-  int lg_cpt, ntaps, nk;
-  int M;
-  int64_t wrs;
-};
+using osk_conv::ConvParams;
 
 OSK_DEV void glds16(const unsigned short* g, unsigned char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -269,9 +256,16 @@ extern "C" int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, 
   if (w_row_stride < Kp || (w_row_stride & 7)) return OSK_EINVAL;  // weight rows zero-padded to a multiple of 64
   p.wrs = w_row_stride;
   p.nk = (int)(Kp / BK);
+  hipStream_t s = (hipStream_t)stream;
+  {
+    // large-tile kernel with the hand-scheduled K loop (conv3d_256.hip); OSK_CONV_VARIANT=0 forces this file's kernel
+    static const int cv = [] { const char* e = getenv("OSK_CONV_VARIANT"); return e ? atoi(e) : -1; }();
+    const int64_t x_bytes = (int64_t)B * T * H * W * Cin * 2;
+    if (cv != 0 && osk_conv::conv256_supported(p, x_bytes, (int64_t)Cout * w_row_stride * 2))
+      return osk_conv::launch_conv256(p, s);
+  }
   const int nblk = ((p.M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
   dim3 grid(nblk), block(256);
-  hipStream_t s = (hipStream_t)stream;
   if (Cin % 64 == 0) hipLaunchKernelGGL((conv3d_kernel<true>), grid, block, SMEM_BYTES, s, p);
   else hipLaunchKernelGGL((conv3d_kernel<false>), grid, block, SMEM_BYTES, s, p);
   return (int)hipGetLastError();

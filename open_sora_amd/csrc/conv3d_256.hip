@@ -1,0 +1,227 @@
+// CausalConv3d for gfx950, large tile + hand-scheduled K loop (Cin % 128 == 0, Cout >= 128, >= 256 output voxels).
+//
+// Same implicit GEMM as conv3d.hip (NDHWC activations, K = tap-major / channel-minor, replicate / causal padding as a
+// CLAMP and the decoder's nearest upsample as a SHIFT of the gathered coordinate, weights pre-laid as [Cout][27 Cin],
+// swapped-operand v_mfma_f32_32x32x16_bf16 so a lane owns one output voxel) on the tile and pipeline of gemm256.hip:
+// 256 voxels x 256 (or 128) output channels x 64, 8 waves, LDS-DMA double buffer, accumulators in AGPRs.
+// The K axis is walked one FILTER TAP at a time: within a tap the A rows are fixed gathered voxels and the K steps only
+// advance the channel block, i.e. exactly a GEMM K loop with per-lane row offsets.  Each tap is one call of the asm
+// segment emitted by tools/gen_gemm_asm.py (conv256_segment_n*.inc); the accumulators persist in the AGPRs between the
+// calls, the last K step of a segment already fetches the next tap's first step (its offsets are passed in), and the
+// per-tap voxel offsets (3 clamps per row slot) are ordinary compiler code between the calls.
+//
+// Roofline: MFMA bf16.  Algorithmic FLOPs = 2 * Cin * Cout * k^3 * B*To*Ho*Wo.
+#include "conv_params.h"
+#include "gemm256_regs_n256.inc"
+#include "gemm256_regs_n128.inc"
+
+namespace osk_conv {
+namespace {
+
+OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v); }
+
+#define OSKC_OUT16                                                                                               \
+  "=v"(v16[0]), "=v"(v16[1]), "=v"(v16[2]), "=v"(v16[3]), "=v"(v16[4]), "=v"(v16[5]), "=v"(v16[6]), "=v"(v16[7]),    \
+      "=v"(v16[8]), "=v"(v16[9]), "=v"(v16[10]), "=v"(v16[11]), "=v"(v16[12]), "=v"(v16[13]), "=v"(v16[14]),          \
+      "=v"(v16[15])
+
+template <int BN, int T>
+OSK_DEV void read_acc(float* v16) {
+  if constexpr (BN == 256) {
+    if constexpr (T == 0) asm volatile(OSKG256_AR0 : OSKC_OUT16);
+    else if constexpr (T == 1) asm volatile(OSKG256_AR1 : OSKC_OUT16);
+    else if constexpr (T == 2) asm volatile(OSKG256_AR2 : OSKC_OUT16);
+    else if constexpr (T == 3) asm volatile(OSKG256_AR3 : OSKC_OUT16);
+    else if constexpr (T == 4) asm volatile(OSKG256_AR4 : OSKC_OUT16);
+    else if constexpr (T == 5) asm volatile(OSKG256_AR5 : OSKC_OUT16);
+    else if constexpr (T == 6) asm volatile(OSKG256_AR6 : OSKC_OUT16);
+    else asm volatile(OSKG256_AR7 : OSKC_OUT16);
+  } else {
+    if constexpr (T == 0) asm volatile(OSKG128_AR0 : OSKC_OUT16);
+    else if constexpr (T == 1) asm volatile(OSKG128_AR1 : OSKC_OUT16);
+    else if constexpr (T == 2) asm volatile(OSKG128_AR2 : OSKC_OUT16);
+    else asm volatile(OSKG128_AR3 : OSKC_OUT16);
+  }
+}
+
+// bias + residual + bf16 store of one 32 x 32 accumulator tile T = tn * TM + tm (lane: voxel m, 4 channels per quad)
+template <int BN, int T>
+OSK_DEV void epilogue_tile(const ConvParams& p, int m0w, int n0w, int l31, int hi) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int tn = T / TM, tm = T % TM;
+  float acc[16];
+  read_acc<BN, T>(acc);
+  const int m = m0w + tm * 32 + l31;
+  if (m >= p.M) return;
+  const int64_t roff = (int64_t)m * p.Cout;
+  const bool vec_ok = (p.Cout & 3) == 0;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const int n = n0w + tn * 32 + qd * 8 + hi * 4;
+    if (n >= p.Cout) continue;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = acc[qd * 4 + j];
+    if (vec_ok && n + 3 < p.Cout) {
+      if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (p.res) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+        v[0] += bf16_lo(rv.x); v[1] += bf16_hi(rv.x); v[2] += bf16_lo(rv.y); v[3] += bf16_hi(rv.y);
+      }
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(p.out + roff + n) = o;
+    } else {
+      for (int j = 0; j < 4 && n + j < p.Cout; ++j) {
+        float t = v[j] + (p.bias ? p.bias[n + j] : 0.f);
+        if (p.res) t += bf16_bits_to_f32(p.res[roff + n + j]);
+        p.out[roff + n + j] = f32_to_bf16_bits(t);
+      }
+    }
+  }
+}
+
+template <int BN, int... Ts>
+OSK_DEV void epilogue_all(const ConvParams& p, int m0w, int n0w, int l31, int hi, std::integer_sequence<int, Ts...>) {
+  (epilogue_tile<BN, Ts>(p, m0w, n0w, l31, hi), ...);
+}
+
+template <int BN>
+__global__ void __launch_bounds__(512, 2) conv256_kernel(const ConvParams p) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
+  constexpr int WN = BN / (TN * 32);
+  constexpr int W_BASE = BN == 256 ? OSKG256_W_BASE : OSKG128_W_BASE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int nbm = (p.M + 255) / 256, nbn = (p.Cout + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * 256, n0 = bn * BN;
+
+  // ---- LDS-DMA row slots of this lane: instruction j = wave + 8 i covers tile rows [8 j, 8 j + 8)
+  const int srow8 = lane >> 3, spos = lane & 7;
+  unsigned woff[4], chunk16[4];
+  int cb[4], cto[4], cho[4], cwo[4];   // batch, output coordinates of the slot's voxel
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 8 * i) * 8 + srow8;
+    const int c = spos ^ ((r >> 1) & 7);
+    chunk16[i] = (unsigned)(c * 16);
+    int n = n0 + (r < BN ? r : 0);
+    n = n < p.Cout ? n : p.Cout - 1;
+    woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
+    int m = m0 + r;
+    m = m < p.M ? m : p.M - 1;
+    cwo[i] = m % p.Wo;
+    int q = m / p.Wo;
+    cho[i] = q % p.Ho;
+    q /= p.Ho;
+    cto[i] = q % p.To;
+    cb[i] = q / p.To;
+  }
+  const int HW = p.H * p.W;
+  const unsigned cin_bytes = (unsigned)p.Cin * 2;
+  // byte offset of the slot's gathered voxel for filter tap (dt, dh, dw): clamp = replicate / causal padding,
+  // shift = nearest upsample (frame 0 is spatial-only)   [conv3d.hip / unet_causal_3d_blocks.py:82-96,136-150]
+  auto tap_offset = [&](int i, int dt, int dh, int dw) -> unsigned {
+    int tu = cto[i] * p.st + dt - (p.ks - 1);
+    tu = tu < 0 ? 0 : (tu > p.Tu - 1 ? p.Tu - 1 : tu);
+    const int ts = p.up_t ? (tu == 0 ? 0 : 1 + ((tu - 1) >> 1)) : tu;
+    int hu = cho[i] * p.sh + dh - (p.ks >> 1);
+    hu = hu < 0 ? 0 : (hu > p.Hu - 1 ? p.Hu - 1 : hu);
+    const int hs = p.up_hw ? (hu >> 1) : hu;
+    int wu = cwo[i] * p.sw + dw - (p.ks >> 1);
+    wu = wu < 0 ? 0 : (wu > p.Wu - 1 ? p.Wu - 1 : wu);
+    const int ws = p.up_hw ? (wu >> 1) : wu;
+    const unsigned pos = (unsigned)((cb[i] * p.T + ts) * HW + hs * p.W + ws);
+    return pos * cin_bytes + chunk16[i];
+  };
+
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int sw = (l31 >> 1) & 7;
+  unsigned faA[4], faW[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const unsigned sz = (unsigned)((((ks << 1) | hi) ^ sw) << 4);
+    faA[ks] = lds_base + (wm * TM * 32 + l31) * 128 + sz;
+    faW[ks] = lds_base + W_BASE + (wn * TN * 32 + l31) * 128 + sz;
+  }
+  const uint64_t xbase = rfl64((uint64_t)(uintptr_t)p.x);
+  const unsigned nk = rfl((unsigned)(p.Cin / 64));   // K steps per tap (even: Cin % 128 == 0)
+  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + W_BASE + wave * 1024);
+
+  unsigned aoffc[4], aoffn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoffc[i] = tap_offset(i, 0, 0, 0);
+  for (int tap = 0; tap < p.ntaps; ++tap) {
+    const int tn_ = tap + 1 < p.ntaps ? tap + 1 : tap;   // last segment: "next" = itself (harmless re-fetch)
+    int dt = 0, dh = 0, dw = 0;
+    if (p.ks == 3) {
+      dt = tn_ / 9;
+      const int r9 = tn_ - dt * 9;
+      dh = r9 / 3;
+      dw = r9 - dh * 3;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoffn[i] = tap_offset(i, dt, dh, dw);
+    const uint64_t wbase = rfl64((uint64_t)(uintptr_t)(p.w + (int64_t)tap * p.Cin));
+    const unsigned flags = rfl((tap == 0 ? 1u : 0u) | (tap + 1 == p.ntaps ? 2u : 0u));
+#define OSKC_OPERANDS                                                                                              \
+  ::"v"(faA[0]), "v"(faA[1]), "v"(faA[2]), "v"(faA[3]), "v"(faW[0]), "v"(faW[1]), "v"(faW[2]), "v"(faW[3]),         \
+      "v"(aoffc[0]), "v"(aoffc[1]), "v"(aoffc[2]), "v"(aoffc[3]), "v"(aoffn[0]), "v"(aoffn[1]), "v"(aoffn[2]),      \
+      "v"(aoffn[3]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "s"(xbase), "s"(wbase), "s"(nk),       \
+      "s"(adst), "s"(wdst), "s"(flags)
+    if constexpr (BN == 256) {
+      asm volatile(
+#include "conv256_segment_n256.inc"
+          OSKC_OPERANDS : OSKG256_SEG_CLOBBERS);
+    } else {
+      asm volatile(
+#include "conv256_segment_n128.inc"
+          OSKC_OPERANDS : OSKG128_SEG_CLOBBERS);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoffc[i] = aoffn[i];
+  }
+
+  epilogue_all<BN>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
+}
+
+template <int BN>
+int launch_one(const ConvParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int SMEM = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;
+  auto kernel = conv256_kernel<BN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int nblk = ((p.M + 255) / 256) * ((p.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL(kernel, dim3(nblk), dim3(512), SMEM, st, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// 32-bit per-lane byte offsets: both tensors must span < 4 GiB; whole K steps per tap in pairs: Cin % 128 == 0
+bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes) {
+  return p.Cin % 128 == 0 && p.Cout >= 128 && p.M >= 256 && x_bytes < (int64_t)0xFFFFFFFF && w_bytes < (int64_t)0xFFFFFFFF;
+}
+
+int launch_conv256(const ConvParams& p, hipStream_t st) {
+  return p.Cout >= 256 ? launch_one<256>(p, st) : launch_one<128>(p, st);
+}
+
+}  // namespace osk_conv

@@ -1,0 +1,28 @@
+// Launch parameters shared by the CausalConv3d kernels (conv3d.hip, conv3d_256.hip).
+#pragma once
+#include "osk_common.h"
+
+namespace osk_conv {
+
+struct ConvParams {
+  const unsigned short* x;
+  const unsigned short* w;
+  const float* bias;
+  const unsigned short* res;
+  unsigned short* out;
+  int B, T, H, W;     // source (pre-upsample) dims
+  int Tu, Hu, Wu;     // dims the conv sees (after the virtual nearest upsample)
+  int To, Ho, Wo;
+  int Cin, Cout;
+  int ks, st, sh, sw, up_t, up_hw;
+  int lg_cpt, ntaps, nk;
+  int M;
+  int64_t wrs;
+};
+
+
+// conv3d_256.hip: 256 voxels x {256,128} channels x 64 tile, 8 waves, one hand-scheduled asm K segment per filter tap
+bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes);
+int launch_conv256(const ConvParams& p, hipStream_t st);
+
+}  // namespace osk_conv

@@ -59,6 +59,13 @@ CONV_CASES = [
     (64, 128, 1, (1, 1, 1), (False, False), 1, 2, 9, 9, False),      # conv_shortcut
     (256, 160, 3, (1, 1, 1), (False, False), 1, 2, 6, 7, True),      # two N tiles, ragged N
     (512, 512, 3, (1, 1, 1), (False, False), 1, 2, 4, 4, True),      # widest layer
+    # >= 256 output voxels, Cin % 128 == 0, Cout >= 128: the large-tile kernel with the asm K segments (conv3d_256.hip)
+    (128, 256, 3, (1, 2, 2), (False, False), 2, 3, 20, 18, True),    # 2 batches, spatial stride, residual, 256-wide tile
+    (256, 160, 3, (1, 1, 1), (False, False), 1, 3, 10, 11, True),    # 128-wide tile, ragged N (160) and ragged M (330)
+    (128, 128, 1, (1, 1, 1), (False, False), 1, 4, 9, 9, False),     # 1x1x1: a single K segment of 2 steps
+    (512, 512, 3, (2, 2, 2), (False, False), 1, 5, 24, 24, True),    # spatio-temporal stride, 8 K steps per tap
+    (256, 256, 3, (1, 1, 1), (True, True), 1, 2, 7, 9, False),       # upsample T,H,W folded into the gather
+    (128, 384, 3, (1, 1, 1), (False, True), 1, 2, 8, 8, False),      # H,W upsample only, ragged N for the 256-wide tile
 ]
 
 

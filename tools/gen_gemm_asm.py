@@ -172,6 +172,130 @@ def gen(c):
     return L
 
 
+SEG_OPERANDS = ["faA0", "faA1", "faA2", "faA3", "faW0", "faW1", "faW2", "faW3", "aoffc0", "aoffc1", "aoffc2", "aoffc3",
+                "aoffn0", "aoffn1", "aoffn2", "aoffn3", "woff0", "woff1", "woff2", "woff3",
+                "xbase", "wbase", "nk", "adst", "wdst", "flags"]
+SOP = {n: "%%%d" % i for i, n in enumerate(SEG_OPERANDS)}
+S_XB, S_FLAGS, S_AE, S_WE = 52, 54, 56, 58  # x base (pair), flags, A / W base of the step being fetched (pairs)
+SEG_S_LAST = 59
+
+
+def gen_segment(c):
+    """One K SEGMENT of the implicit-GEMM convolution (csrc/conv3d_256.hip): nk (even) K steps that share the per-lane
+    activation offsets aoffc (one filter tap: the A rows are gathered voxels), accumulating into the AGPRs that persist
+    between calls.  The LDS-DMA issued in the last K step already fetches the NEXT segment's first step (offsets
+    aoffn), so a call never waits for HBM except the very first one (flags bit 0: zero the accumulators, load stage 0);
+    flags bit 1 = last segment (the weight loader must not run past the end of the K axis).  The weight operand is
+    contiguous along K across segments: its scalar base just keeps advancing."""
+    L = []
+    e = lambda t: L.append("  " + t)
+    lab = lambda n: L.append(".Ls%s_%s_%%=:" % (c.tag, n))
+    VT = c.V0 + c.VN                       # 4 temporaries: the activation offsets of the step being fetched
+
+    def reads(stage, ks, fset):
+        out = []
+        for tm in range(c.TM):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, tm), 4), SOP["faA%d" % ks], stage * c.A_STAGE + tm * 4096))
+        for tn in range(c.TN):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, c.TM + tn), 4), SOP["faW%d" % ks], stage * c.W_STAGE + tn * 4096))
+        return out
+
+    def mfmas(fset):
+        out = []
+        for tn in range(c.TN):
+            for tm in range(c.TM):
+                acc = ar((tn * c.TM + tm) * 16, 16)
+                out.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, c.TM + tn), 4), vr(c.frag(fset, tm), 4), acc))
+        return out
+
+    def dma(stage, aoff_regs):
+        out = []
+        for i in range(c.NA):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (aoff_regs[i], S_AE, S_AE + 1)))
+        for i in range(c.NW):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (SOP["woff%d" % i], S_WE, S_WE + 1)))
+        return out
+
+    # ---- setup
+    e("s_mov_b64 s[%d:%d], %s" % (S_XB, S_XB + 1, SOP["xbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, SOP["wbase"]))
+    e("s_mov_b32 s%d, %s" % (S_NK, SOP["nk"]))
+    e("s_mov_b32 s%d, %s" % (S_ADST, SOP["adst"]))
+    e("s_mov_b32 s%d, %s" % (S_WDST, SOP["wdst"]))
+    e("s_mov_b32 s%d, %s" % (S_FLAGS, SOP["flags"]))
+    e("s_mov_b32 s%d, 0" % S_T)
+    e("s_bitcmp1_b32 s%d, 0" % S_FLAGS)
+    e("s_cbranch_scc0 .Ls%s_go_%%=" % c.tag)
+    # first segment of a tile: clear the accumulators, fetch step 0 of this segment into stage 0
+    for r in range(c.NACC):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    e("s_mov_b64 s[%d:%d], s[%d:%d]" % (S_AE, S_AE + 1, S_XB, S_XB + 1))
+    e("s_mov_b64 s[%d:%d], s[%d:%d]" % (S_WE, S_WE + 1, S_WB, S_WB + 1))
+    for m0w, d in dma(0, [SOP["aoffc%d" % i] for i in range(c.NA)]):
+        e(m0w); e("s_nop 0"); e(d)
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    lab("go")
+
+    for k in range(2):
+        cur = k
+        lab("step%d" % k)
+        for r in reads(cur, 0, 0):
+            e(r)
+        # the step to fetch: t+1 inside the segment (same tap: offsets aoffc, base x + 128 (t+1)) or step 0 of the next
+        # segment (offsets aoffn, base x)
+        e("s_add_u32 s%d, s%d, 1" % (S_TMP, S_T))
+        e("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK))           # scc = the step to fetch lies inside this segment
+        e("s_cselect_b64 vcc, -1, 0")
+        e("s_cselect_b32 s%d, s%d, 0" % (S_STEP, S_TMP))      # A: step t+1 of this tap, or step 0 of the next tap
+        e("s_cselect_b32 s%d, 0, s%d" % (S_KL, S_FLAGS))      # flags only at the segment's last step
+        e("s_lshl_b32 s%d, s%d, 7" % (S_STEP, S_STEP))
+        e("s_add_u32 s%d, s%d, s%d" % (S_AE, S_XB, S_STEP))
+        e("s_addc_u32 s%d, s%d, 0" % (S_AE + 1, S_XB + 1))
+        e("s_bitcmp1_b32 s%d, 1" % S_KL)                      # scc = last step of the LAST segment: K axis ends here
+        e("s_cselect_b32 s%d, s%d, s%d" % (S_STEP, S_T, S_TMP))  # W: contiguous along K across taps; re-fetch at the end
+        e("s_lshl_b32 s%d, s%d, 7" % (S_STEP, S_STEP))
+        e("s_add_u32 s%d, s%d, s%d" % (S_WE, S_WB, S_STEP))
+        e("s_addc_u32 s%d, s%d, 0" % (S_WE + 1, S_WB + 1))
+        for i in range(c.NA):
+            e("v_cndmask_b32_e32 %s, %s, %s, vcc" % (vr(VT + i), SOP["aoffn%d" % i], SOP["aoffc%d" % i]))
+        pieces = dma(cur ^ 1, [vr(VT + i) for i in range(c.NA)])
+        e("s_waitcnt lgkmcnt(0)")
+        mf = mfmas(0)
+        rd = reads(cur, 1, 1)
+        e(pieces[0][0])
+        for i, m in enumerate(mf):
+            e(m)
+            if i < len(rd):
+                e(rd[i])
+            if i < len(pieces):
+                e(pieces[i][1])
+                if i + 1 < len(pieces):
+                    e(pieces[i + 1][0])
+        for m0w, d in pieces[len(mf):]:
+            e(m0w); e("s_nop 0"); e(d)
+        for ks in range(1, 4):
+            fset = ks % 2
+            e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(fset)
+            rd = reads(cur, ks + 1, fset ^ 1) if ks < 3 else []
+            for i, m in enumerate(mf):
+                e(m)
+                if i < len(rd):
+                    e(rd[i])
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_barrier")
+        e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
+        if k == 1:
+            e("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NK))
+            e("s_cbranch_scc1 .Ls%s_step0_%%=" % c.tag)
+    e("s_nop 15")
+    e("s_nop 15")
+    return L
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
@@ -191,6 +315,13 @@ def main():
             f.write("#define %sCLOBBERS %s\n" % (P, ", ".join(clob)))
             for t in range(c.TM * c.TN):
                 f.write("#define %sAR%d %s\n" % (P, t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
+            sclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 4)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                    ['"s%d"' % i for i in range(S_FIRST, SEG_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+            f.write("#define %sSEG_CLOBBERS %s\n" % (P, ", ".join(sclob)))
+        with open(os.path.join(args.out, "conv256_segment_n%d.inc" % bn), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile, one K segment (filter tap).\n" % bn)
+            for ln in gen_segment(c):
+                f.write('"%s\\n"\n' % ln)
 
 
 if __name__ == "__main__":
