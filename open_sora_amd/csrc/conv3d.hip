@@ -258,11 +258,12 @@ extern "C" int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, 
   p.nk = (int)(Kp / BK);
   hipStream_t s = (hipStream_t)stream;
   {
-    // large-tile kernel with the hand-scheduled K loop (conv3d_256.hip); OSK_CONV_VARIANT=0 forces this file's kernel
+    // large-tile kernels with the hand-scheduled K loop (conv3d_256.hip); OSK_CONV_VARIANT=0 forces this file's kernel,
+    // 1 the per-tap segment version
     static const int cv = [] { const char* e = getenv("OSK_CONV_VARIANT"); return e ? atoi(e) : -1; }();
     const int64_t x_bytes = (int64_t)B * T * H * W * Cin * 2;
     if (cv != 0 && osk_conv::conv256_supported(p, x_bytes, (int64_t)Cout * w_row_stride * 2))
-      return osk_conv::launch_conv256(p, s);
+      return osk_conv::launch_conv256(p, cv, s);
   }
   const int nblk = ((p.M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
   dim3 grid(nblk), block(256);

@@ -198,11 +198,113 @@ __global__ void __launch_bounds__(512, 2) conv256_kernel(const ConvParams p) {
   epilogue_all<BN>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One asm call for the whole K axis (conv256_body_n*.inc): the per-tap voxel offsets of the tile's 256 rows come from
+// an LDS table [tap][row] built here, so the full gemm256 pipeline (LDS-DMA one step ahead, last k-sub-step issued
+// across the barrier) runs uninterrupted over all 27 taps.
 template <int BN>
+__global__ void __launch_bounds__(512, 2) conv256t_kernel(const ConvParams p) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
+  constexpr int WN = BN / (TN * 32);
+  constexpr int W_BASE = BN == 256 ? OSKG256_W_BASE : OSKG128_W_BASE;
+  constexpr int TABLE = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;   // the table sits behind the two stages
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int nbm = (p.M + 255) / 256, nbn = (p.Cout + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * 256, n0 = bn * BN;
+
+  // ---- offset table: thread -> tile row tid % 256, taps tid / 256, + 2, + 4, ...
+  {
+    const int r = tid & 255;
+    int m = m0 + r;
+    m = m < p.M ? m : p.M - 1;
+    const int wo = m % p.Wo;
+    int q = m / p.Wo;
+    const int ho = q % p.Ho;
+    q /= p.Ho;
+    const int to = q % p.To;
+    const int b = q / p.To;
+    const int HW = p.H * p.W;
+    const unsigned cin_bytes = (unsigned)p.Cin * 2;
+    unsigned* table = reinterpret_cast<unsigned*>(smem + TABLE);
+    for (int tap = tid >> 8; tap < p.ntaps; tap += 2) {
+      int dt = 0, dh = 0, dw = 0;
+      if (p.ks == 3) {
+        dt = tap / 9;
+        const int r9 = tap - dt * 9;
+        dh = r9 / 3;
+        dw = r9 - dh * 3;
+      }
+      // clamp = replicate / causal padding, shift = nearest upsample (frame 0 is spatial-only)
+      int tu = to * p.st + dt - (p.ks - 1);
+      tu = tu < 0 ? 0 : (tu > p.Tu - 1 ? p.Tu - 1 : tu);
+      const int ts = p.up_t ? (tu == 0 ? 0 : 1 + ((tu - 1) >> 1)) : tu;
+      int hu = ho * p.sh + dh - (p.ks >> 1);
+      hu = hu < 0 ? 0 : (hu > p.Hu - 1 ? p.Hu - 1 : hu);
+      const int hs = p.up_hw ? (hu >> 1) : hu;
+      int wu = wo * p.sw + dw - (p.ks >> 1);
+      wu = wu < 0 ? 0 : (wu > p.Wu - 1 ? p.Wu - 1 : wu);
+      const int ws = p.up_hw ? (wu >> 1) : wu;
+      table[tap * 256 + r] = (unsigned)((b * p.T + ts) * HW + hs * p.W + ws) * cin_bytes;
+    }
+  }
+  __syncthreads();
+
+  // ---- LDS-DMA row slots of this lane: instruction j = wave + 8 i covers tile rows [8 j, 8 j + 8)
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int srow8 = lane >> 3, spos = lane & 7;
+  unsigned woff[4], chk[4], arow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 8 * i) * 8 + srow8;
+    const int c = spos ^ ((r >> 1) & 7);
+    chk[i] = (unsigned)(c * 16);
+    arow[i] = lds_base + TABLE + r * 4;
+    int n = n0 + (r < BN ? r : 0);
+    n = n < p.Cout ? n : p.Cout - 1;
+    woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
+  }
+  const int sw = (l31 >> 1) & 7;
+  unsigned faA[4], faW[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const unsigned sz = (unsigned)((((ks << 1) | hi) ^ sw) << 4);
+    faA[ks] = lds_base + (wm * TM * 32 + l31) * 128 + sz;
+    faW[ks] = lds_base + W_BASE + (wn * TN * 32 + l31) * 128 + sz;
+  }
+  const uint64_t xbase = rfl64((uint64_t)(uintptr_t)p.x), wbase = rfl64((uint64_t)(uintptr_t)p.w);
+  const unsigned nkt = rfl((unsigned)(p.Cin / 64)), nk = rfl((unsigned)(p.ntaps * (p.Cin / 64)));
+  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + W_BASE + wave * 1024);
+#define OSKCT_OPERANDS                                                                                             \
+  ::"v"(faA[0]), "v"(faA[1]), "v"(faA[2]), "v"(faA[3]), "v"(faW[0]), "v"(faW[1]), "v"(faW[2]), "v"(faW[3]),         \
+      "v"(arow[0]), "v"(arow[1]), "v"(arow[2]), "v"(arow[3]), "v"(chk[0]), "v"(chk[1]), "v"(chk[2]), "v"(chk[3]),   \
+      "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "s"(xbase), "s"(wbase), "s"(nk), "s"(nkt), "s"(adst), \
+      "s"(wdst)
+  if constexpr (BN == 256) {
+    asm volatile(
+#include "conv256_body_n256.inc"
+        OSKCT_OPERANDS : OSKG256_CONV_CLOBBERS);
+  } else {
+    asm volatile(
+#include "conv256_body_n128.inc"
+        OSKCT_OPERANDS : OSKG128_CONV_CLOBBERS);
+  }
+  epilogue_all<BN>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
+}
+
+template <int BN, bool TABLE_VERSION>
 int launch_one(const ConvParams& p, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int SMEM = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;
-  auto kernel = conv256_kernel<BN>;
+  constexpr int SMEM = (BN == 256 ? OSKG256_SMEM : OSKG128_SMEM) + (TABLE_VERSION ? 27 * 1024 : 0);
+  auto kernel = TABLE_VERSION ? conv256t_kernel<BN> : conv256_kernel<BN>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
@@ -220,8 +322,10 @@ bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes) {
   return p.Cin % 128 == 0 && p.Cout >= 128 && p.M >= 256 && x_bytes < (int64_t)0xFFFFFFFF && w_bytes < (int64_t)0xFFFFFFFF;
 }
 
-int launch_conv256(const ConvParams& p, hipStream_t st) {
-  return p.Cout >= 256 ? launch_one<256>(p, st) : launch_one<128>(p, st);
+// variant 1: one asm segment per filter tap (conv256_kernel); otherwise the single-call table version
+int launch_conv256(const ConvParams& p, int variant, hipStream_t st) {
+  if (variant == 1) return p.Cout >= 256 ? launch_one<256, false>(p, st) : launch_one<128, false>(p, st);
+  return p.Cout >= 256 ? launch_one<256, true>(p, st) : launch_one<128, true>(p, st);
 }
 
 }  // namespace osk_conv

@@ -23,6 +23,6 @@ struct ConvParams {
 
 // conv3d_256.hip: 256 voxels x {256,128} channels x 64 tile, 8 waves, one hand-scheduled asm K segment per filter tap
 bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes);
-int launch_conv256(const ConvParams& p, hipStream_t st);
+int launch_conv256(const ConvParams& p, int variant, hipStream_t st);
 
 }  // namespace osk_conv

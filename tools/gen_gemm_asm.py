@@ -296,6 +296,175 @@ def gen_segment(c):
     return L
 
 
+CONV_OPERANDS = ["faA0", "faA1", "faA2", "faA3", "faW0", "faW1", "faW2", "faW3", "arow0", "arow1", "arow2", "arow3",
+                 "chk0", "chk1", "chk2", "chk3", "woff0", "woff1", "woff2", "woff3",
+                 "xbase", "wbase", "nk", "nkt", "adst", "wdst"]
+COP = {n: "%%%d" % i for i, n in enumerate(CONV_OPERANDS)}
+S_NKT, S_SIT, S_TAPOFF, S_XB2 = 52, 53, 54, 56     # K steps per tap, step inside the tap, tap * 1024, x base (pair)
+CONV_S_LAST = 57
+
+
+def gen_conv(c):
+    """The whole K axis of the implicit-GEMM convolution (csrc/conv3d_256.hip) in ONE call: the gemm256 pipeline of
+    gen() with gathered A rows.  K = taps x (Cin / 64) steps; inside a tap a step only advances the channel block
+    (scalar base + 128 B), at a tap boundary every row slot takes a new voxel offset.  Those offsets sit in an LDS
+    table [tap][256 rows] (4 B each, built by the wrapper before the call; 27 KB next to the two 64 KB stages): each
+    K step re-reads its 4 entries for the step it is about to fetch (4 ds_read_b32, no branch) and adds the lane's
+    swizzled channel-chunk offset."""
+    L = []
+    e = lambda t: L.append("  " + t)
+    lab = lambda n: L.append(".Lc%s_%s_%%=:" % (c.tag, n))
+    VR = c.V0 + c.VN          # 4 raw table entries (ds_read destinations)
+    VO = VR + 4               # 4 offsets of the step being fetched
+    VA = VO + 4               # 4 table addresses
+
+    def reads(stage, ks, fset):
+        out = []
+        for tm in range(c.TM):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, tm), 4), COP["faA%d" % ks], stage * c.A_STAGE + tm * 4096))
+        for tn in range(c.TN):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, c.TM + tn), 4), COP["faW%d" % ks], stage * c.W_STAGE + tn * 4096))
+        return out
+
+    def mfmas(fset):
+        out = []
+        for tn in range(c.TN):
+            for tm in range(c.TM):
+                acc = ar((tn * c.TM + tm) * 16, 16)
+                out.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, c.TM + tn), 4), vr(c.frag(fset, tm), 4), acc))
+        return out
+
+    def dma(stage):
+        out = []
+        for i in range(c.NA):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (vr(VO + i), S_AB, S_AB + 1)))
+        for i in range(c.NW):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (COP["woff%d" % i], S_WB, S_WB + 1)))
+        return out
+
+    def table_reads():
+        """raw offsets of the step the loaders point at (tap = S_TAPOFF / 1024)"""
+        out = []
+        for i in range(c.NA):
+            out.append("v_add_u32_e32 %s, s%d, %s" % (vr(VA + i), S_TAPOFF, COP["arow%d" % i]))
+        for i in range(c.NA):
+            out.append("ds_read_b32 %s, %s" % (vr(VR + i), vr(VA + i)))
+        return out
+
+    def table_adds():
+        return ["v_add_u32_e32 %s, %s, %s" % (vr(VO + i), vr(VR + i), COP["chk%d" % i]) for i in range(c.NA)]
+
+    def advance():
+        """point the loaders at the next K step (tap-major): inside a tap the A base moves one channel block, at a
+        tap boundary it returns to x and the table row changes; W is contiguous along K.  Past the last step: stay."""
+        return ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
+                "s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK),
+                "s_cselect_b32 s%d, 128, 0" % S_STEP,                       # W step (0 at the very end: re-fetch)
+                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL),
+                "s_cselect_b32 s%d, 1, 0" % S_TMP,                           # 1 while advancing
+                "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1),
+                "s_add_u32 s%d, s%d, s%d" % (S_SIT, S_SIT, S_TMP),           # step inside the tap
+                "s_cmp_ge_u32 s%d, s%d" % (S_SIT, S_NKT),                     # tap boundary?
+                "s_cselect_b32 s%d, 0, s%d" % (S_SIT, S_SIT),
+                "s_cselect_b32 s%d, 1024, 0" % S_STEP,
+                "s_add_u32 s%d, s%d, s%d" % (S_TAPOFF, S_TAPOFF, S_STEP),
+                "s_lshl_b32 s%d, s%d, 7" % (S_STEP, S_SIT),
+                "s_add_u32 s%d, s%d, s%d" % (S_AB, S_XB2, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_XB2 + 1)]
+
+    # ---- setup
+    e("s_mov_b64 s[%d:%d], %s" % (S_XB2, S_XB2 + 1, COP["xbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, COP["xbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, COP["wbase"]))
+    e("s_mov_b32 s%d, %s" % (S_NK, COP["nk"]))
+    e("s_mov_b32 s%d, %s" % (S_NKT, COP["nkt"]))
+    e("s_mov_b32 s%d, %s" % (S_ADST, COP["adst"]))
+    e("s_mov_b32 s%d, %s" % (S_WDST, COP["wdst"]))
+    for sreg in (S_T, S_KL, S_SIT, S_TAPOFF):
+        e("s_mov_b32 s%d, 0" % sreg)
+    for r in range(c.NACC):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    # ---- prologue: offsets of step 0, stage 0; then what step 0 does before its entry point
+    for t in table_reads():
+        e(t)
+    e("s_waitcnt lgkmcnt(0)")
+    for t in table_adds():
+        e(t)
+    e("s_nop 1")
+    for m0w, d in dma(0):
+        e(m0w); e("s_nop 0"); e(d)
+    for a in advance():
+        e(a)
+    for t in table_reads():
+        e(t)
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")     # stage 0 landed AND its DMA has consumed the offset registers
+    for t in table_adds():
+        e(t)
+    e("s_barrier")
+    e("s_nop 1")
+    for m0w, d in dma(1):
+        e(m0w); e("s_nop 0"); e(d)
+    for a in advance():
+        e(a)
+    for r in reads(0, 0, 0):
+        e(r)
+    for t in table_reads():
+        e(t)
+    e("s_branch .Lc%s_entry0_%%=" % c.tag)
+
+    for k in range(2):
+        cur = k
+        lab("step%d" % k)
+        for r in reads(cur, 0, 0):
+            e(r)
+        mf = mfmas(1)                      # trailing k-sub-step 3 of the previous K step
+        pieces = dma(cur ^ 1)              # fetch of the step the loaders point at (offsets VO: refreshed last step)
+        e(pieces[0][0])
+        for i, m in enumerate(mf):
+            e(m)
+            if i < len(pieces):
+                e(pieces[i][1])
+                if i + 1 < len(pieces):
+                    e(pieces[i + 1][0])
+        for m0w, d in pieces[len(mf):]:
+            e(m0w); e("s_nop 0"); e(d)
+        for a in advance():
+            e(a)
+        for t in table_reads():            # offsets for the NEXT fetch; they join the fragment reads' wait below
+            e(t)
+        lab("entry%d" % k)
+        for ks in range(3):
+            fset = ks % 2
+            e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(fset)
+            rd = reads(cur, ks + 1, fset ^ 1)
+            for i, m in enumerate(mf):
+                e(m)
+                if i < len(rd):
+                    e(rd[i])
+            if ks == 2:
+                # VO <- raw + chunk: only now, when this step's LDS-DMA instructions (issued above, reading VO) are
+                # guaranteed to have read their address registers (they precede >= 16 MFMAs in program order)
+                for t in table_adds():
+                    e(t)
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_barrier")
+        e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
+        e("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NK))
+        e("s_cbranch_scc0 .Lc%s_exit_%%=" % c.tag)
+        if k == 1:
+            e("s_branch .Lc%s_step0_%%=" % c.tag)
+    lab("exit")
+    for m in mfmas(1):
+        e(m)
+    e("s_nop 15")
+    e("s_nop 15")
+    return L
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
@@ -318,6 +487,13 @@ def main():
             sclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 4)] + ['"a%d"' % i for i in range(c.NACC)] + \
                     ['"s%d"' % i for i in range(S_FIRST, SEG_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
             f.write("#define %sSEG_CLOBBERS %s\n" % (P, ", ".join(sclob)))
+            cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 12)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                    ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+            f.write("#define %sCONV_CLOBBERS %s\n" % (P, ", ".join(cclob)))
+        with open(os.path.join(args.out, "conv256_body_n%d.inc" % bn), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile, whole K axis (all filter taps).\n" % bn)
+            for ln in gen_conv(c):
+                f.write('"%s\\n"\n' % ln)
         with open(os.path.join(args.out, "conv256_segment_n%d.inc" % bn), "w") as f:
             f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile, one K segment (filter tap).\n" % bn)
             for ln in gen_segment(c):
