@@ -147,7 +147,9 @@ def bench_vae(args, dev):
                    "flops_encode": enc_f, "flops_decode": dec_f},
         "step_tflops": round((enc_f + dec_f) / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round((enc_f + dec_f) / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        "roofline": {"bound": "mfma", "kernel": "conv3d_kernel", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+        # all conv launches of one encode + decode: conv256t_kernel (conv3d_256.hip) where Cin % 128 == 0, Cout >= 128,
+        # conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers
+        "roofline": {"bound": "mfma", "kernel": "conv256t_kernel + conv3d_kernel (by layer shape)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                      "launches": len(prof) // args.steps, "total_conv_ms_per_step": round(conv_ms, 3)},
     }
