@@ -2,6 +2,7 @@
 // V transpose, skinny GEMV task list (adaLN modulation / embedders), timestep embedding, RoPE tables,
 // CFG + Euler update.  All loads/stores are 16 B per lane (8 bf16) where the layout allows (guide G13).
 #include "osk_common.h"
+#include <stdlib.h>
 #include "../../include/osk.h"
 
 // =============================================================================================
@@ -183,6 +184,127 @@ __global__ void __launch_bounds__(256) qknorm_rope_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-per-thread variant (default).  A block owns TPB = 256 / H consecutive tokens = TPB * H (token, head) rows.
+// Global traffic is fully coalesced both ways: the TPB contiguous [H * hd] spans are copied to LDS with 16-byte loads
+// by all lanes, every thread then norms + rotates ONE row out of LDS entirely in registers (no cross-lane reduction,
+// both RoPE conventions lane-local), writes it back to LDS, and the spans leave with 16-byte stores.  cos / sin of
+// the block's tokens and the four scale vectors are staged in LDS once.  Same rounding points as above.
+// LDS row stride hd*2 (+16 when hd % 32 == 0) bytes keeps the per-thread 16-byte row reads off each other's banks.
+// ---------------------------------------------------------------------------------------------
+template <int HD, int MODE>
+__global__ void __launch_bounds__(256) qknorm_rope_rows_kernel(
+    unsigned short* __restrict__ q, unsigned short* __restrict__ k, int64_t bs, int64_t rs,
+    const unsigned short* __restrict__ qs0, const unsigned short* __restrict__ ks0,
+    const unsigned short* __restrict__ qs1, const unsigned short* __restrict__ ks1, int l_split,
+    const float* __restrict__ cos_t, const float* __restrict__ sin_t, int64_t csb, int B, int L, int H,
+    float eps, float q_mult) {
+  constexpr int RS = HD * 2 + ((HD % 32) == 0 ? 16 : 0);  // LDS row stride, bytes
+  constexpr int CPR = HD / 8;                              // 16-byte chunks per row
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const int tpb = 256 / H, rows = tpb * H;
+  unsigned char* s_rows = sm;                                            // [rows][RS]
+  float* s_cs = reinterpret_cast<float*>(sm + 256 * RS);                 // [tpb][2][HD/2]
+  unsigned short* s_sc = reinterpret_cast<unsigned short*>(s_cs + tpb * HD);  // [4][HD]
+  const int tid = threadIdx.x;
+  const int64_t tok0 = (int64_t)blockIdx.x * tpb;                        // first token (over B * L)
+  const int64_t ntok = (int64_t)B * L;
+  // ---- stage cos / sin rows of the block's tokens and the scale vectors
+  for (int i = tid; i < tpb * HD; i += 256) {
+    const int t = i / HD, j = i - t * HD;
+    int64_t tok = tok0 + t;
+    tok = tok < ntok ? tok : ntok - 1;
+    const int l = (int)(tok % L), b = (int)(tok / L);
+    const int64_t off = b * csb + (int64_t)l * (HD / 2);
+    s_cs[i] = j < HD / 2 ? cos_t[off + j] : sin_t[off + j - HD / 2];
+  }
+  for (int i = tid; i < 4 * HD; i += 256) {
+    const unsigned short* src = i < HD ? qs0 : (i < 2 * HD ? ks0 : (i < 3 * HD ? qs1 : ks1));
+    s_sc[i] = src[i % HD];
+  }
+  const int r = tid;                       // this thread's row
+  const int t_loc = r / H, h = r - t_loc * H;
+  int64_t tok_r = tok0 + t_loc;
+  const bool rvalid = r < rows && tok_r < ntok;
+  tok_r = tok_r < ntok ? tok_r : ntok - 1;
+  const int l_r = (int)(tok_r % L);
+  const int span_chunks = H * CPR;         // 16-byte chunks of one token's [H * hd] span
+  {
+    // blockIdx.y picks the tensor: q and k are independent passes, two blocks instead of two serial phases
+    const int which = q && k ? (int)blockIdx.y : (k ? 1 : 0);
+    unsigned short* tb = which ? k : q;
+    __syncthreads();                       // staging visible
+    for (int c = tid; c < tpb * span_chunks; c += 256) {
+      const int t = c / span_chunks, w = c - t * span_chunks;
+      int64_t tok = tok0 + t;
+      tok = tok < ntok ? tok : ntok - 1;
+      const int l = (int)(tok % L), b = (int)(tok / L);
+      const uint4 u = *reinterpret_cast<const uint4*>(tb + b * bs + (int64_t)l * rs + w * 8);
+      const int row = t * H + w / CPR, cir = w % CPR;
+      *reinterpret_cast<uint4*>(s_rows + row * RS + cir * 16) = u;
+    }
+    __syncthreads();
+    if (r < rows) {
+      float v[HD];
+#pragma unroll
+      for (int c = 0; c < CPR; ++c) unpack8(*reinterpret_cast<const uint4*>(s_rows + r * RS + c * 16), v + c * 8);
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < HD; ++j) ss += v[j] * v[j];
+      const float rrms = rsqrtf(ss / (float)HD + eps);
+      const unsigned short* sc = s_sc + (which ? HD : 0) + (l_r < l_split ? 0 : 2 * HD);
+#pragma unroll
+      for (int c = 0; c < CPR; ++c) {        // 8 scales per 16-byte LDS read
+        float w8[8];
+        unpack8(*reinterpret_cast<const uint4*>(sc + c * 8), w8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // reference rounding points: (x*rrms).to(bf16) * scale(bf16) -> bf16   (layers.py:107-111)
+          const float t1 = bf16_bits_to_f32(f32_to_bf16_bits(v[c * 8 + j] * rrms));
+          v[c * 8 + j] = bf16_bits_to_f32(f32_to_bf16_bits(t1 * w8[j]));
+        }
+      }
+      const float* cr = s_cs + t_loc * HD;
+      const float* sr = cr + HD / 2;
+      const float qm = which ? 1.0f : q_mult;
+      float csv[HD / 2], snv[HD / 2];        // 4 angles per 16-byte LDS read (HD / 2 is a multiple of 4)
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) {
+        const float4 c4 = *reinterpret_cast<const float4*>(cr + c * 4);
+        const float4 s4 = *reinterpret_cast<const float4*>(sr + c * 4);
+        csv[c * 4 + 0] = c4.x; csv[c * 4 + 1] = c4.y; csv[c * 4 + 2] = c4.z; csv[c * 4 + 3] = c4.w;
+        snv[c * 4 + 0] = s4.x; snv[c * 4 + 1] = s4.y; snv[c * 4 + 2] = s4.z; snv[c * 4 + 3] = s4.w;
+      }
+#pragma unroll
+      for (int pj = 0; pj < HD / 2; ++pj) {
+        const float cs = csv[pj], sn = snv[pj];
+        if constexpr (MODE == 0) {           // pairs (2j, 2j+1)
+          const float a = v[2 * pj], b2 = v[2 * pj + 1];
+          v[2 * pj] = (cs * a - sn * b2) * qm;
+          v[2 * pj + 1] = (sn * a + cs * b2) * qm;
+        } else {                             // pairs (j, j + hd/2)
+          const float a = v[pj], b2 = v[pj + HD / 2];
+          v[pj] = (a * cs - b2 * sn) * qm;
+          v[pj + HD / 2] = (b2 * cs + a * sn) * qm;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CPR; ++c) *reinterpret_cast<uint4*>(s_rows + r * RS + c * 16) = pack8(v + c * 8);
+    }
+    __syncthreads();
+    for (int c = tid; c < tpb * span_chunks; c += 256) {
+      const int t = c / span_chunks, w = c - t * span_chunks;
+      const int64_t tok = tok0 + t;
+      if (tok >= ntok) continue;
+      const int l = (int)(tok % L), b = (int)(tok / L);
+      const int row = t * H + w / CPR, cir = w % CPR;
+      *reinterpret_cast<uint4*>(tb + b * bs + (int64_t)l * rs + w * 8) =
+          *reinterpret_cast<const uint4*>(s_rows + row * RS + cir * 16);
+    }
+  }
+  (void)rvalid;
+}
+
 extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, const void* qs0,
                                     const void* ks0, const void* qs1, const void* ks1, int l_split,
                                     const float* cos_t, const float* sin_t, int64_t csb, int B, int L,
@@ -191,6 +313,29 @@ extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, co
   if (B <= 0 || L <= 0 || H <= 0 || (bs & 7) || (rs & 7)) return OSK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)B * L * H;
+  {
+    // row-per-thread kernel (coalesced spans through LDS); OSK_QKNORM_VARIANT=0 forces the lane-group kernel below
+    static const int qv = [] { const char* e = getenv("OSK_QKNORM_VARIANT"); return e ? atoi(e) : -1; }();
+    if (qv != 0 && H <= 256 && (hd == 64 || hd == 72) && (rope_mode == 0 || rope_mode == 1)) {  // hd 128: the lane-group
+      // kernel below already uses every lane (16 x 16 B per row) and a whole row per thread would need 256 VGPRs
+      const int tpb = 256 / H;
+      const int64_t ntok = (int64_t)B * L;
+      dim3 grid((unsigned)((ntok + tpb - 1) / tpb), (q && k) ? 2 : 1), block(256);
+#define LAUNCH_ROWS(HD, MODE)                                                                                   \
+  {                                                                                                             \
+    constexpr int RS_ = HD * 2 + ((HD % 32) == 0 ? 16 : 0);                                                     \
+    const size_t smem = 256 * RS_ + (size_t)tpb * HD * 4 + 4 * HD * 2;                                          \
+    hipLaunchKernelGGL((qknorm_rope_rows_kernel<HD, MODE>), grid, block, smem, st, (unsigned short*)q,          \
+                       (unsigned short*)k, bs, rs, (const unsigned short*)qs0, (const unsigned short*)ks0,      \
+                       (const unsigned short*)qs1, (const unsigned short*)ks1, l_split, cos_t, sin_t, csb, B,   \
+                       L, H, eps, q_mult);                                                                      \
+  }
+      if (hd == 64) { if (rope_mode == 0) LAUNCH_ROWS(64, 0) else LAUNCH_ROWS(64, 1) }
+      else { if (rope_mode == 0) LAUNCH_ROWS(72, 0) else LAUNCH_ROWS(72, 1) }
+#undef LAUNCH_ROWS
+      return (int)hipGetLastError();
+    }
+  }
 #define LAUNCH(HD, CW, MODE)                                                                          \
   {                                                                                                   \
     constexpr int NCH = HD / CW;                                                                      \
