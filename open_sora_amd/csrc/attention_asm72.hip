@@ -13,7 +13,8 @@
 //  * the online-softmax reference max M is kept bf16-exact inside the contraction (Q padding dim 72 = -M, K
 //    padding dim 72 = 1.0), so P = exp2(S') with S' straight out of the MFMA; M moves only when a row max exceeds
 //    it by more than 8 (log2 units): P <= 2^8, O and the row sum (ones row of V^T) carry the same factor.
-// Requires seg_len % 64 == 0 (no ragged key tile); the dispatcher falls back to attention_fwd.hip otherwise.
+// Any key count: a ragged last tile of a key segment re-fetches the segment's last key for the missing rows and masks
+// them out of the denominator through the ones row (see the wrapper).
 #include "attention_params.h"
 #include "attention_asm72_regs.inc"
 
@@ -48,7 +49,23 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
     const int slot = tid >> 5;
     reinterpret_cast<unsigned*>(smem + OSK72_VOFF0 + slot * OSK72_VTILE + HD * 128)[tid & 31] = 0x3F803F80u;
   }
-  if (tid == 64) *reinterpret_cast<unsigned*>(smem + OSK72_CONST_OFF) = 0x00003F80u;
+  if (tid == 64 || tid == 65)  // one copy per K ring slot, KTILE apart (the slot is an immediate offset in the asm)
+    *reinterpret_cast<unsigned*>(smem + OSK72_CONST_OFF + (tid - 64) * OSK72_KTILE) = 0x00003F80u;
+  // ragged last key tile of a segment (seg_len % 64 != 0): K rows past the segment re-fetch its last key (finite
+  // scores), V^T is zero there (osk_v_transpose_bf16 pads), and the tile's ones row becomes a validity mask so the
+  // duplicates do not count in the softmax denominator.  The mask is in the V^T tile's baked key order.
+  const int last_valid = p.seg_len - (p.tps - 1) * 64;   // keys in the last tile of a segment (1..64)
+  const bool ragged = last_valid < 64;
+  unsigned maskval = 0;
+  if (lane < 32) {
+    // dword `lane` of LDS row 72: 16-byte position lane / 4 holds logical chunk (lane / 4) ^ ((72 >> 1) & 7) of the
+    // swizzled 128-byte row image; columns of the V^T tile: key = 16 (c / 16) + perm(c % 16)
+    const int c0 = (((lane >> 2) ^ ((HD >> 1) & 7)) << 3) + (lane & 3) * 2, c1 = c0 + 1;
+    auto key_of = [](int c) { const int j = c & 15; return (c & ~15) + ((j & 3) | ((j & 4) << 1) | ((j & 8) >> 1)); };
+    maskval = (key_of(c0) < last_valid ? 0x3F80u : 0u) | (key_of(c1) < last_valid ? 0x3F800000u : 0u);
+  }
+  if (ragged && p.tps == 1 && tid < 32)                  // tile 0 itself is ragged: no loop body precedes it
+    reinterpret_cast<unsigned*>(smem + OSK72_VOFF0 + HD * 128)[tid] = maskval;
   __syncthreads();
 
   // ---- Q fragments, pre-scaled by scale*log2(e), -> AGPRs (u-major, k-step, 4 words)
@@ -92,18 +109,24 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   // ---- per-lane LDS-DMA source offsets (bytes from the loader's tile base) of this wave's instruction slots:
   //      K instruction j = wave + NW i (j = 8: the 8-dim column image), V^T instruction j = (NW - 1 - wave) + NW i
   const int srow8 = lane >> 3, spos = lane & 7;
-  unsigned koff[3] = {0, 0, 0}, voff[3] = {0, 0, 0};
+  unsigned koff[3] = {0, 0, 0}, koffL[3] = {0, 0, 0}, voff[3] = {0, 0, 0};
 #pragma unroll
   for (int i = 0; i < NSLOT; ++i) {
     const int j = wave + NW * i;
-    unsigned o = 0;
+    unsigned o = 0, oL = 0;
     if (j < 8) {
       const int row = j * 8 + srow8;
-      o = (unsigned)(((int64_t)row * p.krs + ((spos ^ ((row >> 1) & 7)) << 3)) * 2);
+      const int rowL = row < last_valid ? row : last_valid - 1;
+      const int ch = (spos ^ ((row >> 1) & 7)) << 3;
+      o = (unsigned)(((int64_t)row * p.krs + ch) * 2);
+      oL = (unsigned)(((int64_t)rowL * p.krs + ch) * 2);
     } else if (j == 8) {
+      const int rowL = lane < last_valid ? lane : last_valid - 1;
       o = (unsigned)(((int64_t)lane * p.krs + 64) * 2);
+      oL = (unsigned)(((int64_t)rowL * p.krs + 64) * 2);
     }
     koff[i] = o;
+    koffL[i] = oL;
     const int jv = (NW - 1 - wave) + NW * i;
     unsigned ov = 0;
     if (jv < HD / 8) {
@@ -114,14 +137,13 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   }
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int sw = (l31 >> 1) & 7;
-  unsigned fo[4], kc[2][2];
+  unsigned fo[4], kc[2];
 #pragma unroll
   for (int j = 0; j < 4; ++j) fo[j] = lds_base + l31 * 128 + (((2 * j + hi) ^ sw) << 4);
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-      kc[s][t2] = hi ? lds_base + OSK72_CONST_OFF : lds_base + s * OSK72_KTILE + 8192 + t2 * 512 + l31 * 16;
+  for (int t2 = 0; t2 < 2; ++t2)   // ring slot 1 = + KTILE (immediate), for the column image and the constant chunk alike
+    kc[t2] = hi ? lds_base + OSK72_CONST_OFF : lds_base + 8192 + t2 * 512 + l31 * 16;
+  const unsigned onesaddr = lds_base + OSK72_VOFF0 + HD * 128 + lane * 4;   // lanes 32..63: the zero row behind it
 
   const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + b * p.kbs + h * HD));
   const uint64_t vbase = rfl64((uint64_t)(uintptr_t)(p.vt + (int64_t)bh * HD * p.seg_lp));
@@ -132,13 +154,15 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   const unsigned kdst = rfl(lds_base + wave * 1024), vdst = rfl(lds_base + OSK72_VOFF0 + (NW - 1 - wave) * 1024);
   // valid loader slots of this wave: the last one only where its instruction index is < 9
   const unsigned nkw = rfl(wave + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1));
-  const unsigned nvw = rfl((NW - 1 - wave) + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1));
+  const unsigned nvw = rfl(((NW - 1 - wave) + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1)) |
+                           (ragged ? 0u : 1u << 8) | ((ragged && wave == 0) ? 1u << 9 : 0u));
 
   float m_ref[2];
 #define OSK72_OPERANDS                                                                                              \
   : "=&v"(m_ref[0]), "=&v"(m_ref[1])                                                                                 \
   : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(fo[0]), "v"(fo[1]),     \
-    "v"(fo[2]), "v"(fo[3]), "v"(kc[0][0]), "v"(kc[0][1]), "v"(kc[1][0]), "v"(kc[1][1]), "s"(kbase), "s"(vbase),     \
+    "v"(fo[2]), "v"(fo[3]), "v"(kc[0]), "v"(kc[1]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(maskval),      \
+    "v"(onesaddr), "s"(kbase), "s"(vbase),                                                                           \
     "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
   if constexpr (NU == 2 && VAR == 0) {
     asm volatile(
@@ -236,7 +260,7 @@ int launch_one(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
-bool asm72_supported(const AttnParams& p, int hd) { return hd == 72 && (p.seg_len % 64) == 0; }
+bool asm72_supported(const AttnParams& p, int hd) { (void)p; return hd == 72; }
 
 // nu = query blocks per wave (2: 4 waves x 64 rows, 1: 8 waves x 32 rows); var 0 = production schedule, 1 = the
 // experimental body emitted by tools/gen_attn_asm.py --exp (default: the hazard-padded debug schedule)

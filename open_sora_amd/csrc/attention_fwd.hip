@@ -730,7 +730,8 @@ extern "C" int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int
 
 extern "C" const char* osk_attention_kernel_name(int hd, int seg_len) {
   const int v = attn_variant();
-  if ((v == -1 || (v >= 5 && v <= 8)) && hd == 72 && seg_len % 64 == 0) return "attn_asm72_kernel";
+  (void)seg_len;
+  if ((v == -1 || (v >= 5 && v <= 8)) && hd == 72) return "attn_asm72_kernel";
   if (v == 3 || v == 4) return "attn_w64_kernel";
   if (v == 9) return "attn_fwd_kernel_v1";
   return "attn_fwd_kernel";

@@ -269,7 +269,12 @@ def test_attention_vs_oracle(hip_lib, hd, Lq, Lk):
 
 @pytest.mark.parametrize("hd", [72, 128])
 def test_attention_rescale_branch(hip_lib, hd):
-    _attn_case(hip_lib, 1, 2, hd, 128, 900, spike=True)
+    # head_dim 72 (hand-scheduled kernel): q as the model path hands it over (scale folded into its single rounding);
+    # a stand-alone call re-rounds scale*q, which moves a logit of ~34 by up to 2^-9 relative: LSE bound scaled with it
+    # (its LSE carries the bf16 rounding of the dominant P, which is 2^(s - M) with a bf16-exact M instead of exactly 1)
+    _attn_case(hip_lib, 1, 2, hd, 128, 900, spike=True, prescaled=(hd == 72), lse_tol=4e-3 if hd == 72 else 2e-3)
+    if hd == 72:
+        _attn_case(hip_lib, 1, 2, hd, 128, 900, spike=True, lse_tol=5e-2)
 
 
 # head_dim 72 with whole 64-key tiles runs the hand-scheduled kernel (attention_asm72.hip): 1, 2, 3 and many key
@@ -280,7 +285,7 @@ def test_attention_hd72_whole_tiles(hip_lib, Lq, Lk):
     # 4e-3 instead of 2e-3; the output bounds are the common ones
     _attn_case(hip_lib, 2, 3, 72, Lq, Lk, seed=11, lse_tol=4e-3)
     # the model path: scale*log2(e) folded into q upstream -> no extra rounding, the common LSE bound holds
-    _attn_case(hip_lib, 2, 3, 72, Lq, Lk, seed=12, prescaled=True)
+    _attn_case(hip_lib, 2, 3, 72, Lq, Lk, seed=12, prescaled=True, lse_tol=4e-3)
 
 
 @pytest.mark.parametrize("hd", [64, 128])
@@ -314,6 +319,33 @@ def test_attention_hd72_reference_max_jump(hip_lib, spike_key):
     # logits of ~57 carry the 2^-9 relative error of the re-rounded, pre-scaled Q: bounds scale with max |s|
     assert (out.float().cpu().double() - ref).abs().max().item() <= 3e-2
     assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() <= 1.5e-3 * s.abs().max().item()
+
+
+@pytest.mark.parametrize("seg,nseg", [(100, 3), (40, 2), (200, 2)])
+def test_attention_hd72_ragged_segments(hip_lib, seg, nseg):
+    """hand-scheduled kernel with ragged key segments (sequence-parallel all-gather layout with L/P % 64 != 0): every
+    segment's last tile re-fetches the segment's last key for the missing rows and masks them out of the denominator."""
+    B, H, hd = 2, 2, 72
+    D, L = H * hd, seg * nseg
+    q = rnd("q", (B, 130, D), seed=31)
+    kv = rnd("kv", (B, L, 2 * D), seed=32)
+    k, v = kv[:, :, :D], kv[:, :, D:]
+    segp = (seg + 63) // 64 * 64
+    kseg = torch.stack([k[:, i * seg:(i + 1) * seg].contiguous() for i in range(nseg)])
+    vts = torch.empty(nseg, B, H, hd, segp, dtype=BF, device=DEV)
+    for s_ in range(nseg):
+        hip_lib.v_transpose(v[:, s_ * seg: (s_ + 1) * seg], vts[s_], H, hd)
+    out = torch.empty(B, 130, D, dtype=BF, device=DEV)
+    lse = torch.empty(B, H, 130, dtype=torch.float32, device=DEV)
+    hip_lib.attention_fwd(q, kseg[0], vts, out, H, hd, hd ** -0.5, lse=lse, n_seg=nseg, seg_len=seg,
+                          k_seg_stride=kseg.stride(0), vt_seg_stride=vts.stride(0))
+    qh = q.float().cpu().view(B, 130, H, hd).permute(0, 2, 1, 3).double()
+    kh = k.float().cpu().view(B, L, H, hd).permute(0, 2, 1, 3).double()
+    vh = v.float().cpu().view(B, L, H, hd).permute(0, 2, 1, 3).double()
+    s = (qh @ kh.transpose(-1, -2)) * hd ** -0.5
+    ref = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B, 130, D)
+    assert (out.float().cpu().double() - ref).abs().max().item() <= 2.5e-2
+    assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() <= 4e-3
 
 
 def test_attention_hd72_segments_and_in_place(hip_lib):

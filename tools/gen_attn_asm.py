@@ -30,13 +30,15 @@ HD, NKS, NDT = 72, 5, 3
 KTILE, VTILE = 9216, 12288
 KOFF = [0, KTILE]
 VOFF = [2 * KTILE, 2 * KTILE + VTILE]
-CONST_OFF = 2 * KTILE + 2 * VTILE          # 16-byte chunk {1.0bf16, 0...}: K's padding dims 72..79
-SMEM = CONST_OFF + 16
+CONST_OFF = 2 * KTILE + 2 * VTILE          # 16-byte chunk {1.0bf16, 0...}: K's padding dims 72..79, one copy per K ring
+SMEM = CONST_OFF + KTILE + 16              # slot at the same distance (KTILE) as the slots: one address register serves both
 THR_BITS = "0x41000000"                    # 8.0: move M when a score exceeds the reference by > 2^8
 NKD = NVD = 9                              # LDS-DMA wave instructions per K / V^T tile
 
 # ---- asm-owned SGPRs
-S_FIRST, S_LAST = 36, 63
+S_FIRST, S_LAST = 36, 65
+S_KRG, S_VRG, S_FLG, S_NRG = 36, 38, 45, 64  # lane masks: K / V^T loader sits on a ragged (segment-last) tile; flags
+# (S_FLG bit 1: this wave maintains the ones rows; S_NRG = 1 when the launch has NO ragged tile)
 S_KB, S_VB, S_KSTEP, S_KJ, S_VJ = 40, 42, 44, 46, 48
 S_TPS, S_NT, S_KDST, S_VDST, S_NKW, S_NVW = 50, 51, 52, 53, 54, 55
 S_T, S_KTT, S_VTT, S_TMP, S_HIM, S_KL, S_VL = 56, 57, 58, 59, 60, 62, 63
@@ -44,7 +46,7 @@ S_T, S_KTT, S_VTT, S_TMP, S_HIM, S_KL, S_VL = 56, 57, 58, 59, 60, 62, 63
 # ---- asm operands (order = operand numbers in the wrapper's asm statement)
 OPERANDS = ["m0out", "m1out",
             "koff0", "koff1", "koff2", "voff0", "voff1", "voff2",
-            "fo0", "fo1", "fo2", "fo3", "kc00", "kc01", "kc10", "kc11",
+            "fo0", "fo1", "fo2", "fo3", "kc0", "kc1", "koffL0", "koffL1", "koffL2", "maskval", "onesaddr",
             "kbase", "vbase", "kstep", "kjump", "vjump", "tps", "nt", "kdst", "vdst", "nkw", "nvw"]
 OP = {n: "%%%d" % i for i, n in enumerate(OPERANDS)}
 
@@ -142,7 +144,7 @@ def k_read(st, L, slot, p, tag):
     if ks < 4:
         st.ds_read(dst, OP["fo%d" % ks], KOFF[slot] + t2 * 4096, tag)
     else:
-        st.ds_read(dst, OP["kc%d%d" % (slot, t2)], 0, tag)
+        st.ds_read(dst, OP["kc%d" % t2], KOFF[slot], tag)
 
 
 def v_read(st, L, slot, r, tag):
@@ -217,13 +219,13 @@ def rowmax_from_chains(st, L):
 
 def k_dma(st, L, slot, i, part=3):
     """K loader slot i of this wave -> ring slot `slot` (instruction j = wave + NW i).  part 1 = M0 write only,
-    2 = the DMA only (one other instruction must sit between them), 3 = both with an s_nop"""
+    2 = the DMA only (one other instruction must sit between them), 3 = both with an s_nop.  On the ragged last tile
+    of a key segment (lane mask S_KRG) the rows past the segment re-fetch its last key (offsets koffL)."""
     if part & 1:
         st.emit("s_add_u32 m0, s%d, %d" % (S_KDST, KOFF[slot] + 1024 * L.NW * i), "s")
-    if part == 3:
-        st.emit("s_nop 0", "n")
+        st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(L.TX[3]), OP["koff%d" % i], OP["koffL%d" % i], S_KRG, S_KRG + 1), "v")
     if part & 2:
-        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["koff%d" % i], S_KB, S_KB + 1), "g")
+        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (vr(L.TX[3]), S_KB, S_KB + 1), "g")
 
 
 def v_dma(st, L, slot, i, part=3):
@@ -263,6 +265,32 @@ def advance(st, which, uid):
     st.emit("s_mov_b32 s%d, 0" % stt, "s")
     st.emit("s_add_u32 s%d, s%d, s%d" % (sb, sb, sj), "s")
     st.emit("s_addc_u32 s%d, s%d, s%d" % (sb + 1, sb + 1, sj + 1), "s")
+    st.label(lab)
+    ragged_mask(st, which)
+
+
+def ragged_mask(st, which):
+    """lane mask (all ones / zero): the loader's current tile is the last one of its key segment AND that tile is
+    ragged (flag bit 0)"""
+    stt, srg = (S_KTT, S_KRG) if which == "k" else (S_VTT, S_VRG)
+    st.emit("s_add_u32 s%d, s%d, 1" % (S_TMP, stt), "s")
+    st.emit("s_sub_u32 s%d, s%d, s%d" % (S_TMP, S_TPS, S_TMP), "s")        # 0 on the segment's last tile
+    st.emit("s_or_b32 s%d, s%d, s%d" % (S_TMP, S_TMP, S_NRG), "s")         # never 0 when the launch has no ragged tile
+    st.emit("s_cmp_eq_u32 s%d, 0" % S_TMP, "s")
+    st.emit("s_cselect_b64 s[%d:%d], -1, 0" % (srg, srg + 1), "s")
+
+
+def ones_row(st, L, slot):
+    """V^T ring slot `slot` is about to receive the tile the V^T loader points at: its ones row (accumulator row 72 =
+    softmax denominator) becomes that tile's key-validity mask (all ones unless the tile is ragged).  Wave 0 only
+    (flag bit 1); lanes 32..63 rewrite the zero row behind it."""
+    lab = ".L@@_or%d_%d" % (slot, len(st.lines))
+    st.emit("s_bitcmp1_b32 s%d, 1" % S_FLG, "s")
+    st.emit("s_cbranch_scc0 %s" % lab, "s")
+    st.emit("v_mov_b32 %s, 0x3f803f80" % vr(L.TX[2]), "v")
+    st.emit("v_cndmask_b32_e64 %s, %s, 0, s[%d:%d]" % (vr(L.TX[2]), vr(L.TX[2]), S_HIM, S_HIM + 1), "v")
+    st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(L.TX[2]), vr(L.TX[2]), OP["maskval"], S_VRG, S_VRG + 1), "v")
+    st.emit("ds_write_b32 %s, %s offset:%d" % (OP["onesaddr"], vr(L.TX[2]), VOFF[slot] - VOFF[0]), "D")
     st.label(lab)
 
 
@@ -358,6 +386,7 @@ def body(st, L, k, safe):
     for i in range(done["v"], L.NSLOT - 1):
         later.append((lambda i=i: v_dma(st, L, cur ^ 1, i), 12))
     later.append((lambda: dma_last(st, L, "v", cur ^ 1, uid), 12))
+    later.append((lambda: ones_row(st, L, cur ^ 1), 8))       # before the V^T loader moves on: S_VRG is tile t+1's
     later.append((lambda: advance(st, "k", uid), 28))
     later.append((lambda: advance(st, "v", uid), 28))
 
@@ -450,6 +479,12 @@ def generate(L, safe=False, ablate=frozenset()):
     for sreg in (S_T, S_KTT, S_VTT, S_KL, S_VL, S_HIM):
         e("s_mov_b32 s%d, 0" % sreg)
     e("s_mov_b32 s%d, -1" % (S_HIM + 1))
+    # nvw = valid V^T loader slots | (no ragged tile in this launch) << 8 | (this wave maintains the ones rows) << 9
+    e("s_lshr_b32 s%d, s%d, 8" % (S_FLG, S_NVW))
+    e("s_and_b32 s%d, s%d, 1" % (S_NRG, S_FLG))
+    e("s_and_b32 s%d, s%d, 0xff" % (S_NVW, S_NVW))
+    ragged_mask(st, "k")
+    ragged_mask(st, "v")
     for u in range(2):
         e("v_mov_b32 %s, 0" % vr(L.MM[u]))
     for r in range(L.A_O0, L.A_Q0):
