@@ -266,7 +266,16 @@ def advance(st, which, uid):
     st.emit("s_add_u32 s%d, s%d, s%d" % (sb, sb, sj), "s")
     st.emit("s_addc_u32 s%d, s%d, s%d" % (sb + 1, sb + 1, sj + 1), "s")
     st.label(lab)
-    ragged_mask(st, which)
+
+
+def ragged_masks(st):
+    """refresh both loaders' ragged-tile lane masks; skipped entirely when the launch has no ragged tile"""
+    lab = ".L@@_rg%d" % len(st.lines)
+    st.emit("s_cmp_lg_u32 s%d, 0" % S_NRG, "s")
+    st.emit("s_cbranch_scc1 %s" % lab, "s")
+    ragged_mask(st, "k")
+    ragged_mask(st, "v")
+    st.label(lab)
 
 
 def ragged_mask(st, which):
@@ -300,6 +309,7 @@ def dma_group(st, L, which, slot, uid):
         (k_dma if which == "k" else v_dma)(st, L, slot, i)
     dma_last(st, L, which, slot, uid)
     advance(st, which, uid)
+    ragged_masks(st)
 
 
 def fixup(st, L, sx, init):
@@ -388,7 +398,7 @@ def body(st, L, k, safe):
     later.append((lambda: dma_last(st, L, "v", cur ^ 1, uid), 12))
     later.append((lambda: ones_row(st, L, cur ^ 1), 8))       # before the V^T loader moves on: S_VRG is tile t+1's
     later.append((lambda: advance(st, "k", uid), 28))
-    later.append((lambda: advance(st, "v", uid), 28))
+    later.append((lambda: (advance(st, "v", uid), ragged_masks(st)), 32))
 
     # -- fillers paced in CYCLES (v_exp 8, other VALU 4): three classes, each spread uniformly over its window
     cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
