@@ -56,6 +56,36 @@ OSK_DEV void epilogue_tile(const ConvParams& p, int m0w, int n0w, int l31, int h
   if (m >= p.M) return;
   const int64_t roff = (int64_t)m * p.Cout;
   const bool vec_ok = (p.Cout & 3) == 0;
+  // whole 32-channel strip inside Cout and the row 16-byte aligned (Cout % 8 == 0): pair the half-waves and store 16 B
+  // (v_permlane32_swap per dword: the lower half-wave takes the whole 8-channel block qd, the upper one block qd + 1)
+  const int nstrip = n0w + tn * 32;
+  if (vec_ok && (p.Cout & 7) == 0 && nstrip + 32 <= p.Cout && (((uintptr_t)p.out) & 15) == 0) {
+    uint2 packed[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int n = nstrip + qd * 8 + hi * 4;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[qd * 4 + j];
+      if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (p.res) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+        v[0] += bf16_lo(rv.x); v[1] += bf16_hi(rv.x); v[2] += bf16_lo(rv.y); v[3] += bf16_hi(rv.y);
+      }
+      packed[qd].x = pack_bf16x2(v[0], v[1]);
+      packed[qd].y = pack_bf16x2(v[2], v[3]);
+    }
+#pragma unroll
+    for (int qd = 0; qd < 4; qd += 2) {
+      auto sx = __builtin_amdgcn_permlane32_swap(packed[qd].x, packed[qd + 1].x, false, false);
+      auto sy = __builtin_amdgcn_permlane32_swap(packed[qd].y, packed[qd + 1].y, false, false);
+      *reinterpret_cast<uint4*>(p.out + roff + nstrip + (qd + hi) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+    }
+    return;
+  }
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     const int n = n0w + tn * 32 + qd * 8 + hi * 4;

@@ -62,6 +62,7 @@ OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int h
     }
     float acc[16];
     read_acc<BN, T>(acc);
+    uint2 packed[4];
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const int n = n0w + tn * 32 + qd * 8 + hi * 4;
@@ -81,10 +82,28 @@ OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int h
       if constexpr (OUT_F32) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + roff + n) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
-        uint2 o;
-        o.x = pack_bf16x2(v[0], v[1]);
-        o.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + roff + n) = o;
+        packed[qd].x = pack_bf16x2(v[0], v[1]);
+        packed[qd].y = pack_bf16x2(v[2], v[3]);
+      }
+    }
+    if constexpr (!OUT_F32) {
+      // a lane holds columns [8 qd + 4 hi, +4) of its row; its partner lane (other half-wave, same row) the other 4 of
+      // every 8-column block.  One v_permlane32_swap per dword hands the lower half-wave the whole block qd and the
+      // upper one the whole block qd + 1: 16-byte stores instead of two 8-byte ones (guide T21).
+      unsigned short* crow = reinterpret_cast<unsigned short*>(p.C) + roff + n0w + tn * 32;
+      const bool wide = (((uintptr_t)crow) & 15) == 0;   // row base 16-byte aligned (c strides are multiples of 4 only)
+#pragma unroll
+      for (int qd = 0; qd < 4; qd += 2) {
+        if (wide) {
+          auto sx = __builtin_amdgcn_permlane32_swap(packed[qd].x, packed[qd + 1].x, false, false);
+          auto sy = __builtin_amdgcn_permlane32_swap(packed[qd].y, packed[qd + 1].y, false, false);
+          // lower half-wave: sx[0], sy[0] = own block-qd columns 0..3, sx[1], sy[1] = partner's columns 4..7;
+          // upper half-wave: sx[0], sy[0] = partner's block-(qd+1) columns 0..3, sx[1], sy[1] = own columns 4..7
+          *reinterpret_cast<uint4*>(crow + (qd + hi) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        } else {
+          *reinterpret_cast<uint2*>(crow + qd * 8 + hi * 4) = packed[qd];
+          *reinterpret_cast<uint2*>(crow + (qd + 1) * 8 + hi * 4) = packed[qd + 1];
+        }
       }
     }
   } else {
