@@ -197,10 +197,12 @@ def main():
         for n_, p_ in model.named_parameters():
             if n_.startswith("cond_in"):
                 p_.normal_(0, 0.02)
+    sp_mode = None
     if world > 1:
         from open_sora_amd import seqpar
 
-        seqpar.enable(model, dist.group.WORLD)
+        sp = seqpar.enable(model, dist.group.WORLD)   # OSK_SP_MODE=allgather|ulysses|auto (auto: head exchange for P >= 4)
+        sp_mode = "all-to-all of q,k,v heads" if sp.head_parallel(H) else "all-gather of K and V^T"
 
     # synthetic inputs, resident in HBM before the timed region
     g = torch.Generator(device=dev).manual_seed(42)
@@ -290,7 +292,7 @@ def main():
         "config": {"workload": f"MMDiT-{args.model} (hidden {D}, {H}x{hd}, {cfg['depth']}+{cfg['depth_single_blocks']} blocks) "
                                f"denoise step, latent {T}x{hw}x{hw} (16x512x512 px), L={L} tokens, CFG batch {nb}, "
                                f"{SAMPLING_STEPS}-step Euler sampling",
-                   "tokens": L, "cfg_batch": nb, "parallelism": "single GPU" if world == 1 else f"sp{world} (token axis, all-gather K/V)"},
+                   "tokens": L, "cfg_batch": nb, "parallelism": "single GPU" if world == 1 else f"sp{world} (token axis; exchange around attention: {sp_mode})"},
         "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world, 1),
         "step_mfma_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4),
         "roofline": roofline,

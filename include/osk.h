@@ -120,13 +120,15 @@ int osk_v_transpose_bf16(const void* v, int64_t batch_stride, int64_t row_stride
  * q_prescaled != 0: q already carries scale * log2(e) (osk_qknorm_rope_bf16's q_mult) and `scale` is ignored;
  * q_prescaled == 0: the kernel applies `scale` itself (the head_dim-72 hand-scheduled kernel then re-rounds
  * scale*log2(e)*q to bf16 once per workgroup: one extra bf16 rounding of q).
+ * kv_batches: 0 (or B) = every query batch has its own keys; otherwise query batch b attends to key/value batch
+ * b % kv_batches (head-parallel sequence parallelism: the B * P received query chunks share B key sets).
  * hd in {64, 72, 128}. */
 int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
                            const void* k, int64_t k_seg_stride, int64_t k_batch_stride, int64_t k_row_stride,
                            const void* vt, int64_t vt_seg_stride,
                            void* out, int64_t o_batch_stride, int64_t o_row_stride,
                            float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
-                           float scale, int q_prescaled, void* stream);
+                           float scale, int q_prescaled, int kv_batches, void* stream);
 
 /* name of the device kernel osk_attention_fwd_bf16 dispatches to for (hd, seg_len) under the current
  * OSK_ATTN_VARIANT (reporting only: bench.py labels its roofline line and the rocprof stats with it). */

@@ -31,7 +31,7 @@ SIGNATURES = {
                              _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
     "osk_v_transpose_bf16": [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "osk_attention_fwd_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
-                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+                               _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp],
     "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
     "osk_causal_conv3d_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                      _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
@@ -185,7 +185,7 @@ PROFILE_ATTENTION = None
 
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, H: int, hd: int,
                   scale: float, *, lse=None, n_seg: int = 1, seg_len: int | None = None,
-                  k_seg_stride: int = 0, vt_seg_stride: int = 0, q_prescaled: bool = False):
+                  k_seg_stride: int = 0, vt_seg_stride: int = 0, q_prescaled: bool = False, kv_batches: int = 0):
     """q bf16 [B, Lq, H*hd] view; k bf16 [B, seg_len, H*hd] view of segment 0 (further segments k_seg_stride
     elements apart); vt from v_transpose (per segment); out bf16 [B, Lq, H*hd] view."""
     B, Lq, _ = q.shape
@@ -198,7 +198,7 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
     _check(lib.osk_attention_fwd_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
                                       k.stride(0), k.stride(1), vt.data_ptr(), vt_seg_stride, out.data_ptr(),
                                       out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg, seg_len, hd,
-                                      scale, int(q_prescaled), _stream()), "osk_attention_fwd_bf16")
+                                      scale, int(q_prescaled), kv_batches, _stream()), "osk_attention_fwd_bf16")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))

@@ -145,8 +145,9 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
     kc[t2] = hi ? lds_base + OSK72_CONST_OFF : lds_base + 8192 + t2 * 512 + l31 * 16;
   const unsigned onesaddr = lds_base + OSK72_VOFF0 + HD * 128 + lane * 4;   // lanes 32..63: the zero row behind it
 
-  const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + b * p.kbs + h * HD));
-  const uint64_t vbase = rfl64((uint64_t)(uintptr_t)(p.vt + (int64_t)bh * HD * p.seg_lp));
+  const int bkv = b % p.Bkv;   // key / value batch of this query batch
+  const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + bkv * p.kbs + h * HD));
+  const uint64_t vbase = rfl64((uint64_t)(uintptr_t)(p.vt + (int64_t)(bkv * p.H + h) * HD * p.seg_lp));
   const unsigned kstep = rfl((unsigned)(128 * p.krs));
   const uint64_t kjump = rfl64((uint64_t)((p.kss - (int64_t)p.tps * 64 * p.krs) * 2));
   const uint64_t vjump = rfl64((uint64_t)((p.vtss - (int64_t)p.tps * 64) * 2));

@@ -87,8 +87,9 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel_v1(const AttnParams p) {
     v_d[it] = i >> 3;
     v_c[it] = i & 7;
   }
-  const unsigned short* kbase_b = p.k + b * p.kbs + h * HD;
-  const unsigned short* vbase_bh = p.vt + (int64_t)bh * HD * p.seg_lp;
+  const int bkv = b % p.Bkv;
+  const unsigned short* kbase_b = p.k + bkv * p.kbs + h * HD;
+  const unsigned short* vbase_bh = p.vt + (int64_t)(bkv * p.H + h) * HD * p.seg_lp;
 
   // staging registers as named scalars (arrays written under a divergent guard were placed in scratch)
   uint4 rk0 = make_uint4(0, 0, 0, 0), rk1 = rk0, rv0 = rk0, rv1 = rk0;
@@ -315,11 +316,12 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
   constexpr bool K1_FULL = C::NKC >= 1024, V1_FULL = C::NVC >= 1024;
   const bool k1_on = C::KIT > 1 && (K1_FULL || (tid + 512 < C::NKC));
   const bool v1_on = C::VIT > 1 && (V1_FULL || (tid + 512 < C::NVC));
-  const unsigned short* kseg = p.k + b * p.kbs + h * HD;           // segment base of the K loader
+  const int bkv = b % p.Bkv;                                        // key / value batch of this query batch
+  const unsigned short* kseg = p.k + bkv * p.kbs + h * HD;         // segment base of the K loader
   const unsigned short* kp0 = kseg + (int64_t)kr0 * p.krs + kc0 * 8;  // this thread's chunk in the loader's tile
   const unsigned short* kp1 = kseg + (int64_t)kr1 * p.krs + kc1 * 8;
-  const unsigned short* vp0 = p.vt + ((int64_t)bh * HD + vd0) * p.seg_lp + vc0 * 8;
-  const unsigned short* vp1 = p.vt + ((int64_t)bh * HD + vd1) * p.seg_lp + vc0 * 8;
+  const unsigned short* vp0 = p.vt + ((int64_t)(bkv * p.H + h) * HD + vd0) * p.seg_lp + vc0 * 8;
+  const unsigned short* vp1 = p.vt + ((int64_t)(bkv * p.H + h) * HD + vd1) * p.seg_lp + vc0 * 8;
   const int64_t k_tile_step = (int64_t)64 * p.krs;
   const int64_t k_seg_jump = p.kss - (int64_t)p.tps * 64 * p.krs;  // from past-the-last tile of a segment to the next
   const int64_t v_seg_jump = p.vtss - (int64_t)p.tps * 64;
@@ -702,7 +704,7 @@ extern "C" int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int
                                       int64_t k_row_stride, const void* vt, int64_t vt_seg_stride,
                                       void* out, int64_t o_batch_stride, int64_t o_row_stride,
                                       float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
-                                      float scale, int q_prescaled, void* stream) {
+                                      float scale, int q_prescaled, int kv_batches, void* stream) {
   if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Lq <= 0 || n_seg <= 0 || seg_len <= 0) return OSK_EINVAL;
   if ((q_batch_stride & 7) || (q_row_stride & 7) || (k_seg_stride & 7) || (k_batch_stride & 7) ||
       (k_row_stride & 7) || (vt_seg_stride & 7) || (o_batch_stride & 3) || (o_row_stride & 3))
@@ -718,6 +720,8 @@ extern "C" int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int
   p.tps = p.seg_lp / 64;
   p.sc = q_prescaled ? 1.0f : scale * 1.4426950408889634f;  // log2 units; 1: q already carries it
   p.q_prescaled = q_prescaled;
+  if (kv_batches < 0 || kv_batches > B) return OSK_EINVAL;
+  p.Bkv = kv_batches > 0 ? kv_batches : B;
   p.map = attn_map();
   hipStream_t st = (hipStream_t)stream;
   switch (hd) {

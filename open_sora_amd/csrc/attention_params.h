@@ -17,6 +17,7 @@ struct AttnParams {
   int B, H, Lq, n_seg, seg_len, seg_lp, tps;
   float sc;   // softmax scale * log2(e); 1.0 when q_prescaled
   int q_prescaled;
+  int Bkv;    // key / value batches: query batch b reads key batch b % Bkv
   int map;    // block -> (head, query block) order: 0 = heads fastest, 1 = XCD-contiguous, query blocks fastest
 };
 

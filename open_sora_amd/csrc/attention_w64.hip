@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(256, 1) attn_w64_kernel(const AttnParams p) {
   const int srow8 = lane >> 3, spos = lane & 7;
   const unsigned short* kp[C::KI];
   int kclamp_row[C::KI];  // key row (inside the tile) this lane fetches for slot i
-  const unsigned short* kseg = p.k + b * p.kbs + h * HD;
+  const int bkv = b % p.Bkv;
+  const unsigned short* kseg = p.k + bkv * p.kbs + h * HD;
 #pragma unroll
   for (int i = 0; i < C::KI; ++i) {
     const int j = wave + 4 * i;
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(256, 1) attn_w64_kernel(const AttnParams p) {
   for (int i = 0; i < C::VI; ++i) {
     const int j = (3 - wave) + 4 * i;
     const int d = (j < C::NVD ? j : 0) * 8 + srow8;
-    vp[i] = p.vt + ((int64_t)bh * HD + d) * p.seg_lp + ((spos ^ ((d >> 1) & 7)) << 3);
+    vp[i] = p.vt + ((int64_t)(bkv * p.H + h) * HD + d) * p.seg_lp + ((spos ^ ((d >> 1) & 7)) << 3);
   }
   const int64_t k_tile_step = (int64_t)64 * p.krs;
   const int64_t k_seg_jump = p.kss - (int64_t)p.tps * 64 * p.krs;

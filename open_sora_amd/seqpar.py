@@ -15,11 +15,22 @@ projection + K-norm, and the Q projection (+ the MLP-up projection in single blo
 meanwhile; the attention launch waits on the collectives' events (stream-level, the host never blocks).
 No reduce-scatter is needed for inference (it is the backward of the all-gather).
 
-Equal chunks keep every collective a plain `all_gather_into_tensor`; the final prediction is gathered as
+Head-parallel exchange ("ulysses", the reference's other mode, distributed.py:473-495): when the head count divides
+by P the block can instead all-to-all q, k, v from "my tokens, all heads" to "all tokens, my H/P heads", run the flash
+kernel on whole sequences of H/P heads and all-to-all the result back.  Per rank and block it moves
+4 (P-1)/P local tensors instead of 2 (P-1) — 4x less at P = 8, 2x less at P = 4, the same at P = 2 — and xGMI's
+bandwidth per link is what bounds this small-hidden-size model at P > 2, so "auto" picks it for P >= 4.
+The received chunks stay in their [source rank][batch][token] order: keys are addressed as P segments (the kernel's
+segment layout), queries as P*B batches that share B key sets (osk_attention_fwd_bf16's kv_batches), and the output
+lands directly in the layout the return all-to-all sends — no re-layout pass on the receive side.
+
+Equal chunks keep every collective a plain `all_gather_into_tensor` / `all_to_all_single`; the final prediction is gathered as
 [P, B, L/P, C] (rank 0 also projects its text rows, which are dropped after the gather) instead of the
 reference's var-len gather (:39-112).
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -34,11 +45,21 @@ class SeqPar:
     """Per-model sequence-parallel state: process group + the gathered K / V^T buffers (allocated once per
     geometry, reused by all 28/57 blocks: 2 * B * L * D * 2 bytes)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, mode: str | None = None):
         self.group = group if group is not None else dist.group.WORLD
         self.P = dist.get_world_size(self.group)
         self.rank = dist.get_rank(self.group)
         self._bufs = {}
+        self.mode = mode or os.environ.get("OSK_SP_MODE", "auto")   # "allgather" | "ulysses" | "auto"
+        if self.mode not in ("allgather", "ulysses", "auto"):
+            raise ValueError(f"unknown sequence-parallel mode {self.mode!r}")
+
+    def head_parallel(self, H: int) -> bool:
+        """exchange heads (all-to-all) instead of gathering K / V^T?"""
+        if self.mode == "ulysses":
+            assert H % self.P == 0, f"Expected {H} % {self.P} == 0"   # distributed.py:477-479
+            return True
+        return self.mode == "auto" and H % self.P == 0 and self.P >= 4
 
     # ------------------------------------------------------------------ sharding
     def shard_range(self, L: int, L_txt: int):
@@ -69,7 +90,9 @@ class SeqPar:
 
     def gather_kv_start(self, ws, k: Tensor, v: Tensor, H: int, hd: int):
         """k, v: this rank's [B, L/P, D] views (K already normed + rotated with GLOBAL positions).  Starts the
-        two all-gathers and returns the handles; the caller keeps computing."""
+        exchange of K and V and returns the handles; the caller keeps computing."""
+        if self.head_parallel(H):
+            return self._heads_kv_start(k, v, H, hd)
         B, Lloc, _ = k.shape
         k_all, vt_all = self._buffers(B, Lloc, H, hd, k.device)
         k_all[self.rank].copy_(k)
@@ -80,12 +103,60 @@ class SeqPar:
 
     def attention(self, ws, pending, q: Tensor, out: Tensor, H: int, hd: int):
         """Local queries against the gathered keys: one launch, P key segments of L/P keys."""
+        if isinstance(pending[0], str):
+            return self._heads_attention(pending, q, out, H, hd)
         k_all, vt_all, wk, wv = pending
         wk.wait()
         wv.wait()
         B, Lloc, D = q.shape
         mmdit.ops().attention_fwd(q, k_all[0], vt_all, out, H, hd, hd ** -0.5, n_seg=self.P, seg_len=Lloc,
                                   k_seg_stride=k_all.stride(0), vt_seg_stride=vt_all.stride(0), q_prescaled=True)
+
+    # ------------------------------------------------------------------ head-parallel exchange (all-to-all)
+    def _heads_buffers(self, B: int, Lloc: int, H: int, hd: int, device):
+        key = ("heads", B, Lloc, H, hd, str(device))
+        b = self._bufs.get(key)
+        if b is None:
+            if len(self._bufs) > 2:
+                self._bufs.clear()
+            Hg, Lp = H // self.P, (Lloc + 63) // 64 * 64
+            mk = lambda: torch.empty(self.P, B, Lloc, Hg * hd, dtype=BF16, device=device)
+            b = self._bufs[key] = dict(ks=mk(), kr=mk(), vs=mk(), vr=mk(), qs=mk(), qr=mk(), os=mk(), orr=mk(),
+                                       vt=torch.zeros(self.P, B, Hg, hd, Lp, dtype=BF16, device=device))
+        return b
+
+    def _to_head_chunks(self, dst: Tensor, x: Tensor):
+        """[B, L/P, H*hd] (all heads of my tokens) -> dst [P, B, L/P, (H/P)*hd]: chunk j = head group j, for rank j"""
+        B, Lloc, D = x.shape
+        dst.copy_(x.view(B, Lloc, self.P, D // self.P).permute(2, 0, 1, 3))
+
+    def _heads_kv_start(self, k: Tensor, v: Tensor, H: int, hd: int):
+        B, Lloc, _ = k.shape
+        bufs = self._heads_buffers(B, Lloc, H, hd, k.device)
+        self._to_head_chunks(bufs["ks"], k)
+        wk = dist.all_to_all_single(bufs["kr"].view(-1), bufs["ks"].view(-1), group=self.group, async_op=True)
+        self._to_head_chunks(bufs["vs"], v)
+        wv = dist.all_to_all_single(bufs["vr"].view(-1), bufs["vs"].view(-1), group=self.group, async_op=True)
+        return "heads", bufs, wk, wv
+
+    def _heads_attention(self, pending, q: Tensor, out: Tensor, H: int, hd: int):
+        _, bufs, wk, wv = pending
+        B, Lloc, D = q.shape
+        P, Hg = self.P, H // self.P
+        self._to_head_chunks(bufs["qs"], q)
+        dist.all_to_all_single(bufs["qr"].view(-1), bufs["qs"].view(-1), group=self.group)
+        wk.wait()
+        wv.wait()
+        # received chunk s = source rank s's tokens = key segment s; [P, B] is also the query "batch" axis
+        ops = mmdit.ops()
+        vt = bufs["vt"]
+        ops.v_transpose(bufs["vr"].view(P * B, Lloc, Hg * hd), vt.view(P * B, Hg, hd, vt.shape[-1]), Hg, hd)
+        ops.attention_fwd(bufs["qr"].view(P * B, Lloc, Hg * hd), bufs["kr"][0], vt, bufs["os"].view(P * B, Lloc, Hg * hd),
+                          Hg, hd, hd ** -0.5, n_seg=P, seg_len=Lloc, k_seg_stride=bufs["kr"].stride(0),
+                          vt_seg_stride=vt.stride(0), q_prescaled=True, kv_batches=B)
+        # chunk s of the output belongs to rank s's tokens: straight back, then head groups side by side
+        dist.all_to_all_single(bufs["orr"].view(-1), bufs["os"].view(-1), group=self.group)
+        out.view(B, Lloc, P, D // P).permute(2, 0, 1, 3).copy_(bufs["orr"])
 
     # ------------------------------------------------------------------ output
     def gather_output(self, ws, project, C_out: int, L_txt: int) -> Tensor:
@@ -98,11 +169,11 @@ class SeqPar:
         return full.permute(1, 0, 2, 3).reshape(B, self.P * Lloc, C_out)[:, L_txt:].contiguous()
 
 
-def enable(model, group=None) -> SeqPar:
+def enable(model, group=None, mode: str | None = None) -> SeqPar:
     """Shard `model`'s denoise step over `group` (default: WORLD).  The counterpart of installing
     MMDiTPolicy / Distributed*Processor through booster.boost (distributed.py:686-760): weights stay replicated,
     MMDiTModel.forward keeps its signature and returns the full prediction on every rank."""
-    sp = SeqPar(group)
+    sp = SeqPar(group, mode)
     model._sp = sp if sp.P > 1 else None
     return sp
 

@@ -106,8 +106,9 @@ def v_transpose(v, vt, H, hd):
 
 
 def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=None, k_seg_stride=0, vt_seg_stride=0,
-                  q_prescaled=False):
-    B, Lq, D = q.shape
+                  q_prescaled=False, kv_batches=0):
+    Bq, Lq, D = q.shape
+    B = kv_batches if kv_batches else Bq     # key / value batches; query batch b reads key batch b % B
     if seg_len is None:
         seg_len = k.shape[1]
     seg_lp = (seg_len + 63) // 64 * 64
@@ -126,10 +127,13 @@ def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=Non
         vs.append(vt_s.float().reshape(B, H, hd, seg_lp)[..., key2pos][..., :seg_len].permute(0, 3, 1, 2))
     K = torch.cat(ks, 1).permute(0, 2, 1, 3)
     V = torch.cat(vs, 1).permute(0, 2, 1, 3)
-    Q = q.float().reshape(B, Lq, H, hd).permute(0, 2, 1, 3)
+    Q = q.float().reshape(Bq, Lq, H, hd).permute(0, 2, 1, 3)
+    if Bq != B:
+        idx = torch.arange(Bq) % B
+        K, V = K[idx], V[idx]
     s_ = (Q @ K.transpose(-1, -2)) * (0.6931471805599453 if q_prescaled else scale)  # prescaled q: log2 units
     o = torch.softmax(s_, -1) @ V
-    res = o.permute(0, 2, 1, 3).reshape(B, Lq, D).to(out.dtype)
+    res = o.permute(0, 2, 1, 3).reshape(Bq, Lq, D).to(out.dtype)
     out.copy_(res)
     if lse is not None:
         lse.copy_(torch.logsumexp(s_, -1))

@@ -43,7 +43,7 @@ def test_invalid_arguments_return_status_not_crash():
     st = lib.osk_gemm_bf16(16, 0, 8, 1, 16, 8, None, 16, 0, 8, 1, None, None, 0, 1, 8, 8, 8, 0, None)
     assert st < 0
     # unsupported head_dim
-    st = lib.osk_attention_fwd_bf16(16, 0, 8, 16, 0, 0, 8, 16, 0, 16, 0, 8, None, 1, 1, 8, 1, 8, 48, 1.0, 0, None)
+    st = lib.osk_attention_fwd_bf16(16, 0, 8, 16, 0, 0, 8, 16, 0, 16, 0, 8, None, 1, 1, 8, 1, 8, 48, 1.0, 0, 0, None)
     assert st < 0
     st = lib.osk_ln_modulate_bf16(None, 0, 0, None, 0, 0, None, None, 0, 1, 1, 8, 1e-6, None)
     assert st < 0

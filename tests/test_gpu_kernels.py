@@ -348,6 +348,31 @@ def test_attention_hd72_ragged_segments(hip_lib, seg, nseg):
     assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() <= 4e-3
 
 
+@pytest.mark.parametrize("hd", [72, 128])
+def test_attention_shared_key_batches_and_segments(hip_lib, hd):
+    """the head-parallel sequence-parallel call shape (seqpar.py): P * B query "batches" of L/P rows each, sharing B
+    key/value sets that arrive as P segments (kv_batches = B) == ordinary attention of the re-assembled sequences."""
+    P, B, H, Lloc = 3, 2, 2, 128
+    D, L = H * hd, P * Lloc
+    q = rnd("q", (B, L, D), seed=41)
+    kv = rnd("kv", (B, L, 2 * D), seed=42)
+    k, v = kv[:, :, :D], kv[:, :, D:]
+    vt = torch.empty(B, H, hd, L, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+    ref = torch.empty(B, L, D, dtype=BF, device=DEV)
+    hip_lib.attention_fwd(q, k, vt, ref, H, hd, hd ** -0.5)
+    # received-chunk layout [P, B, Lloc, D]
+    to_chunks = lambda x: x.view(B, P, Lloc, D).permute(1, 0, 2, 3).contiguous()
+    qr, kr, vr = to_chunks(q), to_chunks(k), to_chunks(v)
+    vts = torch.empty(P, B, H, hd, Lloc, dtype=BF, device=DEV)
+    hip_lib.v_transpose(vr.view(P * B, Lloc, D), vts.view(P * B, H, hd, Lloc), H, hd)
+    out = torch.empty(P, B, Lloc, D, dtype=BF, device=DEV)
+    hip_lib.attention_fwd(qr.view(P * B, Lloc, D), kr[0], vts, out.view(P * B, Lloc, D), H, hd, hd ** -0.5, n_seg=P,
+                          seg_len=Lloc, k_seg_stride=kr.stride(0), vt_seg_stride=vts.stride(0), kv_batches=B)
+    got = out.permute(1, 0, 2, 3).reshape(B, L, D)
+    assert torch.equal(got, ref)   # same tiles in the same order for every query row: bit-identical
+
+
 def test_attention_hd72_segments_and_in_place(hip_lib):
     """hand-scheduled kernel: keys split in 3 segments of 128 (sequence-parallel all-gather layout) == one segment;
     output may overwrite the dead v slot."""

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, geom, q):
+def _worker(rank, world, port, name, geom, q, mode):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -40,7 +40,8 @@ def _worker(rank, world, port, name, geom, q):
         inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=torch.bfloat16)
         with torch.inference_mode():
             single = model(**inp).float().clone()
-            sp = seqpar.enable(model)
+            sp = seqpar.enable(model, mode=mode)
+            assert sp.head_parallel(cfg["num_heads"]) == (mode == "ulysses")
             assert model._sp is not None and sp.P == world
             sharded = model(**inp).float().clone()
             seqpar.disable(model)
@@ -54,11 +55,11 @@ def _worker(rank, world, port, name, geom, q):
         dist.destroy_process_group()
 
 
-def _run(world, name, geom):
+def _run(world, name, geom, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, geom, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, geom, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -85,8 +86,14 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("world,name,geom", CASES)
-def test_seqpar_matches_single_process_and_oracle(world, name, geom):
+# head-parallel ("ulysses") exchange needs num_heads % world == 0: 2 heads / 2 ranks, 8 heads / 4 and 2 ranks
+MODE_CASES = [(c, "allgather") for c in CASES] + [(CASES[0], "ulysses"), (CASES[1], "ulysses"), (CASES[2], "ulysses"),
+                                                    (CASES[3], "ulysses")]
+
+
+@pytest.mark.parametrize("case,mode", MODE_CASES, ids=lambda v: v if isinstance(v, str) else f"w{v[0]}-{v[1]}")
+def test_seqpar_matches_single_process_and_oracle(case, mode):
+    world, name, geom = case
     from oracle import configs, mmdit_oracle as O
     from tests.util import rel_l2, torch_inputs, torch_params
 
@@ -94,7 +101,7 @@ def test_seqpar_matches_single_process_and_oracle(world, name, geom):
     B, T, h, w, L_txt = geom
     L = L_txt + T * h * w
     assert L % world == 0 and L // world > L_txt
-    res = _run(world, name, geom)
+    res = _run(world, name, geom, mode)
     with torch.inference_mode():
         truth = O.forward(torch_params(cfg), cfg, **torch_inputs(cfg, B, T, h, w, L_txt))
         ref_bf16 = O.forward(torch_params(cfg, dtype=torch.bfloat16), cfg,
