@@ -437,6 +437,46 @@ def test_attention_constant_v_property(hip_lib):
     assert (out.float() - c.float()[None, None]).abs().max().item() <= 2 ** -6 * c.float().abs().max().item() + 1e-3
 
 
+# ----------------------------------------------------------------------------- race screens for the asm K loops
+def test_hand_scheduled_kernels_are_deterministic_under_load(hip_lib):
+    """The generated asm loops place their own s_waitcnt / barriers / hazard gaps: a missed one shows up as rare,
+    load-dependent wrong tiles, not as a steady error.  Run each kernel 12 times at a shape that fills the chip for
+    several rounds (uneven tail included) and require bit-identical results, then check one full result against a
+    float64 reference on a sample of rows."""
+    torch.manual_seed(0)
+    # --- attention, head_dim 72, ragged keys + ragged query block
+    B, H, hd, Lq, Lk = 2, 8, 72, 2000, 4133
+    D = H * hd
+    q, k, v = rnd("q", (B, Lq, D), seed=51), rnd("k", (B, Lk, D), seed=52), rnd("v", (B, Lk, D), seed=53)
+    vt = torch.empty(B, H, hd, (Lk + 63) // 64 * 64, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+    outs = []
+    for _ in range(12):
+        o = torch.empty(B, Lq, D, dtype=BF, device=DEV)
+        hip_lib.attention_fwd(q, k, vt, o, H, hd, hd ** -0.5)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:]), "attention: run-to-run difference"
+    rows = torch.tensor([0, 1, 255, 256, 1023, 1999])
+    qh = q[:, rows].float().cpu().view(B, len(rows), H, hd).permute(0, 2, 1, 3).double()
+    kh = k.float().cpu().view(B, Lk, H, hd).permute(0, 2, 1, 3).double()
+    vh = v.float().cpu().view(B, Lk, H, hd).permute(0, 2, 1, 3).double()
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * hd ** -0.5, -1) @ vh).permute(0, 2, 1, 3).reshape(B, len(rows), D)
+    assert (outs[0][:, rows].float().cpu().double() - ref).abs().max().item() <= 2.5e-2
+    # --- large-tile GEMM (ragged M and N tiles, 18 K steps)
+    a = rnd("a", (3, 2100, 1152), seed=54)
+    w = rnd("w", (1160, 1152), std=1152 ** -0.5, seed=55)
+    bias = rnd("b", (1160,), std=0.1, dtype=torch.float32, seed=56)
+    gs = []
+    for _ in range(12):
+        o = torch.empty(3, 2100, 1160, dtype=BF, device=DEV)
+        hip_lib.gemm(a, w, bias, o)
+        gs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(gs[0], o) for o in gs[1:]), "gemm256: run-to-run difference"
+    bf16_ulp_close(gs[0].float().cpu(), _gemm_ref(a, w, bias).float().bfloat16().float(), rel=2 ** -7, abs_=2e-3)
+
+
 # ----------------------------------------------------------------------------- small kernels
 def test_gemv_tasks_and_timestep_embedding(hip_lib):
     Bv, K = 3, 384

@@ -225,6 +225,25 @@ def test_full_size_conv_spot_check(hip_lib):
         assert (got - acc).abs().max() <= 2.0 ** -7 * acc.abs().max() + 1e-3, (t, h, ww)
 
 
+def test_large_tile_conv_is_deterministic_under_load(hip_lib):
+    """race screen for the asm K loop of conv3d_256.hip (see test_hand_scheduled_kernels_are_deterministic_under_load):
+    12 runs of a conv that fills the chip for several rounds, ragged voxel tile at the end, bit-identical."""
+    ci, co = 256, 384
+    T, H, W = 5, 61, 67
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(1, T, H, W, ci, device=DEV, generator=g).to(BF)
+    w = (torch.randn(co, 27 * ci, device=DEV, generator=g) * (27 * ci) ** -0.5).to(BF)
+    b = torch.randn(co, device=DEV, generator=g) * 0.1
+    outs = []
+    for _ in range(12):
+        o = torch.empty(1, T, H, W, co, dtype=BF, device=DEV)
+        hip_lib.causal_conv3d(x, w, b, o, 3)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:]), "conv256t: run-to-run difference"
+    assert torch.isfinite(outs[0].float()).all()
+
+
 def test_full_size_encode_decode_properties(hip_lib):
     """BASELINE config 3: [1,3,33,256,256] through the shipped architecture (128/256/512/512, 2 layers per block).
     Size-independent properties: shapes, finiteness, and batch independence (every kernel treats the batch items
