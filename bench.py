@@ -138,6 +138,13 @@ def bench_vae(args, dev):
     enc_f, dec_f = configs.vae_flops(cfg, T, S, S)
     conv_ms = sum(s.elapsed_time(e) for s, e, _ in prof) / args.steps
     ach = (enc_f + dec_f) / (conv_ms * 1e-3) / 1e12
+    # HBM-side bytes of all conv launches of one step: PMC passes of this same command (tools/gpu_pmc_kernels.sh)
+    traffic, traffic_src = None, None
+    rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "kernel_traffic.json")
+    if os.path.exists(rec_path) and (T, S) == (33, 256):
+        for rec in json.load(open(rec_path)):
+            if rec["kernel"].startswith("conv256t_kernel"):
+                traffic, traffic_src = rec["hbm_bytes_per_step"], rec["source"]
     res = {
         "metric": "vae_video_frames_per_sec (encode + decode; ms per encode+decode in ms_per_step)",
         "value": round(T / (ms * 1e-3), 3), "unit": "video frames/s", "n_gpus": 1, "steps": args.steps,
@@ -150,7 +157,8 @@ def bench_vae(args, dev):
         # all conv launches of one encode + decode: conv256t_kernel (conv3d_256.hip) where Cin % 128 == 0, Cout >= 128,
         # conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers
         "roofline": {"bound": "mfma", "kernel": "conv256t_kernel + conv3d_kernel (by layer shape)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "launches": len(prof) // args.steps, "total_conv_ms_per_step": round(conv_ms, 3)},
     }
     if not args.no_cpu_baseline:

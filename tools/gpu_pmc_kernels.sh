@@ -1,0 +1,29 @@
+#!/bin/bash
+# HBM traffic (PMC FETCH_SIZE / WRITE_SIZE, separate passes) of the GEMM and conv kernels: per-kernel-name totals over one
+# bench step.  Output: gpurun_out/pmc_gemm_conv/summary.txt
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; O=gpurun_out/pmc_gemm_conv; rm -rf $O; mkdir -p $O
+run() {  # name, counters, command...
+  local name=$1 set=$2; shift 2
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/$name -o $name -- "$@" > $O/$name.log 2>&1
+  tail -1 $O/$name.log | cut -c1-160
+}
+run vae_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
+run vae_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
+run dit_fetch "FETCH_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline
+run dit_write "WRITE_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline
+python - "$O" <<'PY' | tee $O/summary.txt
+import csv, glob, collections, sys
+for f in sorted(glob.glob(sys.argv[1] + "/*/*counter_collection.csv")):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        key = next((k for k in ("conv256t_kernel", "conv256_kernel", "conv3d_kernel", "gemm256_kernel", "gemm_bf16_kernel",
+                                "attn_asm72_kernel", "gn_stats", "gn_apply") if k in n), None)
+        if key:
+            agg[(key, r["Counter_Name"])][0] += float(r["Counter_Value"])
+            agg[(key, r["Counter_Name"])][1] += 1
+    run = f.split("/")[-2]
+    for (k, c), (v, n) in sorted(agg.items()):
+        print(f"{run:10s} {k:20s} {c:12s} total {v:.6g} KB over {n} launches")
+PY
+rm -rf $O/*/
