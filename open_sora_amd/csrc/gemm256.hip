@@ -172,8 +172,15 @@ __global__ void __launch_bounds__(512, 2) gemm256_kernel(const GemmParams p) {
   const int hi = lane >> 5, l31 = lane & 31;
 
   const int nbm = (p.M + 255) / 256, nbn = (p.N + BN - 1) / BN;
+  // tile order: every XCD (private 4 MiB L2) owns a contiguous range of the list below; inside it the tiles run in
+  // groups of GRP row bands, N-major within a group: the ~32 tiles resident on an XCD cover GRP bands x a few weight
+  // tiles, so a weight tile is streamed once per GRP bands instead of once per ~2 (OSK_GEMM_GROUP, default 8)
   const int tile = xcd_remap(blockIdx.x, nbm * nbn);
-  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int grp = p.group > 0 ? p.group : 1;
+  const int per_group = grp * nbn;
+  const int g = tile / per_group, r = tile - g * per_group;
+  const int rows_here = nbm - g * grp < grp ? nbm - g * grp : grp;   // last group may be short
+  const int bn = r / rows_here, bm = g * grp + (r - bn * rows_here);
   const int m0 = bm * 256, n0 = bn * BN;
 
   // ---- LDS-DMA sources: instruction j = wave + 8 i covers tile rows [8 j, 8 j + 8); byte offsets from the tensor base

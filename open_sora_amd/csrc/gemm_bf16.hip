@@ -236,6 +236,12 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
   p.C = C; p.cbs = c_batch_stride; p.crs = c_row_stride; p.crpb = c_rows_per_batch;
   p.res = (const unsigned short*)res; p.gate = gate; p.gbs = gate_batch_stride;
   p.M = M; p.N = N; p.K = K; p.gelu_from = gelu_from;
+  {
+    // row bands per tile group of gemm256 (L2 blocking of the tile order; measured at the XL shapes: 8 for wide N,
+    // 4 when there are only a few weight tiles); OSK_GEMM_GROUP overrides
+    static const int grp = [] { const char* e = getenv("OSK_GEMM_GROUP"); return e ? atoi(e) : 0; }();
+    p.group = grp > 0 ? grp : ((N + 255) / 256 <= 6 ? 4 : 8);
+  }
   hipStream_t st = (hipStream_t)stream;
   const int gv = gemm_variant();
   if (gv == -1 || gv >= 2) {

@@ -19,6 +19,7 @@ struct GemmParams {
   const float* gate;
   int64_t gbs;
   int M, N, K, gelu_from;
+  int group;   // gemm256: row bands per tile group (L2 blocking of the tile order)
 };
 
 // gemm256.hip: 256 x {256,128} x 64 tiles, 8 waves, hand-scheduled (generated) K loop
