@@ -27,7 +27,22 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const unsigned short* __r
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  for (int64_t row = row0 + r; row < row1; row += rpp) {
+  // 4 independent 16-byte loads in flight per lane (a single dependent load per iteration left the kernel latency-bound
+  // at ~1.2 TB/s)
+  int64_t row = row0 + r;
+  for (; row + 3 * rpp < row1; row += 4 * rpp) {
+    uint4 u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const uint4*>(xb + (row + i * rpp) * C + c * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v[8];
+      unpack8(u[i], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+    }
+  }
+  for (; row < row1; row += rpp) {
     const uint4 u = *reinterpret_cast<const uint4*>(xb + row * C + c * 8);
     float v[8];
     unpack8(u, v);
@@ -93,8 +108,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const unsigned short* __r
   row1 = row1 < S ? row1 : S;
   const unsigned short* xb = x + (int64_t)b * S * C;
   unsigned short* ob = out + (int64_t)b * S * C;
-  for (int64_t row = row0 + r; row < row1; row += rpp) {
-    const uint4 u = *reinterpret_cast<const uint4*>(xb + row * C + c * 8);
+  auto one = [&](const uint4& u) {
     float v[8];
     unpack8(u, v);
 #pragma unroll
@@ -103,8 +117,18 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const unsigned short* __r
       if (do_silu) y = silu(y);
       v[j] = y;
     }
-    *reinterpret_cast<uint4*>(ob + row * C + c * 8) = pack8(v);
+    return pack8(v);
+  };
+  int64_t row = row0 + r;
+  for (; row + 3 * rpp < row1; row += 4 * rpp) {   // 4 independent loads in flight per lane, then 4 stores
+    uint4 u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const uint4*>(xb + (row + i * rpp) * C + c * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(ob + (row + i * rpp) * C + c * 8) = one(u[i]);
   }
+  for (; row < row1; row += rpp)
+    *reinterpret_cast<uint4*>(ob + row * C + c * 8) = one(*reinterpret_cast<const uint4*>(xb + row * C + c * 8));
 }
 
 // ---------------------------------------------------------------------------------------------
