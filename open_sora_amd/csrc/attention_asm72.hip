@@ -16,7 +16,7 @@
 // Any key count: a ragged last tile of a key segment re-fetches the segment's last key for the missing rows and masks
 // them out of the denominator through the ones row (see the wrapper).
 #include "attention_params.h"
-#include "attention_asm72_regs.inc"
+#include "attention_asm_regs.inc"
 
 namespace osk_attn {
 namespace {
@@ -97,12 +97,12 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
       "v"(w[19])
     if constexpr (NU == 2) {
       if (u == 0) {
-        asm volatile(OSK72N2_QW0 ::OSK_QIN : OSK72N2_A_CLOBBERS);
+        asm volatile(OSK72N2_QW0_0 ::OSK_QIN : OSK72N2_A_CLOBBERS);
       } else {
-        asm volatile(OSK72N2_QW1 ::OSK_QIN : OSK72N2_A_CLOBBERS);
+        asm volatile(OSK72N2_QW1_0 ::OSK_QIN : OSK72N2_A_CLOBBERS);
       }
     } else {
-      asm volatile(OSK72N1_QW0 ::OSK_QIN : OSK72N1_A_CLOBBERS);
+      asm volatile(OSK72N1_QW0_0 ::OSK_QIN : OSK72N1_A_CLOBBERS);
     }
   }
 

@@ -642,8 +642,8 @@ int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-// kernel structure (A/B knob, read once): -1 (default) = best available: the hand-scheduled head_dim-72 kernel
-// (attention_asm72.hip) when it applies, else 0;  0 = 8 waves x 32 rows (this file), 1 / 2 = the same with
+// kernel structure (A/B knob, read once): -1 (default) = best available: the hand-scheduled head_dim-72 / 128 kernels
+// (attention_asm72.hip, attention_asm128.hip) when they apply, else 0;  0 = 8 waves x 32 rows (this file), 1 / 2 = the same with
 // scheduling hints, 9 = v1, 3 / 4 = 4 waves x 64 rows compiler-scheduled (attention_w64.hip) without / with
 // sched_group_barrier pipelines, 5 / 6 = attention_asm72.hip, 4 waves x 64 rows: production / experimental body (hazard-padded debug schedule by
 // default), 7 / 8 = the same for its 8 waves x 32 rows layout
@@ -686,6 +686,8 @@ int launch(const AttnParams& p, hipStream_t st) {
         const int nu = (v == 7 || v == 8) ? 1 : 2, var = (v == 6 || v == 8) ? 1 : 0;
         return osk_attn::launch_asm72(p, v == -1 ? OSK_ATTN_DEFAULT_NU : nu, var, st);
       }
+      if (HD == 128 && attn_variant() < 7)   // head_dim 128 has the 4 waves x 64 rows layout only
+        return osk_attn::launch_asm128(p, attn_variant() == 6 ? 1 : 0, st);
       break;
     case 3: return osk_attn::launch_w64(p, HD, 0, st);
     case 4: return osk_attn::launch_w64(p, HD, 1, st);
@@ -736,6 +738,7 @@ extern "C" const char* osk_attention_kernel_name(int hd, int seg_len) {
   const int v = attn_variant();
   (void)seg_len;
   if ((v == -1 || (v >= 5 && v <= 8)) && hd == 72) return "attn_asm72_kernel";
+  if ((v == -1 || v == 5 || v == 6) && hd == 128) return "attn_asm128_kernel";
   if (v == 3 || v == 4) return "attn_w64_kernel";
   if (v == 9) return "attn_fwd_kernel_v1";
   return "attn_fwd_kernel";

@@ -41,5 +41,7 @@ int launch_w64(const AttnParams& p, int hd, int hints, hipStream_t st);
 // attention_asm72.hip: the same structure for head_dim 72 with a hand-scheduled (generated) main loop
 bool asm72_supported(const AttnParams& p, int hd);
 int launch_asm72(const AttnParams& p, int nu, int var, hipStream_t st);
+// attention_asm128.hip: head_dim 128, 4 waves x 64 rows, generated main loop
+int launch_asm128(const AttnParams& p, int var, hipStream_t st);
 
 }  // namespace osk_attn

@@ -26,29 +26,67 @@ K(t+2), V(t+1), exp2 + pack of tile t, max of tile t+1.
 import argparse
 import os
 
-HD, NKS, NDT = 72, 5, 3
-KTILE, VTILE = 9216, 12288
-KOFF = [0, KTILE]
-VOFF = [2 * KTILE, 2 * KTILE + VTILE]
-CONST_OFF = 2 * KTILE + 2 * VTILE          # 16-byte chunk {1.0bf16, 0...}: K's padding dims 72..79, one copy per K ring
-SMEM = CONST_OFF + KTILE + 16              # slot at the same distance (KTILE) as the slots: one address register serves both
 THR_BITS = "0x41000000"                    # 8.0: move M when a score exceeds the reference by > 2^8
-NKD = NVD = 9                              # LDS-DMA wave instructions per K / V^T tile
+
+
+class Geometry:
+    """head-dim dependent tile geometry.
+    hd 72 : 4 real QK^T k-steps + 1 half-real one (dims 64..79: 8 real dims from the column image, the padding half
+            carries M), 3 O^T row tiles (72 real rows, row 72 = ones row).
+    hd 128: 8 real k-steps + 1 pure padding step whose K fragment is a CONSTANT register quad {1.0, 0...} (no LDS
+            read) and whose Q fragment carries M; 4 real O^T row tiles + a 5th that only holds the ones row 128."""
+
+    def __init__(self, hd):
+        self.HD = hd
+        if hd == 72:
+            self.NKS, self.NDT, self.KIMG, self.HAS_COL = 5, 3, 1, True
+            self.M_KS, self.M_HI = 4, 1          # M sits in k-step 4, lanes 32..63 (dims 72..79), word 0
+            self.NKD = self.NVD = 9
+        elif hd == 128:
+            self.NKS, self.NDT, self.KIMG, self.HAS_COL = 9, 5, 2, False
+            self.M_KS, self.M_HI = 8, 0          # k-step 8 (dims 128..143), lanes 0..31 (dims 128..135), word 0
+            self.NKD = self.NVD = 16
+        else:
+            raise ValueError(hd)
+        self.NPK = 2 * self.NKS                  # QK^T fragment pairs (k-step, 32-key half)
+        self.NPK_READ = 2 * (self.NKS - (0 if self.HAS_COL else 1))   # ... that are read from LDS
+        self.NPV = 4 * self.NDT                  # P.V fragment pairs (key group, row tile)
+        self.KTILE = self.KIMG * 8192 + (1024 if self.HAS_COL else 0)
+        if self.HAS_COL:
+            self.VTILE = self.NDT * 32 * 128
+            self.KOFF = [0, self.KTILE]
+            self.VOFF = [2 * self.KTILE, 2 * self.KTILE + self.VTILE]
+        else:
+            # hd 128: ds_read immediates are 16 bits, so the tiles have to end below 64 KB + one fragment: the V^T
+            # tile keeps only rows 0..129 (128 dims, the ones row, one zero row); the last row tile's fragment reads
+            # run into the NEXT region -- garbage that only reaches accumulator rows 129..159, which nobody reads --
+            # and V^T sits in front of K so that the largest immediate is K slot 1's (61952)
+            self.VTILE = (hd + 2) * 128
+            self.VOFF = [0, self.VTILE]
+            self.KOFF = [2 * self.VTILE, 2 * self.VTILE + self.KTILE]
+        # hd 72: 16-byte chunk {1.0bf16, 0...} = K's padding dims 72..79, one copy per K ring slot, KTILE apart
+        self.CONST_OFF = 2 * self.KTILE + 2 * self.VTILE
+        self.SMEM = self.CONST_OFF + (self.KTILE + 16 if self.HAS_COL else 0)
 
 # ---- asm-owned SGPRs
-S_FIRST, S_LAST = 36, 65
+S_FIRST, S_LAST = 36, 67
+S_HI2 = 66                                 # lanes 32..63 (hd 128, where S_HIM selects lanes 0..31)
 S_KRG, S_VRG, S_FLG, S_NRG = 36, 38, 45, 64  # lane masks: K / V^T loader sits on a ragged (segment-last) tile; flags
 # (S_FLG bit 1: this wave maintains the ones rows; S_NRG = 1 when the launch has NO ragged tile)
 S_KB, S_VB, S_KSTEP, S_KJ, S_VJ = 40, 42, 44, 46, 48
 S_TPS, S_NT, S_KDST, S_VDST, S_NKW, S_NVW = 50, 51, 52, 53, 54, 55
 S_T, S_KTT, S_VTT, S_TMP, S_HIM, S_KL, S_VL = 56, 57, 58, 59, 60, 62, 63
 
-# ---- asm operands (order = operand numbers in the wrapper's asm statement)
-OPERANDS = ["m0out", "m1out",
-            "koff0", "koff1", "koff2", "voff0", "voff1", "voff2",
-            "fo0", "fo1", "fo2", "fo3", "kc0", "kc1", "koffL0", "koffL1", "koffL2", "maskval", "onesaddr",
-            "kbase", "vbase", "kstep", "kjump", "vjump", "tps", "nt", "kdst", "vdst", "nkw", "nvw"]
-OP = {n: "%%%d" % i for i, n in enumerate(OPERANDS)}
+def operand_names(geo, nslot):
+    """asm operands (order = operand numbers in the wrapper's asm statement); at most 30"""
+    names = ["m0out", "m1out"] + ["koff%d" % i for i in range(nslot)] + ["voff%d" % i for i in range(nslot)] + \
+            ["fo0", "fo1", "fo2", "fo3"] + (["kc0", "kc1"] if geo.HAS_COL else []) + \
+            ["koffL%d" % i for i in range(nslot)] + ["maskval", "onesaddr",
+                                                     "kbase", "vbase", "kstep", "kjump", "vjump", "tps", "nt", "kdst", "vdst"]
+    # the K loader's conditional last slot only exists when 4 | NKD does not hold; otherwise no slot count is needed
+    names += (["nkw"] if geo.NKD % 4 or geo.NKD % 8 else []) + ["nvw"]
+    assert len(names) <= 30, len(names)
+    return names
 
 
 def vr(base, n=1):
@@ -62,11 +100,17 @@ def ar(base, n=1):
 class Layout:
     """register file and schedule geometry for NU query blocks per wave"""
 
-    def __init__(self, nu):
+    def __init__(self, nu, hd=72):
         self.NU = nu
+        self.G = G = Geometry(hd)
+        NKS, NDT = G.NKS, G.NDT
         self.NW = 8 // nu                      # waves per workgroup
-        self.NSLOT = (NKD + self.NW - 1) // self.NW   # LDS-DMA slots per wave and tile (last one conditional)
-        self.V_FIRST = 48
+        self.NSLOT = (G.NKD + self.NW - 1) // self.NW   # LDS-DMA slots per wave and tile
+        self.LAST_COND = G.NKD % self.NW != 0  # the last slot only exists on some waves
+        self.OPERANDS = operand_names(G, 3 if hd == 72 else self.NSLOT)   # hd 72: one wrapper operand list for both layouts
+        self.OP = {n: "%%%d" % i for i, n in enumerate(self.OPERANDS)}
+        self.V_FIRST = 48 if G.HAS_COL else 44
+        self.KC0 = None if G.HAS_COL else 44   # constant K fragment of the padding k-step: 4 registers
         self.SA0 = 48
         self.SB0 = self.SA0 + 32 * nu
         self.PB0 = self.SB0 + 32 * nu
@@ -81,12 +125,20 @@ class Layout:
         self.A_Q0 = 16 * NDT * nu
         self.A_END = self.A_Q0 + 4 * NKS * nu
         self.NTRAIL = 2 * nu                   # MFMAs of the 2 trailing fragment pairs
-        self.NQK = 10 * nu
-        self.NPVB = 10 * nu                    # P.V MFMAs inside the body
+        self.NQK = G.NPK * nu
+        self.NPVB = (G.NPV - 2) * nu           # P.V MFMAs inside the body
         self.I_QK0 = self.NTRAIL               # global shadow index of the first QK^T MFMA
-        # first / last shadow of filler classes A (exp2+pack of key groups 0..2), B (group 3), C (max of tile t+1)
-        self.WINDOWS = [4, 25, 24, 40, 26, 43] if nu == 2 else [2, 13, 12, 19, 14, 21]
-        self.C_T2_RELEASE = 28 if nu == 2 else 15   # chains over keys 32..63: their last QK^T MFMAs come last
+        self.I_PV0 = self.I_QK0 + self.NQK
+        last = self.I_PV0 + self.NPVB - 1
+        # first / last shadow of filler classes A (exp2+pack of key groups 0..2), B (group 3: before the P.V MFMAs of
+        # key group 3, which start at pair 3 NDT), C (max of tile t+1: after its last QK^T MFMAs)
+        if hd == 72:
+            self.WINDOWS = [4, 25, 24, 40, 26, 43] if nu == 2 else [2, 13, 12, 19, 14, 21]
+            self.C_T2_RELEASE = 28 if nu == 2 else 15   # chains over keys 32..63: their last QK^T MFMAs come last
+        else:
+            self.WINDOWS = [self.I_QK0, self.I_PV0 + 1, self.I_PV0, self.I_PV0 + 3 * NDT * nu - 2, self.I_PV0 + 2, last]
+            self.C_T2_RELEASE = self.I_PV0 + 2 * nu
+        self.S_ONESMASK = S_HIM if G.M_HI else S_HI2   # lanes 32..63
 
     def S(self, setbase, u, t2, r=0):
         return setbase + (u * 2 + t2) * 16 + r
@@ -95,10 +147,10 @@ class Layout:
         return self.PB0 + (u * 4 + g) * 4 + w
 
     def AO(self, u, d):
-        return self.A_O0 + (u * NDT + d) * 16
+        return self.A_O0 + (u * self.G.NDT + d) * 16
 
     def AQ(self, u, ks):
-        return self.A_Q0 + (u * NKS + ks) * 4
+        return self.A_Q0 + (u * self.G.NKS + ks) * 4
 
 
 class Stream:
@@ -137,32 +189,38 @@ class Stream:
 
 
 # ------------------------------------------------------------------------------------------ pieces
+def k_frag(L, p):
+    """register quad that holds the K fragment of pair p: a ring slot, or the constant padding fragment (hd 128)"""
+    return L.KR0 + (p % 4) * 4 if p < L.G.NPK_READ else L.KC0
+
+
 def k_read(st, L, slot, p, tag):
     """K fragment of pair p = (ks, t2) of the tile in ring slot `slot` -> K ring"""
     ks, t2 = p // 2, p % 2
+    assert p < L.G.NPK_READ
     dst = L.KR0 + (p % 4) * 4
-    if ks < 4:
-        st.ds_read(dst, OP["fo%d" % ks], KOFF[slot] + t2 * 4096, tag)
+    if ks < 4 * L.G.KIMG:
+        st.ds_read(dst, L.OP["fo%d" % (ks % 4)], L.G.KOFF[slot] + (ks // 4) * 8192 + t2 * 4096, tag)
     else:
-        st.ds_read(dst, OP["kc%d" % t2], KOFF[slot], tag)
+        st.ds_read(dst, L.OP["kc%d" % t2], L.G.KOFF[slot], tag)
 
 
 def v_read(st, L, slot, r, tag):
-    g, d = r // NDT, r % NDT
-    st.ds_read(L.VR0 + (r % 4) * 4, OP["fo%d" % g], VOFF[slot] + d * 4096, tag)
+    g, d = r // L.G.NDT, r % L.G.NDT
+    st.ds_read(L.VR0 + (r % 4) * 4, L.OP["fo%d" % g], L.G.VOFF[slot] + d * 4096, tag)
 
 
 def qk_mfma(st, L, sn, a):
     p, u = a // L.NU, a % L.NU
     ks, t2 = p // 2, p % 2
     dst = vr(L.S(sn, u, t2), 16)
-    st.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, vr(L.KR0 + (p % 4) * 4, 4), ar(L.AQ(u, ks), 4),
+    st.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, vr(k_frag(L, p), 4), ar(L.AQ(u, ks), 4),
                                                        "0" if ks == 0 else dst), "M")
 
 
 def pv_mfma(st, L, b):
     r, u = b // L.NU, b % L.NU
-    g, d = r // NDT, r % NDT
+    g, d = r // L.G.NDT, r % L.G.NDT
     dst = ar(L.AO(u, d), 16)
     st.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, vr(L.VR0 + (r % 4) * 4, 4), vr(L.PB(u, g), 4), dst), "M")
 
@@ -222,23 +280,26 @@ def k_dma(st, L, slot, i, part=3):
     2 = the DMA only (one other instruction must sit between them), 3 = both with an s_nop.  On the ragged last tile
     of a key segment (lane mask S_KRG) the rows past the segment re-fetch its last key (offsets koffL)."""
     if part & 1:
-        st.emit("s_add_u32 m0, s%d, %d" % (S_KDST, KOFF[slot] + 1024 * L.NW * i), "s")
-        st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(L.TX[3]), OP["koff%d" % i], OP["koffL%d" % i], S_KRG, S_KRG + 1), "v")
+        st.emit("s_add_u32 m0, s%d, %d" % (S_KDST, L.G.KOFF[slot] + 1024 * L.NW * i), "s")
+        st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(L.TX[3]), L.OP["koff%d" % i], L.OP["koffL%d" % i], S_KRG, S_KRG + 1), "v")
     if part & 2:
         st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (vr(L.TX[3]), S_KB, S_KB + 1), "g")
 
 
 def v_dma(st, L, slot, i, part=3):
     if part & 1:
-        st.emit("s_add_u32 m0, s%d, %d" % (S_VDST, (VOFF[slot] - VOFF[0]) + 1024 * L.NW * i), "s")
+        st.emit("s_add_u32 m0, s%d, %d" % (S_VDST, (L.G.VOFF[slot] - L.G.VOFF[0]) + 1024 * L.NW * i), "s")
     if part == 3:
         st.emit("s_nop 0", "n")
     if part & 2:
-        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["voff%d" % i], S_VB, S_VB + 1), "g")
+        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (L.OP["voff%d" % i], S_VB, S_VB + 1), "g")
 
 
 def dma_last(st, L, which, slot, uid):
-    """last loader slot: only the wave(s) whose instruction index is < 9"""
+    """last loader slot: only the wave(s) whose instruction index is < NKD (all of them when NW | NKD)"""
+    if not L.LAST_COND:
+        (k_dma if which == "k" else v_dma)(st, L, slot, L.NSLOT - 1)
+        return
     lab = ".L@@_%s2%s" % (which, uid)
     st.emit("s_cmp_lt_u32 s%d, %d" % (S_NKW if which == "k" else S_NVW, L.NSLOT), "s")
     st.emit("s_cbranch_scc1 %s" % lab, "s")
@@ -297,9 +358,9 @@ def ones_row(st, L, slot):
     st.emit("s_bitcmp1_b32 s%d, 1" % S_FLG, "s")
     st.emit("s_cbranch_scc0 %s" % lab, "s")
     st.emit("v_mov_b32 %s, 0x3f803f80" % vr(L.TX[2]), "v")
-    st.emit("v_cndmask_b32_e64 %s, %s, 0, s[%d:%d]" % (vr(L.TX[2]), vr(L.TX[2]), S_HIM, S_HIM + 1), "v")
-    st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(L.TX[2]), vr(L.TX[2]), OP["maskval"], S_VRG, S_VRG + 1), "v")
-    st.emit("ds_write_b32 %s, %s offset:%d" % (OP["onesaddr"], vr(L.TX[2]), VOFF[slot] - VOFF[0]), "D")
+    st.emit("v_cndmask_b32_e64 %s, %s, 0, s[%d:%d]" % (vr(L.TX[2]), vr(L.TX[2]), L.S_ONESMASK, L.S_ONESMASK + 1), "v")
+    st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(L.TX[2]), vr(L.TX[2]), L.OP["maskval"], S_VRG, S_VRG + 1), "v")
+    st.emit("ds_write_b32 %s, %s offset:%d" % (L.OP["onesaddr"], vr(L.TX[2]), L.G.VOFF[slot] - L.G.VOFF[0]), "D")
     st.label(lab)
 
 
@@ -334,18 +395,18 @@ def fixup(st, L, sx, init):
         st.emit("v_xor_b32 %s, 0x80000000, %s" % (vr(L.MM[u]), vr(f)))          # M = M_new
         if not init:
             st.emit("v_exp_f32 %s, %s" % (vr(al), vr(de)))                      # alpha = 2^(M_old - M_new)
-        # Q padding dim 72 lives in lanes 32..63 of word 0 of the k-step-4 fragment
-        st.emit("v_accvgpr_read_b32 %s, %s" % (vr(t), ar(L.AQ(u, 4))))
+        # Q's padding dim that carries -M: word 0 of the k-step-M_KS fragment, in the half-wave S_HIM selects
+        st.emit("v_accvgpr_read_b32 %s, %s" % (vr(t), ar(L.AQ(u, L.G.M_KS))))
         st.emit("s_nop 0", "n")
         st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(t), vr(t), vr(pk), S_HIM, S_HIM + 1))
         st.emit("s_nop 0", "n")
-        st.emit("v_accvgpr_write_b32 %s, %s" % (ar(L.AQ(u, 4)), vr(t)))
+        st.emit("v_accvgpr_write_b32 %s, %s" % (ar(L.AQ(u, L.G.M_KS)), vr(t)))
         for t2 in range(2):
             for r in range(16):
                 x = vr(L.S(sx, u, t2, r))
                 st.emit("v_add_f32 %s, %s, %s" % (x, x, vr(de)))
         if not init:
-            for dd in range(NDT):
+            for dd in range(L.G.NDT):
                 for r0 in range(0, 16, 4):
                     for r in range(r0, r0 + 4):
                         st.emit("v_accvgpr_read_b32 %s, %s" % (vr(T + (r - r0)), ar(L.AO(u, dd) + r)))
@@ -369,7 +430,7 @@ def body(st, L, k, safe):
     # -- top: K fragment reads of pairs 0..3 (tile t+1 sits in ring slot cur^1)
     for p in range(4):
         k_read(st, L, cur ^ 1, p, ("k", p))
-    # -- trailing P.V MFMAs of tile t-1 (fragment pairs 10, 11 were read before the barrier); in their shadows the
+    # -- trailing P.V MFMAs of tile t-1 (the last two fragment pairs were read before the barrier); in their shadows the
     #    first LDS-DMA pieces of K(t+2) -> slot cur and V(t+1) -> slot cur^1 (M0 write BEFORE the MFMA: no s_nop)
     pieces = [("k", i) for i in range(L.NSLOT - 1)] + [("v", i) for i in range(L.NSLOT - 1)]
     pieces = pieces[:L.NTRAIL]
@@ -381,7 +442,7 @@ def body(st, L, k, safe):
     for n in range(L.NTRAIL):
         if n < len(pieces):
             piece(pieces[n], 1)
-        pv_mfma(st, L, 10 * NU + n)
+        pv_mfma(st, L, (L.G.NPV - 2) * NU + n)
         if n < len(pieces):
             piece(pieces[n], 2)
     # -- decision: did some score of tile t exceed the reference by more than 2^THR (VCC from the previous body)?
@@ -431,12 +492,14 @@ def body(st, L, k, safe):
         # ring reads: after the last MFMA of pair x its ring slot is free -> read pair x + 4
         if u == NU - 1:
             if kind == "qk":
-                if pair + 4 < 10:
+                NR = L.G.NPK_READ
+                if pair + 4 < NR:
                     k_read(st, L, cur ^ 1, pair + 4, ("k", pair + 4))
-                else:
-                    v_read(st, L, cur, pair + 4 - 10, ("v", pair + 4 - 10))   # V pairs 0..3 behind the last K pairs
-                used += 4
-            elif pair + 4 < 12:
+                    used += 4
+                elif pair < NR:
+                    v_read(st, L, cur, pair + 4 - NR, ("v", pair + 4 - NR))   # V pairs 0..3 behind the last K pairs
+                    used += 4
+            elif pair + 4 < L.G.NPV:
                 v_read(st, L, cur, pair + 4, ("v", pair + 4))
                 used += 4
         if later:
@@ -479,16 +542,27 @@ def generate(L, safe=False, ablate=frozenset()):
     st = Stream(ablate)
     e = st.emit
     # ---- copy the mutable scalars into asm-owned SGPRs
-    e("s_mov_b64 s[%d:%d], %s" % (S_KB, S_KB + 1, OP["kbase"]))
-    e("s_mov_b64 s[%d:%d], %s" % (S_VB, S_VB + 1, OP["vbase"]))
-    e("s_mov_b32 s%d, %s" % (S_KSTEP, OP["kstep"]))
-    e("s_mov_b64 s[%d:%d], %s" % (S_KJ, S_KJ + 1, OP["kjump"]))
-    e("s_mov_b64 s[%d:%d], %s" % (S_VJ, S_VJ + 1, OP["vjump"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_KB, S_KB + 1, L.OP["kbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_VB, S_VB + 1, L.OP["vbase"]))
+    e("s_mov_b32 s%d, %s" % (S_KSTEP, L.OP["kstep"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_KJ, S_KJ + 1, L.OP["kjump"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_VJ, S_VJ + 1, L.OP["vjump"]))
     for sreg, name in ((S_TPS, "tps"), (S_NT, "nt"), (S_KDST, "kdst"), (S_VDST, "vdst"), (S_NKW, "nkw"), (S_NVW, "nvw")):
-        e("s_mov_b32 s%d, %s" % (sreg, OP[name]))
-    for sreg in (S_T, S_KTT, S_VTT, S_KL, S_VL, S_HIM):
+        if name in L.OP:
+            e("s_mov_b32 s%d, %s" % (sreg, L.OP[name]))
+    for sreg in (S_T, S_KTT, S_VTT, S_KL, S_VL):
         e("s_mov_b32 s%d, 0" % sreg)
-    e("s_mov_b32 s%d, -1" % (S_HIM + 1))
+    if L.G.M_HI:       # S_HIM = the half-wave whose lanes hold Q's M-carrying padding dim
+        e("s_mov_b32 s%d, 0" % S_HIM)
+        e("s_mov_b32 s%d, -1" % (S_HIM + 1))
+    else:
+        e("s_mov_b32 s%d, -1" % S_HIM)
+        e("s_mov_b32 s%d, 0" % (S_HIM + 1))
+        e("s_mov_b32 s%d, 0" % S_HI2)
+        e("s_mov_b32 s%d, -1" % (S_HI2 + 1))
+        e("v_mov_b32 %s, 0x3f80" % vr(L.KC0))          # K fragment of the padding k-step: dim HD = 1.0, the rest 0
+        for i in range(1, 4):
+            e("v_mov_b32 %s, 0" % vr(L.KC0 + i))
     # nvw = valid V^T loader slots | (no ragged tile in this launch) << 8 | (this wave maintains the ones rows) << 9
     e("s_lshr_b32 s%d, s%d, 8" % (S_FLG, S_NVW))
     e("s_and_b32 s%d, s%d, 1" % (S_NRG, S_FLG))
@@ -506,9 +580,10 @@ def generate(L, safe=False, ablate=frozenset()):
     e("s_waitcnt vmcnt(0)")
     e("s_barrier")
     # scores of tile 0 -> set A (Q's padding dim is 0: raw scores)
-    for p in range(10):
-        k_read(st, L, 0, p, ("k", p))
-        st.need(("k", p))
+    for p in range(L.G.NPK):
+        if p < L.G.NPK_READ:
+            k_read(st, L, 0, p, ("k", p))
+            st.need(("k", p))
         for u in range(L.NU):
             qk_mfma(st, L, L.SA0, p * L.NU + u)
     e("s_barrier")                      # every wave has read K0: slot 0 may be refilled
@@ -541,28 +616,30 @@ def generate(L, safe=False, ablate=frozenset()):
     # ---- exit: the trailing P.V MFMAs of the last tile
     st.label(".L@@_exit")
     for n in range(L.NTRAIL):
-        pv_mfma(st, L, 10 * L.NU + n)
+        pv_mfma(st, L, (L.G.NPV - 2) * L.NU + n)
     e("s_nop 15")
     e("s_nop 15")
-    e("v_mov_b32 %s, %s" % (OP["m0out"], vr(L.MM[0])))
-    e("v_mov_b32 %s, %s" % (OP["m1out"], vr(L.MM[1])))
+    e("v_mov_b32 %s, %s" % (L.OP["m0out"], vr(L.MM[0])))
+    e("v_mov_b32 %s, %s" % (L.OP["m1out"], vr(L.MM[1])))
     return st
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--table", type=int, default=0, help="print the production schedule of layout NU (1 or 2)")
+    ap.add_argument("--hd", type=int, default=72, help="head dim of the schedule --table prints")
     ap.add_argument("--exp", default="safe", help="experimental variant 1: safe | ablations joined by + (noexp nobar "
                     "nodma nolds novalu nomfma norare nocvt nomax): timing only, wrong results")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
     args = ap.parse_args()
-    for nu in (2, 1):
-        L = Layout(nu)
+    layouts = [(72, 2), (72, 1), (128, 2)]
+    for hd, nu in layouts:
+        L = Layout(nu, hd)
         exp_safe = args.exp == "safe"
         exp_ab = frozenset() if exp_safe else frozenset(args.exp.split("+"))
         for vi, (safe, ablate) in enumerate([(False, frozenset()), (exp_safe, exp_ab)]):
             st = generate(L, safe, ablate)
-            if args.table == nu and vi == 0:
+            if args.table == nu and args.hd == hd and vi == 0:
                 gap = []
                 for kind, text in st.table:
                     if kind == "M":
@@ -572,29 +649,37 @@ def main():
                     else:
                         gap.append({"x": "v"}.get(kind, kind))
                 print("".join(gap))
-            with open(os.path.join(args.out, "attention_asm72_n%d_v%d.inc" % (nu, vi)), "w") as f:
-                f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  layout NU=%d, variant %d: %s\n" %
-                        (nu, vi, "production" if vi == 0 else ("hazard-padded (debug)" if safe else "timing ablation " + "+".join(sorted(ablate)))))
+            with open(os.path.join(args.out, "attention_asm%d_n%d_v%d.inc" % (hd, nu, vi)), "w") as f:
+                f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d, layout NU=%d, variant %d: %s\n" %
+                        (hd, nu, vi, "production" if vi == 0 else ("hazard-padded (debug)" if safe else "timing ablation " + "+".join(sorted(ablate)))))
                 for ln in st.lines:
-                    f.write('"%s\\n"\n' % ln.replace("@@", "osk72n%dv%d" % (nu, vi)))
+                    f.write('"%s\\n"\n' % ln.replace("@@", "osk%dn%dv%d" % (hd, nu, vi)))
     # register / operand contract for the wrapper
-    with open(os.path.join(args.out, "attention_asm72_regs.inc"), "w") as f:
+    with open(os.path.join(args.out, "attention_asm_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.\n")
-        f.write("#define OSK72_SMEM %d\n#define OSK72_CONST_OFF %d\n" % (SMEM, CONST_OFF))
-        f.write("#define OSK72_KTILE %d\n#define OSK72_VTILE %d\n#define OSK72_VOFF0 %d\n" % (KTILE, VTILE, VOFF[0]))
-        for nu in (2, 1):
-            L = Layout(nu)
-            P = "OSK72N%d_" % nu
+        for hd in sorted({h for h, _ in layouts}):
+            G = Geometry(hd)
+            P = "OSK%d_" % hd
+            f.write("#define %sSMEM %d\n#define %sCONST_OFF %d\n" % (P, G.SMEM, P, G.CONST_OFF))
+            f.write("#define %sKTILE %d\n#define %sVTILE %d\n#define %sVOFF0 %d\n#define %sKOFF0 %d\n" % (P, G.KTILE, P, G.VTILE, P, G.VOFF[0], P, G.KOFF[0]))
+            f.write("#define %sNKS %d\n#define %sNDT %d\n#define %sNKD %d\n#define %sKIMG %d\n" % (P, G.NKS, P, G.NDT, P, G.NKD, P, G.KIMG))
+        for hd, nu in layouts:
+            L = Layout(nu, hd)
+            G = L.G
+            P = "OSK%dN%d_" % (hd, nu)
             clob = ['"v%d"' % i for i in range(L.V_FIRST, L.V_END)] + ['"a%d"' % i for i in range(0, L.A_END)] + \
                    ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
             f.write("#define %sCLOBBERS %s\n" % (P, ", ".join(clob)))
             f.write("#define %sA_CLOBBERS %s\n" % (P, ", ".join('"a%d"' % i for i in range(0, L.A_END))))
             f.write("#define %sNSLOT %d\n" % (P, L.NSLOT))
-            for u in range(nu):   # Q fragment words of query block u (operands %0..%19) -> AGPRs
-                f.write("#define %sQW%d %s\n" % (P, u, " ".join('"v_accvgpr_write_b32 a%d, %%%d\\n"' % (L.AQ(u, 0) + i, i) for i in range(NKS * 4))))
+            for u in range(nu):   # Q fragment words of query block u -> AGPRs, at most 20 operands per statement
+                words = G.NKS * 4
+                for part, w0 in enumerate(range(0, words, 20)):
+                    n = min(20, words - w0)
+                    f.write("#define %sQW%d_%d %s\n" % (P, u, part, " ".join('"v_accvgpr_write_b32 a%d, %%%d\\n"' % (L.AQ(u, 0) + w0 + i, i) for i in range(n))))
             for u in range(nu):   # O^T row tile (u, d) -> operands %0..%15
-                for d in range(NDT):
-                    f.write("#define %sOR%d %s\n" % (P, u * NDT + d, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, L.AO(u, d) + i) for i in range(16))))
+                for d in range(G.NDT):
+                    f.write("#define %sOR%d %s\n" % (P, u * G.NDT + d, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, L.AO(u, d) + i) for i in range(16))))
 
 
 if __name__ == "__main__":
