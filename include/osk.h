@@ -53,6 +53,22 @@ int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride, i
                   const void* res, const float* gate, int64_t gate_batch_stride,
                   int M, int N, int K, int gelu_from, int out_f32, void* stream);
 
+/* ---- FP8 (OCP e4m3fn) variant of the Linear GEMM: BASELINE configs[4] ("fp8 MFMA"); the reference itself runs its
+ * nn.Linear layers (same call sites as osk_gemm_bf16) in bf16, so this is an opt-in mode.
+ * osk_quantize_rows_fp8: dynamic per-row quantisation of a bf16 [M, K] activation (rows_per_batch addressing):
+ *   scales[m] = absmax(x[m, :]) / 448  (1.0 for an all-zero row),  out8[m, k] = e4m3(clamp(x[m, k] * (448 / absmax)))
+ *   out8 is contiguous [M, K] bytes.  K % 8 == 0.  Also used once per weight matrix at load time.
+ * osk_gemm_fp8: C = epilogue(a_scale[m] * w_scale[n] * (A8 @ W8^T) + bias), the epilogue of osk_gemm_bf16, on
+ *   v_mfma_f32_32x32x64_f8f6f4 (f32 accumulate).  Strides of A8 / W8 in bytes, multiples of 16; K % 128 == 0,
+ *   M >= 256, N >= 128 (returns OSK_EUNSUPPORTED (-2) otherwise: such layers stay on osk_gemm_bf16). */
+int osk_quantize_rows_fp8(const void* x, int64_t x_batch_stride, int64_t x_row_stride, int rows_per_batch,
+                          void* out8, float* scales, int M, int K, void* stream);
+int osk_gemm_fp8(const void* A8, int64_t a_batch_stride, int64_t a_row_stride, int a_rows_per_batch,
+                 const float* a_scale, const void* W8, int64_t w_row_stride, const float* w_scale,
+                 const float* bias, void* C, int64_t c_batch_stride, int64_t c_row_stride, int c_rows_per_batch,
+                 const void* res, const float* gate, int64_t gate_batch_stride,
+                 int M, int N, int K, int gelu_from, int out_f32, void* stream);
+
 /* ---- skinny matrix-vector batch (M = Bv <= 8 rows): out[b, n] (+)= act_in(x[b, :]) . W[n, :] + bias[n]
  * replaces Modulation (layers.py:184-191), MLPEmbedder (layers.py:91-99) and LastLayer.adaLN_modulation
  * (layers.py:396,399): weight-bandwidth bound.  One launch covers a LIST of layers that share x:

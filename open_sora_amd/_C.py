@@ -24,6 +24,9 @@ SIGNATURES = {
     "osk_ln_modulate_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_gemm_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
                       _i32, _i32, _i32, _i32, _i32, _vp],
+    "osk_quantize_rows_fp8": [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _i32, _vp],
+    "osk_gemm_fp8": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
+                     _i32, _i32, _i32, _i32, _i32, _vp],
     "osk_gemv_tasks_bf16": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp],
     "osk_timestep_embedding": [_vp, _i32, _i32, _f32, _f32, _vp, _vp],
     "osk_rope_table": [_vp, _i64, _i32, C.POINTER(_i32), _f64, _i32, _vp, _vp, _vp],
@@ -102,6 +105,45 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, *, res=None,
                              out.data_ptr(), out.stride(0), out.stride(1), L, _p(res), _p(gate),
                              gate_batch_stride, B * L, N, K, N if gelu_from is None else gelu_from,
                              1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_bf16")
+    return out
+
+
+def quantize_rows_fp8(x: torch.Tensor, out8: torch.Tensor | None = None, scales: torch.Tensor | None = None):
+    """x bf16 [B, L, K] view (or [N, K] weight) -> (e4m3 bytes as uint8 [B*L, K] contiguous, f32 scales [B*L])."""
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    B, L, K = x.shape
+    M = B * L
+    if out8 is None:
+        out8 = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    if scales is None:
+        scales = torch.empty(M, dtype=torch.float32, device=x.device)
+    assert out8.is_contiguous() and out8.numel() == M * K and scales.numel() >= M
+    _check(lib.osk_quantize_rows_fp8(x.data_ptr(), x.stride(0), x.stride(1), L, out8.data_ptr(), scales.data_ptr(),
+                                     M, K, _stream()), "osk_quantize_rows_fp8")
+    return out8, scales
+
+
+def gemm_fp8_supported(M: int, N: int, K: int) -> bool:
+    """shapes the fp8 instantiation of the large-tile kernel takes (include/osk.h); others stay on gemm()"""
+    return M >= 256 and N >= 128 and K % 128 == 0
+
+
+def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias,
+             out: torch.Tensor, *, res=None, gate=None, gate_batch_stride: int = 0,
+             gelu_from: int | None = None) -> torch.Tensor:
+    """a8 uint8 (e4m3) [M, K] contiguous with scales f32 [M]; w8 uint8 [N, K] with scales f32 [N]; out bf16/f32
+    [B, L, N] view with B * L == M; epilogue arguments as gemm()."""
+    M, K = a8.shape
+    N = w8.shape[0]
+    B, L = out.shape[0], out.shape[1]
+    assert B * L == M and out.shape[2] == N and w8.shape[1] == K
+    if res is not None:
+        assert res.stride() == out.stride()
+    _check(lib.osk_gemm_fp8(a8.data_ptr(), 0, a8.stride(0), M, a_scale.data_ptr(), w8.data_ptr(), w8.stride(0),
+                            w_scale.data_ptr(), _p(bias), out.data_ptr(), out.stride(0), out.stride(1), L, _p(res),
+                            _p(gate), gate_batch_stride, M, N, K, N if gelu_from is None else gelu_from,
+                            1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_fp8")
     return out
 
 

@@ -8,10 +8,16 @@
 // gate*x+residual / f32 out; a lane owns one output row and 4 consecutive columns per quad) are those of
 // gemm_bf16.hip, which remains the kernel for small or odd shapes (the dispatcher is in gemm_bf16.hip).
 //
-// Roofline: MFMA bf16.  Algorithmic FLOPs = 2*M*N*K.
+// FP8 instantiation (osk_gemm_fp8): A and W are OCP e4m3 bytes with one f32 scale per row (activation row m, weight
+// row n); the same tile, LDS image (a 128-byte row now holds 128 K elements) and loaders, K loop from
+// gemm256_fp8_body_n*.inc on v_mfma_f32_32x32x64_f8f6f4 (2x the bf16 MAC rate), epilogue v = acc * sa[m] * sw[n] first.
+//
+// Roofline: MFMA bf16 (fp8 instantiation: MFMA fp8).  Algorithmic FLOPs = 2*M*N*K.
 #include "gemm_params.h"
 #include "gemm256_regs_n256.inc"
 #include "gemm256_regs_n128.inc"
+#include "gemm256_fp8_regs_n256.inc"
+#include "gemm256_fp8_regs_n128.inc"
 
 namespace osk_gemm {
 namespace {
@@ -45,8 +51,9 @@ OSK_DEV void read_acc(float* v16) {
 
 // one 32 x 32 accumulator tile T = tn * TM + tm.  INTERIOR: the wave's whole tile lies inside C (wave-uniform), so
 // there is no per-element bounds check and the column vectors (bias, gate) were loaded once per tn by the caller.
-template <int BN, bool OUT_F32, bool INTERIOR, int T>
-OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int hi, const float4* bq, const float4* gq) {
+template <int BN, bool OUT_F32, bool FP8, bool INTERIOR, int T>
+OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int hi, const float4* bq, const float4* gq,
+                           const float4* sq) {
   constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   constexpr int tn = T / TM, tm = T % TM;
   const int m = m0w + tm * 32 + l31;
@@ -62,6 +69,8 @@ OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int h
     }
     float acc[16];
     read_acc<BN, T>(acc);
+    float sa = 1.f;
+    if constexpr (FP8) sa = p.sa[mc];
     uint2 packed[4];
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -69,6 +78,7 @@ OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int h
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[qd * 4 + j];
+      if constexpr (FP8) { v[0] *= sa * sq[qd].x; v[1] *= sa * sq[qd].y; v[2] *= sa * sq[qd].z; v[3] *= sa * sq[qd].w; }
       if (p.bias) { v[0] += bq[qd].x; v[1] += bq[qd].y; v[2] += bq[qd].z; v[3] += bq[qd].w; }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -115,7 +125,9 @@ OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int h
     for (int qd = 0; qd < 4; ++qd) {
       const int n = n0w + tn * 32 + qd * 8 + hi * 4;
       for (int j = 0; j < 4 && n + j < p.N; ++j) {
-        float t = acc[qd * 4 + j] + (p.bias ? p.bias[n + j] : 0.f);
+        float t = acc[qd * 4 + j];
+        if constexpr (FP8) t *= p.sa[m] * p.sw[n + j];
+        t += p.bias ? p.bias[n + j] : 0.f;
         if (n + j >= p.gelu_from) t = gelu_tanh(t);
         if (grow) t = bf16_bits_to_f32(p.res[roff + n + j]) + grow[n + j] * t;
         if constexpr (OUT_F32) reinterpret_cast<float*>(p.C)[roff + n + j] = t;
@@ -125,12 +137,12 @@ OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int h
   }
 }
 
-template <int BN, bool OUT_F32, bool INTERIOR, int... Ts>
+template <int BN, bool OUT_F32, bool FP8, bool INTERIOR, int... Ts>
 OSK_DEV void epilogue_tn(const GemmParams& p, int m0w, int n0w, int l31, int hi, std::integer_sequence<int, Ts...>) {
   // Ts = the TM tiles of one tn: column vectors once, then the row tiles
   constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   constexpr int tn = ((Ts, ...)) / TM;  // all Ts share tn
-  float4 bq[4], gq[4];
+  float4 bq[4], gq[4], sq[4];
   if constexpr (INTERIOR) {
     // the gate vector belongs to the batch of the tile's rows; a 256-row tile may straddle two batches only when
     // c_rows_per_batch is not a multiple of 256 -- then INTERIOR is refused by the caller
@@ -140,25 +152,27 @@ OSK_DEV void epilogue_tn(const GemmParams& p, int m0w, int n0w, int l31, int hi,
       const int n = n0w + tn * 32 + qd * 8 + hi * 4;
       if (p.bias) bq[qd] = *reinterpret_cast<const float4*>(p.bias + n);
       if (p.gate) gq[qd] = *reinterpret_cast<const float4*>(p.gate + b * p.gbs + n);
+      if constexpr (FP8) sq[qd] = *reinterpret_cast<const float4*>(p.sw + n);
     }
   }
-  (epilogue_tile<BN, OUT_F32, INTERIOR, Ts>(p, m0w, n0w, l31, hi, bq, gq), ...);
+  (epilogue_tile<BN, OUT_F32, FP8, INTERIOR, Ts>(p, m0w, n0w, l31, hi, bq, gq, sq), ...);
 }
 
-template <int BN, bool OUT_F32, bool INTERIOR>
+template <int BN, bool OUT_F32, bool FP8, bool INTERIOR>
 OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l31, int hi) {
   constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   if constexpr (TM == 4) {
-    epilogue_tn<BN, OUT_F32, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1, 2, 3>{});
-    epilogue_tn<BN, OUT_F32, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 4, 5, 6, 7>{});
+    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1, 2, 3>{});
+    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 4, 5, 6, 7>{});
   } else {
-    epilogue_tn<BN, OUT_F32, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1>{});
-    epilogue_tn<BN, OUT_F32, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 2, 3>{});
+    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1>{});
+    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 2, 3>{});
   }
 }
 
-template <int BN, bool OUT_F32>
+template <int BN, bool OUT_F32, bool FP8>
 __global__ void __launch_bounds__(512, 2) gemm256_kernel(const GemmParams p) {
+  constexpr int ES = FP8 ? 1 : 2;              // bytes per operand element; a 128-byte LDS row = 128 / ES K elements
   constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
   constexpr int WN = BN / (TN * 32);           // waves along N (4 or 2); waves along M = 8 / WN
@@ -193,10 +207,10 @@ __global__ void __launch_bounds__(512, 2) gemm256_kernel(const GemmParams p) {
     int m = m0 + r;
     m = m < p.M ? m : p.M - 1;
     const int b = m / p.arpb, l = m - b * p.arpb;
-    aoff[i] = (unsigned)((b * p.abs_ + (int64_t)l * p.ars + c * 8) * 2);
+    aoff[i] = (unsigned)((b * p.abs_ + (int64_t)l * p.ars) * ES + c * 16);
     int n = n0 + (r < BN ? r : 0);
     n = n < p.N ? n : p.N - 1;
-    woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
+    woff[i] = (unsigned)((int64_t)n * p.wrs * ES + c * 16);
   }
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int sw = (l31 >> 1) & 7;
@@ -208,21 +222,29 @@ __global__ void __launch_bounds__(512, 2) gemm256_kernel(const GemmParams p) {
     faW[ks] = lds_base + W_BASE + (wn * TN * 32 + l31) * 128 + sz;
   }
   const uint64_t abase = rfl64((uint64_t)(uintptr_t)p.A), wbase = rfl64((uint64_t)(uintptr_t)p.W);
-  const unsigned nk = rfl((unsigned)(p.K / 64));
+  const unsigned nk = rfl((unsigned)(p.K / (128 / ES)));
   const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + W_BASE + wave * 1024);
 
 #define OSKG_OPERANDS                                                                                              \
   ::"v"(faA[0]), "v"(faA[1]), "v"(faA[2]), "v"(faA[3]), "v"(faW[0]), "v"(faW[1]), "v"(faW[2]), "v"(faW[3]),         \
       "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), \
       "s"(abase), "s"(wbase), "s"(nk), "s"(adst), "s"(wdst)
-  if constexpr (BN == 256) {
+  if constexpr (BN == 256 && !FP8) {
     asm volatile(
 #include "gemm256_body_n256.inc"
         OSKG_OPERANDS : OSKG256_CLOBBERS);
-  } else {
+  } else if constexpr (!FP8) {
     asm volatile(
 #include "gemm256_body_n128.inc"
         OSKG_OPERANDS : OSKG128_CLOBBERS);
+  } else if constexpr (BN == 256) {
+    asm volatile(
+#include "gemm256_fp8_body_n256.inc"
+        OSKG_OPERANDS : OSKQ256_CLOBBERS);
+  } else {
+    asm volatile(
+#include "gemm256_fp8_body_n128.inc"
+        OSKG_OPERANDS : OSKQ128_CLOBBERS);
   }
   (void)NWD;
 
@@ -230,15 +252,15 @@ __global__ void __launch_bounds__(512, 2) gemm256_kernel(const GemmParams p) {
   const int m0w = m0 + wm * TM * 32, n0w = n0 + wn * TN * 32;
   const int b_first = m0w / p.crpb, b_last = (m0w + TM * 32 - 1) / p.crpb;
   const bool interior = m0w + TM * 32 <= p.M && n0w + TN * 32 <= p.N && b_first == b_last;  // wave-uniform
-  if (interior) epilogue_all<BN, OUT_F32, true>(p, m0w, n0w, l31, hi);
-  else epilogue_all<BN, OUT_F32, false>(p, m0w, n0w, l31, hi);
+  if (interior) epilogue_all<BN, OUT_F32, FP8, true>(p, m0w, n0w, l31, hi);
+  else epilogue_all<BN, OUT_F32, FP8, false>(p, m0w, n0w, l31, hi);
 }
 
-template <int BN, bool OUT_F32>
+template <int BN, bool OUT_F32, bool FP8 = false>
 int launch_one(const GemmParams& p, hipStream_t st) {
   static bool attr_set = false;
   constexpr int SMEM = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;
-  auto kernel = gemm256_kernel<BN, OUT_F32>;
+  auto kernel = gemm256_kernel<BN, OUT_F32, FP8>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
@@ -260,6 +282,17 @@ bool gemm256_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span
 int launch_gemm256(const GemmParams& p, int bn, int out_f32, hipStream_t st) {
   if (bn == 256) return out_f32 ? launch_one<256, true>(p, st) : launch_one<256, false>(p, st);
   return out_f32 ? launch_one<128, true>(p, st) : launch_one<128, false>(p, st);
+}
+
+// fp8 operands (1 byte per element: spans in bytes), K % 128 == 0, per-row scales p.sa / p.sw
+bool gemm256_fp8_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems) {
+  return p.K % 128 == 0 && p.M >= 256 && p.N >= 128 && a_span_elems < (int64_t)0xFFFFFFFF &&
+         w_span_elems < (int64_t)0xFFFFFFFF;
+}
+
+int launch_gemm256_fp8(const GemmParams& p, int bn, int out_f32, hipStream_t st) {
+  if (bn == 256) return out_f32 ? launch_one<256, true, true>(p, st) : launch_one<256, false, true>(p, st);
+  return out_f32 ? launch_one<128, true, true>(p, st) : launch_one<128, false, true>(p, st);
 }
 
 }  // namespace osk_gemm

@@ -20,10 +20,15 @@ struct GemmParams {
   int64_t gbs;
   int M, N, K, gelu_from;
   int group;   // gemm256: row bands per tile group (L2 blocking of the tile order)
+  const float* sa = nullptr;   // fp8 instantiation: per-row scales of A [M] and of W [N]
+  const float* sw = nullptr;
 };
 
 // gemm256.hip: 256 x {256,128} x 64 tiles, 8 waves, hand-scheduled (generated) K loop
 bool gemm256_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
 int launch_gemm256(const GemmParams& p, int bn, int out_f32, hipStream_t st);
+// the same kernel on OCP e4m3 operands (A, W point at bytes; strides in elements = bytes)
+bool gemm256_fp8_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
+int launch_gemm256_fp8(const GemmParams& p, int bn, int out_f32, hipStream_t st);
 
 }  // namespace osk_gemm

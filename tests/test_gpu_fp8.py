@@ -1,0 +1,131 @@
+"""GPU parity tests of the opt-in fp8 (OCP e4m3fn) GEMM path (BASELINE configs[4]: "fp8 MFMA"), through the C ABI.
+
+Two separate claims, tested separately:
+  * the quantiser is bit-exact against torch's own float8_e4m3fn conversion on the CPU (same f32 arithmetic);
+  * the fp8 GEMM kernel equals an f64 matmul of the DEQUANTISED operands up to f32 accumulation + one bf16 rounding
+    -- i.e. the kernel adds no error of its own; the quantisation error itself (vs the bf16 path, which is what the
+    reference computes) is measured and bounded in test_fp8_error_vs_bf16_path.
+"""
+import pytest
+import torch
+
+from tests.test_gpu_kernels import BF, DEV, bf16_ulp_close, rnd
+
+pytestmark = pytest.mark.gpu
+F8 = torch.float8_e4m3fn
+
+
+def _quant_ref(x):
+    """x bf16 [M, K] on the CPU -> (uint8 e4m3 bytes, f32 scales): the arithmetic of osk_quantize_rows_fp8 in f32"""
+    xf = x.float()
+    amax = xf.abs().amax(-1)
+    inv = torch.where(amax > 0, torch.tensor(448.0) / amax, torch.zeros_like(amax))
+    q = (xf * inv[:, None]).clamp(-448.0, 448.0).to(F8).view(torch.uint8)
+    return q, torch.where(amax > 0, amax / torch.tensor(448.0), torch.ones_like(amax))
+
+
+def _deq(q8, s):
+    return q8.cpu().view(F8).double() * s.cpu().double()[:, None]
+
+
+@pytest.mark.parametrize("M_L,K", [((1, 7), 64), ((2, 130), 1152), ((1, 33), 4608), ((1, 5), 15360)])
+def test_quantize_rows_bit_exact(hip_lib, M_L, K):
+    B, L = M_L
+    x = rnd("x", (B, L, K), std=1.7, seed=61)
+    x[0, 0] = 0                      # an all-zero row: scale 1, bytes 0
+    x[0, 1, 3] = 300.0               # an outlier that owns the row's scale
+    q, s = hip_lib.quantize_rows_fp8(x)
+    qr, sr = _quant_ref(x.cpu().view(B * L, K))
+    assert torch.equal(s.cpu(), sr)
+    # -0 and +0 are the same value: compare after mapping 0x80 -> 0x00
+    fix = lambda t: torch.where(t == 0x80, torch.zeros_like(t), t)
+    assert torch.equal(fix(q.cpu()), fix(qr))
+
+
+def test_quantize_rows_strided_view(hip_lib):
+    B, L, D = 2, 40, 256
+    y = rnd("y", (B, L, 3 * D), seed=62)
+    q, s = hip_lib.quantize_rows_fp8(y[:, :, D: 2 * D])
+    qr, sr = _quant_ref(y[:, :, D: 2 * D].cpu().reshape(B * L, D))
+    assert torch.equal(s.cpu(), sr) and torch.equal(q.cpu() & 0x7F | (q.cpu() & 0x80) * (q.cpu() != 0x80), qr & 0x7F | (qr & 0x80) * (qr != 0x80))
+
+
+def _fp8_case(hip_lib, B, L, N, K, gelu_from=None, gated=False, out_f32=False, seed=70):
+    a = rnd("a", (B, L, K), seed=seed)
+    w = rnd("w", (N, K), std=K ** -0.5, seed=seed + 1)
+    bias = rnd("b", (N,), std=0.1, dtype=torch.float32, seed=seed + 2)
+    a8, sa = hip_lib.quantize_rows_fp8(a)
+    w8, sw = hip_lib.quantize_rows_fp8(w)
+    out = torch.empty(B, L, N, dtype=torch.float32 if out_f32 else BF, device=DEV)
+    res = gate = None
+    if gated:
+        res = rnd("r", (B, L, N), seed=seed + 3)
+        gate = rnd("g", (B, N), std=0.5, dtype=torch.float32, seed=seed + 4)
+        out = res.clone()           # res may alias C
+        hip_lib.gemm_fp8(a8, sa, w8, sw, bias, out, res=out, gate=gate, gate_batch_stride=gate.stride(0))
+    else:
+        hip_lib.gemm_fp8(a8, sa, w8, sw, bias, out, gelu_from=gelu_from)
+    v = _deq(a8, sa) @ _deq(w8, sw).T + bias.double().cpu()
+    v = v.view(B, L, N)
+    if gelu_from is not None:
+        g = torch.nn.functional.gelu(v[..., gelu_from:].float(), approximate="tanh").double()
+        v = torch.cat([v[..., :gelu_from], g], -1)
+    if gated:
+        v = res.double().cpu() + gate.double().cpu()[:, None] * v
+    if out_f32:
+        assert (out.cpu().double() - v).abs().max().item() <= 2e-4 * max(1.0, v.abs().max().item())
+    else:
+        bf16_ulp_close(out.float().cpu(), v.float().bfloat16().float(), rel=2 ** -7, abs_=2e-3)
+    return a, w, bias, out
+
+
+# exact tiles, ragged M and N tails, tiles straddling a batch boundary, one K step (K = 128), both tile widths
+@pytest.mark.parametrize("B,L,N,K", [(1, 256, 256, 128), (1, 512, 512, 256), (2, 300, 384, 256), (3, 700, 1152, 1152),
+                                     (1, 1000, 520, 256), (2, 1024, 2304, 640), (1, 257, 132, 128), (1, 300, 200, 384)])
+def test_gemm_fp8_vs_dequantised_f64(hip_lib, B, L, N, K):
+    _fp8_case(hip_lib, B, L, N, K)
+
+
+def test_gemm_fp8_epilogues(hip_lib):
+    _fp8_case(hip_lib, 2, 384, 1024, 256, gelu_from=256, seed=80)       # linear1-style: GELU on the MLP columns only
+    _fp8_case(hip_lib, 2, 384, 512, 512, gated=True, seed=81)            # gate * x + residual, in place
+    _fp8_case(hip_lib, 1, 300, 260, 256, gated=True, seed=82)            # the same on ragged tiles
+    _fp8_case(hip_lib, 1, 512, 256, 256, out_f32=True, seed=83)
+
+
+def test_gemm_fp8_unsupported_shapes_are_refused(hip_lib):
+    a8 = torch.zeros(64, 128, dtype=torch.uint8, device=DEV)
+    w8 = torch.zeros(128, 128, dtype=torch.uint8, device=DEV)
+    s = torch.ones(128, dtype=torch.float32, device=DEV)
+    out = torch.empty(1, 64, 128, dtype=BF, device=DEV)
+    with pytest.raises(RuntimeError):                                    # M < 256: this layer stays on the bf16 GEMM
+        hip_lib.gemm_fp8(a8, s, w8, s, None, out)
+    assert not hip_lib.gemm_fp8_supported(64, 128, 128) and hip_lib.gemm_fp8_supported(256, 128, 128)
+    assert not hip_lib.gemm_fp8_supported(256, 128, 192)
+
+
+def test_fp8_error_vs_bf16_path(hip_lib):
+    """quantisation error of one Linear at the XL width against the bf16 kernel (what the reference computes):
+    relL2 of the fp8 result vs the f64 product of the bf16 operands; e4m3 with per-row scales gives ~2.5-3 %."""
+    B, L, N, K = 1, 2048, 1152, 1152
+    a, w, bias, out8 = _fp8_case(hip_lib, B, L, N, K, seed=90)
+    ref = a.double().cpu() @ w.double().cpu().T + bias.double().cpu()
+    out16 = torch.empty(B, L, N, dtype=BF, device=DEV)
+    hip_lib.gemm(a, w, bias, out16)
+    e8 = ((out8.double().cpu() - ref).norm() / ref.norm()).item()
+    e16 = ((out16.double().cpu() - ref).norm() / ref.norm()).item()
+    assert e16 <= 4e-3 and e8 <= 4e-2, (e8, e16)
+
+
+def test_gemm_fp8_deterministic_under_load(hip_lib):
+    a = rnd("a", (3, 2100, 1152), seed=95)
+    w = rnd("w", (1160, 1152), std=1152 ** -0.5, seed=96)
+    a8, sa = hip_lib.quantize_rows_fp8(a)
+    w8, sw = hip_lib.quantize_rows_fp8(w)
+    outs = []
+    for _ in range(12):
+        o = torch.empty(3, 2100, 1160, dtype=BF, device=DEV)
+        hip_lib.gemm_fp8(a8, sa, w8, sw, None, o)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])

@@ -25,8 +25,9 @@ OP = {n: "%%%d" % i for i, n in enumerate(OPERANDS)}
 
 
 class Cfg:
-    def __init__(self, bn):
+    def __init__(self, bn, fp8=False):
         self.BN = bn
+        self.FP8 = fp8
         self.TM, self.TN = (4, 2) if bn == 256 else (2, 2)
         self.NA, self.NW = 4, bn // 64           # LDS-DMA instructions per wave and stage (A: 32 / 8, W: BN/8 / 8)
         self.A_STAGE, self.W_STAGE = 32768, bn * 128
@@ -34,12 +35,15 @@ class Cfg:
         self.SMEM = self.W_BASE + 2 * self.W_STAGE
         self.NACC = 16 * self.TM * self.TN
         self.NFRAG = self.TM + self.TN
-        self.V0 = 64                             # first asm-owned VGPR: two fragment sets
-        self.VN = 2 * self.NFRAG * 4
-        self.tag = "g%d" % bn
+        # first asm-owned VGPR: two fragment sets.  fp8: a fragment is 32 bytes (8 registers), and with 128
+        # accumulator AGPRs of the 256 registers a wave may own (two waves per SIMD) the VGPR half ends at v127
+        self.FW = 8 if fp8 else 4
+        self.V0 = (32 if bn == 256 else 64) if fp8 else 64
+        self.VN = 2 * self.NFRAG * self.FW
+        self.tag = ("q%d" if fp8 else "g%d") % bn
 
     def frag(self, fset, idx):                   # idx: 0..TM-1 activation fragments, TM.. weight fragments
-        return self.V0 + (fset * self.NFRAG + idx) * 4
+        return self.V0 + (fset * self.NFRAG + idx) * self.FW
 
 
 def vr(b, n=1):
@@ -157,6 +161,128 @@ def gen(c):
             for i, r in enumerate(rd):
                 fill[i].append(r)
             interleave(mf, fill)
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_barrier")
+        e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
+        e("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NK))
+        e("s_cbranch_scc0 .L%s_exit_%%=" % c.tag)
+        if k == 1:
+            e("s_branch .L%s_step0_%%=" % c.tag)
+    lab("exit")
+    for m in mfmas(1):
+        e(m)
+    e("s_nop 15")
+    e("s_nop 15")
+    return L
+
+
+def gen_fp8(c):
+    """K loop of the fp8 (OCP e4m3) GEMM: the SAME tile, LDS image (128-byte rows = 128 K elements now), LDS-DMA
+    loaders and operands as gen(); one v_mfma_f32_32x32x64_f8f6f4 (64 cycles, 2x the bf16 MAC rate) consumes what
+    two consecutive bf16 k-sub-steps read: a 32-byte fragment = the 16-byte chunks (2 ks | hi) of k-sub-steps
+    ks = 2 kp and 2 kp + 1.  (Which K element lands in which byte of the MFMA operand does not matter: activation
+    and weight fragments are assembled identically, and a contraction is invariant under a common K permutation.)
+    One K step of a wave = 2 k-sub-steps: reads of sub-step 0 | the trailing sub-step 1 of the previous K step with
+    the LDS-DMA of the other stage in its shadows | sub-step 0 with the reads of sub-step 1 in its shadows |
+    vmcnt(0) lgkmcnt(0), barrier."""
+    assert c.FP8
+    L = []
+    e = lambda t: L.append("  " + t)
+    lab = lambda n: L.append(".L%s_%s_%%=:" % (c.tag, n))
+
+    def reads(stage, kp, fset):
+        out = []
+        for half in range(2):
+            ks = 2 * kp + half
+            for tm in range(c.TM):
+                out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, tm) + 4 * half, 4), OP["faA%d" % ks], stage * c.A_STAGE + tm * 4096))
+            for tn in range(c.TN):
+                out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, c.TM + tn) + 4 * half, 4), OP["faW%d" % ks], stage * c.W_STAGE + tn * 4096))
+        return out
+
+    def mfmas(fset):
+        out = []
+        for tn in range(c.TN):
+            for tm in range(c.TM):
+                acc = ar((tn * c.TM + tm) * 16, 16)
+                out.append("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s" % (acc, vr(c.frag(fset, c.TM + tn), 8), vr(c.frag(fset, tm), 8), acc))
+        return out
+
+    def dma(stage):
+        out = []
+        for i in range(c.NA):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["aoff%d" % i], S_AB, S_AB + 1)))
+        for i in range(c.NW):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (OP["woff%d" % i], S_WB, S_WB + 1)))
+        return out
+
+    def advance():
+        return ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
+                "s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK),
+                "s_cselect_b32 s%d, 128, 0" % S_STEP,
+                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL),
+                "s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1),
+                "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1)]
+
+    def spread(mf, fill_items):
+        """MFMAs with the filler instructions spread evenly over their shadows"""
+        n = len(mf)
+        per = [[] for _ in mf]
+        for i, it in enumerate(fill_items):
+            per[i * n // max(1, len(fill_items))].append(it)
+        for m, f in zip(mf, per):
+            e(m)
+            for x in f:
+                e(x)
+
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, OP["abase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, OP["wbase"]))
+    e("s_mov_b32 s%d, %s" % (S_NK, OP["nk"]))
+    e("s_mov_b32 s%d, %s" % (S_ADST, OP["adst"]))
+    e("s_mov_b32 s%d, %s" % (S_WDST, OP["wdst"]))
+    e("s_mov_b32 s%d, 0" % S_T)
+    e("s_mov_b32 s%d, 0" % S_KL)
+    for r in range(c.NACC):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    for m0w, d in dma(0):
+        e(m0w); e("s_nop 0"); e(d)
+    for a in advance():
+        e(a)
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    for m0w, d in dma(1):
+        e(m0w); e("s_nop 0"); e(d)
+    for a in advance():
+        e(a)
+    for r in reads(0, 0, 0):
+        e(r)
+    e("s_branch .L%s_entry0_%%=" % c.tag)
+
+    for k in range(2):
+        cur = k
+        lab("step%d" % k)
+        for r in reads(cur, 0, 0):
+            e(r)
+        mf = mfmas(1)                      # trailing sub-step 1 of the previous K step
+        pieces = dma(cur ^ 1)
+        e(pieces[0][0])                    # M0 write before MFMA i, its DMA after it, the next M0 write behind that
+        for i, m in enumerate(mf):
+            e(m)
+            if i < len(pieces):
+                e(pieces[i][1])
+                if i + 1 < len(pieces):
+                    e(pieces[i + 1][0])
+        for m0w, d in pieces[len(mf):]:
+            e(m0w); e("s_nop 0"); e(d)
+        for a in advance():
+            e(a)
+        lab("entry%d" % k)
+        e("s_waitcnt lgkmcnt(0)")
+        spread(mfmas(0), reads(cur, 1, 1))
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         e("s_barrier")
         e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
@@ -498,6 +624,17 @@ def main():
             f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile, one K segment (filter tap).\n" % bn)
             for ln in gen_segment(c):
                 f.write('"%s\\n"\n' % ln)
+    for bn in (256, 128):
+        c = Cfg(bn, fp8=True)
+        with open(os.path.join(args.out, "gemm256_fp8_body_n%d.inc" % bn), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  fp8 (e4m3) 256 x %d x 128 tile K loop.\n" % bn)
+            for ln in gen_fp8(c):
+                f.write('"%s\\n"\n' % ln)
+        with open(os.path.join(args.out, "gemm256_fp8_regs_n%d.inc" % bn), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
+            clob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                   ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+            f.write("#define OSKQ%d_CLOBBERS %s\n" % (bn, ", ".join(clob)))
 
 
 if __name__ == "__main__":

@@ -42,6 +42,19 @@ def bench_gemm(M, N, K, tag):
          tflops=round(2.0 * M * N * K / ms / 1e9, 1))
 
 
+def bench_gemm_fp8(M, N, K, tag):
+    a = torch.randn(1, M, K, device=DEV).to(BF)
+    w = (torch.randn(N, K, device=DEV) * K ** -0.5).to(BF)
+    bias = torch.randn(N, device=DEV)
+    out = torch.empty(1, M, N, dtype=BF, device=DEV)
+    a8, sa = _C.quantize_rows_fp8(a)
+    w8, sw = _C.quantize_rows_fp8(w)
+    ms = timeit(lambda: _C.gemm_fp8(a8, sa, w8, sw, bias, out), iters=40, warm=10)
+    emit(kernel="gemm_fp8", tag=tag, M=M, N=N, K=K, ms=round(ms, 4), tflops=round(2.0 * M * N * K / ms / 1e9, 1))
+    ms = timeit(lambda: _C.quantize_rows_fp8(a, a8, sa), iters=20, warm=5)
+    emit(kernel="quantize_rows_fp8", tag=tag, M=M, K=K, ms=round(ms, 4), gbps=round(3.0 * M * K / ms / 1e6, 1))
+
+
 def bench_attn(B, H, L, hd, tag):
     D = H * hd
     y = torch.randn(B, L, 3 * D, device=DEV).to(BF)
@@ -88,6 +101,13 @@ def main():
         bench_gemm(8192, 8192, 8192, "square8k")
         bench_gemm(4096, 4096, 4096, "square4k")
         bench_gemm(26484, 3072 * 3, 3072, "11b.qkv")
+    if "--fp8" in sys.argv:
+        for (N, K, tag) in [(3 * D, D, "xl.qkv"), (4 * D, D, "xl.mlp_up"), (D, 4 * D, "xl.mlp_down"), (D, D, "xl.proj"),
+                            (7 * D, D, "xl.linear1"), (D, 5 * D, "xl.linear2")]:
+            bench_gemm_fp8(M, N, K, tag)
+        bench_gemm_fp8(8192, 8192, 8192, "square8k")
+        bench_gemm_fp8(26484, 3072 * 3, 3072, "11b.qkv")
+        return
     if gemm_only:
         return
     bench_attn(3, 16, L, 72, "xl.cfg2.b3")
