@@ -45,6 +45,9 @@ def parse():
                     help="dit = BASELINE configs[1] (default, the headline metric); vae = configs[2]")
     ap.add_argument("--vae-frames", type=int, default=33)
     ap.add_argument("--vae-size", type=int, default=256)
+    ap.add_argument("--fp8", action="store_true",
+                    help="opt-in reduced precision (BASELINE configs[4]): block Linears on the fp8 (e4m3) MFMA; "
+                         "never the default line -- the reference computes in bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
     return ap.parse_args()
@@ -205,6 +208,8 @@ def main():
         for n_, p_ in model.named_parameters():
             if n_.startswith("cond_in"):
                 p_.normal_(0, 0.02)
+    if args.fp8:
+        model.enable_fp8()
     sp_mode = None
     if world > 1:
         from open_sora_amd import seqpar
@@ -296,7 +301,9 @@ def main():
         "metric": "latent_frames_per_sec (30-step rectified-flow sampling; denoise-step ms in ms_per_step)",
         "value": round(frames_per_s, 4), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "fp8-e4m3 block Linears (per-row scales), bf16 attention / norms / embedders" if args.fp8 else "bf16",
+        "data": "synthetic",
         "config": {"workload": f"MMDiT-{args.model} (hidden {D}, {H}x{hd}, {cfg['depth']}+{cfg['depth_single_blocks']} blocks) "
                                f"denoise step, latent {T}x{hw}x{hw} (16x512x512 px), L={L} tokens, CFG batch {nb}, "
                                f"{SAMPLING_STEPS}-step Euler sampling",

@@ -247,6 +247,38 @@ def _pad_k(w: Tensor, mult: int = 64) -> Tensor:
     return out
 
 
+class Fp8Weight:
+    """A Linear weight in both precisions for the opt-in fp8 mode (MMDiTModel.enable_fp8): OCP e4m3 bytes with one
+    f32 scale per output row for the large-tile fp8 GEMM, and the bf16 rows for the shapes that kernel does not take
+    (M < 256: e.g. a short text shard under sequence parallelism).  Row slices stay views."""
+
+    def __init__(self, w: Tensor, w8: Tensor | None = None, sw: Tensor | None = None):
+        self.w = w
+        if w8 is None:
+            w8, sw = _OPS.quantize_rows_fp8(w)
+        self.w8, self.sw = w8, sw
+
+    @property
+    def shape(self):
+        return self.w.shape
+
+    def __getitem__(self, rows):
+        assert isinstance(rows, slice) and (rows.start or 0) % 4 == 0   # the scale vector is read 16 bytes at a time
+        return Fp8Weight(self.w[rows], self.w8[rows], self.sw[rows])
+
+
+def _linear(a: Tensor, w, b, out: Tensor, **epi) -> Tensor:
+    """nn.Linear + fused epilogue: bf16 GEMM, or -- when w is an Fp8Weight and the shape qualifies -- dynamic per-row
+    quantisation of the activation followed by the fp8 GEMM."""
+    if isinstance(w, Fp8Weight):
+        B, L, K = a.shape
+        if B * L > 0 and _OPS.gemm_fp8_supported(B * L, w.shape[0], K):
+            a8, sa = _OPS.quantize_rows_fp8(a)
+            return _OPS.gemm_fp8(a8, sa, w.w8, w.sw, b, out, **epi)
+        w = w.w
+    return _OPS.gemm(a, w, b, out, **epi)
+
+
 @dataclass
 class _AttnW:
     qkv_w: Tensor
@@ -277,12 +309,18 @@ class _SinglePlan:
     mod_layers: list = field(default_factory=list)
 
 
-def _attn_weights(sa) -> _AttnW:
+def _attn_weights(sa, wrap=lambda w: w) -> _AttnW:
     if getattr(sa, "fused_qkv", hasattr(sa, "qkv")):
         w, b = _cat_linear(sa.qkv)
     else:
         w, b = _cat_linear(sa.q_proj, sa.k_proj, sa.v_proj)
-    return _AttnW(w, b, _w(sa.norm.query_norm.scale), _w(sa.norm.key_norm.scale), _w(sa.proj.weight), _b32(sa.proj.bias))
+    return _AttnW(wrap(w), b, _w(sa.norm.query_norm.scale), _w(sa.norm.key_norm.scale), wrap(_w(sa.proj.weight)),
+                  _b32(sa.proj.bias))
+
+
+def _wrap_for(block):
+    """weights of a block whose model runs in fp8 mode are kept as Fp8Weight (quantised once, here)"""
+    return Fp8Weight if getattr(block, "_osk_fp8", False) else (lambda w: w)
 
 
 def _mod_layer(mod) -> tuple:
@@ -292,11 +330,12 @@ def _mod_layer(mod) -> tuple:
 def plan_double(block) -> _DoublePlan:
     p = getattr(block, "_osk_plan", None)
     if p is None:
+        wr = _wrap_for(block)
         p = _DoublePlan(
-            img=_attn_weights(block.img_attn),
-            txt=_attn_weights(block.txt_attn),
-            img_mlp=(_w(block.img_mlp[0].weight), _b32(block.img_mlp[0].bias), _w(block.img_mlp[2].weight), _b32(block.img_mlp[2].bias)),
-            txt_mlp=(_w(block.txt_mlp[0].weight), _b32(block.txt_mlp[0].bias), _w(block.txt_mlp[2].weight), _b32(block.txt_mlp[2].bias)),
+            img=_attn_weights(block.img_attn, wr),
+            txt=_attn_weights(block.txt_attn, wr),
+            img_mlp=(wr(_w(block.img_mlp[0].weight)), _b32(block.img_mlp[0].bias), wr(_w(block.img_mlp[2].weight)), _b32(block.img_mlp[2].bias)),
+            txt_mlp=(wr(_w(block.txt_mlp[0].weight)), _b32(block.txt_mlp[0].bias), wr(_w(block.txt_mlp[2].weight)), _b32(block.txt_mlp[2].bias)),
             mod_layers=[_mod_layer(block.img_mod), _mod_layer(block.txt_mod)],
         )
         object.__setattr__(block, "_osk_plan", p)
@@ -310,7 +349,8 @@ def plan_single(block) -> _SinglePlan:
             w1, b1 = _cat_linear(block.linear1)
         else:
             w1, b1 = _cat_linear(block.q_proj, block.k_proj, block.v_mlp)
-        p = _SinglePlan(w1, b1, _w(block.linear2.weight), _b32(block.linear2.bias),
+        wr = _wrap_for(block)
+        p = _SinglePlan(wr(w1), b1, wr(_w(block.linear2.weight)), _b32(block.linear2.bias),
                         _w(block.norm.query_norm.scale), _w(block.norm.key_norm.scale),
                         mod_layers=[_mod_layer(block.modulation)])
         object.__setattr__(block, "_osk_plan", p)
@@ -439,30 +479,30 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
     scales = (plan.txt.q_scale, plan.txt.k_scale, plan.img.q_scale, plan.img.k_scale)
     if sp is None:
         for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
-            _OPS.gemm(xm_s, aw.qkv_w, aw.qkv_b, y_s)
+            _linear(xm_s, aw.qkv_w, aw.qkv_b, y_s)
         _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         _joint_attention(ws, q, k, v, H, hd)
     else:
         for aw, x_s, xm_s, y_s, sh1, sc1 in streams:  # K, V first: their all-gather overlaps the Q projection
-            _OPS.gemm(xm_s, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
+            _linear(xm_s, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
         _OPS.qknorm_rope(None, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode)
         pending = sp.gather_kv_start(ws, k, v, H, hd)
         for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
-            _OPS.gemm(xm_s, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
+            _linear(xm_s, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
         _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         sp.attention(ws, pending, q, v, H, hd)
     if Li:  # img stream
-        _OPS.gemm(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=x_img, gate=i_g1, gate_batch_stride=mbs)
+        _linear(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=x_img, gate=i_g1, gate_batch_stride=mbs)
         _OPS.ln_modulate(x_img, i_sh2, i_sc2, xm_img, mbs)
         w0, b0, w2, b2 = plan.img_mlp
-        _OPS.gemm(xm_img, w0, b0, ws.h[:, Lt:], gelu_from=0)
-        _OPS.gemm(ws.h[:, Lt:], w2, b2, x_img, res=x_img, gate=i_g2, gate_batch_stride=mbs)
+        _linear(xm_img, w0, b0, ws.h[:, Lt:], gelu_from=0)
+        _linear(ws.h[:, Lt:], w2, b2, x_img, res=x_img, gate=i_g2, gate_batch_stride=mbs)
     if Lt:  # txt stream
-        _OPS.gemm(v[:, :Lt], plan.txt.proj_w, plan.txt.proj_b, x_txt, res=x_txt, gate=t_g1, gate_batch_stride=mbs)
+        _linear(v[:, :Lt], plan.txt.proj_w, plan.txt.proj_b, x_txt, res=x_txt, gate=t_g1, gate_batch_stride=mbs)
         _OPS.ln_modulate(x_txt, t_sh2, t_sc2, xm_txt, mbs)
         w0, b0, w2, b2 = plan.txt_mlp
-        _OPS.gemm(xm_txt, w0, b0, ws.h[:, :Lt], gelu_from=0)
-        _OPS.gemm(ws.h[:, :Lt], w2, b2, x_txt, res=x_txt, gate=t_g2, gate_batch_stride=mbs)
+        _linear(xm_txt, w0, b0, ws.h[:, :Lt], gelu_from=0)
+        _linear(ws.h[:, :Lt], w2, b2, x_txt, res=x_txt, gate=t_g2, gate_batch_stride=mbs)
 
 
 def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, rope: _RopeTable, H: int, hd: int,
@@ -478,19 +518,19 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D: 3 * D]
     scales = (plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale)
     if sp is None:
-        _OPS.gemm(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
+        _linear(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
         _OPS.qknorm_rope(q, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         _joint_attention(ws, q, k, v, H, hd)
     else:
         b1 = plan.b1
-        _OPS.gemm(ws.xm, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])
+        _linear(ws.xm, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])
         _OPS.qknorm_rope(None, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
         pending = sp.gather_kv_start(ws, k, v, H, hd)
-        _OPS.gemm(ws.xm, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
-        _OPS.gemm(ws.xm, plan.w1[:D], None if b1 is None else b1[:D], q)
+        _linear(ws.xm, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
+        _linear(ws.xm, plan.w1[:D], None if b1 is None else b1[:D], q)
         _OPS.qknorm_rope(q, None, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         sp.attention(ws, pending, q, v, H, hd)
-    _OPS.gemm(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=ws.x, gate=gate, gate_batch_stride=mbs)
+    _linear(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=ws.x, gate=gate, gate_batch_stride=mbs)
 
 
 def _run_modulation(vec32: Tensor, layers, D: int) -> Tensor:
@@ -588,6 +628,17 @@ class MMDiTModel(nn.Module):
         self._plan = None
         self._sp = None  # set by open_sora_amd.seqpar.enable
         self.forward = self.forward_ckpt  # instance attribute, as the reference does (model.py:143-146)
+
+    # ------------------------------------------------------------------ fp8 mode
+    def enable_fp8(self, on: bool = True):
+        """Opt-in reduced-precision mode (BASELINE configs[4], "fp8 MFMA"): the Linear layers of the double / single
+        blocks (QKV, proj, MLP, linear1, linear2 -- >99 % of the GEMM FLOPs) run on the fp8 MFMA with per-row dynamic
+        activation scales and per-output-row weight scales; attention, norms, modulation, embedders and the final
+        layer stay bf16.  The reference computes in bf16: results differ by the e4m3 quantisation error."""
+        for b in list(self.double_blocks) + list(self.single_blocks):
+            object.__setattr__(b, "_osk_fp8", bool(on))
+        self.invalidate_plan()
+        return self
 
     # ------------------------------------------------------------------ planning
     def invalidate_plan(self):

@@ -47,6 +47,39 @@ def gemm(a, w, bias, out, *, res=None, gate=None, gate_batch_stride=0, gelu_from
     return out
 
 
+def quantize_rows_fp8(x, out8=None, scales=None):
+    """CPU statement of osk_quantize_rows_fp8 (torch's own float8_e4m3fn conversion)"""
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    B, L, K = x.shape
+    xf = x.float().reshape(B * L, K)
+    amax = xf.abs().amax(-1)
+    inv = torch.where(amax > 0, torch.tensor(448.0) / amax, torch.zeros_like(amax))
+    q = (xf * inv[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    return q, torch.where(amax > 0, amax / torch.tensor(448.0), torch.ones_like(amax))
+
+
+def gemm_fp8_supported(M, N, K):
+    return M >= 256 and N >= 128 and K % 128 == 0
+
+
+def gemm_fp8(a8, a_scale, w8, w_scale, bias, out, *, res=None, gate=None, gate_batch_stride=0, gelu_from=None):
+    M, K = a8.shape
+    B, L, N = out.shape
+    assert gemm_fp8_supported(M, N, K), "osk_gemm_fp8 refuses this shape"
+    a = (a8.view(torch.float8_e4m3fn).float() * a_scale[:, None]).view(B, L, K)
+    w = w8.view(torch.float8_e4m3fn).float() * w_scale[:, None]
+    v = a @ w.T
+    if bias is not None:
+        v = v + bias.float()
+    if gelu_from is not None and gelu_from < N:
+        v = torch.cat([v[..., :gelu_from], F.gelu(v[..., gelu_from:], approximate="tanh")], -1)
+    if gate is not None:
+        v = res.float() + _mod_rows(gate, gate_batch_stride, B, N)[:, None] * v
+    out.copy_(v.to(out.dtype))
+    return out
+
+
 class GemvTasks:
     def __init__(self, layers, device):
         self.layers = layers

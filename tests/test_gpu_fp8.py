@@ -129,3 +129,35 @@ def test_gemm_fp8_deterministic_under_load(hip_lib):
         outs.append(o)
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_mmdit_forward_fp8_mode(hip_lib):
+    """MMDiTModel.enable_fp8(): the block Linears on the fp8 MFMA.  Gate of SURVEY.md 8(d) for the fp8 configuration:
+    relL2 <= 5e-2 against our bf16 path and against the fp32 oracle; the bf16 mode is restored bit-exactly."""
+    from oracle import configs, mmdit_oracle as O
+    from open_sora_amd import mmdit
+    from tests.util import torch_inputs, torch_params
+
+    cfg = dict(configs.GOLDEN["hd128_eager_fused"][0], depth=1, depth_single_blocks=1)
+    geom = (2, 2, 12, 12, 160)
+    model = mmdit.Flux(device_map="cuda", torch_dtype=BF, **cfg)
+    model.load_state_dict(torch_params(cfg, dtype=BF, device="cuda"), strict=True)
+    inp = torch_inputs(cfg, *geom, dtype=BF, device="cuda")
+    calls = []
+    real = hip_lib.gemm_fp8
+    try:
+        hip_lib.gemm_fp8 = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        with torch.inference_mode():
+            ref16 = model(**inp).clone()
+            assert not calls
+            out8 = model.enable_fp8()(**inp).clone()
+            n8 = len(calls)
+            again16 = model.enable_fp8(False)(**inp).clone()
+    finally:
+        hip_lib.gemm_fp8 = real
+    assert n8 == 10 and len(calls) == 10
+    assert torch.equal(again16, ref16)
+    with torch.inference_mode():
+        truth = O.forward(torch_params(cfg), cfg, **torch_inputs(cfg, *geom))
+    rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm()).item()
+    assert rel(out8, ref16) <= 5e-2 and rel(out8, truth) <= 5e-2, (rel(out8, ref16), rel(out8, truth))
