@@ -441,6 +441,40 @@ def test_attention_constant_v_property(hip_lib):
     assert (out.float() - c.float()[None, None]).abs().max().item() <= 2 ** -6 * c.float().abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("hd,H", [(72, 16), (128, 6)])
+def test_attention_sequence_parallel_rank_shape_720p(hip_lib, hd, H):
+    """BASELINE configs[3] per-rank call shape (51 x 720p latent, SP = 8): 23,014 query rows of one rank against the
+    184,112 gathered keys, 8 key segments of 23,014 (ragged last tile in every segment).  Full size on the key axis --
+    this is where a 32-bit offset would wrap (K / V^T are 0.4 GB each) -- a slice of the query rows; checked against
+    fp64 on sample rows and through the constant-V property on all of them."""
+    P, Lloc, Lq = 8, 23014, 1100
+    L, D = P * Lloc, H * hd
+    g = torch.Generator(device=DEV).manual_seed(77)
+    q = (torch.randn(1, Lq, D, device=DEV, generator=g)).to(BF)
+    k = (torch.randn(P, 1, Lloc, D, device=DEV, generator=g)).to(BF)
+    v = (torch.randn(P, 1, Lloc, D, device=DEV, generator=g)).to(BF)
+    segp = (Lloc + 63) // 64 * 64
+    vts = torch.empty(P, 1, H, hd, segp, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v.view(P, Lloc, D), vts.view(P, H, hd, segp), H, hd)
+    out = torch.empty(1, Lq, D, dtype=BF, device=DEV)
+    lse = torch.empty(1, H, Lq, dtype=torch.float32, device=DEV)
+    hip_lib.attention_fwd(q, k[0], vts, out, H, hd, hd ** -0.5, lse=lse, n_seg=P, seg_len=Lloc,
+                          k_seg_stride=k.stride(0), vt_seg_stride=vts.stride(0))
+    rows = torch.tensor([0, 31, 255, 256, 1023, 1099], device=DEV)
+    qh = q[0, rows].double().view(len(rows), H, hd).permute(1, 0, 2)                      # [H, r, hd]
+    kh = k.view(L, H, hd).double().permute(1, 2, 0)                                        # [H, hd, L]
+    s_ = (qh @ kh) * hd ** -0.5
+    ref = (torch.softmax(s_, -1) @ v.view(L, H, hd).double().permute(1, 0, 2)).permute(1, 0, 2).reshape(len(rows), D)
+    assert (out[0, rows].double() - ref).abs().max().item() <= 2.5e-2
+    assert (lse[0][:, rows].double() - torch.logsumexp(s_, -1)).abs().max().item() <= 4e-3
+    # constant V: softmax rows sum to one over all 184,112 keys, for every query row
+    c = (torch.randn(D, device=DEV, generator=g)).to(BF)
+    hip_lib.v_transpose(c[None, None].expand(P, Lloc, D).contiguous(), vts.view(P, H, hd, segp), H, hd)
+    hip_lib.attention_fwd(q, k[0], vts, out, H, hd, hd ** -0.5, n_seg=P, seg_len=Lloc,
+                          k_seg_stride=k.stride(0), vt_seg_stride=vts.stride(0))
+    assert (out.float() - c.float()[None, None]).abs().max().item() <= 2 ** -6 * c.float().abs().max().item() + 1e-3
+
+
 # ----------------------------------------------------------------------------- race screens for the asm K loops
 def _attention_determinism(hip_lib, hd):
     # ragged keys + ragged query block, several rounds of workgroups
