@@ -9,16 +9,21 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------
 // statistics: sums[b][g] = (sum x, sum x^2) over the S voxels x (C/G) channels of group g, in f64.
-// A block walks a contiguous slab of voxels; thread = (row-in-pass, 16-B channel chunk); per-thread f32
-// partials over <= a few hundred values, block reduction through LDS, one f64 atomic pair per (block, group).
+// A 1024-thread block walks a contiguous slab of voxels; thread = (row-in-pass, 16-B channel chunk); per-thread f32
+// partials, fixed-order reduction (wave shuffles, then across the 16 waves through LDS), one f64 atomic pair per
+// (block, group).  FEW, FAT blocks on purpose: all blocks add into the same 2 G addresses, and same-address f64
+// atomics retire at ~45 ns each -- with 2048 blocks per tensor that tail (~90 us) was longer than the streaming
+// itself for every tensor below ~300 MB.
 // Algorithmic bytes: 2 * S * C per batch item (read once).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_stats_kernel(const unsigned short* __restrict__ x, int64_t S, int C, int G,
-                                                      int rows_per_block, double* __restrict__ sums) {
-  __shared__ float red[2][256][8];
+constexpr int GN_NT = 1024;
+
+__global__ void __launch_bounds__(GN_NT) gn_stats_kernel(const unsigned short* __restrict__ x, int64_t S, int C, int G,
+                                                        int rows_per_block, double* __restrict__ sums) {
+  __shared__ float red[GN_NT / 64][512];
   const int b = blockIdx.y;
   const int cpr = C >> 3;            // 16-B chunks per voxel row (4..64, power of two)
-  const int rpp = 256 / cpr;         // voxel rows per pass
+  const int rpp = GN_NT / cpr;       // voxel rows per pass
   const int c = threadIdx.x % cpr, r = threadIdx.x / cpr;
   const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t row1 = row0 + rows_per_block;
@@ -27,8 +32,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const unsigned short* __r
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  // 4 independent 16-byte loads in flight per lane (a single dependent load per iteration left the kernel latency-bound
-  // at ~1.2 TB/s)
+  // 4 independent 16-byte loads in flight per lane
   int64_t row = row0 + r;
   for (; row + 3 * rpp < row1; row += 4 * rpp) {
     uint4 u[4];
@@ -49,17 +53,31 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const unsigned short* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
   }
+  // lanes of a wave that hold the same chunk are cpr apart
+  for (int o = cpr; o < 64; o <<= 1) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { red[0][threadIdx.x][j] = s[j]; red[1][threadIdx.x][j] = q[j]; }
-  __syncthreads();
-  // thread t < C handles channel t: sum over the rpp row slots
-  for (int ch = threadIdx.x; ch < C; ch += 256) {
-    const int cc = ch >> 3, j = ch & 7;
-    float a = 0.f, a2 = 0.f;
-    for (int rr = 0; rr < rpp; ++rr) {
-      a += red[0][rr * cpr + cc][j];
-      a2 += red[1][rr * cpr + cc][j];
+    for (int j = 0; j < 8; ++j) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float tot[2] = {0.f, 0.f};         // thread ch < C: the block's sums of channel ch
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (lane < cpr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = pass ? q[j] : s[j];
     }
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < GN_NT / 64; ++w) a += red[w][threadIdx.x];
+      tot[pass] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < C) {
+    const int ch = threadIdx.x;
+    float a = tot[0], a2 = tot[1];
     // channels of one group are adjacent lanes: reduce cpg = C/G lanes (power of two <= 16) by shuffles
     const int cpg = C / G;
     for (int o = cpg >> 1; o >= 1; o >>= 1) {
@@ -166,13 +184,15 @@ extern "C" int osk_groupnorm_stats_ndhwc_bf16(const void* x, int B, int64_t S, i
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, st);
   if (e != hipSuccess) return (int)e;
-  const int rpp = 256 / (C >> 3);
-  int64_t nblk = (S + 2047) / 2048;           // >= 2048 voxels per block ...
-  if (nblk > 2048) nblk = 2048;               // ... and at most 2048 blocks per batch item
-  int64_t rows = (S + nblk - 1) / nblk;
+  const int rpp = GN_NT / (C >> 3);
+  // 256 blocks per batch item (one per CU) for small tensors, 512 above 64 MB; at least one pass of the 4-deep
+  // unrolled loop per block
+  const int64_t target = S * C * 2 < (int64_t)64 << 20 ? 256 : 512;
+  int64_t rows = (S + target - 1) / target;
+  if (rows < 4 * rpp) rows = 4 * rpp;
   rows = (rows + rpp - 1) / rpp * rpp;
-  nblk = (S + rows - 1) / rows;
-  dim3 grid((unsigned)nblk, B), block(256);
+  const int64_t nblk = (S + rows - 1) / rows;
+  dim3 grid((unsigned)nblk, B), block(GN_NT);
   hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, (const unsigned short*)x, S, C, G, (int)rows, sums);
   return (int)hipGetLastError();
 }
@@ -183,11 +203,10 @@ extern "C" int osk_groupnorm_apply_ndhwc_bf16(const void* x, const double* sums,
   if (!x || !sums || !gamma || !beta || !out || B <= 0 || S <= 0 || C < 32 || C > 512 || G <= 0) return OSK_EINVAL;
   if ((C & (C - 1)) || C % G || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return OSK_EUNSUPPORTED;
   const int rpp = 256 / (C >> 3);
-  int64_t nblk = (S + 1023) / 1024;
-  if (nblk > 4096) nblk = 4096;
-  int64_t rows = (S + nblk - 1) / nblk;
+  int64_t rows = (S + 4095) / 4096;           // about 4096 blocks per batch item, >= one 4-deep unrolled pass each
+  if (rows < 4 * rpp) rows = 4 * rpp;
   rows = (rows + rpp - 1) / rpp * rpp;
-  nblk = (S + rows - 1) / rows;
+  int64_t nblk = (S + rows - 1) / rows;
   dim3 grid((unsigned)nblk, B), block(256);
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, (const unsigned short*)x, sums, gamma, beta,
                      (unsigned short*)out, S, C, G, eps, silu, (int)rows);
