@@ -17,6 +17,18 @@ PROFILE_ATTENTION = None
 _PERM = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
 
 
+def _abi_check(what: str, *conds) -> None:
+    """the argument checks of the C ABI entry points (OSK_EINVAL conditions of csrc/*.hip), so that host logic
+    exercised on the CPU cannot hand the kernels a view they would refuse on the GPU"""
+    if not all(conds):
+        raise RuntimeError(f"{what} failed: status -1 (invalid argument / unsupported shape)")
+
+
+def _al(t, nbytes: int) -> bool:
+    """data pointer alignment of a view whose storage base is allocator-aligned"""
+    return t is None or (t.storage_offset() * t.element_size()) % nbytes == 0
+
+
 def _mod_rows(t: torch.Tensor, batch_stride: int, B: int, D: int) -> torch.Tensor:
     """f32 view whose row b starts batch_stride elements after row b-1 (pointer-carrier convention of _C)."""
     if B == 1:
@@ -36,6 +48,9 @@ def gemm(a, w, bias, out, *, res=None, gate=None, gate_batch_stride=0, gelu_from
     B, L, K = a.shape
     N = w.shape[0]
     assert K % 64 == 0, "osk_gemm_bf16 requires K % 64 == 0"
+    _abi_check("osk_gemm_bf16", a.stride(2) == 1, a.stride(0) % 8 == 0, a.stride(1) % 8 == 0, w.stride(0) % 8 == 0,
+               out.stride(0) % 4 == 0, out.stride(1) % 4 == 0, _al(a, 16), _al(w, 16), _al(out, 8), _al(bias, 16),
+               gate is None or (res is not None and _al(gate, 16) and gate_batch_stride % 4 == 0 and _al(res, 8)))
     v = a.float() @ w.float().T
     if bias is not None:
         v = v + bias.float()
@@ -142,6 +157,9 @@ def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=Non
                   q_prescaled=False, kv_batches=0):
     Bq, Lq, D = q.shape
     B = kv_batches if kv_batches else Bq     # key / value batches; query batch b reads key batch b % B
+    _abi_check("osk_attention_fwd_bf16", q.stride(0) % 8 == 0, q.stride(1) % 8 == 0, k.stride(0) % 8 == 0,
+               k.stride(1) % 8 == 0, k_seg_stride % 8 == 0, vt_seg_stride % 8 == 0, out.stride(0) % 4 == 0,
+               out.stride(1) % 4 == 0, _al(q, 16), _al(k, 16), _al(vt, 16), _al(out, 8), 0 <= kv_batches <= Bq)
     if seg_len is None:
         seg_len = k.shape[1]
     seg_lp = (seg_len + 63) // 64 * 64
