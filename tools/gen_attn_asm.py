@@ -1,11 +1,12 @@
 #!/usr/bin/env python
-"""Generator of the hand-scheduled gfx950 main loop of the head_dim-72 flash-attention kernels
-(open_sora_amd/csrc/attention_asm72.hip includes the emitted attention_asm72_n{NU}_v{VAR}.inc).
+"""Generator of the hand-scheduled gfx950 main loops of the flash-attention kernels for head_dim 72
+(open_sora_amd/csrc/attention_asm72.hip includes the emitted attention_asm72_n{NU}_v{VAR}.inc) and head_dim 128
+(attention_asm128.hip, attention_asm128_n2_v{VAR}.inc); class Geometry holds what differs between the two.
 
 Why a generator: the MFMA shadow (32 cycles, ~5 issue slots) has to be filled by hand; hipcc's scheduler clusters
 the softmax VALU work behind the MFMAs and shuffles accumulators between the VGPR and AGPR halves
 (tools/isa_stream.py on attention_w64.hip shows it).  The schedule below is explicit and reproducible;
-`python tools/gen_attn_asm.py --table NU` prints it shadow by shadow.
+`python tools/gen_attn_asm.py --table NU [--hd 128]` prints it shadow by shadow.
 
 Two layouts of the same dataflow, workgroup = 256 query rows, KV tile = 64 keys:
   NU = 2: 4 waves x 64 rows (two 32-row query blocks u per wave share every K / V^T fragment), one wave per SIMD,
