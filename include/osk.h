@@ -146,6 +146,23 @@ int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_
                            float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
                            float scale, int q_prescaled, int kv_batches, void* stream);
 
+/* The same call with a caller-owned workspace (16-byte aligned, osk_attention_workspace_bytes() is always enough).
+ * A workgroup owns a CU for its whole key loop, so a launch takes ceil(units / CUs) rounds; with a workspace the
+ * work units of the last, partial round are cut into up to 8 key parts (whole key segments when n_seg > 1, runs of
+ * 64-key tiles otherwise) that fill the idle CUs, and a small merge kernel combines the parts by their LSE
+ * (head_dim 72 / 128; other head dims and workspace == NULL: exactly osk_attention_fwd_bf16).  Partials are kept in
+ * f32 and rounded to bf16 once; a split row differs from the unsplit one only through the bf16 rounding of P against
+ * the reference max of its own key part (same error bound against the exact result). */
+int64_t osk_attention_workspace_bytes(void);
+/* reporting / tests: the number of key parts (1 = no split) osk_attention_fwd_ws_bf16 would use for this launch */
+int osk_attention_tail_split_factor(int B, int H, int Lq, int n_seg, int seg_len, int hd, int64_t workspace_bytes);
+int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+                           const void* k, int64_t k_seg_stride, int64_t k_batch_stride, int64_t k_row_stride,
+                           const void* vt, int64_t vt_seg_stride,
+                           void* out, int64_t o_batch_stride, int64_t o_row_stride,
+                           float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                           float scale, int q_prescaled, int kv_batches, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* name of the device kernel osk_attention_fwd_bf16 dispatches to for (hd, seg_len) under the current
  * OSK_ATTN_VARIANT (reporting only: bench.py labels its roofline line and the rocprof stats with it). */
 const char* osk_attention_kernel_name(int hd, int seg_len);

@@ -35,6 +35,10 @@ SIGNATURES = {
     "osk_v_transpose_bf16": [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "osk_attention_fwd_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
                                _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp],
+    "osk_attention_fwd_ws_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
+                                  _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _i64, _vp],
+    "osk_attention_workspace_bytes": [],
+    "osk_attention_tail_split_factor": [_i32, _i32, _i32, _i32, _i32, _i32, _i64],
     "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
     "osk_causal_conv3d_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                      _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
@@ -54,7 +58,8 @@ def _load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name in ("osk_arch", "osk_attention_kernel_name") else _i32
+        fn.restype = (C.c_char_p if name in ("osk_arch", "osk_attention_kernel_name") else
+                      _i64 if name == "osk_attention_workspace_bytes" else _i32)
     if lib.osk_abi_version() != 1:
         raise ImportError("libosk_hip.so ABI version mismatch")
     return lib
@@ -225,11 +230,26 @@ def v_transpose(v: torch.Tensor, vt: torch.Tensor, H: int, hd: int):
 PROFILE_ATTENTION = None
 
 
+_ATTN_WS: dict = {}
+
+
+def attention_workspace(device) -> torch.Tensor:
+    """per-device workspace for the tail split of osk_attention_fwd_ws_bf16 (allocated once, reused by every launch on
+    the device's compute stream: launches are stream-ordered, the merge kernel of one has consumed it before the next)."""
+    key = str(device)
+    ws = _ATTN_WS.get(key)
+    if ws is None:
+        ws = _ATTN_WS[key] = torch.empty(lib.osk_attention_workspace_bytes(), dtype=torch.uint8, device=device)
+    return ws
+
+
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, H: int, hd: int,
                   scale: float, *, lse=None, n_seg: int = 1, seg_len: int | None = None,
-                  k_seg_stride: int = 0, vt_seg_stride: int = 0, q_prescaled: bool = False, kv_batches: int = 0):
+                  k_seg_stride: int = 0, vt_seg_stride: int = 0, q_prescaled: bool = False, kv_batches: int = 0,
+                  workspace: torch.Tensor | None = None):
     """q bf16 [B, Lq, H*hd] view; k bf16 [B, seg_len, H*hd] view of segment 0 (further segments k_seg_stride
-    elements apart); vt from v_transpose (per segment); out bf16 [B, Lq, H*hd] view."""
+    elements apart); vt from v_transpose (per segment); out bf16 [B, Lq, H*hd] view.  workspace (uint8, from
+    attention_workspace()): lets the library split the workgroups of the grid's last partial round along the keys."""
     B, Lq, _ = q.shape
     if seg_len is None:
         seg_len = k.shape[1]
@@ -237,10 +257,12 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _check(lib.osk_attention_fwd_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
-                                      k.stride(0), k.stride(1), vt.data_ptr(), vt_seg_stride, out.data_ptr(),
-                                      out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg, seg_len, hd,
-                                      scale, int(q_prescaled), kv_batches, _stream()), "osk_attention_fwd_bf16")
+    _check(lib.osk_attention_fwd_ws_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
+                                         k.stride(0), k.stride(1), vt.data_ptr(), vt_seg_stride, out.data_ptr(),
+                                         out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg, seg_len, hd,
+                                         scale, int(q_prescaled), kv_batches, _p(workspace),
+                                         0 if workspace is None else workspace.numel(), _stream()),
+           "osk_attention_fwd_ws_bf16")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))

@@ -29,8 +29,8 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  int bh, qb;
-  block_to_work(p, (p.Lq + 255) / 256, bh, qb);
+  int bh, qb, part, tail_unit;
+  const bool tail = block_to_work_split(p, (p.Lq + 255) / 256, bh, qb, part, tail_unit);
   const int b = bh / p.H, h = bh - b * p.H;
 
   // ---- LDS: zero (rows 129..159 of the V^T slots stay zero for good), ones row 128 of both V^T slots
@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
   }
   // ragged last key tile of a segment: see attention_asm72.hip (clamped K rows + validity-mask ones row)
   const int last_valid = p.seg_len - (p.tps - 1) * 64;
-  const bool ragged = last_valid < 64;
+  const KeyPart kp = key_part(p, tail, part, last_valid < 64);   // the whole key axis, or one part of a split tail unit
+  const bool ragged = kp.ragged;
   unsigned maskval = 0;
   if (lane < 32) {
     // row 128 is not swizzled ((128 >> 1) & 7 == 0): dword `lane` = columns 2 lane, 2 lane + 1 of the V^T tile,
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
     auto key_of = [](int c) { const int j = c & 15; return (c & ~15) + ((j & 3) | ((j & 4) << 1) | ((j & 8) >> 1)); };
     maskval = (key_of(c0) < last_valid ? 0x3F80u : 0u) | (key_of(c1) < last_valid ? 0x3F800000u : 0u);
   }
-  if (ragged && p.tps == 1 && tid < 32)
+  if (ragged && kp.tps == 1 && tid < 32)
     reinterpret_cast<unsigned*>(smem + OSK128_VOFF0 + HD * 128)[tid] = maskval;
   __syncthreads();
 
@@ -117,12 +118,12 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
   const unsigned onesaddr = lds_base + OSK128_VOFF0 + HD * 128 + lane * 4;   // lanes 32..63: the zero row behind it
 
   const int bkv = b % p.Bkv;
-  const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + bkv * p.kbs + h * HD));
-  const uint64_t vbase = rfl64((uint64_t)(uintptr_t)(p.vt + (int64_t)(bkv * p.H + h) * HD * p.seg_lp));
+  const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + bkv * p.kbs + h * HD + kp.k_off));
+  const uint64_t vbase = rfl64((uint64_t)(uintptr_t)(p.vt + (int64_t)(bkv * p.H + h) * HD * p.seg_lp + kp.v_off));
   const unsigned kstep = rfl((unsigned)(128 * p.krs));
   const uint64_t kjump = rfl64((uint64_t)((p.kss - (int64_t)p.tps * 64 * p.krs) * 2));
   const uint64_t vjump = rfl64((uint64_t)((p.vtss - (int64_t)p.tps * 64) * 2));
-  const unsigned tps = rfl((unsigned)p.tps), nt = rfl((unsigned)(p.n_seg * p.tps));
+  const unsigned tps = rfl((unsigned)kp.tps), nt = rfl((unsigned)kp.nt);
   const unsigned kdst = rfl(lds_base + wave * 1024), vdst = rfl(lds_base + OSK128_VOFF0 + (NW - 1 - wave) * 1024);
   const unsigned nvw = rfl((unsigned)NSLOT | (ragged ? 0u : 1u << 8) | ((ragged && wave == 0) ? 1u << 9 : 0u));
 
@@ -171,7 +172,25 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
     auto sw2 = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
     const float l_tot = __uint_as_float(sw2[0]);
     const float inv = 1.0f / l_tot;
-    if (qi[u] < p.Lq) {
+    if (tail) {
+      // part of a split tail unit: normalised partial O (f32) + log2-domain LSE -> workspace (attn_merge_kernel)
+      if (qi[u] < p.Lq) {
+        const int64_t slot = ((int64_t)tail_unit * p.tail_split + part) * 256 + (wave * 64 + u * 32 + l31);
+        float* wo = p.ws_o + slot * HD;
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d) {
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int d0 = d * 32 + qd * 8 + hi * 4;
+          {
+              *reinterpret_cast<float4*>(wo + d0) = make_float4(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv,
+                                                                 o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+            }
+          }
+        }
+        if (hi == 0) p.ws_lse[slot] = m_ref[u] + __builtin_amdgcn_logf(l_tot);
+      }
+    } else if (qi[u] < p.Lq) {
       unsigned short* orow = p.out + b * p.obs + (int64_t)qi[u] * p.ors + h * HD;
 #pragma unroll
       for (int d = 0; d < HD / 32; ++d) {
@@ -200,8 +219,9 @@ int launch_one(const AttnParams& p, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int nqb = (p.Lq + 255) / 256;
-  dim3 grid(nqb * p.B * p.H), block(64 * NW);
+  const int units = ((p.Lq + 255) / 256) * p.B * p.H;
+  const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
+  dim3 grid(units + tail_units * (p.tail_split - 1)), block(64 * NW);
   hipLaunchKernelGGL(kernel, grid, block, OSK128_SMEM, st, p);
   return (int)hipGetLastError();
 }

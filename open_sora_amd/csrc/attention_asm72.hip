@@ -37,8 +37,8 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  int bh, qb;
-  block_to_work(p, (p.Lq + 255) / 256, bh, qb);
+  int bh, qb, part, tail_unit;
+  const bool tail = block_to_work_split(p, (p.Lq + 255) / 256, bh, qb, part, tail_unit);
   const int b = bh / p.H, h = bh - b * p.H;
 
   // ---- LDS: zero (a tile slot that is never filled must hold finite data), ones row of both V^T slots,
@@ -55,7 +55,8 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   // scores), V^T is zero there (osk_v_transpose_bf16 pads), and the tile's ones row becomes a validity mask so the
   // duplicates do not count in the softmax denominator.  The mask is in the V^T tile's baked key order.
   const int last_valid = p.seg_len - (p.tps - 1) * 64;   // keys in the last tile of a segment (1..64)
-  const bool ragged = last_valid < 64;
+  const KeyPart kp = key_part(p, tail, part, last_valid < 64);   // the whole key axis, or one part of a split tail unit
+  const bool ragged = kp.ragged;
   unsigned maskval = 0;
   if (lane < 32) {
     // dword `lane` of LDS row 72: 16-byte position lane / 4 holds logical chunk (lane / 4) ^ ((72 >> 1) & 7) of the
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
     auto key_of = [](int c) { const int j = c & 15; return (c & ~15) + ((j & 3) | ((j & 4) << 1) | ((j & 8) >> 1)); };
     maskval = (key_of(c0) < last_valid ? 0x3F80u : 0u) | (key_of(c1) < last_valid ? 0x3F800000u : 0u);
   }
-  if (ragged && p.tps == 1 && tid < 32)                  // tile 0 itself is ragged: no loop body precedes it
+  if (ragged && kp.tps == 1 && tid < 32)                 // tile 0 itself is ragged: no loop body precedes it
     reinterpret_cast<unsigned*>(smem + OSK72_VOFF0 + HD * 128)[tid] = maskval;
   __syncthreads();
 
@@ -146,12 +147,12 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   const unsigned onesaddr = lds_base + OSK72_VOFF0 + HD * 128 + lane * 4;   // lanes 32..63: the zero row behind it
 
   const int bkv = b % p.Bkv;   // key / value batch of this query batch
-  const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + bkv * p.kbs + h * HD));
-  const uint64_t vbase = rfl64((uint64_t)(uintptr_t)(p.vt + (int64_t)(bkv * p.H + h) * HD * p.seg_lp));
+  const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + bkv * p.kbs + h * HD + kp.k_off));
+  const uint64_t vbase = rfl64((uint64_t)(uintptr_t)(p.vt + (int64_t)(bkv * p.H + h) * HD * p.seg_lp + kp.v_off));
   const unsigned kstep = rfl((unsigned)(128 * p.krs));
   const uint64_t kjump = rfl64((uint64_t)((p.kss - (int64_t)p.tps * 64 * p.krs) * 2));
   const uint64_t vjump = rfl64((uint64_t)((p.vtss - (int64_t)p.tps * 64) * 2));
-  const unsigned tps = rfl((unsigned)p.tps), nt = rfl((unsigned)(p.n_seg * p.tps));
+  const unsigned tps = rfl((unsigned)kp.tps), nt = rfl((unsigned)kp.nt);
   const unsigned kdst = rfl(lds_base + wave * 1024), vdst = rfl(lds_base + OSK72_VOFF0 + (NW - 1 - wave) * 1024);
   // valid loader slots of this wave: the last one only where its instruction index is < 9
   const unsigned nkw = rfl(wave + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1));
@@ -222,7 +223,25 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
     auto sw2 = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
     const float l_tot = __uint_as_float(sw2[0]);
     const float inv = 1.0f / l_tot;
-    if (qi[u] < p.Lq) {
+    if (tail) {
+      // part of a split tail unit: normalised partial O (f32) + log2-domain LSE -> workspace (attn_merge_kernel)
+      if (qi[u] < p.Lq) {
+        const int64_t slot = ((int64_t)tail_unit * p.tail_split + part) * 256 + (wave * (32 * NU) + u * 32 + l31);
+        float* wo = p.ws_o + slot * HD;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int d0 = d * 32 + qd * 8 + hi * 4;
+          if (d0 < HD) {
+              *reinterpret_cast<float4*>(wo + d0) = make_float4(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv,
+                                                                 o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+            }
+          }
+        }
+        if (hi == 0) p.ws_lse[slot] = m_ref[u] + __builtin_amdgcn_logf(l_tot);
+      }
+    } else if (qi[u] < p.Lq) {
       unsigned short* orow = p.out + b * p.obs + (int64_t)qi[u] * p.ors + h * HD;
 #pragma unroll
       for (int d = 0; d < NDT; ++d) {
@@ -253,8 +272,9 @@ int launch_one(const AttnParams& p, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int nqb = (p.Lq + 255) / 256;
-  dim3 grid(nqb * p.B * p.H), block(64 * (8 / NU));
+  const int units = ((p.Lq + 255) / 256) * p.B * p.H;
+  const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
+  dim3 grid(units + tail_units * (p.tail_split - 1)), block(64 * (8 / NU));
   hipLaunchKernelGGL(kernel, grid, block, OSK72_SMEM, st, p);
   return (int)hipGetLastError();
 }

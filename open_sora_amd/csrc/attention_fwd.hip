@@ -684,10 +684,13 @@ int launch(const AttnParams& p, hipStream_t st) {
         const int v = attn_variant();
         // 5 / 6: 4 waves x 64 rows production / experimental body; 7 / 8: 8 waves x 32 rows production / experimental
         const int nu = (v == 7 || v == 8) ? 1 : 2, var = (v == 6 || v == 8) ? 1 : 0;
-        return osk_attn::launch_asm72(p, v == -1 ? OSK_ATTN_DEFAULT_NU : nu, var, st);
+        const int rc = osk_attn::launch_asm72(p, v == -1 ? OSK_ATTN_DEFAULT_NU : nu, var, st);
+        return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, HD, st);
       }
-      if (HD == 128 && attn_variant() < 7)   // head_dim 128 has the 4 waves x 64 rows layout only
-        return osk_attn::launch_asm128(p, attn_variant() == 6 ? 1 : 0, st);
+      if (HD == 128 && attn_variant() < 7) {   // head_dim 128 has the 4 waves x 64 rows layout only
+        const int rc = osk_attn::launch_asm128(p, attn_variant() == 6 ? 1 : 0, st);
+        return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, HD, st);
+      }
       break;
     case 3: return osk_attn::launch_w64(p, HD, 0, st);
     case 4: return osk_attn::launch_w64(p, HD, 1, st);
@@ -701,12 +704,129 @@ int launch(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
+namespace osk_attn {
+namespace {
+
+// combine the key parts of the split tail units: out = sum_p 2^(lse_p - lse) O_p, lse = log2 sum_p 2^lse_p.
+// One block per tail unit, one thread per query row; a few MB in all.
+template <int HD>
+__global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
+  const int nqb = (p.Lq + 255) / 256;
+  int bh, qb;
+  unit_to_work(p, nqb, p.tail_first + (int)blockIdx.x, bh, qb);
+  const int row = qb * 256 + threadIdx.x;
+  if (row >= p.Lq) return;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int S = p.tail_split;
+  const int64_t slot0 = (int64_t)blockIdx.x * S * 256 + threadIdx.x;
+  float m = -INFINITY;
+  for (int s = 0; s < S; ++s) m = fmaxf(m, p.ws_lse[slot0 + s * 256]);
+  float wgt[8], tot = 0.f;
+  for (int s = 0; s < S; ++s) { wgt[s] = exp2f(p.ws_lse[slot0 + s * 256] - m); tot += wgt[s]; }
+  const float inv = 1.0f / tot;
+  unsigned short* orow = p.out + b * p.obs + (int64_t)row * p.ors + h * HD;
+  for (int d = 0; d < HD; d += 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(p.ws_o + (slot0 + s * 256) * HD + d);
+      acc.x += wgt[s] * v.x; acc.y += wgt[s] * v.y; acc.z += wgt[s] * v.z; acc.w += wgt[s] * v.w;
+    }
+    uint2 w2;
+    w2.x = pack_bf16x2(acc.x * inv, acc.y * inv);
+    w2.y = pack_bf16x2(acc.z * inv, acc.w * inv);
+    *reinterpret_cast<uint2*>(orow + d) = w2;
+  }
+  if (p.lse) p.lse[(int64_t)bh * p.Lq + row] = (m + log2f(tot)) * 0.6931471805599453f;
+}
+
+int device_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      v = 256;
+    return v > 0 ? v : 256;
+  }();
+  return n;
+}
+
+}  // namespace
+
+// A workgroup owns a CU for its whole key loop, so a launch takes ceil(units / CUs) rounds and the last round may run
+// a fraction of the chip (3168 units on 256 CUs: 12.4 -> 13; sequence-parallel ranks: 1.7 -> 2, 3.2 -> 4).  With a
+// workspace the units of that last round are cut into `s` key parts (whole key segments when there are several,
+// else runs of 64-key tiles) so that the round costs ceil(R s / CUs) / s instead of 1; only those units pay the
+// partial-result traffic.  s <= 8, chosen to minimise that cost; no split when it saves < 15 % of a round.
+void split_tail(AttnParams& p, int units, int hd, void* workspace, int64_t workspace_bytes) {
+  p.tail_split = 1;
+  p.tail_first = 0x7fffffff;
+  const int v = attn_variant();
+  if (!workspace || !(v == -1 || (v >= 5 && v <= 8))) return;   // the hand-scheduled kernels only
+  static const int enable = env_int("OSK_ATTN_TAILSPLIT", 1);
+  if (!enable) return;
+  const int cus = device_cus();
+  const int R = units % cus;
+  if (R == 0) return;
+  auto cost = [&](int s) { return (double)((R * s + cus - 1) / cus) / s; };
+  int best = 1;
+  for (int s = 2; s <= 8; ++s) {
+    if (p.n_seg > 1 ? (p.n_seg % s != 0) : (s > p.tps)) continue;
+    const int64_t need = (int64_t)R * s * 256 * (hd + 1) * 4;
+    if (need > workspace_bytes) continue;
+    if (cost(s) < cost(best) - 1e-9) best = s;
+  }
+  if (cost(1) - cost(best) < 0.15) return;
+  p.tail_split = best;
+  p.tail_first = units - R;
+  p.ws_o = (float*)workspace;
+  p.ws_lse = p.ws_o + (int64_t)R * best * 256 * hd;
+}
+
+int launch_merge(const AttnParams& p, int hd, hipStream_t st) {
+  const int units = ((p.Lq + 255) / 256) * p.B * p.H;
+  dim3 grid(units - p.tail_first), block(256);
+  if (hd == 72) hipLaunchKernelGGL(attn_merge_kernel<72>, grid, block, 0, st, p);
+  else if (hd == 128) hipLaunchKernelGGL(attn_merge_kernel<128>, grid, block, 0, st, p);
+  else return OSK_EUNSUPPORTED;
+  return (int)hipGetLastError();
+}
+
+}  // namespace osk_attn
+
+extern "C" int osk_attention_tail_split_factor(int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                                               int64_t workspace_bytes) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || n_seg <= 0 || seg_len <= 0 || (hd != 72 && hd != 128)) return 1;
+  osk_attn::AttnParams p{};
+  p.B = B; p.H = H; p.Lq = Lq; p.n_seg = n_seg; p.seg_len = seg_len;
+  p.seg_lp = (seg_len + 63) / 64 * 64;
+  p.tps = p.seg_lp / 64;
+  static char dummy[16] __attribute__((aligned(16)));
+  osk_attn::split_tail(p, ((Lq + 255) / 256) * B * H, hd, dummy, workspace_bytes);
+  return p.tail_split;
+}
+
+extern "C" int64_t osk_attention_workspace_bytes(void) {
+  // enough for 512 key parts (two rounds of a 256-CU chip) of 256 rows at head_dim 128: partial O + LSE in f32
+  return (int64_t)512 * 256 * (128 + 1) * 4;
+}
+
 extern "C" int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
                                       const void* k, int64_t k_seg_stride, int64_t k_batch_stride,
                                       int64_t k_row_stride, const void* vt, int64_t vt_seg_stride,
                                       void* out, int64_t o_batch_stride, int64_t o_row_stride,
                                       float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
                                       float scale, int q_prescaled, int kv_batches, void* stream) {
+  return osk_attention_fwd_ws_bf16(q, q_batch_stride, q_row_stride, k, k_seg_stride, k_batch_stride, k_row_stride, vt,
+                                   vt_seg_stride, out, o_batch_stride, o_row_stride, lse, B, H, Lq, n_seg, seg_len, hd,
+                                   scale, q_prescaled, kv_batches, nullptr, 0, stream);
+}
+
+extern "C" int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+                                         const void* k, int64_t k_seg_stride, int64_t k_batch_stride,
+                                         int64_t k_row_stride, const void* vt, int64_t vt_seg_stride,
+                                         void* out, int64_t o_batch_stride, int64_t o_row_stride,
+                                         float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                                         float scale, int q_prescaled, int kv_batches, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
   if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Lq <= 0 || n_seg <= 0 || seg_len <= 0) return OSK_EINVAL;
   if ((q_batch_stride & 7) || (q_row_stride & 7) || (k_seg_stride & 7) || (k_batch_stride & 7) ||
       (k_row_stride & 7) || (vt_seg_stride & 7) || (o_batch_stride & 3) || (o_row_stride & 3))
@@ -725,6 +845,8 @@ extern "C" int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int
   if (kv_batches < 0 || kv_batches > B) return OSK_EINVAL;
   p.Bkv = kv_batches > 0 ? kv_batches : B;
   p.map = attn_map();
+  if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 0)) return OSK_EINVAL;
+  if (hd == 72 || hd == 128) osk_attn::split_tail(p, ((Lq + 255) / 256) * B * H, hd, workspace, workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   switch (hd) {
     case 64: return launch<64>(p, st);

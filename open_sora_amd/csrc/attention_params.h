@@ -19,6 +19,12 @@ struct AttnParams {
   int q_prescaled;
   int Bkv;    // key / value batches: query batch b reads key batch b % Bkv
   int map;    // block -> (head, query block) order: 0 = heads fastest, 1 = XCD-contiguous, query blocks fastest
+  // tail split (hand-scheduled kernels only; see split_tail()): the workgroups of the last, partial round of the grid
+  // -- work units >= tail_first in launch order -- are cut into tail_split parts along the key axis; a part writes its
+  // normalised partial O (f32) and its log2-domain LSE into the workspace and attn_merge_kernel combines them
+  int tail_first = 0x7fffffff, tail_split = 1;
+  float* ws_o = nullptr;
+  float* ws_lse = nullptr;
 };
 
 // (batch*head, query block) of a workgroup.  map 1 hands every XCD (block b runs on XCD b % 8) a contiguous
@@ -35,6 +41,65 @@ OSK_DEV void block_to_work(const AttnParams& p, int nqb, int& bh, int& qb) {
     qb = blockIdx.x / nbh;
   }
 }
+
+// work unit index (launch order) -> (batch*head, query block)
+OSK_DEV void unit_to_work(const AttnParams& p, int nqb, int unit, int& bh, int& qb) {
+  const int nbh = p.B * p.H;
+  if (p.map == 1) {
+    const int w = xcd_remap(unit, nqb * nbh);
+    bh = w / nqb;
+    qb = w - bh * nqb;
+  } else {
+    bh = unit % nbh;
+    qb = unit / nbh;
+  }
+}
+
+// block -> work unit (+ key part of a split tail unit).  Returns true for a part of a split unit; tail_unit = its index
+// among the tail units (workspace slot).
+OSK_DEV bool block_to_work_split(const AttnParams& p, int nqb, int& bh, int& qb, int& part, int& tail_unit) {
+  int unit = blockIdx.x;
+  part = 0;
+  tail_unit = 0;
+  const bool tail = p.tail_split > 1 && unit >= p.tail_first;
+  if (tail) {
+    const int j = unit - p.tail_first;
+    tail_unit = j / p.tail_split;
+    part = j - tail_unit * p.tail_split;
+    unit = p.tail_first + tail_unit;
+  }
+  unit_to_work(p, nqb, unit, bh, qb);
+  return tail;
+}
+
+// key range of a part: element offsets of its first tile into K and V^T, its tile counts, whether it ends in the ragged tile
+struct KeyPart {
+  int64_t k_off, v_off;
+  int tps, nt;
+  bool ragged;
+};
+OSK_DEV KeyPart key_part(const AttnParams& p, bool tail, int part, bool ragged) {
+  KeyPart r{0, 0, p.tps, p.n_seg * p.tps, ragged};
+  if (tail) {
+    if (p.n_seg > 1) {   // whole key segments per part (tail_split divides n_seg)
+      const int per = p.n_seg / p.tail_split;
+      r.k_off = (int64_t)part * per * p.kss;
+      r.v_off = (int64_t)part * per * p.vtss;
+      r.nt = per * p.tps;
+    } else {             // a run of tiles of the single segment; only the last part ends in the (possibly ragged) last tile
+      const int t0 = part * p.tps / p.tail_split, t1 = (part + 1) * p.tps / p.tail_split;
+      r.k_off = (int64_t)t0 * 64 * p.krs;
+      r.v_off = (int64_t)t0 * 64;
+      r.tps = r.nt = t1 - t0;
+      r.ragged = ragged && part == p.tail_split - 1;
+    }
+  }
+  return r;
+}
+
+// host: decide the tail split of a launch of `units` work units given the workspace (attention_fwd.hip)
+void split_tail(AttnParams& p, int units, int hd, void* workspace, int64_t workspace_bytes);
+int launch_merge(const AttnParams& p, int hd, hipStream_t st);
 
 // attention_w64.hip: 4 waves x 64 query rows, one wave per SIMD, LDS-DMA staged K / V^T
 int launch_w64(const AttnParams& p, int hd, int hints, hipStream_t st);

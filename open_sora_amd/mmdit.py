@@ -450,7 +450,7 @@ def q_mult(hd: int) -> float:
 def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd: int):
     """attention() of math.py:22-36 on the joint [txt;img] sequence; the output overwrites the (dead) v slot."""
     _OPS.v_transpose(v, ws.vt, H, hd)
-    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5, q_prescaled=True)
+    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=_OPS.attention_workspace(q.device))
 
 
 def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: int, col_txt: int, rope: _RopeTable,

@@ -110,7 +110,8 @@ class SeqPar:
         wv.wait()
         B, Lloc, D = q.shape
         mmdit.ops().attention_fwd(q, k_all[0], vt_all, out, H, hd, hd ** -0.5, n_seg=self.P, seg_len=Lloc,
-                                  k_seg_stride=k_all.stride(0), vt_seg_stride=vt_all.stride(0), q_prescaled=True)
+                                  k_seg_stride=k_all.stride(0), vt_seg_stride=vt_all.stride(0), q_prescaled=True,
+                                  workspace=mmdit.ops().attention_workspace(q.device))
 
     # ------------------------------------------------------------------ head-parallel exchange (all-to-all)
     def _heads_buffers(self, B: int, Lloc: int, H: int, hd: int, device):
@@ -153,7 +154,8 @@ class SeqPar:
         ops.v_transpose(bufs["vr"].view(P * B, Lloc, Hg * hd), vt.view(P * B, Hg, hd, vt.shape[-1]), Hg, hd)
         ops.attention_fwd(bufs["qr"].view(P * B, Lloc, Hg * hd), bufs["kr"][0], vt, bufs["os"].view(P * B, Lloc, Hg * hd),
                           Hg, hd, hd ** -0.5, n_seg=P, seg_len=Lloc, k_seg_stride=bufs["kr"].stride(0),
-                          vt_seg_stride=vt.stride(0), q_prescaled=True, kv_batches=B)
+                          vt_seg_stride=vt.stride(0), q_prescaled=True, kv_batches=B,
+                          workspace=ops.attention_workspace(q.device))
         # chunk s of the output belongs to rank s's tokens: straight back, then head groups side by side
         dist.all_to_all_single(bufs["orr"].view(-1), bufs["os"].view(-1), group=self.group)
         out.view(B, Lloc, P, D // P).permute(2, 0, 1, 3).copy_(bufs["orr"])

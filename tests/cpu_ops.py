@@ -153,8 +153,12 @@ def v_transpose(v, vt, H, hd):
     vt.copy_(pad[:, pos2key].permute(0, 2, 3, 1))
 
 
+def attention_workspace(device):
+    return torch.empty(16, dtype=torch.uint8, device=device)
+
+
 def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=None, k_seg_stride=0, vt_seg_stride=0,
-                  q_prescaled=False, kv_batches=0):
+                  q_prescaled=False, kv_batches=0, workspace=None):
     Bq, Lq, D = q.shape
     B = kv_batches if kv_batches else Bq     # key / value batches; query batch b reads key batch b % B
     _abi_check("osk_attention_fwd_bf16", q.stride(0) % 8 == 0, q.stride(1) % 8 == 0, k.stride(0) % 8 == 0,

@@ -570,3 +570,59 @@ def test_errors_raise(hip_lib):
     out = torch.zeros(1, 8, 16, dtype=BF, device=DEV)
     with pytest.raises(RuntimeError):
         hip_lib.gemm(a, w, None, out)  # K % 64 != 0
+
+
+# ----------------------------------------------------------------------------- tail split (workspace variant)
+@pytest.mark.parametrize("hd", [72, 128])
+@pytest.mark.parametrize("case", ["one_segment_ragged", "few_units", "segments", "shared_key_batches", "one_tile_per_part"])
+def test_attention_tail_split_matches_unsplit(hip_lib, hd, case):
+    """osk_attention_fwd_ws_bf16: the work units of the grid's last partial round are cut into key parts and merged by
+    LSE.  Same inputs with and without the workspace: a split row sees its P values rounded to bf16 against the
+    reference max of its own key part instead of the global one, so the two results differ at the kernel's own
+    rounding level (a fraction of its 2.5e-2 bound against fp64), nowhere more; LSE within 1e-3; the split really
+    happens (osk_attention_tail_split_factor > 1)."""
+    kw, Bkv = {}, None
+    if case == "one_segment_ragged":      # 272 units on 256 CUs: 16 tail units x 8 parts of 2 tiles (last one ragged)
+        B, H, Lq, Lk, n_seg = 1, 17, 4096, 1000, 1
+    elif case == "few_units":             # the whole launch is a tail: 32 units x 8 parts
+        B, H, Lq, Lk, n_seg = 1, 4, 2048, 4133, 1
+    elif case == "segments":              # 4 ragged key segments: parts = whole segments
+        B, H, Lq, Lk, n_seg = 2, 9, 4000, 400, 4
+    elif case == "shared_key_batches":    # head-parallel sequence-parallel call shape: 6 query batches share 2 key sets
+        B, H, Lq, Lk, n_seg, Bkv = 6, 3, 4000, 512, 2, 2
+    else:                                 # parts of a single tile each, ragged last one
+        B, H, Lq, Lk, n_seg = 1, 17, 4096, 100 + 64 * 3, 1
+    D = H * hd
+    seg = Lk // n_seg
+    q = rnd("q", (B, Lq, D), seed=101)
+    nb = Bkv or B
+    k = rnd("k", (n_seg, nb, seg, D), seed=102)
+    v = rnd("v", (n_seg, nb, seg, D), seed=103)
+    segp = (seg + 63) // 64 * 64
+    vts = torch.empty(n_seg, nb, H, hd, segp, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v.view(n_seg * nb, seg, D), vts.view(n_seg * nb, H, hd, segp), H, hd)
+    args = dict(n_seg=n_seg, seg_len=seg, k_seg_stride=k.stride(0), vt_seg_stride=vts.stride(0), kv_batches=Bkv or 0)
+    ws = hip_lib.attention_workspace(q.device)
+    assert hip_lib.lib.osk_attention_tail_split_factor(B, H, Lq, n_seg, seg, hd, ws.numel()) > 1
+    outs, lses = [], []
+    for w in (None, ws):
+        o = torch.empty(B, Lq, D, dtype=BF, device=DEV)
+        l = torch.empty(B, H, Lq, dtype=torch.float32, device=DEV)
+        hip_lib.attention_fwd(q, k[0], vts, o, H, hd, hd ** -0.5, lse=l, workspace=w, **args)
+        outs.append(o.float())
+        lses.append(l)
+    d = (outs[0] - outs[1]).abs()
+    assert d.max().item() <= 1.2e-2, d.max().item()
+    rel = (d.double().norm() / outs[0].double().norm()).item()
+    assert rel <= 5e-3, rel
+    assert (lses[0] - lses[1]).abs().max().item() <= 1e-3
+    # and both against fp64 on sample rows of the last query block (a tail unit)
+    rows = torch.tensor([Lq - 1, Lq - 77, Lq - 200], device=DEV)
+    kk = k.permute(1, 0, 2, 3).reshape(nb, n_seg * seg, H, hd).double()
+    vv = v.permute(1, 0, 2, 3).reshape(nb, n_seg * seg, H, hd).double()
+    for b in range(B):
+        qh = q[b, rows].double().view(len(rows), H, hd).permute(1, 0, 2)
+        s_ = (qh @ kk[b % nb].permute(1, 2, 0)) * hd ** -0.5
+        ref = (torch.softmax(s_, -1) @ vv[b % nb].permute(1, 0, 2)).permute(1, 0, 2).reshape(len(rows), D)
+        for o in outs:
+            assert (o[b, rows].double() - ref).abs().max().item() <= 2.5e-2

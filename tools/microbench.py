@@ -68,6 +68,11 @@ def bench_attn(B, H, L, hd, tag):
     ms = timeit(lambda: _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5), iters=5, warm=2)
     emit(kernel="attention_fwd", tag=tag, B=B, H=H, L=L, hd=hd, ms=round(ms, 4),
          tflops=round(4.0 * B * H * L * L * hd / ms / 1e9, 1))
+    ws = _C.attention_workspace(q.device)
+    ms = timeit(lambda: _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5, workspace=ws), iters=5, warm=2)
+    emit(kernel="attention_fwd+tailsplit", tag=tag, B=B, H=H, L=L, hd=hd, ms=round(ms, 4),
+         tflops=round(4.0 * B * H * L * L * hd / ms / 1e9, 1),
+         parts=_C.lib.osk_attention_tail_split_factor(B, H, L, 1, L, hd, ws.numel()))
     ms = timeit(lambda: _C.v_transpose(v, vt, H, hd))
     emit(kernel="v_transpose", tag=tag, ms=round(ms, 4), gbps=round(4.0 * B * L * D / ms / 1e6, 1))
 
