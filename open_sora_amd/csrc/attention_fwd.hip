@@ -708,35 +708,37 @@ namespace osk_attn {
 namespace {
 
 // combine the key parts of the split tail units: out = sum_p 2^(lse_p - lse) O_p, lse = log2 sum_p 2^lse_p.
-// One block per tail unit, one thread per query row; a few MB in all.
+// grid (tail units, 4): a block owns 64 query rows; thread = (row, 16-byte chunk of the head dim), so the partial rows
+// -- contiguous [row][hd] f32 in the workspace -- are read as one linear stream per part.  A few tens of MB in all.
 template <int HD>
 __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
+  constexpr int CPR = HD / 4;                    // float4 chunks per row
   const int nqb = (p.Lq + 255) / 256;
   int bh, qb;
   unit_to_work(p, nqb, p.tail_first + (int)blockIdx.x, bh, qb);
-  const int row = qb * 256 + threadIdx.x;
-  if (row >= p.Lq) return;
   const int b = bh / p.H, h = bh - b * p.H;
   const int S = p.tail_split;
-  const int64_t slot0 = (int64_t)blockIdx.x * S * 256 + threadIdx.x;
-  float m = -INFINITY;
-  for (int s = 0; s < S; ++s) m = fmaxf(m, p.ws_lse[slot0 + s * 256]);
-  float wgt[8], tot = 0.f;
-  for (int s = 0; s < S; ++s) { wgt[s] = exp2f(p.ws_lse[slot0 + s * 256] - m); tot += wgt[s]; }
-  const float inv = 1.0f / tot;
-  unsigned short* orow = p.out + b * p.obs + (int64_t)row * p.ors + h * HD;
-  for (int d = 0; d < HD; d += 4) {
+  for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
+    const int r = blockIdx.y * 64 + i / CPR, c = i % CPR;
+    const int row = qb * 256 + r;
+    if (row >= p.Lq) continue;
+    const int64_t slot0 = (int64_t)blockIdx.x * S * 256 + r;
+    float l[8], m = -INFINITY;
+    for (int s = 0; s < S; ++s) { l[s] = p.ws_lse[slot0 + s * 256]; m = fmaxf(m, l[s]); }
+    float tot = 0.f;
+    for (int s = 0; s < S; ++s) { l[s] = exp2f(l[s] - m); tot += l[s]; }
+    const float inv = 1.0f / tot;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < S; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(p.ws_o + (slot0 + s * 256) * HD + d);
-      acc.x += wgt[s] * v.x; acc.y += wgt[s] * v.y; acc.z += wgt[s] * v.z; acc.w += wgt[s] * v.w;
+      const float4 v = *reinterpret_cast<const float4*>(p.ws_o + (slot0 + s * 256) * HD + c * 4);
+      acc.x += l[s] * v.x; acc.y += l[s] * v.y; acc.z += l[s] * v.z; acc.w += l[s] * v.w;
     }
     uint2 w2;
     w2.x = pack_bf16x2(acc.x * inv, acc.y * inv);
     w2.y = pack_bf16x2(acc.z * inv, acc.w * inv);
-    *reinterpret_cast<uint2*>(orow + d) = w2;
+    *reinterpret_cast<uint2*>(p.out + b * p.obs + (int64_t)row * p.ors + h * HD + c * 4) = w2;
+    if (p.lse && c == 0) p.lse[(int64_t)bh * p.Lq + row] = (m + log2f(tot)) * 0.6931471805599453f;
   }
-  if (p.lse) p.lse[(int64_t)bh * p.Lq + row] = (m + log2f(tot)) * 0.6931471805599453f;
 }
 
 int device_cus() {
@@ -783,7 +785,7 @@ void split_tail(AttnParams& p, int units, int hd, void* workspace, int64_t works
 
 int launch_merge(const AttnParams& p, int hd, hipStream_t st) {
   const int units = ((p.Lq + 255) / 256) * p.B * p.H;
-  dim3 grid(units - p.tail_first), block(256);
+  dim3 grid(units - p.tail_first, 4), block(256);
   if (hd == 72) hipLaunchKernelGGL(attn_merge_kernel<72>, grid, block, 0, st, p);
   else if (hd == 128) hipLaunchKernelGGL(attn_merge_kernel<128>, grid, block, 0, st, p);
   else return OSK_EUNSUPPORTED;
