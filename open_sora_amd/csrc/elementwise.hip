@@ -234,14 +234,19 @@ __global__ void __launch_bounds__(256) qknorm_rope_rows_kernel(
     const int which = q && k ? (int)blockIdx.y : (k ? 1 : 0);
     unsigned short* tb = which ? k : q;
     __syncthreads();                       // staging visible
-    for (int c = tid; c < tpb * span_chunks; c += 256) {
-      const int t = c / span_chunks, w = c - t * span_chunks;
-      int64_t tok = tok0 + t;
-      tok = tok < ntok ? tok : ntok - 1;
-      const int l = (int)(tok % L), b = (int)(tok / L);
-      const uint4 u = *reinterpret_cast<const uint4*>(tb + b * bs + (int64_t)l * rs + w * 8);
-      const int row = t * H + w / CPR, cir = w % CPR;
-      *reinterpret_cast<uint4*>(s_rows + row * RS + cir * 16) = u;
+    // copy loops: TPT = 256 / tpb consecutive threads walk ONE token's span (TPT x 16 contiguous bytes per step), so the
+    // token -> (batch, position) division happens once per thread instead of once per 16-byte chunk
+    const int tpt = 256 / tpb;
+    const int ct = tid / tpt, cj = tid - ct * tpt;
+    int64_t ctok = tok0 + ct;
+    const bool cvalid = ct < tpb && ctok < ntok;
+    ctok = ctok < ntok ? ctok : ntok - 1;
+    unsigned short* cspan = tb + (ctok / L) * bs + (ctok % L) * rs;
+    if (ct < tpb) {
+      for (int w = cj; w < span_chunks; w += tpt) {
+        const uint4 u = *reinterpret_cast<const uint4*>(cspan + w * 8);
+        *reinterpret_cast<uint4*>(s_rows + (ct * H + w / CPR) * RS + (w % CPR) * 16) = u;
+      }
     }
     __syncthreads();
     if (r < rows) {
@@ -292,14 +297,10 @@ __global__ void __launch_bounds__(256) qknorm_rope_rows_kernel(
       for (int c = 0; c < CPR; ++c) *reinterpret_cast<uint4*>(s_rows + r * RS + c * 16) = pack8(v + c * 8);
     }
     __syncthreads();
-    for (int c = tid; c < tpb * span_chunks; c += 256) {
-      const int t = c / span_chunks, w = c - t * span_chunks;
-      const int64_t tok = tok0 + t;
-      if (tok >= ntok) continue;
-      const int l = (int)(tok % L), b = (int)(tok / L);
-      const int row = t * H + w / CPR, cir = w % CPR;
-      *reinterpret_cast<uint4*>(tb + b * bs + (int64_t)l * rs + w * 8) =
-          *reinterpret_cast<const uint4*>(s_rows + row * RS + cir * 16);
+    if (cvalid) {
+      for (int w = cj; w < span_chunks; w += tpt)
+        *reinterpret_cast<uint4*>(cspan + w * 8) =
+            *reinterpret_cast<const uint4*>(s_rows + (ct * H + w / CPR) * RS + (w % CPR) * 16);
     }
   }
   (void)rvalid;
