@@ -163,6 +163,25 @@ int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_r
                            float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
                            float scale, int q_prescaled, int kv_batches, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- fp8 P.V variant of the attention (opt-in fp8 mode, BASELINE configs[4]; head_dim 72 / 128): QK^T, the softmax and
+ * the output as osk_attention_fwd_ws_bf16, but P (<= 2^8 by construction) and V^T are OCP e4m3 and a 64-key tile's P.V
+ * is one v_mfma_f32_32x32x64_f8f6f4 per O^T row tile.
+ * osk_v_transpose_fp8: V bf16 [B, L, H*hd] view -> vt8 e4m3 bytes [B, H, RP, Lp], RP = (hd + 1) rounded up to 16
+ *   (80 / 144), Lp = L rounded up to 64: rows 0..hd-1 = clamp(V / scales[b*H + h]) in the key order the kernel's
+ *   accumulator layout dictates, row hd = 1.0 for keys < L else 0 (softmax denominator / key validity), further rows 0.
+ *   scales f32 [B, H] (device memory; typically absmax over the head / 448, computed by the caller).
+ * osk_attention_fwd_pv8_bf16: vt8 from the call above (per key segment, vt8_seg_stride in BYTES), v_scale = the same
+ *   scales indexed by (key batch, head); everything else as osk_attention_fwd_ws_bf16. */
+int osk_v_transpose_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, const float* scales, void* vt8,
+                        int B, int L, int H, int hd, void* stream);
+int osk_attention_fwd_pv8_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+                               const void* k, int64_t k_seg_stride, int64_t k_batch_stride, int64_t k_row_stride,
+                               const void* vt8, int64_t vt8_seg_stride, const float* v_scale,
+                               void* out, int64_t o_batch_stride, int64_t o_row_stride,
+                               float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                               float scale, int q_prescaled, int kv_batches, void* workspace, int64_t workspace_bytes,
+                               void* stream);
+
 /* name of the device kernel osk_attention_fwd_bf16 dispatches to for (hd, seg_len) under the current
  * OSK_ATTN_VARIANT (reporting only: bench.py labels its roofline line and the rocprof stats with it). */
 const char* osk_attention_kernel_name(int hd, int seg_len);

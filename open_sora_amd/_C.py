@@ -38,6 +38,9 @@ SIGNATURES = {
     "osk_attention_fwd_ws_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
                                   _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _i64, _vp],
     "osk_attention_workspace_bytes": [],
+    "osk_v_transpose_fp8": [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "osk_attention_fwd_pv8_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp,
+                                   _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _i64, _vp],
     "osk_attention_tail_split_factor": [_i32, _i32, _i32, _i32, _i32, _i32, _i64],
     "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
     "osk_causal_conv3d_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
@@ -263,6 +266,45 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
                                          scale, int(q_prescaled), kv_batches, _p(workspace),
                                          0 if workspace is None else workspace.numel(), _stream()),
            "osk_attention_fwd_ws_bf16")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1))
+    return out
+
+
+def vt8_rows(hd: int) -> int:
+    """rows per head of the e4m3 V^T tensor: hd dims + the ones row, rounded up to 16"""
+    return (hd + 1 + 15) // 16 * 16
+
+
+def v_transpose_fp8(v: torch.Tensor, scales: torch.Tensor, vt8: torch.Tensor, H: int, hd: int) -> torch.Tensor:
+    """v bf16 [B, L, H*hd] view, scales f32 [B, H] -> vt8 uint8 [B, H, vt8_rows(hd), Lp] (e4m3 bytes, kernel key order)."""
+    B, L, _ = v.shape
+    assert vt8.dtype == torch.uint8 and vt8.is_contiguous() and vt8.shape[-2] == vt8_rows(hd)
+    assert scales.dtype == torch.float32 and scales.is_contiguous() and scales.numel() == B * H
+    _check(lib.osk_v_transpose_fp8(v.data_ptr(), v.stride(0), v.stride(1), scales.data_ptr(), vt8.data_ptr(), B, L, H, hd,
+                                   _stream()), "osk_v_transpose_fp8")
+    return vt8
+
+
+def attention_fwd_pv8(q: torch.Tensor, k: torch.Tensor, vt8: torch.Tensor, v_scale: torch.Tensor, out: torch.Tensor,
+                      H: int, hd: int, scale: float, *, lse=None, n_seg: int = 1, seg_len: int | None = None,
+                      k_seg_stride: int = 0, vt_seg_stride: int = 0, q_prescaled: bool = False, kv_batches: int = 0,
+                      workspace: torch.Tensor | None = None):
+    """attention_fwd with the P.V product on the fp8 MFMA: vt8 / v_scale from v_transpose_fp8 (vt_seg_stride in bytes)."""
+    B, Lq, _ = q.shape
+    if seg_len is None:
+        seg_len = k.shape[1]
+    prof = PROFILE_ATTENTION
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _check(lib.osk_attention_fwd_pv8_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
+                                          k.stride(0), k.stride(1), vt8.data_ptr(), vt_seg_stride, v_scale.data_ptr(),
+                                          out.data_ptr(), out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg,
+                                          seg_len, hd, scale, int(q_prescaled), kv_batches, _p(workspace),
+                                          0 if workspace is None else workspace.numel(), _stream()),
+           "osk_attention_fwd_pv8_bf16")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))

@@ -1,0 +1,239 @@
+// Flash-attention forward for head_dim 128, gfx950, with the P.V product on the fp8 MFMA (opt-in fp8 mode).
+//
+// attention_asm128.hip with one change of arithmetic: P (<= 2^8 by construction) and V^T are OCP e4m3, and a 64-key tile's
+// P.V is ONE v_mfma_f32_32x32x64_f8f6f4 per O^T row tile (5 x 64 cycles instead of 20 x 32).  A lane's 32 P values of
+// a tile (two 32 x 32 score tiles x 16 accumulator registers) are exactly one fp8 B operand; the byte order that falls
+// out of the accumulator layout -- byte t2*16 + j*4 + i of half-wave hi <-> key 32 t2 + 8 j + 4 hi + i -- is baked into
+// the V^T rows by osk_v_transpose_fp8, which also quantises V with one scale per (batch, head) and appends the ones /
+// key-validity row and zero rows (RP = 144 rows per head), so the kernel keeps no ones row of its own.  QK^T, the
+// softmax bookkeeping and the output stay as in the bf16 kernel; O is multiplied by the V scale in the epilogue.
+//
+// Same dataflow and generator as attention_asm72.hip (see tools/gen_attn_asm.py), 4 waves x 64 query rows, one wave
+// per SIMD; what differs with 128 real dims:
+//  * K tile = two swizzled 64-dim LDS images (dims 0..63, 64..127), 16 LDS-DMA instructions, 4 per wave;
+//  * the reference max M rides in a NINTH, pure-padding QK^T k-step whose K fragment is a constant register quad
+//    {1.0, 0, ...} (no LDS read) and whose Q fragment holds -M in dim 128;
+//  * V^T tile = 128 dim rows + the ones row 128 (softmax denominator = accumulator row 128, a fifth O^T row tile).
+// Numerics are those of the head_dim-72 kernel: P = exp2(S') with S' = q.k - M straight out of the MFMA, M moves only
+// when a row max exceeds it by more than 8 (log2 units).
+#include "attention_params.h"
+#include "attention_asm_regs.inc"
+
+namespace osk_attn {
+namespace {
+
+constexpr int HD = 128, NKS = OSK128P8_NKS, NDT = OSK128P8_NDT, NU = 2, NW = 4, NSLOT = OSK128P8N2_NSLOT;
+constexpr int NSLOT_V = OSK128P8N2_NSLOT_V, RP = OSK128P8_RP, NVD = OSK128P8_NVD;
+static_assert(NKS == 9 && NDT == 5 && NSLOT == 4 && NSLOT_V == 3 && RP == 144 && NVD == 9, "generated geometry changed: update the wrapper");
+
+OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+OSK_DEV uint64_t rfl64(uint64_t v) {
+  return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
+}
+
+template <int VAR>
+__global__ void __launch_bounds__(256, 1) attn_asm128p8_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  int bh, qb, part, tail_unit;
+  const bool tail = block_to_work_split(p, (p.Lq + 255) / 256, bh, qb, part, tail_unit);
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  // ---- LDS: zero (a tile slot that is never filled must hold finite data)
+  for (int i = tid; i < OSK128P8_SMEM / 16; i += 64 * NW) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  // ragged last key tile of a segment: K rows past the segment re-fetch its last key (finite scores); the key-validity
+  // row of V^T comes baked from osk_v_transpose_fp8
+  const int last_valid = p.seg_len - (p.tps - 1) * 64;
+  const KeyPart kp = key_part(p, tail, part, last_valid < 64);   // the whole key axis, or one part of a split tail unit
+  const bool ragged = kp.ragged;
+  __syncthreads();
+
+  // ---- Q fragments (pre-scaled by scale*log2(e)) -> AGPRs; k-step 8 = padding (zero; dim 128 receives -M in the asm)
+  int qi[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    qi[u] = qb * 256 + wave * 64 + u * 32 + l31;
+    const int qc = qi[u] < p.Lq ? qi[u] : p.Lq - 1;
+    const unsigned short* qrow = p.q + b * p.qbs + (int64_t)qc * p.qrs + h * HD;
+    unsigned w[NKS * 4];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      uint4 s = make_uint4(0, 0, 0, 0);
+      if (ks < HD / 16) {
+        s = *reinterpret_cast<const uint4*>(qrow + ks * 16 + hi * 8);
+        if (!p.q_prescaled) {
+          float f[8];
+          unpack8(s, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] *= p.sc;
+          s = pack8(f);
+        }
+      }
+      w[ks * 4 + 0] = s.x; w[ks * 4 + 1] = s.y; w[ks * 4 + 2] = s.z; w[ks * 4 + 3] = s.w;
+    }
+#define OSK_QIN_A                                                                                            \
+  "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),    \
+      "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]), "v"(w[16]), "v"(w[17]), "v"(w[18]), \
+      "v"(w[19])
+#define OSK_QIN_B                                                                                            \
+  "v"(w[20]), "v"(w[21]), "v"(w[22]), "v"(w[23]), "v"(w[24]), "v"(w[25]), "v"(w[26]), "v"(w[27]), "v"(w[28]),     \
+      "v"(w[29]), "v"(w[30]), "v"(w[31]), "v"(w[32]), "v"(w[33]), "v"(w[34]), "v"(w[35])
+    if (u == 0) {
+      asm volatile(OSK128P8N2_QW0_0 ::OSK_QIN_A : OSK128P8N2_A_CLOBBERS);
+      asm volatile(OSK128P8N2_QW0_1 ::OSK_QIN_B : OSK128P8N2_A_CLOBBERS);
+    } else {
+      asm volatile(OSK128P8N2_QW1_0 ::OSK_QIN_A : OSK128P8N2_A_CLOBBERS);
+      asm volatile(OSK128P8N2_QW1_1 ::OSK_QIN_B : OSK128P8N2_A_CLOBBERS);
+    }
+  }
+
+  // ---- per-lane LDS-DMA source offsets: K instruction j = wave + 4 i -> image j / 8, key rows 8 (j % 8) + lane / 8;
+  //      V^T instruction j = (3 - wave) + 4 i -> dim rows 8 j + lane / 8
+  const int srow8 = lane >> 3, spos = lane & 7;
+  unsigned koff[NSLOT], koffL[NSLOT], voff[NSLOT_V];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int j = wave + NW * i;
+    const int img = j >> 3, row = (j & 7) * 8 + srow8;
+    const int rowL = row < last_valid ? row : last_valid - 1;
+    const int ch = img * 64 + ((spos ^ ((row >> 1) & 7)) << 3);
+    koff[i] = (unsigned)(((int64_t)row * p.krs + ch) * 2);
+    koffL[i] = (unsigned)(((int64_t)rowL * p.krs + ch) * 2);
+  }
+  // V^T (e4m3, 64-byte rows): instruction j = (3 - wave) + 4 i moves rows [16 j, 16 j + 16); LDS position lane % 4 of a
+  // row holds the 16-byte chunk (lane % 4) ^ ((row >> 1) & 3) of it
+#pragma unroll
+  for (int i = 0; i < NSLOT_V; ++i) {
+    const int jv = (NW - 1 - wave) + NW * i;
+    const int row = (jv < NVD ? jv : 0) * 16 + (lane >> 2);
+    voff[i] = (unsigned)((int64_t)row * p.seg_lp + (((lane & 3) ^ ((row >> 1) & 3)) << 4));
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int sw = (l31 >> 1) & 7;
+  unsigned fo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fo[j] = lds_base + l31 * 128 + (((2 * j + hi) ^ sw) << 4);
+  // V^T fragment of a row tile: row l31, the 32-byte half hi of its 64 keys = logical chunks 2 hi, 2 hi + 1
+  const unsigned vf0 = lds_base + l31 * 64 + ((((2 * hi) ^ sw) & 3) << 4), vf1 = lds_base + l31 * 64 + ((((2 * hi + 1) ^ sw) & 3) << 4);
+
+  const int bkv = b % p.Bkv;
+  const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + bkv * p.kbs + h * HD + kp.k_off));
+  const uint64_t vbase = rfl64((uint64_t)(uintptr_t)(p.vt8 + (int64_t)(bkv * p.H + h) * RP * p.seg_lp + kp.v_off));
+  const unsigned kstep = rfl((unsigned)(128 * p.krs));
+  const uint64_t kjump = rfl64((uint64_t)((p.kss - (int64_t)p.tps * 64 * p.krs) * 2));
+  const uint64_t vjump = rfl64((uint64_t)(p.vtss - (int64_t)p.tps * 64));   // V^T strides are bytes here
+  const unsigned tps = rfl((unsigned)kp.tps), nt = rfl((unsigned)kp.nt);
+  const unsigned kdst = rfl(lds_base + wave * 1024), vdst = rfl(lds_base + OSK128P8_VOFF0 + (NW - 1 - wave) * 1024);
+  const unsigned nvw = rfl(((NW - 1 - wave) + NW * (NSLOT_V - 1) < NVD ? (unsigned)NSLOT_V : (unsigned)(NSLOT_V - 1)) |
+                           (ragged ? 0u : 1u << 8));
+
+  float m_ref[2];
+#define OSK128P8_OPERANDS                                                                                           \
+  : "=&v"(m_ref[0]), "=&v"(m_ref[1])                                                                                 \
+  : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(koff[3]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]),               \
+    "v"(fo[0]), "v"(fo[1]), "v"(fo[2]), "v"(fo[3]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(koffL[3]),      \
+    "v"(vf0), "v"(vf1), "s"(kbase), "s"(vbase),                                                                      \
+    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nvw)
+  if constexpr (VAR == 0) {
+    asm volatile(
+#include "attention_asm128p8_n2_v0.inc"
+        OSK128P8_OPERANDS : OSK128P8N2_CLOBBERS);
+  } else {
+    asm volatile(
+#include "attention_asm128p8_n2_v1.inc"
+        OSK128P8_OPERANDS : OSK128P8N2_CLOBBERS);
+  }
+
+  // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 128 (sum of P), store
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    float o[NDT][16];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+#define OSK_OOUT                                                                                             \
+  "=v"(o[d][0]), "=v"(o[d][1]), "=v"(o[d][2]), "=v"(o[d][3]), "=v"(o[d][4]), "=v"(o[d][5]), "=v"(o[d][6]),          \
+      "=v"(o[d][7]), "=v"(o[d][8]), "=v"(o[d][9]), "=v"(o[d][10]), "=v"(o[d][11]), "=v"(o[d][12]), "=v"(o[d][13]), \
+      "=v"(o[d][14]), "=v"(o[d][15])
+      switch (u * NDT + d) {
+        case 0: asm volatile(OSK128P8N2_OR0 : OSK_OOUT); break;
+        case 1: asm volatile(OSK128P8N2_OR1 : OSK_OOUT); break;
+        case 2: asm volatile(OSK128P8N2_OR2 : OSK_OOUT); break;
+        case 3: asm volatile(OSK128P8N2_OR3 : OSK_OOUT); break;
+        case 4: asm volatile(OSK128P8N2_OR4 : OSK_OOUT); break;
+        case 5: asm volatile(OSK128P8N2_OR5 : OSK_OOUT); break;
+        case 6: asm volatile(OSK128P8N2_OR6 : OSK_OOUT); break;
+        case 7: asm volatile(OSK128P8N2_OR7 : OSK_OOUT); break;
+        case 8: asm volatile(OSK128P8N2_OR8 : OSK_OOUT); break;
+        default: asm volatile(OSK128P8N2_OR9 : OSK_OOUT); break;
+      }
+    }
+    // row 128 of O^T = sum_k P: row 0 of row tile 4 = lanes hi == 0, register 0
+    const unsigned lu = __float_as_uint(o[4][0]);
+    auto sw2 = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
+    const float l_tot = __uint_as_float(sw2[0]);
+    const float inv = p.v_scale[bkv * p.H + h] / l_tot;   // 1 / sum(P) and the e4m3 scale of V in one factor
+    if (tail) {
+      // part of a split tail unit: normalised partial O (f32) + log2-domain LSE -> workspace (attn_merge_kernel)
+      if (qi[u] < p.Lq) {
+        const int64_t slot = ((int64_t)tail_unit * p.tail_split + part) * 256 + (wave * 64 + u * 32 + l31);
+        float* wo = p.ws_o + slot * HD;
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d) {
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int d0 = d * 32 + qd * 8 + hi * 4;
+          {
+              *reinterpret_cast<float4*>(wo + d0) = make_float4(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv,
+                                                                 o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+            }
+          }
+        }
+        if (hi == 0) p.ws_lse[slot] = m_ref[u] + __builtin_amdgcn_logf(l_tot);
+      }
+    } else if (qi[u] < p.Lq) {
+      unsigned short* orow = p.out + b * p.obs + (int64_t)qi[u] * p.ors + h * HD;
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int d0 = d * 32 + qd * 8 + hi * 4;
+          uint2 w2;
+          w2.x = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
+          w2.y = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+          *reinterpret_cast<uint2*>(orow + d0) = w2;
+        }
+      }
+      if (p.lse && hi == 0)
+        p.lse[(int64_t)bh * p.Lq + qi[u]] = (m_ref[u] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+    }
+  }
+}
+
+template <int VAR>
+int launch_one(const AttnParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  auto kernel = attn_asm128p8_kernel<VAR>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, OSK128P8_SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int units = ((p.Lq + 255) / 256) * p.B * p.H;
+  const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
+  dim3 grid(units + tail_units * (p.tail_split - 1)), block(64 * NW);
+  hipLaunchKernelGGL(kernel, grid, block, OSK128P8_SMEM, st, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// var 0 = production schedule, 1 = the experimental body of tools/gen_attn_asm.py --exp (default: hazard-padded debug)
+int launch_asm128p8(const AttnParams& p, int var, hipStream_t st) {
+  return var ? launch_one<1>(p, st) : launch_one<0>(p, st);
+}
+
+}  // namespace osk_attn

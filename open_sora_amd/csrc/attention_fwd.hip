@@ -867,3 +867,116 @@ extern "C" const char* osk_attention_kernel_name(int hd, int seg_len) {
   if (v == 9) return "attn_fwd_kernel_v1";
   return "attn_fwd_kernel";
 }
+
+
+// =============================================================================================
+// fp8 P.V variant: V -> e4m3 V^T with the key order, ones row and zero rows the kernels expect; entry point
+// =============================================================================================
+namespace {
+
+// V [B, L, H, hd] bf16 (strided) -> vt8 [B, H, RP, Lp] e4m3 bytes, RP = (hd + 1) rounded up to 16.
+// One block = one 64-key tile of one head.  Row d < hd: byte hi*32 + t2*16 + j*4 + i of the tile holds key
+// 32 t2 + 8 j + 4 hi + i (the order in which a lane of the score accumulators holds its 32 P values), quantised
+// with the (batch, head) scale; row hd: 1.0 for keys < L, 0 behind them (softmax denominator / key validity);
+// rows hd+1 .. RP-1: zero.
+template <int HD>
+__global__ void __launch_bounds__(256) v_transpose_fp8_kernel(const unsigned short* __restrict__ v, int64_t bs,
+                                                              int64_t rs, const float* __restrict__ scales,
+                                                              unsigned char* __restrict__ vt8, int L, int Lp, int H) {
+  constexpr int RP = (HD + 1 + 15) / 16 * 16;
+  __shared__ unsigned short tile[64][HD + 2];
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int key0 = kt * 64;
+  constexpr int CPR = HD / 8;
+  for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
+    const int r = i / CPR, c = i % CPR;
+    const int key = key0 + r;
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (key < L) u = *reinterpret_cast<const uint4*>(v + b * bs + (int64_t)key * rs + h * HD + c * 8);
+    unsigned* dst = reinterpret_cast<unsigned*>(&tile[r][c * 8]);
+    dst[0] = u.x; dst[1] = u.y; dst[2] = u.z; dst[3] = u.w;
+  }
+  __syncthreads();
+  const float inv = 1.0f / scales[b * H + h];
+  unsigned char* obase = vt8 + ((int64_t)(b * H + h) * RP) * Lp + key0;
+  // thread = (row, 16-byte chunk of the 64-byte row)
+  for (int i = threadIdx.x; i < RP * 4; i += 256) {
+    const int d = i >> 2, c = i & 3;
+    unsigned w[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {          // dword q4 of the chunk: bytes pos = c*16 + q4*4 + 0..3
+      const int pos = c * 16 + q4 * 4;
+      const int hi = pos >> 5, s5 = pos & 31, t2 = s5 >> 4, j = (s5 & 15) >> 2;
+      const int k0 = 32 * t2 + 8 * j + 4 * hi;   // keys k0 .. k0 + 3
+      if (d < HD) {
+        float f[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          f[e] = fminf(fmaxf(bf16_bits_to_f32(tile[k0 + e][d]) * inv, -448.0f), 448.0f);
+        int r = 0;
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], r, false);
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], r, true);
+        w[q4] = (unsigned)r;
+      } else if (d == HD) {
+        unsigned r = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r |= (key0 + k0 + e < L ? 0x38u : 0u) << (8 * e);
+        w[q4] = r;
+      } else {
+        w[q4] = 0;
+      }
+    }
+    *reinterpret_cast<uint4*>(obase + (int64_t)d * Lp + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int osk_v_transpose_fp8(const void* v, int64_t bs, int64_t rs, const float* scales, void* vt8, int B, int L,
+                                   int H, int hd, void* stream) {
+  if (!v || !vt8 || !scales || B <= 0 || L <= 0 || H <= 0 || (bs & 7) || (rs & 7) || ((uintptr_t)vt8 & 15)) return OSK_EINVAL;
+  const int Lp = (L + 63) / 64 * 64;
+  dim3 grid(Lp / 64, H, B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (hd == 72)
+    hipLaunchKernelGGL(v_transpose_fp8_kernel<72>, grid, block, 0, st, (const unsigned short*)v, bs, rs, scales, (unsigned char*)vt8, L, Lp, H);
+  else if (hd == 128)
+    hipLaunchKernelGGL(v_transpose_fp8_kernel<128>, grid, block, 0, st, (const unsigned short*)v, bs, rs, scales, (unsigned char*)vt8, L, Lp, H);
+  else
+    return OSK_EUNSUPPORTED;
+  return (int)hipGetLastError();
+}
+
+extern "C" int osk_attention_fwd_pv8_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+                                          const void* k, int64_t k_seg_stride, int64_t k_batch_stride,
+                                          int64_t k_row_stride, const void* vt8, int64_t vt8_seg_stride,
+                                          const float* v_scale, void* out, int64_t o_batch_stride, int64_t o_row_stride,
+                                          float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                                          float scale, int q_prescaled, int kv_batches, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  if (!q || !k || !vt8 || !v_scale || !out || B <= 0 || H <= 0 || Lq <= 0 || n_seg <= 0 || seg_len <= 0) return OSK_EINVAL;
+  if ((q_batch_stride & 7) || (q_row_stride & 7) || (k_seg_stride & 7) || (k_batch_stride & 7) ||
+      (k_row_stride & 7) || (vt8_seg_stride & 15) || (o_batch_stride & 3) || (o_row_stride & 3))
+    return OSK_EINVAL;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)vt8 & 15) || ((uintptr_t)out & 7)) return OSK_EINVAL;
+  if (hd != 128 && hd != 72) return OSK_EUNSUPPORTED;
+  osk_attn::AttnParams p;
+  p.q = (const unsigned short*)q; p.qbs = q_batch_stride; p.qrs = q_row_stride;
+  p.k = (const unsigned short*)k; p.kss = k_seg_stride; p.kbs = k_batch_stride; p.krs = k_row_stride;
+  p.vt = nullptr; p.vt8 = (const unsigned char*)vt8; p.vtss = vt8_seg_stride; p.v_scale = v_scale;
+  p.out = (unsigned short*)out; p.obs = o_batch_stride; p.ors = o_row_stride;
+  p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.n_seg = n_seg; p.seg_len = seg_len;
+  p.seg_lp = (seg_len + 63) / 64 * 64;
+  p.tps = p.seg_lp / 64;
+  p.sc = q_prescaled ? 1.0f : scale * 1.4426950408889634f;
+  p.q_prescaled = q_prescaled;
+  if (kv_batches < 0 || kv_batches > B) return OSK_EINVAL;
+  p.Bkv = kv_batches > 0 ? kv_batches : B;
+  p.map = attn_map();
+  if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 0)) return OSK_EINVAL;
+  osk_attn::split_tail(p, ((Lq + 255) / 256) * B * H, hd, workspace, workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int var = attn_variant() == 6 ? 1 : 0;
+  const int rc = hd == 128 ? osk_attn::launch_asm128p8(p, var, st) : osk_attn::launch_asm72p8(p, var, st);
+  return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, hd, st);
+}

@@ -25,6 +25,10 @@ struct AttnParams {
   int tail_first = 0x7fffffff, tail_split = 1;
   float* ws_o = nullptr;
   float* ws_lse = nullptr;
+  // fp8 P.V variant (attention_asm*p8.hip): V^T as e4m3 [Bkv, H, RP, seg_lp] per segment (vtss in BYTES) from
+  // osk_v_transpose_fp8, one f32 scale per (key batch, head)
+  const unsigned char* vt8 = nullptr;
+  const float* v_scale = nullptr;
 };
 
 // (batch*head, query block) of a workgroup.  map 1 hands every XCD (block b runs on XCD b % 8) a contiguous
@@ -108,5 +112,8 @@ bool asm72_supported(const AttnParams& p, int hd);
 int launch_asm72(const AttnParams& p, int nu, int var, hipStream_t st);
 // attention_asm128.hip: head_dim 128, 4 waves x 64 rows, generated main loop
 int launch_asm128(const AttnParams& p, int var, hipStream_t st);
+// attention_asm128p8.hip / attention_asm72p8.hip: the same with the P.V product on the fp8 MFMA
+int launch_asm128p8(const AttnParams& p, int var, hipStream_t st);
+int launch_asm72p8(const AttnParams& p, int var, hipStream_t st);
 
 }  // namespace osk_attn

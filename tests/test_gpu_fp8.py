@@ -161,3 +161,81 @@ def test_mmdit_forward_fp8_mode(hip_lib):
         truth = O.forward(torch_params(cfg), cfg, **torch_inputs(cfg, *geom))
     rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm()).item()
     assert rel(out8, ref16) <= 5e-2 and rel(out8, truth) <= 5e-2, (rel(out8, ref16), rel(out8, truth))
+
+
+# ----------------------------------------------------------------------------- attention with the fp8 P.V product
+def _pv8_case(hip_lib, B, H, hd, Lq, Lk, n_seg=1, spike=False, workspace=False, seed=120):
+    D = H * hd
+    seg = Lk // n_seg
+    q = rnd("q", (B, Lq, D), seed=seed)
+    k = rnd("k", (n_seg, B, seg, D), seed=seed + 1)
+    v = rnd("v", (n_seg, B, seg, D), seed=seed + 2)
+    if spike:
+        k[-1, :, seg - 3] = q[:, 0] * 4.0
+    segp = (seg + 63) // 64 * 64
+    RP = hip_lib.vt8_rows(hd)
+    # one scale per (batch, head) over ALL segments (the kernel accumulates across segments)
+    amax = v.float().abs().view(n_seg, B, seg, H, hd).amax(dim=(0, 2, 4))
+    sv = (amax / 448.0).contiguous()
+    vt8 = torch.empty(n_seg, B, H, RP, segp, dtype=torch.uint8, device=DEV)
+    for s_ in range(n_seg):
+        hip_lib.v_transpose_fp8(v[s_], sv, vt8[s_], H, hd)
+    out = torch.empty(B, Lq, D, dtype=BF, device=DEV)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=DEV)
+    ws = hip_lib.attention_workspace(q.device) if workspace else None
+    hip_lib.attention_fwd_pv8(q, k[0], vt8, sv, out, H, hd, hd ** -0.5, lse=lse, n_seg=n_seg, seg_len=seg,
+                              k_seg_stride=k.stride(0), vt_seg_stride=vt8.stride(0), workspace=ws)
+    kk = k.permute(1, 0, 2, 3).reshape(B, n_seg * seg, H, hd).double().permute(0, 2, 1, 3)
+    vv = v.permute(1, 0, 2, 3).reshape(B, n_seg * seg, H, hd).float()
+    v8 = ((vv / sv[:, None, :, None]).clamp(-448, 448).to(F8).float() * sv[:, None, :, None]).double().permute(0, 2, 1, 3)
+    qh = q.double().view(B, Lq, H, hd).permute(0, 2, 1, 3)
+    s_ = (qh @ kk.transpose(-1, -2)) * hd ** -0.5
+    p_ = torch.softmax(s_, -1)
+    ref8 = (p_ @ v8).permute(0, 2, 1, 3).reshape(B, Lq, D)                 # exact P, the kernel's e4m3 V
+    ref = (p_ @ vv.double().permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, Lq, D)
+    o = out.double()
+    rel8 = ((o - ref8).norm() / ref8.norm()).item()
+    rel = ((o - ref).norm() / ref.norm()).item()
+    # e4m3 has 3 mantissa bits: P and V each carry ~3 % rounding noise per element
+    assert rel8 <= 4e-2 and rel <= 6e-2, (rel8, rel)
+    # the softmax denominator is the sum of the e4m3 P: a row dominated by one key carries that key's rounding,
+    # up to half an e4m3 step (2^-4): ln(1 + 2^-4) = 0.061
+    assert (lse.double() - torch.logsumexp(s_, -1)).abs().max().item() <= 7e-2
+    return out
+
+
+@pytest.mark.parametrize("hd", [72, 128])
+@pytest.mark.parametrize("Lq,Lk", [(256, 256), (300, 1000), (64, 65), (512, 4096), (33, 704)])
+def test_attention_pv8_vs_f64(hip_lib, hd, Lq, Lk):
+    _pv8_case(hip_lib, 2, 2, hd, Lq, Lk)
+
+
+@pytest.mark.parametrize("hd", [72, 128])
+def test_attention_pv8_segments_spike_and_tail_split(hip_lib, hd):
+    _pv8_case(hip_lib, 2, 2, hd, 130, 300, n_seg=3, seed=130)               # ragged key segments
+    _pv8_case(hip_lib, 1, 2, hd, 128, 900, spike=True, seed=131)            # reference-max move (rare path)
+    _pv8_case(hip_lib, 1, 17, hd, 4096, 1000, workspace=True, seed=132)     # tail units split along the keys
+    _pv8_case(hip_lib, 2, 9, hd, 4000, 400, n_seg=4, workspace=True, seed=133)
+
+
+@pytest.mark.parametrize("hd", [72, 128])
+def test_attention_pv8_constant_v_and_determinism(hip_lib, hd):
+    """V == c per channel: out == e4m3(c / s) * s exactly (the denominator is the ones row of the SAME fp8 product);
+    12 runs bit-identical."""
+    B, H, Lq, Lk = 1, 8, 2000, 4133
+    D = H * hd
+    q, k = rnd("q", (B, Lq, D), seed=141), rnd("k", (B, Lk, D), seed=142)
+    c = rnd("c", (D,), seed=143)
+    v = c[None, None].expand(B, Lk, D).contiguous()
+    sv = (v.float().abs().view(B, Lk, H, hd).amax(dim=(1, 3)) / 448.0).contiguous()
+    vt8 = torch.empty(B, H, hip_lib.vt8_rows(hd), (Lk + 63) // 64 * 64, dtype=torch.uint8, device=DEV)
+    hip_lib.v_transpose_fp8(v, sv, vt8, H, hd)
+    outs = []
+    for _ in range(12):
+        o = torch.empty(B, Lq, D, dtype=BF, device=DEV)
+        hip_lib.attention_fwd_pv8(q, k, vt8, sv, o, H, hd, hd ** -0.5)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    c8 = (c.float().view(H, hd) / sv[0][:, None]).clamp(-448, 448).to(F8).float() * sv[0][:, None]
+    assert (outs[0].float() - c8.view(1, 1, D)).abs().max().item() <= 2 ** -7 * c8.abs().max().item() + 1e-3

@@ -37,8 +37,9 @@ class Geometry:
     hd 128: 8 real k-steps + 1 pure padding step whose K fragment is a CONSTANT register quad {1.0, 0...} (no LDS
             read) and whose Q fragment carries M; 4 real O^T row tiles + a 5th that only holds the ones row 128."""
 
-    def __init__(self, hd):
+    def __init__(self, hd, pv8=False):
         self.HD = hd
+        self.PV8 = pv8   # P.V on the fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4): P and V^T as OCP e4m3, see the header
         if hd == 72:
             self.NKS, self.NDT, self.KIMG, self.HAS_COL = 5, 3, 1, True
             self.M_KS, self.M_HI = 4, 1          # M sits in k-step 4, lanes 32..63 (dims 72..79), word 0
@@ -51,10 +52,23 @@ class Geometry:
             raise ValueError(hd)
         self.NPK = 2 * self.NKS                  # QK^T fragment pairs (k-step, 32-key half)
         self.NPK_READ = 2 * (self.NKS - (0 if self.HAS_COL else 1))   # ... that are read from LDS
-        self.NPV = 4 * self.NDT                  # P.V fragment pairs (key group, row tile)
         self.KTILE = self.KIMG * 8192 + (1024 if self.HAS_COL else 0)
+        if pv8:
+            # V^T tile in e4m3: 64-byte rows (64 keys), ONE fp8 MFMA (K = 64) per O^T row tile.  The global tensor
+            # carries RP rows per head: the hd dims, the baked ones / key-validity row hd, zero rows up to a multiple
+            # of 16 (one LDS-DMA instruction moves 16 rows), so the kernel maintains no ones row itself.
+            self.NPV = self.NDT                  # P.V "pairs" = O^T row tiles
+            self.RP = (hd + 1 + 15) // 16 * 16
+            self.NVD = self.RP // 16
+            self.VROW = 64
+            self.VTILE = max(self.RP, self.NDT * 32 if self.HAS_COL else self.RP) * 64
+            self.VSTEP = 64                      # bytes per 64-key tile along a V^T row
+        else:
+            self.NPV = 4 * self.NDT              # P.V fragment pairs (key group, row tile)
+            self.VROW = 128
+            self.VSTEP = 128
+            self.VTILE = self.NDT * 32 * 128 if self.HAS_COL else (hd + 2) * 128
         if self.HAS_COL:
-            self.VTILE = self.NDT * 32 * 128
             self.KOFF = [0, self.KTILE]
             self.VOFF = [2 * self.KTILE, 2 * self.KTILE + self.VTILE]
         else:
@@ -62,7 +76,6 @@ class Geometry:
             # tile keeps only rows 0..129 (128 dims, the ones row, one zero row); the last row tile's fragment reads
             # run into the NEXT region -- garbage that only reaches accumulator rows 129..159, which nobody reads --
             # and V^T sits in front of K so that the largest immediate is K slot 1's (61952)
-            self.VTILE = (hd + 2) * 128
             self.VOFF = [0, self.VTILE]
             self.KOFF = [2 * self.VTILE, 2 * self.VTILE + self.KTILE]
         # hd 72: 16-byte chunk {1.0bf16, 0...} = K's padding dims 72..79, one copy per K ring slot, KTILE apart
@@ -78,12 +91,13 @@ S_KB, S_VB, S_KSTEP, S_KJ, S_VJ = 40, 42, 44, 46, 48
 S_TPS, S_NT, S_KDST, S_VDST, S_NKW, S_NVW = 50, 51, 52, 53, 54, 55
 S_T, S_KTT, S_VTT, S_TMP, S_HIM, S_KL, S_VL = 56, 57, 58, 59, 60, 62, 63
 
-def operand_names(geo, nslot):
+def operand_names(geo, nslot_k, nslot_v):
     """asm operands (order = operand numbers in the wrapper's asm statement); at most 30"""
-    names = ["m0out", "m1out"] + ["koff%d" % i for i in range(nslot)] + ["voff%d" % i for i in range(nslot)] + \
+    names = ["m0out", "m1out"] + ["koff%d" % i for i in range(nslot_k)] + ["voff%d" % i for i in range(nslot_v)] + \
             ["fo0", "fo1", "fo2", "fo3"] + (["kc0", "kc1"] if geo.HAS_COL else []) + \
-            ["koffL%d" % i for i in range(nslot)] + ["maskval", "onesaddr",
-                                                     "kbase", "vbase", "kstep", "kjump", "vjump", "tps", "nt", "kdst", "vdst"]
+            ["koffL%d" % i for i in range(nslot_k)] + \
+            (["vf0", "vf1"] if geo.PV8 else ["maskval", "onesaddr"]) + \
+            ["kbase", "vbase", "kstep", "kjump", "vjump", "tps", "nt", "kdst", "vdst"]
     # the K loader's conditional last slot only exists when 4 | NKD does not hold; otherwise no slot count is needed
     names += (["nkw"] if geo.NKD % 4 or geo.NKD % 8 else []) + ["nvw"]
     assert len(names) <= 30, len(names)
@@ -101,21 +115,27 @@ def ar(base, n=1):
 class Layout:
     """register file and schedule geometry for NU query blocks per wave"""
 
-    def __init__(self, nu, hd=72):
+    def __init__(self, nu, hd=72, pv8=False):
         self.NU = nu
-        self.G = G = Geometry(hd)
+        self.G = G = Geometry(hd, pv8)
+        self.PV8 = pv8
         NKS, NDT = G.NKS, G.NDT
         self.NW = 8 // nu                      # waves per workgroup
-        self.NSLOT = (G.NKD + self.NW - 1) // self.NW   # LDS-DMA slots per wave and tile
+        self.NSLOT = (G.NKD + self.NW - 1) // self.NW   # K LDS-DMA slots per wave and tile
         self.LAST_COND = G.NKD % self.NW != 0  # the last slot only exists on some waves
-        self.OPERANDS = operand_names(G, 3 if hd == 72 else self.NSLOT)   # hd 72: one wrapper operand list for both layouts
+        self.NSLOT_V = (G.NVD + self.NW - 1) // self.NW
+        self.LAST_COND_V = G.NVD % self.NW != 0
+        nk_ops = 3 if hd == 72 else self.NSLOT  # hd 72: one wrapper operand list for both layouts
+        self.OPERANDS = operand_names(G, nk_ops, self.NSLOT_V if pv8 else nk_ops)
         self.OP = {n: "%%%d" % i for i, n in enumerate(self.OPERANDS)}
+        self.RD = 2 if pv8 else 4              # depth of the V^T fragment ring, in P.V pairs
+        self.NTP = 1 if pv8 else 2             # P.V pairs whose MFMAs trail across the tile barrier
         self.V_FIRST = 48 if G.HAS_COL else 44
         self.KC0 = None if G.HAS_COL else 44   # constant K fragment of the padding k-step: 4 registers
         self.SA0 = 48
         self.SB0 = self.SA0 + 32 * nu
         self.PB0 = self.SB0 + 32 * nu
-        self.KR0 = self.PB0 + 16 * nu          # fragment rings, 4 slots x 4 registers each
+        self.KR0 = self.PB0 + (8 if pv8 else 16) * nu   # fragment rings, 16 registers each (pv8: V^T 2 slots x 8)
         self.VR0 = self.KR0 + 16
         self.TMP0 = self.VR0 + 16              # 8 temporaries
         self.MT = [self.TMP0 + 8, self.TMP0 + 9]
@@ -125,15 +145,21 @@ class Layout:
         self.A_O0 = 0
         self.A_Q0 = 16 * NDT * nu
         self.A_END = self.A_Q0 + 4 * NKS * nu
-        self.NTRAIL = 2 * nu                   # MFMAs of the 2 trailing fragment pairs
+        self.NTRAIL = self.NTP * nu            # MFMAs of the trailing P.V pairs
         self.NQK = G.NPK * nu
-        self.NPVB = (G.NPV - 2) * nu           # P.V MFMAs inside the body
+        self.NPVB = (G.NPV - self.NTP) * nu    # P.V MFMAs inside the body
         self.I_QK0 = self.NTRAIL               # global shadow index of the first QK^T MFMA
         self.I_PV0 = self.I_QK0 + self.NQK
         last = self.I_PV0 + self.NPVB - 1
         # first / last shadow of filler classes A (exp2+pack of key groups 0..2), B (group 3: before the P.V MFMAs of
         # key group 3, which start at pair 3 NDT), C (max of tile t+1: after its last QK^T MFMAs)
-        if hd == 72:
+        if pv8:
+            # every P fragment of the tile has to be packed before the FIRST P.V MFMA (it consumes all 64 keys): exp2 +
+            # pack of all four key groups sit under the QK^T MFMAs of the next tile, the max of that tile under the
+            # (64-cycle) P.V MFMAs
+            self.WINDOWS = [self.I_QK0, self.I_PV0 - 3, self.I_QK0 + self.NQK // 2, self.I_PV0 - 2, self.I_PV0 + 1, last]
+            self.C_T2_RELEASE = self.I_PV0 + 2
+        elif hd == 72:
             self.WINDOWS = [4, 25, 24, 40, 26, 43] if nu == 2 else [2, 13, 12, 19, 14, 21]
             self.C_T2_RELEASE = 28 if nu == 2 else 15   # chains over keys 32..63: their last QK^T MFMAs come last
         else:
@@ -145,7 +171,8 @@ class Layout:
         return setbase + (u * 2 + t2) * 16 + r
 
     def PB(self, u, g, w=0):
-        return self.PB0 + (u * 4 + g) * 4 + w
+        """bf16: P fragment of key group g (4 registers).  pv8: register w (0..7) of the one 32-byte fragment (g = 0)"""
+        return self.PB0 + u * 8 + w if self.PV8 else self.PB0 + (u * 4 + g) * 4 + w
 
     def AO(self, u, d):
         return self.A_O0 + (u * self.G.NDT + d) * 16
@@ -207,6 +234,11 @@ def k_read(st, L, slot, p, tag):
 
 
 def v_read(st, L, slot, r, tag):
+    if L.PV8:   # row tile r: 32 rows of 64 bytes; a lane's 32-byte half row = two swizzled 16-byte chunks
+        base = L.VR0 + (r % 2) * 8
+        st.ds_read(base, L.OP["vf0"], L.G.VOFF[slot] + r * 2048, ("vx", tag[1]))
+        st.ds_read(base + 4, L.OP["vf1"], L.G.VOFF[slot] + r * 2048, tag)
+        return
     g, d = r // L.G.NDT, r % L.G.NDT
     st.ds_read(L.VR0 + (r % 4) * 4, L.OP["fo%d" % g], L.G.VOFF[slot] + d * 4096, tag)
 
@@ -221,6 +253,10 @@ def qk_mfma(st, L, sn, a):
 
 def pv_mfma(st, L, b):
     r, u = b // L.NU, b % L.NU
+    if L.PV8:   # one K = 64 fp8 MFMA per O^T row tile: all 64 keys of the tile at once
+        dst = ar(L.AO(u, r), 16)
+        st.emit("v_mfma_f32_32x32x64_f8f6f4 %s, %s, %s, %s" % (dst, vr(L.VR0 + (r % 2) * 8, 8), vr(L.PB(u, 0), 8), dst), "F")
+        return
     g, d = r // L.G.NDT, r % L.G.NDT
     dst = ar(L.AO(u, d), 16)
     st.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, vr(L.VR0 + (r % 4) * 4, 4), vr(L.PB(u, g), 4), dst), "M")
@@ -233,6 +269,15 @@ def exp_group(L, sc, u, g):
     for r in range(8):
         x = vr(L.S(sc, u, t2, r0 + r))
         ops.append(("e", "v_exp_f32 %s, %s" % (x, x)))
+    if L.PV8:
+        # e4m3 bytes: dword t2 * 4 + j (j = accumulator register / 4) holds keys 32 t2 + 8 j + 4 (lane / 32) + 0..3 --
+        # the byte order osk_v_transpose_fp8 bakes into the V^T rows
+        for w2 in range(2):
+            dst = vr(L.PB(u, 0, t2 * 4 + (g & 1) * 2 + w2))
+            x = lambda i: vr(L.S(sc, u, t2, r0 + 4 * w2 + i))
+            ops.append(("v", "v_cvt_pk_fp8_f32 %s, %s, %s" % (dst, x(0), x(1))))
+            ops.append(("v", "v_cvt_pk_fp8_f32 %s, %s, %s op_sel:[0,0,1]" % (dst, x(2), x(3))))
+        return ops
     for w in range(4):
         ops.append(("v", "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(L.PB(u, g, w)), vr(L.S(sc, u, t2, r0 + 2 * w)),
                                                            vr(L.S(sc, u, t2, r0 + 2 * w + 1)))))
@@ -296,19 +341,24 @@ def v_dma(st, L, slot, i, part=3):
         st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (L.OP["voff%d" % i], S_VB, S_VB + 1), "g")
 
 
+def nslot(L, which):
+    return L.NSLOT if which == "k" or not L.PV8 else L.NSLOT_V
+
+
 def dma_last(st, L, which, slot, uid):
-    """last loader slot: only the wave(s) whose instruction index is < NKD (all of them when NW | NKD)"""
-    if not L.LAST_COND:
-        (k_dma if which == "k" else v_dma)(st, L, slot, L.NSLOT - 1)
+    """last loader slot: only the wave(s) whose instruction index is < NKD / NVD (all of them when NW divides it)"""
+    n = nslot(L, which)
+    if not (L.LAST_COND if which == "k" or not L.PV8 else L.LAST_COND_V):
+        (k_dma if which == "k" else v_dma)(st, L, slot, n - 1)
         return
     lab = ".L@@_%s2%s" % (which, uid)
-    st.emit("s_cmp_lt_u32 s%d, %d" % (S_NKW if which == "k" else S_NVW, L.NSLOT), "s")
+    st.emit("s_cmp_lt_u32 s%d, %d" % (S_NKW if which == "k" else S_NVW, n), "s")
     st.emit("s_cbranch_scc1 %s" % lab, "s")
-    (k_dma if which == "k" else v_dma)(st, L, slot, L.NSLOT - 1)
+    (k_dma if which == "k" else v_dma)(st, L, slot, n - 1)
     st.label(lab)
 
 
-def advance(st, which, uid):
+def advance(st, which, uid, vstep=128):
     """point the loader at its next tile; past the last tile it stays (harmless re-fetch of the last tile)"""
     lab = ".L@@_%sa%s" % (which, uid)
     sl, sb, stt, sj = (S_KL, S_KB, S_KTT, S_KJ) if which == "k" else (S_VL, S_VB, S_VTT, S_VJ)
@@ -319,7 +369,7 @@ def advance(st, which, uid):
     if which == "k":
         st.emit("s_add_u32 s%d, s%d, s%d" % (sb, sb, S_KSTEP), "s")
     else:
-        st.emit("s_add_u32 s%d, s%d, 128" % (sb, sb), "s")
+        st.emit("s_add_u32 s%d, s%d, %d" % (sb, sb, vstep), "s")
     st.emit("s_addc_u32 s%d, s%d, 0" % (sb + 1, sb + 1), "s")
     st.emit("s_add_u32 s%d, s%d, 1" % (stt, stt), "s")
     st.emit("s_cmp_lg_u32 s%d, s%d" % (stt, S_TPS), "s")
@@ -367,10 +417,10 @@ def ones_row(st, L, slot):
 
 def dma_group(st, L, which, slot, uid):
     """all LDS-DMA instructions of this wave for one K (or V^T) tile + loader advance (prologue form)"""
-    for i in range(L.NSLOT - 1):
+    for i in range(nslot(L, which) - 1):
         (k_dma if which == "k" else v_dma)(st, L, slot, i)
     dma_last(st, L, which, slot, uid)
-    advance(st, which, uid)
+    advance(st, which, uid, L.G.VSTEP)
     ragged_masks(st)
 
 
@@ -433,7 +483,7 @@ def body(st, L, k, safe):
         k_read(st, L, cur ^ 1, p, ("k", p))
     # -- trailing P.V MFMAs of tile t-1 (the last two fragment pairs were read before the barrier); in their shadows the
     #    first LDS-DMA pieces of K(t+2) -> slot cur and V(t+1) -> slot cur^1 (M0 write BEFORE the MFMA: no s_nop)
-    pieces = [("k", i) for i in range(L.NSLOT - 1)] + [("v", i) for i in range(L.NSLOT - 1)]
+    pieces = [("k", i) for i in range(nslot(L, "k") - 1)] + [("v", i) for i in range(nslot(L, "v") - 1)]
     pieces = pieces[:L.NTRAIL]
     done = {"k": sum(1 for w, _ in pieces if w == "k"), "v": sum(1 for w, _ in pieces if w == "v")}
 
@@ -443,7 +493,7 @@ def body(st, L, k, safe):
     for n in range(L.NTRAIL):
         if n < len(pieces):
             piece(pieces[n], 1)
-        pv_mfma(st, L, (L.G.NPV - 2) * NU + n)
+        pv_mfma(st, L, (L.G.NPV - L.NTP) * NU + n)
         if n < len(pieces):
             piece(pieces[n], 2)
     # -- decision: did some score of tile t exceed the reference by more than 2^THR (VCC from the previous body)?
@@ -452,15 +502,16 @@ def body(st, L, k, safe):
 
     # -- remaining LDS-DMA work, one item per shadow right after the entry point: (emitter, cycles)
     later = []
-    for i in range(done["k"], L.NSLOT - 1):
+    for i in range(done["k"], nslot(L, "k") - 1):
         later.append((lambda i=i: k_dma(st, L, cur, i), 12))
     later.append((lambda: dma_last(st, L, "k", cur, uid), 12))
-    for i in range(done["v"], L.NSLOT - 1):
+    for i in range(done["v"], nslot(L, "v") - 1):
         later.append((lambda i=i: v_dma(st, L, cur ^ 1, i), 12))
     later.append((lambda: dma_last(st, L, "v", cur ^ 1, uid), 12))
-    later.append((lambda: ones_row(st, L, cur ^ 1), 8))       # before the V^T loader moves on: S_VRG is tile t+1's
+    if not L.PV8:   # pv8: the ones / key-validity row arrives with the V^T tile itself
+        later.append((lambda: ones_row(st, L, cur ^ 1), 8))   # before the V^T loader moves on: S_VRG is tile t+1's
     later.append((lambda: advance(st, "k", uid), 28))
-    later.append((lambda: (advance(st, "v", uid), ragged_masks(st)), 32))
+    later.append((lambda: (advance(st, "v", uid, L.G.VSTEP), ragged_masks(st)), 32))
 
     # -- fillers paced in CYCLES (v_exp 8, other VALU 4): three classes, each spread uniformly over its window
     cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
@@ -481,7 +532,10 @@ def body(st, L, k, safe):
     for n, (kind, idx) in enumerate(mf):
         i = L.I_QK0 + n
         pair, u = idx // NU, idx % NU
-        if u == 0 and pair % 2 == 0:     # pairs 2m and 2m+1 with one wait (both were issued >= 3 pairs ago)
+        if kind == "pv" and L.PV8:
+            if u == 0:
+                st.need(("v", pair))
+        elif u == 0 and pair % 2 == 0:   # pairs 2m and 2m+1 with one wait (both were issued >= 3 pairs ago)
             st.need(("k" if kind == "qk" else "v", pair + 1))
         if kind == "qk":
             qk_mfma(st, L, sn, idx)
@@ -497,12 +551,12 @@ def body(st, L, k, safe):
                 if pair + 4 < NR:
                     k_read(st, L, cur ^ 1, pair + 4, ("k", pair + 4))
                     used += 4
-                elif pair < NR:
-                    v_read(st, L, cur, pair + 4 - NR, ("v", pair + 4 - NR))   # V pairs 0..3 behind the last K pairs
-                    used += 4
-            elif pair + 4 < L.G.NPV:
-                v_read(st, L, cur, pair + 4, ("v", pair + 4))
-                used += 4
+                elif pair < NR and pair + 4 - NR < L.RD:
+                    v_read(st, L, cur, pair + 4 - NR, ("v", pair + 4 - NR))   # first V pairs behind the last K pairs
+                    used += 8 if L.PV8 else 4
+            elif pair + L.RD < L.G.NPV:
+                v_read(st, L, cur, pair + L.RD, ("v", pair + L.RD))
+                used += 8 if L.PV8 else 4
         if later:
             fn, cyc = later.pop(0)
             fn()
@@ -518,7 +572,7 @@ def body(st, L, k, safe):
                     break
                 if totals[ci] * frac - c[4] <= 0 and i < last:
                     break
-                if used >= 30 and i < last:
+                if used >= (60 if kind == "pv" and L.PV8 else 30) and i < last:
                     break
                 st.emit(text, kind_)
                 used += cost(kind_)
@@ -617,7 +671,7 @@ def generate(L, safe=False, ablate=frozenset()):
     # ---- exit: the trailing P.V MFMAs of the last tile
     st.label(".L@@_exit")
     for n in range(L.NTRAIL):
-        pv_mfma(st, L, (L.G.NPV - 2) * L.NU + n)
+        pv_mfma(st, L, (L.G.NPV - L.NTP) * L.NU + n)
     e("s_nop 15")
     e("s_nop 15")
     e("v_mov_b32 %s, %s" % (L.OP["m0out"], vr(L.MM[0])))
@@ -629,50 +683,57 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--table", type=int, default=0, help="print the production schedule of layout NU (1 or 2)")
     ap.add_argument("--hd", type=int, default=72, help="head dim of the schedule --table prints")
+    ap.add_argument("--pv8", action="store_true", help="--table: the fp8 P.V variant")
     ap.add_argument("--exp", default="safe", help="experimental variant 1: safe | ablations joined by + (noexp nobar "
                     "nodma nolds novalu nomfma norare nocvt nomax): timing only, wrong results")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
     args = ap.parse_args()
-    layouts = [(72, 2), (72, 1), (128, 2)]
-    for hd, nu in layouts:
-        L = Layout(nu, hd)
+    layouts = [(72, 2, False), (72, 1, False), (128, 2, False), (72, 2, True), (128, 2, True)]
+    tagof = lambda hd, pv8: "%d%s" % (hd, "p8" if pv8 else "")
+    for hd, nu, pv8 in layouts:
+        L = Layout(nu, hd, pv8)
         exp_safe = args.exp == "safe"
         exp_ab = frozenset() if exp_safe else frozenset(args.exp.split("+"))
         for vi, (safe, ablate) in enumerate([(False, frozenset()), (exp_safe, exp_ab)]):
             st = generate(L, safe, ablate)
-            if args.table == nu and args.hd == hd and vi == 0:
+            if args.table == nu and args.hd == hd and vi == 0 and args.pv8 == pv8:
                 gap = []
                 for kind, text in st.table:
-                    if kind == "M":
-                        print("".join(gap)); gap = ["M "]
+                    if kind in ("M", "F"):
+                        print("".join(gap)); gap = [kind + " "]
                     elif kind == "L":
                         print("".join(gap)); gap = []; print(text + ":")
                     else:
                         gap.append({"x": "v"}.get(kind, kind))
                 print("".join(gap))
-            with open(os.path.join(args.out, "attention_asm%d_n%d_v%d.inc" % (hd, nu, vi)), "w") as f:
-                f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d, layout NU=%d, variant %d: %s\n" %
-                        (hd, nu, vi, "production" if vi == 0 else ("hazard-padded (debug)" if safe else "timing ablation " + "+".join(sorted(ablate)))))
+            with open(os.path.join(args.out, "attention_asm%s_n%d_v%d.inc" % (tagof(hd, pv8), nu, vi)), "w") as f:
+                f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d%s, layout NU=%d, variant %d: %s\n" %
+                        (hd, ", fp8 P.V" if pv8 else "", nu, vi,
+                         "production" if vi == 0 else ("hazard-padded (debug)" if safe else "timing ablation " + "+".join(sorted(ablate)))))
                 for ln in st.lines:
-                    f.write('"%s\\n"\n' % ln.replace("@@", "osk%dn%dv%d" % (hd, nu, vi)))
+                    f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%dv%d" % (tagof(hd, pv8), nu, vi)))
     # register / operand contract for the wrapper
     with open(os.path.join(args.out, "attention_asm_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.\n")
-        for hd in sorted({h for h, _ in layouts}):
-            G = Geometry(hd)
-            P = "OSK%d_" % hd
+        for hd, pv8 in sorted({(h, p8) for h, _, p8 in layouts}):
+            G = Geometry(hd, pv8)
+            P = "OSK%s_" % tagof(hd, pv8).upper()
             f.write("#define %sSMEM %d\n#define %sCONST_OFF %d\n" % (P, G.SMEM, P, G.CONST_OFF))
             f.write("#define %sKTILE %d\n#define %sVTILE %d\n#define %sVOFF0 %d\n#define %sKOFF0 %d\n" % (P, G.KTILE, P, G.VTILE, P, G.VOFF[0], P, G.KOFF[0]))
             f.write("#define %sNKS %d\n#define %sNDT %d\n#define %sNKD %d\n#define %sKIMG %d\n" % (P, G.NKS, P, G.NDT, P, G.NKD, P, G.KIMG))
-        for hd, nu in layouts:
-            L = Layout(nu, hd)
+            if pv8:
+                f.write("#define %sRP %d\n#define %sNVD %d\n" % (P, G.RP, P, G.NVD))
+        for hd, nu, pv8 in layouts:
+            L = Layout(nu, hd, pv8)
             G = L.G
-            P = "OSK%dN%d_" % (hd, nu)
+            P = "OSK%sN%d_" % (tagof(hd, pv8).upper(), nu)
             clob = ['"v%d"' % i for i in range(L.V_FIRST, L.V_END)] + ['"a%d"' % i for i in range(0, L.A_END)] + \
                    ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
             f.write("#define %sCLOBBERS %s\n" % (P, ", ".join(clob)))
             f.write("#define %sA_CLOBBERS %s\n" % (P, ", ".join('"a%d"' % i for i in range(0, L.A_END))))
             f.write("#define %sNSLOT %d\n" % (P, L.NSLOT))
+            if pv8:
+                f.write("#define %sNSLOT_V %d\n" % (P, L.NSLOT_V))
             for u in range(nu):   # Q fragment words of query block u -> AGPRs, at most 20 operands per statement
                 words = G.NKS * 4
                 for part, w0 in enumerate(range(0, words, 20)):

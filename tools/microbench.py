@@ -75,6 +75,15 @@ def bench_attn(B, H, L, hd, tag):
          parts=_C.lib.osk_attention_tail_split_factor(B, H, L, 1, L, hd, ws.numel()))
     ms = timeit(lambda: _C.v_transpose(v, vt, H, hd))
     emit(kernel="v_transpose", tag=tag, ms=round(ms, 4), gbps=round(4.0 * B * L * D / ms / 1e6, 1))
+    if hd in (72, 128):
+        sv = (v.float().abs().view(B, L, H, hd).amax(dim=(1, 3)) / 448.0).contiguous()
+        vt8 = torch.empty(B, H, _C.vt8_rows(hd), Lp, dtype=torch.uint8, device=DEV)
+        _C.v_transpose_fp8(v, sv, vt8, H, hd)
+        ms = timeit(lambda: _C.attention_fwd_pv8(q, k, vt8, sv, out, H, hd, hd ** -0.5, workspace=ws), iters=5, warm=2)
+        emit(kernel="attention_fwd_pv8+tailsplit", tag=tag, B=B, H=H, L=L, hd=hd, ms=round(ms, 4),
+             tflops=round(4.0 * B * H * L * L * hd / ms / 1e9, 1))
+        ms = timeit(lambda: _C.v_transpose_fp8(v, sv, vt8, H, hd))
+        emit(kernel="v_transpose_fp8", tag=tag, ms=round(ms, 4), gbps=round(3.0 * B * L * D / ms / 1e6, 1))
 
 
 def bench_elementwise(B, L, D, H, hd):
