@@ -285,6 +285,8 @@ def main():
         fl = configs.attention_flops(nb, H, Lq, L, hd)  # per launch on this rank
         ach = fl / (avg_ms * 1e-3) / 1e12
         kname = _C.lib.osk_attention_kernel_name(hd, L // world).decode()
+        if args.fp8 and hd in (72, 128):
+            kname = f"attn_asm{hd}p8_kernel"   # fp8 mode: the fp8 P.V variant
         # HBM bytes per launch: PMC passes (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE) of the same
         # kernel at the same shape, collected by tools/gpu_attn_round.sh and committed under profiles/
         traffic, traffic_src = None, None
@@ -304,7 +306,7 @@ def main():
         "value": round(frames_per_s, 4), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
-        "dtype": "fp8-e4m3 block Linears (per-row scales), bf16 attention / norms / embedders" if args.fp8 else "bf16",
+        "dtype": "fp8-e4m3 block Linears (per-row scales) and attention P.V (per-head V scale); bf16 QK^T / norms / embedders" if args.fp8 else "bf16",
         "data": "synthetic",
         "config": {"workload": f"MMDiT-{args.model} (hidden {D}, {H}x{hd}, {cfg['depth']}+{cfg['depth_single_blocks']} blocks) "
                                f"denoise step, latent {T}x{hw}x{hw} (16x512x512 px), L={L} tokens, CFG batch {nb}, "

@@ -296,6 +296,7 @@ class _DoublePlan:
     img_mlp: tuple = ()
     txt_mlp: tuple = ()
     mod_layers: list = field(default_factory=list)  # [(w bf16, b bf16)] img then txt
+    pv8: bool = False   # fp8 mode: attention with the P.V product on the fp8 MFMA
 
 
 @dataclass
@@ -307,6 +308,7 @@ class _SinglePlan:
     q_scale: Tensor
     k_scale: Tensor
     mod_layers: list = field(default_factory=list)
+    pv8: bool = False
 
 
 def _attn_weights(sa, wrap=lambda w: w) -> _AttnW:
@@ -337,6 +339,7 @@ def plan_double(block) -> _DoublePlan:
             img_mlp=(wr(_w(block.img_mlp[0].weight)), _b32(block.img_mlp[0].bias), wr(_w(block.img_mlp[2].weight)), _b32(block.img_mlp[2].bias)),
             txt_mlp=(wr(_w(block.txt_mlp[0].weight)), _b32(block.txt_mlp[0].bias), wr(_w(block.txt_mlp[2].weight)), _b32(block.txt_mlp[2].bias)),
             mod_layers=[_mod_layer(block.img_mod), _mod_layer(block.txt_mod)],
+            pv8=bool(getattr(block, "_osk_fp8", False)),
         )
         object.__setattr__(block, "_osk_plan", p)
     return p
@@ -352,7 +355,7 @@ def plan_single(block) -> _SinglePlan:
         wr = _wrap_for(block)
         p = _SinglePlan(wr(w1), b1, wr(_w(block.linear2.weight)), _b32(block.linear2.bias),
                         _w(block.norm.query_norm.scale), _w(block.norm.key_norm.scale),
-                        mod_layers=[_mod_layer(block.modulation)])
+                        mod_layers=[_mod_layer(block.modulation)], pv8=bool(getattr(block, "_osk_fp8", False)))
         object.__setattr__(block, "_osk_plan", p)
     return p
 
@@ -447,10 +450,28 @@ def q_mult(hd: int) -> float:
     return hd ** -0.5 * 1.4426950408889634
 
 
-def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd: int):
-    """attention() of math.py:22-36 on the joint [txt;img] sequence; the output overwrites the (dead) v slot."""
+def v_scale_fp8(v: Tensor, H: int, hd: int) -> Tensor:
+    """one e4m3 scale per (batch, head) of a [B, L, H*hd] V view: absmax / 448 (f32 [B, H], device)"""
+    B, L, _ = v.shape
+    amax = torch.linalg.vector_norm(v.view(B, L, H, hd), ord=float("inf"), dim=(1, 3), dtype=torch.float32)
+    return (amax / 448.0).clamp_min_(1e-30).contiguous()
+
+
+def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False):
+    """attention() of math.py:22-36 on the joint [txt;img] sequence; the output overwrites the (dead) v slot.
+    pv8 (fp8 mode, head_dim 72 / 128): V^T as e4m3 with one scale per (batch, head), P.V on the fp8 MFMA."""
+    wsp = _OPS.attention_workspace(q.device)
+    if pv8 and hd in (72, 128):
+        B = v.shape[0]
+        vt8 = getattr(ws, "vt8", None)
+        if vt8 is None:
+            vt8 = ws.vt8 = torch.empty(B, H, _OPS.vt8_rows(hd), ws.vt.shape[-1], dtype=torch.uint8, device=v.device)
+        sv = v_scale_fp8(v, H, hd)
+        _OPS.v_transpose_fp8(v, sv, vt8, H, hd)
+        _OPS.attention_fwd_pv8(q, k, vt8, sv, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=wsp)
+        return
     _OPS.v_transpose(v, ws.vt, H, hd)
-    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=_OPS.attention_workspace(q.device))
+    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=wsp)
 
 
 def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: int, col_txt: int, rope: _RopeTable,
@@ -481,12 +502,12 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
         for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
             _linear(xm_s, aw.qkv_w, aw.qkv_b, y_s)
         _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
-        _joint_attention(ws, q, k, v, H, hd)
+        _joint_attention(ws, q, k, v, H, hd, plan.pv8)
     else:
         for aw, x_s, xm_s, y_s, sh1, sc1 in streams:  # K, V first: their all-gather overlaps the Q projection
             _linear(xm_s, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
         _OPS.qknorm_rope(None, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode)
-        pending = sp.gather_kv_start(ws, k, v, H, hd)
+        pending = sp.gather_kv_start(ws, k, v, H, hd, plan.pv8)
         for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
             _linear(xm_s, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
         _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
@@ -520,12 +541,12 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
     if sp is None:
         _linear(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
         _OPS.qknorm_rope(q, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
-        _joint_attention(ws, q, k, v, H, hd)
+        _joint_attention(ws, q, k, v, H, hd, plan.pv8)
     else:
         b1 = plan.b1
         _linear(ws.xm, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])
         _OPS.qknorm_rope(None, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
-        pending = sp.gather_kv_start(ws, k, v, H, hd)
+        pending = sp.gather_kv_start(ws, k, v, H, hd, plan.pv8)
         _linear(ws.xm, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
         _linear(ws.xm, plan.w1[:D], None if b1 is None else b1[:D], q)
         _OPS.qknorm_rope(q, None, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))

@@ -88,12 +88,36 @@ class SeqPar:
             b = self._bufs[key] = (k_all, vt_all)
         return b
 
-    def gather_kv_start(self, ws, k: Tensor, v: Tensor, H: int, hd: int):
+    def _buffers8(self, B: int, Lloc: int, H: int, hd: int, device):
+        key = ("pv8", B, Lloc, H, hd, str(device))
+        b = self._bufs.get(key)
+        if b is None:
+            if len(self._bufs) > 2:
+                self._bufs.clear()
+            Lp = (Lloc + 63) // 64 * 64
+            k_all = torch.empty(self.P, B, Lloc, H * hd, dtype=BF16, device=device)
+            vt8_all = torch.zeros(self.P, B, H, mmdit.ops().vt8_rows(hd), Lp, dtype=torch.uint8, device=device)
+            b = self._bufs[key] = (k_all, vt8_all)
+        return b
+
+    def gather_kv_start(self, ws, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False):
         """k, v: this rank's [B, L/P, D] views (K already normed + rotated with GLOBAL positions).  Starts the
-        exchange of K and V and returns the handles; the caller keeps computing."""
+        exchange of K and V and returns the handles; the caller keeps computing.
+        pv8 (fp8 mode): V travels as e4m3 V^T (half the bytes); its per-(batch, head) scale must be the same on
+        every rank -- the kernel accumulates P.V across all key segments -- so the local absmax is max-reduced first."""
+        pv8 = pv8 and hd in (72, 128)
         if self.head_parallel(H):
-            return self._heads_kv_start(k, v, H, hd)
+            return self._heads_kv_start(k, v, H, hd, pv8)
         B, Lloc, _ = k.shape
+        if pv8:
+            sv = mmdit.v_scale_fp8(v, H, hd)
+            dist.all_reduce(sv, op=dist.ReduceOp.MAX, group=self.group)
+            k_all, vt8_all = self._buffers8(B, Lloc, H, hd, k.device)
+            k_all[self.rank].copy_(k)
+            mmdit.ops().v_transpose_fp8(v, sv, vt8_all[self.rank], H, hd)
+            wk = dist.all_gather_into_tensor(k_all.view(-1), k_all[self.rank].view(-1), group=self.group, async_op=True)
+            wv = dist.all_gather_into_tensor(vt8_all.view(-1), vt8_all[self.rank].view(-1), group=self.group, async_op=True)
+            return "pv8", k_all, vt8_all, sv, wk, wv
         k_all, vt_all = self._buffers(B, Lloc, H, hd, k.device)
         k_all[self.rank].copy_(k)
         mmdit.ops().v_transpose(v, vt_all[self.rank], H, hd)
@@ -103,15 +127,24 @@ class SeqPar:
 
     def attention(self, ws, pending, q: Tensor, out: Tensor, H: int, hd: int):
         """Local queries against the gathered keys: one launch, P key segments of L/P keys."""
-        if isinstance(pending[0], str):
+        if isinstance(pending[0], str) and pending[0] == "heads":
             return self._heads_attention(pending, q, out, H, hd)
+        B, Lloc, D = q.shape
+        ops = mmdit.ops()
+        if isinstance(pending[0], str):   # "pv8"
+            _, k_all, vt8_all, sv, wk, wv = pending
+            wk.wait()
+            wv.wait()
+            ops.attention_fwd_pv8(q, k_all[0], vt8_all, sv, out, H, hd, hd ** -0.5, n_seg=self.P, seg_len=Lloc,
+                                  k_seg_stride=k_all.stride(0), vt_seg_stride=vt8_all.stride(0), q_prescaled=True,
+                                  workspace=ops.attention_workspace(q.device))
+            return
         k_all, vt_all, wk, wv = pending
         wk.wait()
         wv.wait()
-        B, Lloc, D = q.shape
-        mmdit.ops().attention_fwd(q, k_all[0], vt_all, out, H, hd, hd ** -0.5, n_seg=self.P, seg_len=Lloc,
-                                  k_seg_stride=k_all.stride(0), vt_seg_stride=vt_all.stride(0), q_prescaled=True,
-                                  workspace=mmdit.ops().attention_workspace(q.device))
+        ops.attention_fwd(q, k_all[0], vt_all, out, H, hd, hd ** -0.5, n_seg=self.P, seg_len=Lloc,
+                          k_seg_stride=k_all.stride(0), vt_seg_stride=vt_all.stride(0), q_prescaled=True,
+                          workspace=ops.attention_workspace(q.device))
 
     # ------------------------------------------------------------------ head-parallel exchange (all-to-all)
     def _heads_buffers(self, B: int, Lloc: int, H: int, hd: int, device):
@@ -124,6 +157,8 @@ class SeqPar:
             mk = lambda: torch.empty(self.P, B, Lloc, Hg * hd, dtype=BF16, device=device)
             b = self._bufs[key] = dict(ks=mk(), kr=mk(), vs=mk(), vr=mk(), qs=mk(), qr=mk(), os=mk(), orr=mk(),
                                        vt=torch.zeros(self.P, B, Hg, hd, Lp, dtype=BF16, device=device))
+            if hd in (72, 128):   # fp8 mode: e4m3 V^T of the received chunks
+                b["vt8"] = torch.zeros(self.P, B, Hg, mmdit.ops().vt8_rows(hd), Lp, dtype=torch.uint8, device=device)
         return b
 
     def _to_head_chunks(self, dst: Tensor, x: Tensor):
@@ -131,17 +166,17 @@ class SeqPar:
         B, Lloc, D = x.shape
         dst.copy_(x.view(B, Lloc, self.P, D // self.P).permute(2, 0, 1, 3))
 
-    def _heads_kv_start(self, k: Tensor, v: Tensor, H: int, hd: int):
+    def _heads_kv_start(self, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False):
         B, Lloc, _ = k.shape
         bufs = self._heads_buffers(B, Lloc, H, hd, k.device)
         self._to_head_chunks(bufs["ks"], k)
         wk = dist.all_to_all_single(bufs["kr"].view(-1), bufs["ks"].view(-1), group=self.group, async_op=True)
         self._to_head_chunks(bufs["vs"], v)
         wv = dist.all_to_all_single(bufs["vr"].view(-1), bufs["vs"].view(-1), group=self.group, async_op=True)
-        return "heads", bufs, wk, wv
+        return "heads", bufs, wk, wv, pv8
 
     def _heads_attention(self, pending, q: Tensor, out: Tensor, H: int, hd: int):
-        _, bufs, wk, wv = pending
+        _, bufs, wk, wv, pv8 = pending
         B, Lloc, D = q.shape
         P, Hg = self.P, H // self.P
         self._to_head_chunks(bufs["qs"], q)
@@ -150,12 +185,23 @@ class SeqPar:
         wv.wait()
         # received chunk s = source rank s's tokens = key segment s; [P, B] is also the query "batch" axis
         ops = mmdit.ops()
-        vt = bufs["vt"]
-        ops.v_transpose(bufs["vr"].view(P * B, Lloc, Hg * hd), vt.view(P * B, Hg, hd, vt.shape[-1]), Hg, hd)
-        ops.attention_fwd(bufs["qr"].view(P * B, Lloc, Hg * hd), bufs["kr"][0], vt, bufs["os"].view(P * B, Lloc, Hg * hd),
-                          Hg, hd, hd ** -0.5, n_seg=P, seg_len=Lloc, k_seg_stride=bufs["kr"].stride(0),
-                          vt_seg_stride=vt.stride(0), q_prescaled=True, kv_batches=B,
-                          workspace=ops.attention_workspace(q.device))
+        qr, kr, os_ = bufs["qr"].view(P * B, Lloc, Hg * hd), bufs["kr"], bufs["os"].view(P * B, Lloc, Hg * hd)
+        if pv8:   # this rank holds the WHOLE sequence of its heads: the e4m3 scale needs no collective
+            vr = bufs["vr"]
+            amax = torch.linalg.vector_norm(vr.view(P, B, Lloc, Hg, hd), ord=float("inf"), dim=(0, 2, 4), dtype=torch.float32)
+            sv = (amax / 448.0).clamp_min_(1e-30).contiguous()                      # [B, Hg]
+            vt8 = bufs["vt8"]
+            ops.v_transpose_fp8(vr.view(P * B, Lloc, Hg * hd), sv.repeat(P, 1).contiguous(),
+                                vt8.view(P * B, Hg, vt8.shape[-2], vt8.shape[-1]), Hg, hd)
+            ops.attention_fwd_pv8(qr, kr[0], vt8, sv, os_, Hg, hd, hd ** -0.5, n_seg=P, seg_len=Lloc,
+                                  k_seg_stride=kr.stride(0), vt_seg_stride=vt8.stride(0), q_prescaled=True, kv_batches=B,
+                                  workspace=ops.attention_workspace(q.device))
+        else:
+            vt = bufs["vt"]
+            ops.v_transpose(bufs["vr"].view(P * B, Lloc, Hg * hd), vt.view(P * B, Hg, hd, vt.shape[-1]), Hg, hd)
+            ops.attention_fwd(qr, kr[0], vt, os_, Hg, hd, hd ** -0.5, n_seg=P, seg_len=Lloc, k_seg_stride=kr.stride(0),
+                              vt_seg_stride=vt.stride(0), q_prescaled=True, kv_batches=B,
+                              workspace=ops.attention_workspace(q.device))
         # chunk s of the output belongs to rank s's tokens: straight back, then head groups side by side
         dist.all_to_all_single(bufs["orr"].view(-1), bufs["os"].view(-1), group=self.group)
         out.view(B, Lloc, P, D // P).permute(2, 0, 1, 3).copy_(bufs["orr"])

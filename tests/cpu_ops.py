@@ -153,6 +153,66 @@ def v_transpose(v, vt, H, hd):
     vt.copy_(pad[:, pos2key].permute(0, 2, 3, 1))
 
 
+def vt8_rows(hd):
+    return (hd + 1 + 15) // 16 * 16
+
+
+def v_transpose_fp8(v, scales, vt8, H, hd):
+    """CPU statement of osk_v_transpose_fp8.  The key order inside a 64-key tile is the kernel's private business (it only
+    has to agree with attention_fwd_pv8); this emulation keeps the natural order."""
+    B, L, _ = v.shape
+    Lp = vt8.shape[-1]
+    _abi_check("osk_v_transpose_fp8", v.stride(0) % 8 == 0, v.stride(1) % 8 == 0, _al(v, 16), _al(vt8, 16),
+               vt8.shape[-2] == vt8_rows(hd), Lp == (L + 63) // 64 * 64, scales.numel() == B * H)
+    x = v.float().reshape(B, L, H, hd) / scales.reshape(B, 1, H, 1)
+    q = x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).permute(0, 2, 3, 1)        # [B, H, hd, L]
+    vt8.zero_()
+    vt8[:, :, :hd, :L] = q
+    vt8[:, :, hd, :L] = 0x38                                                                          # 1.0 in e4m3
+    return vt8
+
+
+def attention_fwd_pv8(q, k, vt8, v_scale, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=None, k_seg_stride=0,
+                      vt_seg_stride=0, q_prescaled=False, kv_batches=0, workspace=None):
+    """CPU statement of osk_attention_fwd_pv8_bf16: exact QK^T and softmax bookkeeping, P and V as e4m3, the
+    denominator = the sum of the SAME e4m3 P (ones row of V^T)."""
+    Bq, Lq, D = q.shape
+    B = kv_batches if kv_batches else Bq
+    if seg_len is None:
+        seg_len = k.shape[1]
+    seg_lp = (seg_len + 63) // 64 * 64
+    RP = vt8_rows(hd)
+    _abi_check("osk_attention_fwd_pv8_bf16", q.stride(0) % 8 == 0, q.stride(1) % 8 == 0, k.stride(0) % 8 == 0,
+               k.stride(1) % 8 == 0, k_seg_stride % 8 == 0, vt_seg_stride % 16 == 0, out.stride(0) % 4 == 0,
+               out.stride(1) % 4 == 0, _al(q, 16), _al(k, 16), _al(vt8, 16), _al(out, 8), 0 <= kv_batches <= Bq,
+               v_scale.numel() == B * H)
+    ks, vs, ones = [], [], []
+    for s in range(n_seg):
+        k_s = k if n_seg == 1 else torch.as_strided(k, (B, seg_len, D), k.stride(), k.storage_offset() + s * k_seg_stride)
+        vt_s = torch.as_strided(vt8, (B, H, RP, seg_lp), (H * RP * seg_lp, RP * seg_lp, seg_lp, 1),
+                                vt8.storage_offset() + s * vt_seg_stride)
+        ks.append(k_s.float().reshape(B, seg_len, H, hd))
+        f = vt_s.view(torch.float8_e4m3fn).float()
+        vs.append(f[:, :, :hd, :seg_len].permute(0, 3, 1, 2))                                       # [B, seg, H, hd]
+        ones.append(f[:, :, hd, :seg_len])                                                           # [B, H, seg]
+    K = torch.cat(ks, 1).permute(0, 2, 1, 3)
+    V = torch.cat(vs, 1).permute(0, 2, 1, 3) * v_scale.reshape(B, H, 1, 1)
+    valid = torch.cat(ones, 2)                                                                       # [B, H, Lk]
+    Q = q.float().reshape(Bq, Lq, H, hd).permute(0, 2, 1, 3)
+    if Bq != B:
+        idx = torch.arange(Bq) % B
+        K, V, valid = K[idx], V[idx], valid[idx]
+    s_ = (Q @ K.transpose(-1, -2)) * (1.0 if q_prescaled else scale * 1.4426950408889634)            # log2 units
+    m = s_.max(-1, keepdim=True).values
+    P = torch.exp2(s_ - m).to(torch.float8_e4m3fn).float()
+    l = (P * valid[:, :, None, :]).sum(-1, keepdim=True)
+    o = (P @ V) / l
+    out.copy_(o.permute(0, 2, 1, 3).reshape(Bq, Lq, D).to(out.dtype))
+    if lse is not None:
+        lse.copy_(((m + torch.log2(l)) * 0.6931471805599453).squeeze(-1))
+    return out
+
+
 def attention_workspace(device):
     return torch.empty(16, dtype=torch.uint8, device=device)
 

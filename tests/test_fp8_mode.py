@@ -33,6 +33,10 @@ class _Counting:
         self.n_fp8 += 1
         return cpu_ops.gemm_fp8(*a, **kw)
 
+    def attention_fwd_pv8(self, *a, **kw):
+        self.n_pv8 = getattr(self, "n_pv8", 0) + 1
+        return cpu_ops.attention_fwd_pv8(*a, **kw)
+
 
 @pytest.fixture()
 def counting_mmdit(hip_lib):
@@ -70,6 +74,7 @@ def test_fp8_mode_routes_block_linears_and_bounds_the_error(counting_mmdit):
     # double block: 2 streams x (qkv, proj, mlp up, mlp down); single block: linear1, linear2
     assert ops.n_fp8 == 2 * 4 + 2
     assert ops.n_bf16 == n16 - ops.n_fp8          # embedders and the final layer stay bf16
+    assert ops.n_pv8 == 2                         # both blocks' attention with the fp8 P.V product (head_dim 128)
     e8, e16 = _rel(out8, truth), _rel(ref16, truth)
     assert e16 <= 2e-2 and e8 <= 5e-2, (e8, e16)  # fp8 gate = relL2 <= 5e-2
     assert _rel(out8, ref16) <= 5e-2

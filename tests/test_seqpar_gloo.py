@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, geom, q, mode):
+def _worker(rank, world, port, name, geom, q, mode, fp8=False):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,6 +37,8 @@ def _worker(rank, world, port, name, geom, q, mode):
         B, T, h, w, L_txt = geom
         model = mmdit.Flux(device_map="cpu", torch_dtype=torch.bfloat16, **cfg)
         model.load_state_dict(torch_params(cfg, dtype=torch.bfloat16), strict=True)
+        if fp8:   # fp8 mode: attention with the fp8 P.V product (the tiny Linears of these geometries stay bf16)
+            model.enable_fp8()
         inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=torch.bfloat16)
         with torch.inference_mode():
             single = model(**inp).float().clone()
@@ -55,11 +57,11 @@ def _worker(rank, world, port, name, geom, q, mode):
         dist.destroy_process_group()
 
 
-def _run(world, name, geom, mode):
+def _run(world, name, geom, mode, fp8=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, geom, q, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, geom, q, mode, fp8)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -115,4 +117,22 @@ def test_seqpar_matches_single_process_and_oracle(case, mode):
         # same kernels and per-row arithmetic; only the key order inside the softmax sums differs
         assert rel_l2(sharded, single) <= 2.0 ** -7, (rank, rel_l2(sharded, single))
     for rank, _, sharded in res[1:]:  # every rank returns the same full prediction
+        assert np.array_equal(sharded, res[0][2])
+
+
+@pytest.mark.parametrize("case,mode", [(CASES[2], "allgather"), (CASES[3], "allgather"), (CASES[1], "ulysses"), (CASES[3], "ulysses")],
+                         ids=lambda v: v if isinstance(v, str) else f"w{v[0]}-{v[1]}")
+def test_seqpar_fp8_mode(case, mode):
+    """fp8 mode under sequence parallelism: V travels / is re-laid out as e4m3 V^T, its per-(batch, head) scale agreed
+    across ranks (all-reduce max when K / V^T are gathered; local when heads are exchanged), attention with the fp8 P.V
+    product over P key segments.  Sharded == single-process fp8 mode up to the e4m3 rounding of P against different
+    reference maxima; every rank returns the same prediction."""
+    world, name, geom = case
+    from tests.util import rel_l2
+
+    res = _run(world, name, geom, mode, fp8=True)
+    for rank, single, sharded in res:
+        single, sharded = torch.from_numpy(single), torch.from_numpy(sharded)
+        assert rel_l2(sharded, single) <= 2e-2, (rank, rel_l2(sharded, single))
+    for rank, _, sharded in res[1:]:
         assert np.array_equal(sharded, res[0][2])
