@@ -295,8 +295,13 @@ def main():
             for rec in json.load(open(rec_path)):
                 if rec["kernel"] == kname and rec["shape"] == [nb, H, L, hd] and world == 1:
                     traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
+        peak = MFMA_BF16_PEAK_TFLOPS
+        if args.fp8 and hd in (72, 128):
+            # fp8 mode: QK^T (half the FLOPs) on the bf16 MFMA at 2.5 PF, P.V (the other half) on the fp8 MFMA at 5 PF:
+            # the time-weighted peak for equal FLOP shares is the harmonic mean, 3.33 PF
+            peak = round(2.0 / (1.0 / MFMA_BF16_PEAK_TFLOPS + 1.0 / (2 * MFMA_BF16_PEAK_TFLOPS)), 1)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
-                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": 4 * nb * Lq * H * hd * 2 if world == 1 else None,
                     "launches": len(durs), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": fl}
