@@ -104,12 +104,13 @@ __global__ void __launch_bounds__(256, 1) attn_asm128p8_kernel(const AttnParams 
     koffL[i] = (unsigned)(((int64_t)rowL * p.krs + ch) * 2);
   }
   // V^T (e4m3, 64-byte rows): instruction j = (3 - wave) + 4 i moves rows [16 j, 16 j + 16); LDS position lane % 4 of a
-  // row holds the 16-byte chunk (lane % 4) ^ ((row >> 1) & 3) of it
+  // row holds the 16-byte chunk (lane % 4) ^ ((row >> 2) & 3) of it
+  // (64-byte rows: rows r, r + 4, r + 8, r + 12 share a 16-bank group, so the swizzle must tell THOSE apart)
 #pragma unroll
   for (int i = 0; i < NSLOT_V; ++i) {
     const int jv = (NW - 1 - wave) + NW * i;
     const int row = (jv < NVD ? jv : 0) * 16 + (lane >> 2);
-    voff[i] = (unsigned)((int64_t)row * p.seg_lp + (((lane & 3) ^ ((row >> 1) & 3)) << 4));
+    voff[i] = (unsigned)((int64_t)row * p.seg_lp + (((lane & 3) ^ ((row >> 2) & 3)) << 4));
   }
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int sw = (l31 >> 1) & 7;
@@ -117,7 +118,8 @@ __global__ void __launch_bounds__(256, 1) attn_asm128p8_kernel(const AttnParams 
 #pragma unroll
   for (int j = 0; j < 4; ++j) fo[j] = lds_base + l31 * 128 + (((2 * j + hi) ^ sw) << 4);
   // V^T fragment of a row tile: row l31, the 32-byte half hi of its 64 keys = logical chunks 2 hi, 2 hi + 1
-  const unsigned vf0 = lds_base + l31 * 64 + ((((2 * hi) ^ sw) & 3) << 4), vf1 = lds_base + l31 * 64 + ((((2 * hi + 1) ^ sw) & 3) << 4);
+  const int sw4 = (l31 >> 2) & 3;
+  const unsigned vf0 = lds_base + l31 * 64 + (((2 * hi) ^ sw4) << 4), vf1 = lds_base + l31 * 64 + (((2 * hi + 1) ^ sw4) << 4);
 
   const int bkv = b % p.Bkv;
   const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + bkv * p.kbs + h * HD + kp.k_off));

@@ -101,13 +101,14 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
     koffL[i] = oL;
   }
   // V^T (e4m3, 64-byte rows): instruction j = (NW - 1 - wave) + NW i moves rows [16 j, 16 j + 16); LDS position lane % 4
-  // of a row holds the 16-byte chunk (lane % 4) ^ ((row >> 1) & 3) of it
+  // of a row holds the 16-byte chunk (lane % 4) ^ ((row >> 2) & 3) of it
+  // (64-byte rows: rows r, r + 4, r + 8, r + 12 share a 16-bank group, so the swizzle must tell THOSE apart)
   unsigned voff8[NSLOT_V];
 #pragma unroll
   for (int i = 0; i < NSLOT_V; ++i) {
     const int jv = (NW - 1 - wave) + NW * i;
     const int row = (jv < NVD ? jv : 0) * 16 + (lane >> 2);
-    voff8[i] = (unsigned)((int64_t)row * p.seg_lp + (((lane & 3) ^ ((row >> 1) & 3)) << 4));
+    voff8[i] = (unsigned)((int64_t)row * p.seg_lp + (((lane & 3) ^ ((row >> 2) & 3)) << 4));
   }
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int sw = (l31 >> 1) & 7;
@@ -118,7 +119,8 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   for (int t2 = 0; t2 < 2; ++t2)   // ring slot 1 = + KTILE (immediate), for the column image and the constant chunk alike
     kc[t2] = hi ? lds_base + OSK72P8_CONST_OFF : lds_base + 8192 + t2 * 512 + l31 * 16;
   // V^T fragment of a row tile: row l31, the 32-byte half hi of its 64 keys = logical chunks 2 hi, 2 hi + 1
-  const unsigned vf0 = lds_base + l31 * 64 + ((((2 * hi) ^ sw) & 3) << 4), vf1 = lds_base + l31 * 64 + ((((2 * hi + 1) ^ sw) & 3) << 4);
+  const int sw4 = (l31 >> 2) & 3;
+  const unsigned vf0 = lds_base + l31 * 64 + (((2 * hi) ^ sw4) << 4), vf1 = lds_base + l31 * 64 + (((2 * hi + 1) ^ sw4) << 4);
 
   const int bkv = b % p.Bkv;   // key / value batch of this query batch
   const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + bkv * p.kbs + h * HD + kp.k_off));

@@ -12,6 +12,14 @@ q, k, v = y[:, :, :D], y[:, :, D:2 * D], y[:, :, 2 * D:]
 vt = torch.empty(B, H, hd, (L + 63) // 64 * 64, dtype=torch.bfloat16, device="cuda")
 _C.v_transpose(v, vt, H, hd)
 out = torch.empty(B, L, D, dtype=torch.bfloat16, device="cuda")
+pv8 = len(sys.argv) > 5 and sys.argv[5] == "pv8"
+if pv8:
+    sv = (v.float().abs().view(B, L, H, hd).amax(dim=(1, 3)) / 448.0).contiguous()
+    vt8 = torch.empty(B, H, _C.vt8_rows(hd), (L + 63) // 64 * 64, dtype=torch.uint8, device="cuda")
+    _C.v_transpose_fp8(v, sv, vt8, H, hd)
 for _ in range(3):
-    _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5)
+    if pv8:
+        _C.attention_fwd_pv8(q, k, vt8, sv, out, H, hd, hd ** -0.5)
+    else:
+        _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5)
 torch.cuda.synchronize()
