@@ -61,6 +61,11 @@ int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride, i
  * osk_gemm_fp8: C = epilogue(a_scale[m] * w_scale[n] * (A8 @ W8^T) + bias), the epilogue of osk_gemm_bf16, on
  *   v_mfma_f32_32x32x64_f8f6f4 (f32 accumulate).  Strides of A8 / W8 in bytes, multiples of 16; K % 128 == 0,
  *   M >= 256, N >= 128 (returns OSK_EUNSUPPORTED (-2) otherwise: such layers stay on osk_gemm_bf16). */
+/* osk_ln_modulate_fp8: osk_ln_modulate_bf16 followed by osk_quantize_rows_fp8 in one pass (bit-identical to the pair:
+ * the modulated row is rounded to bf16 first): out8 = e4m3 bytes [B*L, D] contiguous, scales f32 [B*L]. */
+int osk_ln_modulate_fp8(const void* x, int64_t x_batch_stride, int64_t x_row_stride, void* out8, float* scales,
+                        const float* shift, const float* scale, int64_t mod_batch_stride,
+                        int B, int L, int D, float eps, void* stream);
 int osk_quantize_rows_fp8(const void* x, int64_t x_batch_stride, int64_t x_row_stride, int rows_per_batch,
                           void* out8, float* scales, int M, int K, void* stream);
 int osk_gemm_fp8(const void* A8, int64_t a_batch_stride, int64_t a_row_stride, int a_rows_per_batch,

@@ -24,6 +24,7 @@ SIGNATURES = {
     "osk_ln_modulate_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_gemm_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
                       _i32, _i32, _i32, _i32, _i32, _vp],
+    "osk_ln_modulate_fp8": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_quantize_rows_fp8": [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _i32, _vp],
     "osk_gemm_fp8": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
                      _i32, _i32, _i32, _i32, _i32, _vp],
@@ -114,6 +115,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, *, res=None,
                              gate_batch_stride, B * L, N, K, N if gelu_from is None else gelu_from,
                              1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_bf16")
     return out
+
+
+def ln_modulate_fp8(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, mod_batch_stride: int, eps: float = 1e-6):
+    """ln_modulate + quantize_rows_fp8 in one pass: x bf16 [B, L, D] view -> (e4m3 bytes uint8 [B*L, D], f32 scales [B*L])."""
+    B, L, D = x.shape
+    out8 = torch.empty(B * L, D, dtype=torch.uint8, device=x.device)
+    scales = torch.empty(B * L, dtype=torch.float32, device=x.device)
+    _check(lib.osk_ln_modulate_fp8(x.data_ptr(), x.stride(0), x.stride(1), out8.data_ptr(), scales.data_ptr(),
+                                   shift.data_ptr(), scale.data_ptr(), mod_batch_stride, B, L, D, eps, _stream()),
+           "osk_ln_modulate_fp8")
+    return out8, scales
 
 
 def quantize_rows_fp8(x: torch.Tensor, out8: torch.Tensor | None = None, scales: torch.Tensor | None = None):

@@ -9,11 +9,14 @@
 // LayerNorm (no affine) + modulate.  One wave per row, row kept in registers (<= 8 chunks of 8 per
 // lane -> D <= 4096), two-pass mean/variance in f32.  Algorithmic bytes: 4*D per row (2 in, 2 out).
 // =============================================================================================
-template <int MAXC>
+// FP8 instantiation (osk_ln_modulate_fp8, opt-in fp8 mode): the modulated row is rounded to bf16 exactly as above, then
+// quantised like osk_quantize_rows_fp8 (absmax / 448 per row, e4m3) without leaving the registers: out = e4m3 bytes
+// [M, D] contiguous, row scales to scales8[M].  Bytes: 3*D per row instead of 4*D + 3*D for the two kernels.
+template <int MAXC, bool FP8 = false>
 __global__ void __launch_bounds__(256) ln_modulate_kernel(
     const unsigned short* __restrict__ x, int64_t xbs, int64_t xrs, unsigned short* __restrict__ out,
     int64_t obs, int64_t ors, const float* __restrict__ shift, const float* __restrict__ scale,
-    int64_t mbs, int M, int L, int D, float eps) {
+    int64_t mbs, int M, int L, int D, float eps, float* __restrict__ scales8 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -62,7 +65,41 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (1.0f + scv[j]) * ((v[i][j] - mean) * rstd) + shv[j];
-      *reinterpret_cast<uint4*>(orow + c * 8) = pack8(o);
+      if constexpr (FP8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = bf16_bits_to_f32(f32_to_bf16_bits(o[j]));   // the bf16 value the GEMM would read
+      } else {
+        *reinterpret_cast<uint4*>(orow + c * 8) = pack8(o);
+      }
+    }
+  }
+  if constexpr (FP8) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      if (lane + i * 64 < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[i][j]));
+      }
+    }
+    amax = wave_max(amax);
+    const float inv = amax > 0.f ? 448.0f / amax : 0.f;
+    if (lane == 0) scales8[row] = amax > 0.f ? amax / 448.0f : 1.0f;
+    unsigned char* o8 = reinterpret_cast<unsigned char*>(out) + (int64_t)row * D;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(v[i][j] * inv, -448.0f), 448.0f);
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+        *reinterpret_cast<uint2*>(o8 + c * 8) = make_uint2((unsigned)w0, (unsigned)w1);
+      }
     }
   }
 }
@@ -77,8 +114,8 @@ extern "C" int osk_ln_modulate_bf16(const void* x, int64_t xbs, int64_t xrs, voi
   hipStream_t st = (hipStream_t)stream;
   const int nch = (D / 8 + 63) / 64;
 #define LAUNCH(MC)                                                                              \
-  hipLaunchKernelGGL(ln_modulate_kernel<MC>, grid, block, 0, st, (const unsigned short*)x, xbs, xrs, \
-                     (unsigned short*)out, obs, ors, shift, scale, mbs, M, L, D, eps)
+  hipLaunchKernelGGL((ln_modulate_kernel<MC, false>), grid, block, 0, st, (const unsigned short*)x, xbs, xrs, \
+                     (unsigned short*)out, obs, ors, shift, scale, mbs, M, L, D, eps, (float*)nullptr)
   if (nch <= 1) LAUNCH(1);
   else if (nch <= 2) LAUNCH(2);
   else if (nch <= 3) LAUNCH(3);
@@ -86,6 +123,28 @@ extern "C" int osk_ln_modulate_bf16(const void* x, int64_t xbs, int64_t xrs, voi
   else if (nch <= 6) LAUNCH(6);
   else LAUNCH(8);
 #undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+extern "C" int osk_ln_modulate_fp8(const void* x, int64_t xbs, int64_t xrs, void* out8, float* scales,
+                                   const float* shift, const float* scale, int64_t mbs, int B, int L, int D, float eps,
+                                   void* stream) {
+  if (!x || !out8 || !scales || !shift || !scale || B <= 0 || L <= 0 || D <= 0) return OSK_EINVAL;
+  if ((D & 7) || D > 8 * 64 * 8 || (xrs & 7) || (xbs & 7) || (mbs & 3) || ((uintptr_t)out8 & 7)) return OSK_EINVAL;
+  const int M = B * L;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (D / 8 + 63) / 64;
+#define LAUNCH8(MC)                                                                                     \
+  hipLaunchKernelGGL((ln_modulate_kernel<MC, true>), grid, block, 0, st, (const unsigned short*)x, xbs, xrs, \
+                     (unsigned short*)out8, (int64_t)0, (int64_t)0, shift, scale, mbs, M, L, D, eps, scales)
+  if (nch <= 1) LAUNCH8(1);
+  else if (nch <= 2) LAUNCH8(2);
+  else if (nch <= 3) LAUNCH8(3);
+  else if (nch <= 4) LAUNCH8(4);
+  else if (nch <= 6) LAUNCH8(6);
+  else LAUNCH8(8);
+#undef LAUNCH8
   return (int)hipGetLastError();
 }
 

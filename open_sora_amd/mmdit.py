@@ -267,9 +267,13 @@ class Fp8Weight:
         return Fp8Weight(self.w[rows], self.w8[rows], self.sw[rows])
 
 
-def _linear(a: Tensor, w, b, out: Tensor, **epi) -> Tensor:
+def _linear(a, w, b, out: Tensor, **epi) -> Tensor:
     """nn.Linear + fused epilogue: bf16 GEMM, or -- when w is an Fp8Weight and the shape qualifies -- dynamic per-row
-    quantisation of the activation followed by the fp8 GEMM."""
+    quantisation of the activation followed by the fp8 GEMM.  `a` is a bf16 [B, L, K] view or an already quantised
+    activation (a8, row scales) from _ln_modulate_for()."""
+    if isinstance(a, tuple):
+        a8, sa = a
+        return _OPS.gemm_fp8(a8, sa, w.w8, w.sw, b, out, **epi)
     if isinstance(w, Fp8Weight):
         B, L, K = a.shape
         if B * L > 0 and _OPS.gemm_fp8_supported(B * L, w.shape[0], K):
@@ -277,6 +281,16 @@ def _linear(a: Tensor, w, b, out: Tensor, **epi) -> Tensor:
             return _OPS.gemm_fp8(a8, sa, w.w8, w.sw, b, out, **epi)
         w = w.w
     return _OPS.gemm(a, w, b, out, **epi)
+
+
+def _ln_modulate_for(w, x: Tensor, shift: Tensor, scale: Tensor, xm: Tensor, mbs: int):
+    """LN + modulate of x as the input of Linear layer(s) with weight w (row slices of w included): the bf16 rows in
+    xm, or -- fp8 mode, shapes the fp8 GEMM takes -- quantised on the fly (one pass, nothing written to xm)."""
+    B, L, K = x.shape
+    if isinstance(w, Fp8Weight) and B * L > 0 and _OPS.gemm_fp8_supported(B * L, 128, K):
+        return _OPS.ln_modulate_fp8(x, shift, scale, mbs)
+    _OPS.ln_modulate(x, shift, scale, xm, mbs)
+    return xm
 
 
 @dataclass
@@ -494,35 +508,32 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
     if Lt:
         streams.append((plan.txt, x_txt, xm_txt, y[:, :Lt], t_sh1, t_sc1))
 
-    for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
-        _OPS.ln_modulate(x_s, sh1, sc1, xm_s, mbs)
+    acts = [_ln_modulate_for(aw.qkv_w, x_s, sh1, sc1, xm_s, mbs) for aw, x_s, xm_s, y_s, sh1, sc1 in streams]
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D:]
     scales = (plan.txt.q_scale, plan.txt.k_scale, plan.img.q_scale, plan.img.k_scale)
     if sp is None:
-        for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
-            _linear(xm_s, aw.qkv_w, aw.qkv_b, y_s)
+        for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):
+            _linear(act, aw.qkv_w, aw.qkv_b, y_s)
         _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         _joint_attention(ws, q, k, v, H, hd, plan.pv8)
     else:
-        for aw, x_s, xm_s, y_s, sh1, sc1 in streams:  # K, V first: their all-gather overlaps the Q projection
-            _linear(xm_s, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
+        for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):  # K, V first: their all-gather overlaps the Q projection
+            _linear(act, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
         _OPS.qknorm_rope(None, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode)
         pending = sp.gather_kv_start(ws, k, v, H, hd, plan.pv8)
-        for aw, x_s, xm_s, y_s, sh1, sc1 in streams:
-            _linear(xm_s, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
+        for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):
+            _linear(act, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
         _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         sp.attention(ws, pending, q, v, H, hd)
     if Li:  # img stream
         _linear(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=x_img, gate=i_g1, gate_batch_stride=mbs)
-        _OPS.ln_modulate(x_img, i_sh2, i_sc2, xm_img, mbs)
         w0, b0, w2, b2 = plan.img_mlp
-        _linear(xm_img, w0, b0, ws.h[:, Lt:], gelu_from=0)
+        _linear(_ln_modulate_for(w0, x_img, i_sh2, i_sc2, xm_img, mbs), w0, b0, ws.h[:, Lt:], gelu_from=0)
         _linear(ws.h[:, Lt:], w2, b2, x_img, res=x_img, gate=i_g2, gate_batch_stride=mbs)
     if Lt:  # txt stream
         _linear(v[:, :Lt], plan.txt.proj_w, plan.txt.proj_b, x_txt, res=x_txt, gate=t_g1, gate_batch_stride=mbs)
-        _OPS.ln_modulate(x_txt, t_sh2, t_sc2, xm_txt, mbs)
         w0, b0, w2, b2 = plan.txt_mlp
-        _linear(xm_txt, w0, b0, ws.h[:, :Lt], gelu_from=0)
+        _linear(_ln_modulate_for(w0, x_txt, t_sh2, t_sc2, xm_txt, mbs), w0, b0, ws.h[:, :Lt], gelu_from=0)
         _linear(ws.h[:, :Lt], w2, b2, x_txt, res=x_txt, gate=t_g2, gate_batch_stride=mbs)
 
 
@@ -535,20 +546,20 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
     y = ws.y_single(D, R)
     (shift, scale, gate), mbs = _mod_views(mod, col, 3, D)
     csb = rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0
-    _OPS.ln_modulate(ws.x, shift, scale, ws.xm, mbs)
+    act = _ln_modulate_for(plan.w1, ws.x, shift, scale, ws.xm, mbs)
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D: 3 * D]
     scales = (plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale)
     if sp is None:
-        _linear(ws.xm, plan.w1, plan.b1, y, gelu_from=3 * D)
+        _linear(act, plan.w1, plan.b1, y, gelu_from=3 * D)
         _OPS.qknorm_rope(q, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         _joint_attention(ws, q, k, v, H, hd, plan.pv8)
     else:
         b1 = plan.b1
-        _linear(ws.xm, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])
+        _linear(act, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])
         _OPS.qknorm_rope(None, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
         pending = sp.gather_kv_start(ws, k, v, H, hd, plan.pv8)
-        _linear(ws.xm, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
-        _linear(ws.xm, plan.w1[:D], None if b1 is None else b1[:D], q)
+        _linear(act, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
+        _linear(act, plan.w1[:D], None if b1 is None else b1[:D], q)
         _OPS.qknorm_rope(q, None, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         sp.attention(ws, pending, q, v, H, hd)
     _linear(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=ws.x, gate=gate, gate_batch_stride=mbs)

@@ -62,6 +62,13 @@ def gemm(a, w, bias, out, *, res=None, gate=None, gate_batch_stride=0, gelu_from
     return out
 
 
+def ln_modulate_fp8(x, shift, scale, mod_batch_stride, eps=1e-6):
+    """osk_ln_modulate_fp8 == osk_ln_modulate_bf16 followed by osk_quantize_rows_fp8 (bit-identical by construction)"""
+    xm = torch.empty(x.shape, dtype=torch.bfloat16)
+    ln_modulate(x, shift, scale, xm, mod_batch_stride, eps)
+    return quantize_rows_fp8(xm)
+
+
 def quantize_rows_fp8(x, out8=None, scales=None):
     """CPU statement of osk_quantize_rows_fp8 (torch's own float8_e4m3fn conversion)"""
     if x.dim() == 2:

@@ -239,3 +239,19 @@ def test_attention_pv8_constant_v_and_determinism(hip_lib, hd):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     c8 = (c.float().view(H, hd) / sv[0][:, None]).clamp(-448, 448).to(F8).float() * sv[0][:, None]
     assert (outs[0].float() - c8.view(1, 1, D)).abs().max().item() <= 2 ** -7 * c8.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("D", [256, 1152, 3072])
+def test_ln_modulate_fp8_equals_the_two_kernel_path(hip_lib, D):
+    """osk_ln_modulate_fp8 == osk_ln_modulate_bf16 + osk_quantize_rows_fp8, bit for bit (bytes and row scales),
+    on a strided input view."""
+    B, L = 2, 133
+    buf = rnd("x", (B, L + 5, D), std=2.0, seed=151)
+    x = buf[:, 5:]
+    mod = rnd("mod", (B, 2 * D + 8), std=0.5, dtype=torch.float32, seed=152)
+    shift, scale = mod[:, :D], mod[:, D + 8: 2 * D + 8]
+    xm = torch.empty(B, L, D, dtype=BF, device=DEV)
+    hip_lib.ln_modulate(x, shift, scale, xm, mod.stride(0))
+    q_ref, s_ref = hip_lib.quantize_rows_fp8(xm)
+    q, s = hip_lib.ln_modulate_fp8(x, shift, scale, mod.stride(0))
+    assert torch.equal(s, s_ref) and torch.equal(q, q_ref)
