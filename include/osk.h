@@ -177,6 +177,10 @@ int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_r
  *   scales f32 [B, H] (device memory; typically absmax over the head / 448, computed by the caller).
  * osk_attention_fwd_pv8_bf16: vt8 from the call above (per key segment, vt8_seg_stride in BYTES), v_scale = the same
  *   scales indexed by (key batch, head); everything else as osk_attention_fwd_ws_bf16. */
+/* osk_v_scale_fp8: scales[b*H + h] = absmax(V[b, :, h, :]) / 448 (1.0 for an all-zero head): the e4m3 scales
+ * osk_v_transpose_fp8 / osk_attention_fwd_pv8_bf16 take.  (Under sequence parallelism max-reduce them over the ranks.) */
+int osk_v_scale_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, float* scales, int B, int L, int H,
+                    int hd, void* stream);
 int osk_v_transpose_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, const float* scales, void* vt8,
                         int B, int L, int H, int hd, void* stream);
 int osk_attention_fwd_pv8_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,

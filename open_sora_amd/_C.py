@@ -39,6 +39,7 @@ SIGNATURES = {
     "osk_attention_fwd_ws_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
                                   _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _i64, _vp],
     "osk_attention_workspace_bytes": [],
+    "osk_v_scale_fp8": [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "osk_v_transpose_fp8": [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "osk_attention_fwd_pv8_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp,
                                    _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _i64, _vp],
@@ -287,6 +288,15 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
 def vt8_rows(hd: int) -> int:
     """rows per head of the e4m3 V^T tensor: hd dims + the ones row, rounded up to 16"""
     return (hd + 1 + 15) // 16 * 16
+
+
+def v_scale_fp8(v: torch.Tensor, H: int, hd: int) -> torch.Tensor:
+    """v bf16 [B, L, H*hd] view -> e4m3 scales f32 [B, H] = absmax per (batch, head) / 448"""
+    B, L, _ = v.shape
+    scales = torch.empty(B, H, dtype=torch.float32, device=v.device)
+    _check(lib.osk_v_scale_fp8(v.data_ptr(), v.stride(0), v.stride(1), scales.data_ptr(), B, L, H, hd, _stream()),
+           "osk_v_scale_fp8")
+    return scales
 
 
 def v_transpose_fp8(v: torch.Tensor, scales: torch.Tensor, vt8: torch.Tensor, H: int, hd: int) -> torch.Tensor:

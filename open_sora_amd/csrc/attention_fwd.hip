@@ -932,6 +932,81 @@ __global__ void __launch_bounds__(256) v_transpose_fp8_kernel(const unsigned sho
 
 }  // namespace
 
+namespace {
+
+// absmax of V per (batch, head) -> e4m3 scale: bit patterns of |bf16| order like the values, so the reduction runs on
+// integers.  grid (row slabs, B); a thread owns 16-byte chunks of the [H*hd] row (one head each), walks the slab's rows,
+// then one LDS atomic per chunk and one global atomic per (block, head): few, fat blocks (same-address atomics are slow).
+__global__ void __launch_bounds__(256) v_absmax_kernel(const unsigned short* __restrict__ v, int64_t bs, int64_t rs,
+                                                       int L, int H, int hd, int rows_per_block,
+                                                       unsigned* __restrict__ amax_bits) {
+  __shared__ unsigned smax[256];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < H; i += 256) smax[i] = 0;
+  __syncthreads();
+  const int cpr = (H * hd) >> 3;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = r0 + rows_per_block < L ? r0 + rows_per_block : L;
+  for (int c = threadIdx.x; c < cpr; c += 256) {
+    const unsigned short* p = v + b * bs + c * 8;
+    unsigned m = 0;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+      uint4 u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const uint4*>(p + (int64_t)(r + i) * rs);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned w[4] = {u[i].x, u[i].y, u[i].z, u[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned a = w[j] & 0x7FFF7FFFu;
+          m = max(m, max(a & 0xFFFFu, a >> 16));
+        }
+      }
+    }
+    for (; r < r1; ++r) {
+      const uint4 u = *reinterpret_cast<const uint4*>(p + (int64_t)r * rs);
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned a = w[j] & 0x7FFF7FFFu;
+        m = max(m, max(a & 0xFFFFu, a >> 16));
+      }
+    }
+    atomicMax(&smax[(c * 8) / hd], m);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += 256)
+    if (smax[i]) atomicMax(&amax_bits[b * H + i], smax[i]);
+}
+
+__global__ void v_scale_finalize_kernel(unsigned* __restrict__ amax_bits, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float amax = __uint_as_float(amax_bits[i] << 16);
+  reinterpret_cast<float*>(amax_bits)[i] = amax > 0.f ? amax / 448.0f : 1.0f;
+}
+
+}  // namespace
+
+extern "C" int osk_v_scale_fp8(const void* v, int64_t bs, int64_t rs, float* scales, int B, int L, int H, int hd,
+                               void* stream) {
+  if (!v || !scales || B <= 0 || L <= 0 || H <= 0 || H > 256 || (hd & 7) || (bs & 7) || (rs & 7) || ((uintptr_t)v & 15))
+    return OSK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(scales, 0, sizeof(float) * B * H, st);
+  if (e != hipSuccess) return (int)e;
+  int rows = (L + 127) / 128;            // about 128 blocks per batch item
+  if (rows < 16) rows = 16;
+  dim3 grid((L + rows - 1) / rows, B), block(256);
+  hipLaunchKernelGGL(v_absmax_kernel, grid, block, 0, st, (const unsigned short*)v, bs, rs, L, H, hd, rows,
+                     reinterpret_cast<unsigned*>(scales));
+  hipLaunchKernelGGL(v_scale_finalize_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st,
+                     reinterpret_cast<unsigned*>(scales), B * H);
+  return (int)hipGetLastError();
+}
+
 extern "C" int osk_v_transpose_fp8(const void* v, int64_t bs, int64_t rs, const float* scales, void* vt8, int B, int L,
                                    int H, int hd, void* stream) {
   if (!v || !vt8 || !scales || B <= 0 || L <= 0 || H <= 0 || (bs & 7) || (rs & 7) || ((uintptr_t)vt8 & 15)) return OSK_EINVAL;

@@ -466,9 +466,7 @@ def q_mult(hd: int) -> float:
 
 def v_scale_fp8(v: Tensor, H: int, hd: int) -> Tensor:
     """one e4m3 scale per (batch, head) of a [B, L, H*hd] V view: absmax / 448 (f32 [B, H], device)"""
-    B, L, _ = v.shape
-    amax = torch.linalg.vector_norm(v.view(B, L, H, hd), ord=float("inf"), dim=(1, 3), dtype=torch.float32)
-    return (amax / 448.0).clamp_min_(1e-30).contiguous()
+    return _OPS.v_scale_fp8(v, H, hd)
 
 
 def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False):

@@ -188,8 +188,7 @@ class SeqPar:
         qr, kr, os_ = bufs["qr"].view(P * B, Lloc, Hg * hd), bufs["kr"], bufs["os"].view(P * B, Lloc, Hg * hd)
         if pv8:   # this rank holds the WHOLE sequence of its heads: the e4m3 scale needs no collective
             vr = bufs["vr"]
-            amax = torch.linalg.vector_norm(vr.view(P, B, Lloc, Hg, hd), ord=float("inf"), dim=(0, 2, 4), dtype=torch.float32)
-            sv = (amax / 448.0).clamp_min_(1e-30).contiguous()                      # [B, Hg]
+            sv = ops.v_scale_fp8(vr.view(P * B, Lloc, Hg * hd), Hg, hd).view(P, B, Hg).amax(0).contiguous()   # [B, Hg]
             vt8 = bufs["vt8"]
             ops.v_transpose_fp8(vr.view(P * B, Lloc, Hg * hd), sv.repeat(P, 1).contiguous(),
                                 vt8.view(P * B, Hg, vt8.shape[-2], vt8.shape[-1]), Hg, hd)

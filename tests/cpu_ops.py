@@ -164,6 +164,12 @@ def vt8_rows(hd):
     return (hd + 1 + 15) // 16 * 16
 
 
+def v_scale_fp8(v, H, hd):
+    B, L, _ = v.shape
+    amax = v.float().reshape(B, L, H, hd).abs().amax(dim=(1, 3))
+    return torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)).contiguous()
+
+
 def v_transpose_fp8(v, scales, vt8, H, hd):
     """CPU statement of osk_v_transpose_fp8.  The key order inside a 64-key tile is the kernel's private business (it only
     has to agree with attention_fwd_pv8); this emulation keeps the natural order."""

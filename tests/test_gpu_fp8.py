@@ -255,3 +255,15 @@ def test_ln_modulate_fp8_equals_the_two_kernel_path(hip_lib, D):
     q_ref, s_ref = hip_lib.quantize_rows_fp8(xm)
     q, s = hip_lib.ln_modulate_fp8(x, shift, scale, mod.stride(0))
     assert torch.equal(s, s_ref) and torch.equal(q, q_ref)
+
+
+@pytest.mark.parametrize("H,hd,L", [(16, 72, 1000), (24, 128, 333), (2, 64, 77)])
+def test_v_scale_fp8_exact(hip_lib, H, hd, L):
+    B = 3
+    y = rnd("y", (B, L, 3 * H * hd), seed=161)
+    v = y[:, :, 2 * H * hd:]
+    v[1, :, hd: 2 * hd] = 0            # an all-zero head: scale 1
+    s = hip_lib.v_scale_fp8(v, H, hd)
+    amax = v.float().view(B, L, H, hd).abs().amax(dim=(1, 3)).cpu()     # the division on the CPU: IEEE, like the kernel's
+    ref = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.equal(s.cpu(), ref)
