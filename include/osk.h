@@ -74,7 +74,8 @@ int osk_gemm_fp8(const void* A8, int64_t a_batch_stride, int64_t a_row_stride, i
                  const void* res, const float* gate, int64_t gate_batch_stride,
                  int M, int N, int K, int gelu_from, int out_f32, void* stream);
 
-/* ---- skinny matrix-vector batch (M = Bv <= 8 rows): out[b, n] (+)= act_in(x[b, :]) . W[n, :] + bias[n]
+/* ---- skinny matrix-vector batch (any Bv; launched in slices of <= 8 rows, K <= 16384):
+ * out[b, n] (+)= act_in(x[b, :]) . W[n, :] + bias[n]
  * replaces Modulation (layers.py:184-191), MLPEmbedder (layers.py:91-99) and LastLayer.adaLN_modulation
  * (layers.py:396,399): weight-bandwidth bound.  One launch covers a LIST of layers that share x:
  * descriptor arrays (device memory, n_tasks entries each, one task = up to 64 consecutive rows of one

@@ -95,6 +95,7 @@ def ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: 
     """x, out: bf16 [B, L, D] views with contiguous last dim; shift/scale f32 views whose row b starts at
     data_ptr + b*mod_batch_stride."""
     B, L, D = x.shape
+    assert x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and shift.dtype == torch.float32, (x.dtype, out.dtype)
     _check(lib.osk_ln_modulate_bf16(x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), out.stride(0),
                                     out.stride(1), shift.data_ptr(), scale.data_ptr(), mod_batch_stride,
                                     B, L, D, eps, _stream()), "osk_ln_modulate_bf16")
@@ -109,8 +110,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, *, res=None,
     B, L, K = a.shape
     N = w.shape[0]
     assert out.shape[0] == B and out.shape[1] == L and out.shape[2] == N
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out.dtype in (torch.bfloat16, torch.float32), \
+        (a.dtype, w.dtype, out.dtype)
     if res is not None:
-        assert res.stride() == out.stride()
+        assert res.stride() == out.stride() and res.dtype == torch.bfloat16
     _check(lib.osk_gemm_bf16(a.data_ptr(), a.stride(0), a.stride(1), L, w.data_ptr(), w.stride(0), _p(bias),
                              out.data_ptr(), out.stride(0), out.stride(1), L, _p(res), _p(gate),
                              gate_batch_stride, B * L, N, K, N if gelu_from is None else gelu_from,
@@ -146,8 +149,10 @@ def quantize_rows_fp8(x: torch.Tensor, out8: torch.Tensor | None = None, scales:
 
 
 def gemm_fp8_supported(M: int, N: int, K: int) -> bool:
-    """shapes the fp8 instantiation of the large-tile kernel takes (include/osk.h); others stay on gemm()"""
-    return M >= 256 and N >= 128 and K % 128 == 0
+    """shapes the fp8 instantiation of the large-tile kernel takes (include/osk.h); others stay on gemm().
+    Mirrors gemm256_fp8_supported (csrc/gemm256.hip): the kernel's 32-bit per-lane source offsets need both the
+    (contiguous, as the host passes them) activation and weight images to span < 4 GiB."""
+    return M >= 256 and N >= 128 and K % 128 == 0 and M * K < 0xFFFFFFFF and N * K < 0xFFFFFFFF
 
 
 def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias,
@@ -338,6 +343,8 @@ def cfg_euler(pred: torch.Tensor, x: torch.Tensor, x_out: torch.Tensor, g_txt: f
     """pred bf16 [3, ...] contiguous (cond, uncond, uncond_2); x, x_out bf16 [...] contiguous."""
     n = x.numel()
     assert pred.numel() == 3 * n and pred.is_contiguous() and x.is_contiguous() and x_out.is_contiguous()
+    assert pred.dtype == x.dtype == x_out.dtype == torch.bfloat16, \
+        f"osk_cfg_euler_bf16 reads and writes bf16; got {pred.dtype}, {x.dtype}, {x_out.dtype}"
     _check(lib.osk_cfg_euler_bf16(pred.data_ptr(), n, x.data_ptr(), x_out.data_ptr(), g_txt, g_img,
                                   _p(g_img_vec), dt, _stream()), "osk_cfg_euler_bf16")
     return x_out

@@ -303,13 +303,15 @@ def prepare_api(model, model_ae, model_t5, model_clip, optional_models: dict, re
             x[0, :, -1:] = references[0][1]
         x = model_ae.decode(x)
         x = x[:, :, : opt.num_frames]
-        if not opt.is_causal_vae:
-            pad_len = model_ae.compression[0] - 1
+        if not opt.is_causal_vae:   # sampling.py:713-722: `compression` is only read inside the i2v branches
             if cond_type == "i2v_head":
+                pad_len = model_ae.compression[0] - 1
                 x = x[:, :, pad_len:]
             elif cond_type == "i2v_tail":
+                pad_len = model_ae.compression[0] - 1
                 x = x[:, :, :-pad_len]
             elif cond_type == "i2v_loop":
+                pad_len = model_ae.compression[0] - 1
                 x = x[:, :, pad_len:-pad_len]
         return x
 

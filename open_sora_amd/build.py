@@ -2,6 +2,10 @@
 
 hipcc cross-compiles without a GPU; the built .so is git-ignored but travels to the GPU box with the
 source snapshot.  `python -m open_sora_amd.build` rebuilds unconditionally.
+
+Every .hip file is its own translation unit: they are compiled to objects in parallel (one hipcc process per
+file, object files cached under lib/obj/ and re-used while neither the source nor anything it can include
+changed) and linked into the shared library.
 """
 from __future__ import annotations
 
@@ -10,43 +14,79 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libosk_hip.so")
 ARCH = "gfx950"
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"]
 
 
 def sources() -> list[str]:
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _shared_deps() -> list[str]:
+    """files any translation unit may include: the headers and the generators' output (*.inc: where every hot loop
+    lives), plus the generators themselves (a changed generator whose output was not re-emitted is caught by
+    tests/test_generated_kernels.py; here it only forces a rebuild)"""
+    return (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) +
+            glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h")) +
+            glob.glob(os.path.join(PKG_DIR, "..", "tools", "gen_*_asm.py")))
+
+
+def _newest(paths) -> float:
+    return max((os.path.getmtime(p) for p in paths), default=0.0)
+
+
 def _stale() -> bool:
     if not os.path.isfile(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h"))
-    return any(os.path.getmtime(s) > t for s in deps)
+    return _newest(sources() + _shared_deps()) > os.path.getmtime(LIB_PATH)
+
+
+def _hipcc() -> str:
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libosk_hip.so (ROCm toolchain required)")
+    return hipcc
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        raise RuntimeError("hipcc not found: cannot build libosk_hip.so (ROCm toolchain required)")
-    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    shared_t = _newest(_shared_deps() + [os.path.abspath(__file__)])
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.isfile(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), shared_t):
+            return obj
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {os.path.basename(src)} ({r.returncode}):\n{r.stderr[-4000:]}")
+        os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
     tmp = LIB_PATH + ".tmp"
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + sources()
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stderr[-4000:]}")
+        raise RuntimeError(f"hipcc link failed ({r.returncode}):\n{r.stderr[-4000:]}")
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
 if __name__ == "__main__":
-    print(build_lib(force=True, verbose=True))
+    print(build_lib(force="--incremental" not in sys.argv, verbose=True))

@@ -552,19 +552,29 @@ extern "C" int osk_gemv_tasks_bf16(const float* x, int64_t xbs, int Bv, int K, c
                                    const int32_t* n_rows, int n_tasks, float* out, int64_t obs,
                                    int act_in, int accumulate, void* stream) {
   if (!x || !w_ptrs || !b_ptrs || !out_cols || !n_rows || !out) return OSK_EINVAL;
-  if (Bv <= 0 || Bv > 8 || K <= 0 || (K & 7) || n_tasks <= 0) return OSK_EINVAL;
+  if (Bv <= 0 || K <= 0 || (K & 7) || n_tasks <= 0) return OSK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(n_tasks), block(256);
-  if (Bv <= 4) {
-    const size_t sm = (size_t)4 * K * sizeof(float);
-    if (sm > 64 * 1024) return OSK_EINVAL;
-    hipLaunchKernelGGL(gemv_tasks_kernel<4>, grid, block, sm, st, x, xbs, Bv, K, w_ptrs, b_ptrs,
-                       out_cols, n_rows, out, obs, act_in, accumulate);
-  } else {
-    const size_t sm = (size_t)8 * K * sizeof(float);
-    if (sm > 64 * 1024) return OSK_EINVAL;
-    hipLaunchKernelGGL(gemv_tasks_kernel<8>, grid, block, sm, st, x, xbs, Bv, K, w_ptrs, b_ptrs,
-                       out_cols, n_rows, out, obs, act_in, accumulate);
+  // The x rows of one launch live in LDS as f32 [MB][K] (<= 64 KiB): any batch is cut into slices of MB = 8 rows
+  // (K <= 2048), 4 rows (K <= 4096) or 1 row (K <= 16384); the reference's Linear has no batch limit.
+  const int mb = (size_t)8 * K * sizeof(float) <= 64 * 1024 && Bv > 4 ? 8
+               : (size_t)4 * K * sizeof(float) <= 64 * 1024 ? 4
+               : (size_t)K * sizeof(float) <= 64 * 1024 ? 1 : 0;
+  if (mb == 0) return OSK_EUNSUPPORTED;
+  const size_t sm = (size_t)mb * K * sizeof(float);
+  for (int b0 = 0; b0 < Bv; b0 += mb) {
+    const int nb = Bv - b0 < mb ? Bv - b0 : mb;
+    const float* xb = x + (int64_t)b0 * xbs;
+    float* ob = out + (int64_t)b0 * obs;
+    if (mb == 8)
+      hipLaunchKernelGGL(gemv_tasks_kernel<8>, grid, block, sm, st, xb, xbs, nb, K, w_ptrs, b_ptrs, out_cols, n_rows,
+                         ob, obs, act_in, accumulate);
+    else if (mb == 4)
+      hipLaunchKernelGGL(gemv_tasks_kernel<4>, grid, block, sm, st, xb, xbs, nb, K, w_ptrs, b_ptrs, out_cols, n_rows,
+                         ob, obs, act_in, accumulate);
+    else
+      hipLaunchKernelGGL(gemv_tasks_kernel<1>, grid, block, sm, st, xb, xbs, nb, K, w_ptrs, b_ptrs, out_cols, n_rows,
+                         ob, obs, act_in, accumulate);
   }
   return (int)hipGetLastError();
 }

@@ -230,6 +230,7 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
   if ((c_batch_stride & 3) || (c_row_stride & 3)) return OSK_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) || ((uintptr_t)bias & 15)) return OSK_EINVAL;
   if (gate && (!res || ((uintptr_t)gate & 15) || (gate_batch_stride & 3) || ((uintptr_t)res & 7))) return OSK_EINVAL;
+  if (out_f32 && ((uintptr_t)C & 15)) return OSK_EINVAL;   // the f32 epilogue stores float4
   GemmParams p;
   p.A = (const unsigned short*)A; p.abs_ = a_batch_stride; p.ars = a_row_stride; p.arpb = a_rows_per_batch;
   p.W = (const unsigned short*)W; p.wrs = w_row_stride; p.bias = bias;

@@ -231,7 +231,11 @@ class _ConvPlan:
 
 
 def _plan(mod, kind):
-    p = getattr(mod, "_osk_plan", None)
+    """kernel-side image of a layer's parameters, cached on the module and keyed on the parameters' (storage pointer,
+    in-place version): a swapped or rewritten weight rebuilds it"""
+    key = tuple((q.data_ptr(), q._version) for q in mod.parameters())
+    c = getattr(mod, "_osk_plan", None)
+    p = c[1] if c is not None and c[0] == key else None
     if p is None:
         if kind == "conv":
             p = _ConvPlan(mod.conv if isinstance(mod, CausalConv3d) else mod)
@@ -239,7 +243,7 @@ def _plan(mod, kind):
             p = (mod.weight.detach().float().contiguous(), mod.bias.detach().float().contiguous(), mod.num_groups, mod.eps)
         elif kind == "lin":
             p = (mod.weight.detach().to(BF16).contiguous(), mod.bias.detach().float().contiguous())
-        object.__setattr__(mod, "_osk_plan", p)
+        object.__setattr__(mod, "_osk_plan", (key, p))
     return p
 
 
@@ -388,6 +392,10 @@ class AutoencoderKLCausal3D(nn.Module):
         self.time_compression_ratio = config.time_compression_ratio
         self.spatial_compression_ratio = config.spatial_compression_ratio
         self.z_channels = config.latent_channels
+        # (t, h, w) compression of the latent grid; api_fn's non-causal i2v trimming reads compression[0]
+        # (/root/reference/opensora/utils/sampling.py:713-722)
+        self.compression = (config.time_compression_ratio, config.spatial_compression_ratio,
+                            config.spatial_compression_ratio)
         common = dict(block_out_channels=config.block_out_channels, layers_per_block=config.layers_per_block,
                       act_fn=config.act_fn, norm_num_groups=config.norm_num_groups,
                       time_compression_ratio=config.time_compression_ratio,
@@ -435,9 +443,22 @@ class AutoencoderKLCausal3D(nn.Module):
         self.use_slicing = False
 
     def invalidate_plan(self):
+        """drop every cached kernel-side weight image (re-laid conv weights, f32 biases): they are rebuilt from the
+        parameters on the next call"""
         for m in self.modules():
             if hasattr(m, "_osk_plan"):
                 object.__delattr__(m, "_osk_plan")
+
+    # the cached weight images alias / copy parameter storage: any operation that replaces or rewrites the
+    # parameters (load_state_dict, .to(), .cuda(), .half() ...) must drop them
+    def _apply(self, fn, *a, **k):
+        self.invalidate_plan()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_plan()
+        return r
 
     # ---- un-tiled cores on NCTHW tensors
     def _moments(self, x: Tensor) -> Tensor:

@@ -311,6 +311,7 @@ class _DoublePlan:
     txt_mlp: tuple = ()
     mod_layers: list = field(default_factory=list)  # [(w bf16, b bf16)] img then txt
     pv8: bool = False   # fp8 mode: attention with the P.V product on the fp8 MFMA
+    key: tuple = ()     # _param_key of the block the plan was built from
 
 
 @dataclass
@@ -323,6 +324,7 @@ class _SinglePlan:
     k_scale: Tensor
     mod_layers: list = field(default_factory=list)
     pv8: bool = False
+    key: tuple = ()
 
 
 def _attn_weights(sa, wrap=lambda w: w) -> _AttnW:
@@ -343,8 +345,15 @@ def _mod_layer(mod) -> tuple:
     return (_w(mod.lin.weight), None if mod.lin.bias is None else _w(mod.lin.bias))
 
 
+def _param_key(module):
+    """(storage pointer, in-place version) of the module's parameters: a cached plan built from other values is stale"""
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
 def plan_double(block) -> _DoublePlan:
     p = getattr(block, "_osk_plan", None)
+    if p is not None and p.key != _param_key(block):
+        p = None
     if p is None:
         wr = _wrap_for(block)
         p = _DoublePlan(
@@ -355,12 +364,15 @@ def plan_double(block) -> _DoublePlan:
             mod_layers=[_mod_layer(block.img_mod), _mod_layer(block.txt_mod)],
             pv8=bool(getattr(block, "_osk_fp8", False)),
         )
+        p.key = _param_key(block)
         object.__setattr__(block, "_osk_plan", p)
     return p
 
 
 def plan_single(block) -> _SinglePlan:
     p = getattr(block, "_osk_plan", None)
+    if p is not None and p.key != _param_key(block):
+        p = None
     if p is None:
         if getattr(block, "fused_qkv", hasattr(block, "linear1")):
             w1, b1 = _cat_linear(block.linear1)
@@ -370,6 +382,7 @@ def plan_single(block) -> _SinglePlan:
         p = _SinglePlan(wr(w1), b1, wr(_w(block.linear2.weight)), _b32(block.linear2.bias),
                         _w(block.norm.query_norm.scale), _w(block.norm.key_norm.scale),
                         mod_layers=[_mod_layer(block.modulation)], pv8=bool(getattr(block, "_osk_fp8", False)))
+        p.key = _param_key(block)
         object.__setattr__(block, "_osk_plan", p)
     return p
 
@@ -673,9 +686,25 @@ class MMDiTModel(nn.Module):
     # ------------------------------------------------------------------ planning
     def invalidate_plan(self):
         self._plan = None
-        for b in list(self.double_blocks) + list(self.single_blocks):
+        for b in list(getattr(self, "double_blocks", ())) + list(getattr(self, "single_blocks", ())):
             if hasattr(b, "_osk_plan"):
                 object.__delattr__(b, "_osk_plan")
+
+    # The plan holds copies (f32 biases, concatenated / K-padded / fp8-quantised weights) and raw device pointers
+    # (GemvTasks) derived from the parameters: anything that replaces or rewrites parameter storage must drop it.
+    def _apply(self, fn, *a, **k):
+        self.invalidate_plan()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_plan()
+        return r
+
+    def _plan_key(self):
+        """(storage pointer, in-place version counter) of every parameter: the plan is rebuilt when a weight was
+        swapped or written in place (e.g. a LoRA merge, `p.data.copy_`, an optimizer step) since it was built"""
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _build_plan(self, device):
         cfg = self.config
@@ -724,6 +753,7 @@ class MMDiTModel(nn.Module):
         p["time_in"] = emb(self.time_in)
         p["vector_in"] = emb(self.vector_in)
         p["guidance_in"] = emb(self.guidance_in) if cfg.guidance_embed else None
+        p["key"] = self._plan_key()
         self._plan = p
         return p
 
@@ -741,7 +771,12 @@ class MMDiTModel(nn.Module):
         if cfg.guidance_embed and guidance is None:
             raise ValueError("Didn't get guidance strength for guidance distilled model.")
         dev = img.device
-        p = self._plan or self._build_plan(dev)
+        p = self._plan
+        if p is not None and p["key"] != self._plan_key():
+            self.invalidate_plan()
+            p = None
+        if p is None:
+            p = self._build_plan(dev)
         D, H = self.hidden_size, self.num_heads
         hd = D // H
         R = int(D * cfg.mlp_ratio)

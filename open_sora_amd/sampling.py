@@ -114,7 +114,10 @@ class I2VDenoiser:
         b, c, t, w_, h_ = masked_ref.size()
         cond = pack(torch.cat((masks, masked_ref), dim=1), patch_size=patch_size)
         cond3 = torch.cat([cond, cond, torch.zeros_like(cond)], dim=0)  # 3rd branch drops the image condition
-        x = img[:n].clone()  # private state: the ping-pong below must not write into the caller's tensor
+        # private state (the ping-pong below must not write into the caller's tensor), kept in bf16 -- the dtype the
+        # update kernel computes in and the reference samples in (configs/diffusion/inference/256px.py:4); a model in
+        # another dtype is fed / read through casts at this boundary
+        x = img[:n].to(torch.bfloat16, copy=True).contiguous()
         x_next = torch.empty_like(x)
         img3 = torch.empty(n3, *x.shape[1:], device=dev, dtype=dt)
         for i, (t_curr, t_prev) in enumerate(zip(timesteps[:-1], timesteps[1:])):
@@ -129,9 +132,10 @@ class I2VDenoiser:
                 ramp = torch.linspace(1.0, float(upper), t)[None, None, :, None, None].repeat(b, c, 1, h_, w_)
                 gvec = pack(ramp, patch_size=patch_size).to(dev, torch.float32).contiguous()
                 image_gs = 1.0
-            _ops().cfg_euler(pred.contiguous(), x, x_next, float(text_gs), float(image_gs), float(t_prev - t_curr), gvec)
+            _ops().cfg_euler(pred.to(torch.bfloat16).contiguous(), x, x_next, float(text_gs), float(image_gs),
+                             float(t_prev - t_curr), gvec)
             x, x_next = x_next, x
-        return x
+        return x.to(dt)
 
     def prepare_guidance(self, text: list, optional_models: dict, device, dtype, **kwargs):
         ret = {"guidance_img": kwargs.pop("guidance_img")}

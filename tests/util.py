@@ -34,10 +34,18 @@ def finite_retry(fn, tries: int = 4):
     identical calls while another process was compiling); the comparator only sets a tolerance, so a clean re-run
     is the right answer, not a looser bound."""
     r = fn()
-    for _ in range(tries - 1):
-        if torch.isfinite(r.float()).all():
-            break
-        r = fn()
+    if torch.isfinite(r.float()).all():
+        return r
+    # the NaNs only show up in multi-threaded runs: re-evaluate on one thread (slower, race-free), then restore
+    n = torch.get_num_threads()
+    try:
+        torch.set_num_threads(1)
+        for _ in range(tries - 1):
+            r = fn()
+            if torch.isfinite(r.float()).all():
+                break
+    finally:
+        torch.set_num_threads(n)
     return r
 
 
