@@ -51,6 +51,7 @@ def parse():
                     help="opt-in reduced precision (BASELINE configs[4]): block Linears on the fp8 (e4m3) MFMA; "
                          "never the default line -- the reference computes in bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b1", action="store_true", help="skip the extra CFG-batch-1 timing")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
     return ap.parse_args()
 
@@ -85,6 +86,49 @@ def cpu_baseline(cfg, L_img, L_txt, cfg_batch, budget_s):
     t_double, t_single = t1 - t0, t2 - t1
     step_s = cfg_batch * (cfg["depth"] * t_double + cfg["depth_single_blocks"] * t_single)
     return t_double, t_single, step_s, ncores
+
+
+def cfg1_line(dev, budget_s):
+    """BASELINE configs[0] (SURVEY.md section 8(d) cfg 1): ONE whole forward of the S-width MMDiT on a 1x128x128 latent
+    (L_img 4096 + 512 text tokens, B = 1), the oracle (fp32, all host cores) timed whole -- no extrapolation -- beside
+    the HIP path on the same weights and inputs; also reports their relative L2 difference."""
+    from open_sora_amd import configs, mmdit
+    from oracle import mmdit_oracle as O
+    from oracle import synth
+
+    cfg = dict(configs.MMDIT["S"])
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(synth.mmdit_param_shapes(cfg), 0).items()}
+    inp = {k: torch.from_numpy(v) for k, v in synth.mmdit_inputs(cfg, 1, 1, 64, 64, 512).items()}
+    model = mmdit.Flux(device_map=dev, torch_dtype=torch.bfloat16, **cfg)
+    model.load_state_dict({k: v.to(dev, torch.bfloat16) for k, v in sd.items()}, strict=True)
+    ginp = {k: (v.to(dev) if k in ("img_ids", "txt_ids") else v.to(dev, torch.bfloat16)) for k, v in inp.items()}
+    with torch.inference_mode():
+        for _ in range(2):
+            out = model(**ginp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            out = model(**ginp)
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t0) / n * 1e3
+        t0 = time.perf_counter()
+        truth = O.forward(sd, cfg, **inp)                       # warm-up (thread pool, allocator) and the parity reference
+        t_first = time.perf_counter() - t0
+        times = []
+        while len(times) < 3 and sum(times) + t_first < budget_s:
+            t0 = time.perf_counter()
+            O.forward(sd, cfg, **inp)
+            times.append(time.perf_counter() - t0)
+    cpu_ms = (min(times) if times else t_first) * 1e3
+    o = out.float().cpu()
+    rel = float((o - truth).norm() / truth.norm())
+    fl = configs.flops_per_forward(cfg, 1, 4096, 512)
+    return {"workload": "MMDiT-S (hidden 384, 6x64, 4+8 blocks) single forward, latent 1x128x128, L=4608, B=1",
+            "cpu_ms": round(cpu_ms, 1), "cpu_timed_forwards": max(1, len(times)), "cpu_tflops": round(fl / cpu_ms / 1e9, 3),
+            "cores": ncores, "kind": "port", "gpu_ms": round(gpu_ms, 3), "rel_l2_gpu_vs_cpu_fp32": round(rel, 5)}
 
 
 def vae_cpu_baseline(budget_s):
@@ -175,8 +219,24 @@ def bench_vae(args, dev):
     print(json.dumps(res), flush=True)
 
 
+def _self_spawn(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute this command line under torch.distributed.run with one
+    rank per GPU (what the driver does for N > 1) and pass its output through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_spawn(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -222,45 +282,68 @@ def main():
     # synthetic inputs, resident in HBM before the timed region
     g = torch.Generator(device=dev).manual_seed(42)
     z = torch.randn(1, 16, T, hw, hw, device=dev, dtype=torch.bfloat16, generator=g)
-    x = sampling.pack(z).contiguous()                                        # [1, L_img, 64]
-    g2 = torch.Generator(device=dev).manual_seed(43)
-    txt = (torch.randn(nb, L_txt, cfg["context_in_dim"], device=dev, generator=g2) * 0.2).to(torch.bfloat16)
-    y_vec = torch.randn(nb, cfg["vec_in_dim"], device=dev, generator=g2).to(torch.bfloat16)
-    img_ids, txt_ids = sampling.prepare_ids(nb, T, hw, hw, L_txt, dev, torch.bfloat16)
-    cond = torch.zeros(nb, L_img, 68, device=dev, dtype=torch.bfloat16)      # t2v: masks = 0, masked_ref = 0
     ts = sampling.get_schedule(SAMPLING_STEPS, (hw // 2) * (hw // 2), T)
 
-    x_next = torch.empty_like(x)
-    img3 = torch.empty(nb, L_img, 64, device=dev, dtype=torch.bfloat16)
+    def make_step(nb):
+        """one denoise step of the sampler at CFG batch nb (3 = the reference's triple, 1 = the pure step)"""
+        st = {"x": sampling.pack(z).contiguous()}                                # [1, L_img, 64]
+        st["x_next"] = torch.empty_like(st["x"])
+        g2 = torch.Generator(device=dev).manual_seed(43)
+        txt = (torch.randn(nb, L_txt, cfg["context_in_dim"], device=dev, generator=g2) * 0.2).to(torch.bfloat16)
+        y_vec = torch.randn(nb, cfg["vec_in_dim"], device=dev, generator=g2).to(torch.bfloat16)
+        img_ids, txt_ids = sampling.prepare_ids(nb, T, hw, hw, L_txt, dev, torch.bfloat16)
+        cond = torch.zeros(nb, L_img, 68, device=dev, dtype=torch.bfloat16)  # t2v: masks = 0, masked_ref = 0
+        img3 = torch.empty(nb, L_img, 64, device=dev, dtype=torch.bfloat16)
 
-    def step(i, x, x_next):
-        t_curr, t_prev = ts[i % SAMPLING_STEPS], ts[i % SAMPLING_STEPS + 1]
-        t_vec = torch.full((nb,), t_curr, dtype=torch.bfloat16, device=dev)
-        img3.copy_(x.expand(nb, -1, -1))
-        pred = model(img=img3, img_ids=img_ids, txt=txt, txt_ids=txt_ids, timesteps=t_vec, y_vec=y_vec, cond=cond)
-        if nb == 3:
-            _C.cfg_euler(pred, x, x_next, 7.5, 3.0, float(t_prev - t_curr))
-        else:
-            _C.cfg_euler(pred.expand(3, -1, -1).contiguous(), x, x_next, 1.0, 1.0, float(t_prev - t_curr))
-        return x_next, x
+        def step(i):
+            x, x_next = st["x"], st["x_next"]
+            t_curr, t_prev = ts[i % SAMPLING_STEPS], ts[i % SAMPLING_STEPS + 1]
+            t_vec = torch.full((nb,), t_curr, dtype=torch.bfloat16, device=dev)
+            img3.copy_(x.expand(nb, -1, -1))
+            pred = model(img=img3, img_ids=img_ids, txt=txt, txt_ids=txt_ids, timesteps=t_vec, y_vec=y_vec, cond=cond)
+            if nb == 3:
+                _C.cfg_euler(pred, x, x_next, 7.5, 3.0, float(t_prev - t_curr))
+            else:
+                _C.cfg_euler(pred.expand(3, -1, -1).contiguous(), x, x_next, 1.0, 1.0, float(t_prev - t_curr))
+            st["x"], st["x_next"] = x_next, x
+
+        return step, st
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.inference_mode():
-        for i in range(args.warmup):
-            x, x_next = step(i, x, x_next)
-        _C.PROFILE_ATTENTION = [] if rank == 0 else None
+    def timed(step, n_warm, n_steps, profile):
+        for i in range(n_warm):
+            step(i)
+        _C.PROFILE_ATTENTION = [] if profile else None
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            x, x_next = step(i, x, x_next)
+        for i in range(n_steps):
+            step(i)
         barrier()
-        elapsed = time.perf_counter() - t0
-        prof = _C.PROFILE_ATTENTION
-        _C.PROFILE_ATTENTION = None
+        dt = time.perf_counter() - t0
+        prof, _C.PROFILE_ATTENTION = _C.PROFILE_ATTENTION, None
+        return dt, prof
+
+    nb = args.cfg_batch
+    with torch.inference_mode():
+        step, st = make_step(nb)
+        elapsed, prof = timed(step, args.warmup, args.steps, rank == 0)
+        x = st["x"]
+        # SURVEY.md section 8(d) cfg 2 asks for B = 1 (the pure step) next to the reference's CFG triple: a second, separately
+        # timed run of the same loop at batch 1 (reported under "b1", never part of `value`)
+        b1 = None
+        if nb != 1 and world == 1 and not args.no_b1:
+            step1, st1 = make_step(1)
+            n1 = max(3, min(args.steps, 10))
+            e1, _ = timed(step1, 1, n1, False)
+            assert torch.isfinite(st1["x"].float()).all()
+            b1 = {"cfg_batch": 1, "steps": n1, "ms_per_step": round(e1 / n1 * 1e3, 3),
+                  "latent_frames_per_sec": round(T / (SAMPLING_STEPS * e1 / n1), 4),
+                  "step_tflops": round(configs.flops_per_forward(cfg, 1, L_img, L_txt) / (e1 / n1) / 1e12, 1)}
+            del step1, st1
 
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -321,13 +404,19 @@ def main():
         "step_mfma_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4),
         "roofline": roofline,
     }
+    if b1 is not None:
+        out["b1"] = b1
+    if world > 1:
+        out["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "exchange": sp_mode}
     if world == 1 and not args.no_cpu_baseline:
         td, tsg, cpu_step, ncores = cpu_baseline(cfg, L_img, L_txt, nb, args.cpu_budget_s)
         out["cpu_baseline"] = {
             "value": round(T / (SAMPLING_STEPS * cpu_step), 6), "unit": "latent frames/s", "cores": ncores,
             "kind": "port",
-            "sample": f"oracle fp32 on {ncores} host threads: 1 double block ({td:.2f} s) + 1 single block ({tsg:.2f} s) "
-                      f"at B=1, L={L}; step extrapolated x({cfg['depth']},{cfg['depth_single_blocks']}) x CFG batch {nb} = {cpu_step:.1f} s",
+            "sample": f"EXTRAPOLATED: oracle fp32 on {ncores} host threads timed on 1 double block ({td:.2f} s) + 1 single block "
+                      f"({tsg:.2f} s) at B=1, L={L}; step = x({cfg['depth']},{cfg['depth_single_blocks']}) x CFG batch {nb} = {cpu_step:.1f} s "
+                      f"(a whole XL step is ~1 h of CPU; the un-extrapolated whole-forward line is cfg1)",
+            "cfg1": cfg1_line(dev, args.cpu_budget_s),
         }
     print(json.dumps(out), flush=True)
     if dist is not None:

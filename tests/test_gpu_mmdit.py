@@ -117,3 +117,47 @@ def test_s_config_single_step(hip_lib):
         ref_bf16 = O.forward({k: v.bfloat16() for k, v in sd32.items()}, cfg,
                              **torch_inputs(cfg, 1, 1, 64, 64, 512, dtype=BF))
     assert_parity(out, truth, ref_bf16, "MMDiT-S single step (cfg 1)")
+
+
+def test_denoise_step_is_hipgraph_capturable(hip_lib):
+    """include/osk.h promises entry points without allocation, synchronisation or global state, i.e. capturable in a
+    hipGraph: capture ONE whole denoise step (MMDiT forward on the CFG triple + the fused CFG / Euler update) with
+    torch.cuda.graph, replay it on new inputs written into the captured buffers, and compare with the eager step."""
+    from open_sora_amd import _C
+
+    cfg, _, T, h, w, L_txt = configs.GOLDEN["hd72_eager_split"]
+    B = 3
+    model = _build(cfg)
+    inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF, device="cuda")
+    x = inp["img"][:1].clone().contiguous()
+    x_next = torch.empty_like(x)
+
+    def step():
+        inp["img"].copy_(x.expand(B, -1, -1))
+        pred = model(**inp)
+        _C.cfg_euler(pred, x, x_next, 7.5, 3.0, -0.05)
+
+    with torch.inference_mode():
+        step()                                   # warm-up: builds the plan and the workspaces outside the capture
+        torch.cuda.synchronize()
+        x0 = x.clone()
+        eager = []
+        for i in range(2):                       # eager results for two different latent states
+            x.copy_(x0 * (1.0 + 0.5 * i))
+            step()
+            eager.append(x_next.clone())
+        graph = torch.cuda.CUDAGraph()
+        x.copy_(x0)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()                               # side-stream warm-up, as torch's capture recipe asks
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(graph):
+            step()
+        for i in range(2):
+            x.copy_(x0 * (1.0 + 0.5 * i))
+            x_next.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(x_next, eager[i]), f"hipGraph replay {i} differs from the eager step"

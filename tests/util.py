@@ -61,3 +61,26 @@ def torch_inputs(cfg, B, T, h, w, L_txt, dtype=torch.float32, device="cpu"):
         t = torch.from_numpy(v).to(device)
         out[k] = t if k in ("img_ids", "txt_ids") else t.to(dtype)
     return out
+
+
+def fast_params(shapes: dict, seed: int = 0, dtype=torch.float32, device="cpu") -> dict:
+    """Synthetic parameters for the LARGE geometries (XL denoiser 0.8 G parameters, shipped-width VAE): the same
+    distributions as synth.make_params (weights N(0, 1/fan_in), biases N(0, 0.02^2), norm scales 1 + 0.1 N, all
+    bf16-representable) from torch's CPU generator -- seconds instead of the minutes the portable counter-based numpy
+    generator needs at this size.  Both sides of a parity test are fed from the same call in the same process, so
+    nothing here has to be reproducible across machines (the committed goldens keep using synth)."""
+    g = torch.Generator().manual_seed(1000003 * seed + 17)
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(int(s) for s in shape)
+        if name.endswith(".scale") or (name.endswith(".weight") and len(shape) == 1):
+            a = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith(".bias"):
+            a = 0.02 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            a = torch.randn(shape, generator=g) * fan_in ** -0.5
+        out[name] = a.bfloat16().to(device=device, dtype=dtype)
+    return out
