@@ -97,7 +97,9 @@ def cfg1_line(dev, budget_s):
     from oracle import synth
 
     cfg = dict(configs.MMDIT["S"])
-    ncores = os.cpu_count() or 1
+    # this small model's operators do not scale past a few dozen threads (256 threads: 101 s per forward on the GPU
+    # box, 13x slower than 8 threads): use at most 32 and report that count
+    ncores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(ncores)
     sd = {k: torch.from_numpy(v) for k, v in synth.make_params(synth.mmdit_param_shapes(cfg), 0).items()}
     inp = {k: torch.from_numpy(v) for k, v in synth.mmdit_inputs(cfg, 1, 1, 64, 64, 512).items()}

@@ -33,7 +33,7 @@ for d in sorted(glob.glob(O + "/*/")):
         continue
     # skip the first (cold) launch
     c, t = cnt[1:n] or cnt[:n], dur[name][1:n] or dur[name][:n]
-    ghz = sum(c) / sum(t)
+    ghz = sum(c) / sum(t) / 8.0   # the counter is summed over the 8 XCDs
     clocks[spec] = {"kernel": name[:100], "launches": n, "avg_us": round(sum(t) / len(t) / 1e3, 1), "effective_clock_ghz": round(ghz, 3)}
     print(spec, clocks[spec])
 p = "gpurun_out/ab_vendor.json"
