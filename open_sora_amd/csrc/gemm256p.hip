@@ -1,0 +1,314 @@
+// Persistent-workgroup form of the large-tile bf16 GEMM (gemm256.hip):  C = epi(A[M,K] @ W[N,K]^T + bias)
+//
+// One 512-thread workgroup per CU walks a list of 256 x BN output tiles (tile i, i + grid, i + 2 grid, ... of the
+// XCD-aware grouped order of gemm256.hip).  Same tile, LDS image, LDS-DMA loaders, fragment layout and K-step schedule;
+// what changes is everything AROUND the K loop -- measured in round 1 at ~11 us per round of tiles against 1.7 us per
+// K step, i.e. 27 % of a K = 1152 GEMM (every CU issuing its 64 KiB prologue fetch and its 128 KiB store burst at the
+// same moment, with the matrix pipe idle):
+//   * the next tile's first two K steps are fetched by LDS-DMA at the END of this tile's K loop (both LDS stages are
+//     free once the last fragments sit in registers) and land while the epilogue runs: a tile never starts with a
+//     cold fetch except the first one of the workgroup (tools/gen_gemm_asm.py::gen_pers);
+//   * the accumulators start from the bias, so the epilogue of an un-gated Linear has no load to wait for and no
+//     add; GELU is decided per 32-column tile (wave-uniform), not per element, and uses v_exp_f32 + v_rcp_f32
+//     (the old epilogue spent ~30 instructions per element on exec-mask branches and an IEEE division sequence);
+//   * CUs drift apart instead of marching in lock-step, so the store bursts spread out.
+// The vendor kernel this was measured against (profiles/r02_ab_vendor.json): hipBLASLt MT256x256x64, +7..16 % over the
+// round-1 kernel at the K = 1152 shapes.
+//
+// Roofline: MFMA bf16.  Algorithmic FLOPs = 2*M*N*K.
+#include "gemm_params.h"
+#include "gemm256_regs_n256.inc"
+#include "gemm256_regs_n128.inc"
+#include "gemm256p_regs_n256.inc"
+#include "gemm256p_regs_n128.inc"
+
+namespace osk_gemm {
+namespace {
+
+OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v); }
+
+#define OSKP_OUT16                                                                                               \
+  "=v"(v16[0]), "=v"(v16[1]), "=v"(v16[2]), "=v"(v16[3]), "=v"(v16[4]), "=v"(v16[5]), "=v"(v16[6]), "=v"(v16[7]),    \
+      "=v"(v16[8]), "=v"(v16[9]), "=v"(v16[10]), "=v"(v16[11]), "=v"(v16[12]), "=v"(v16[13]), "=v"(v16[14]),          \
+      "=v"(v16[15])
+
+template <int BN, int T>
+OSK_DEV void read_acc(float* v16) {
+  if constexpr (BN == 256) {
+    if constexpr (T == 0) asm volatile(OSKG256_AR0 : OSKP_OUT16);
+    else if constexpr (T == 1) asm volatile(OSKG256_AR1 : OSKP_OUT16);
+    else if constexpr (T == 2) asm volatile(OSKG256_AR2 : OSKP_OUT16);
+    else if constexpr (T == 3) asm volatile(OSKG256_AR3 : OSKP_OUT16);
+    else if constexpr (T == 4) asm volatile(OSKG256_AR4 : OSKP_OUT16);
+    else if constexpr (T == 5) asm volatile(OSKG256_AR5 : OSKP_OUT16);
+    else if constexpr (T == 6) asm volatile(OSKG256_AR6 : OSKP_OUT16);
+    else asm volatile(OSKG256_AR7 : OSKP_OUT16);
+  } else {
+    if constexpr (T == 0) asm volatile(OSKG128_AR0 : OSKP_OUT16);
+    else if constexpr (T == 1) asm volatile(OSKG128_AR1 : OSKP_OUT16);
+    else if constexpr (T == 2) asm volatile(OSKG128_AR2 : OSKP_OUT16);
+    else asm volatile(OSKG128_AR3 : OSKP_OUT16);
+  }
+}
+
+enum { GELU_NONE = 0, GELU_ALL = 1, GELU_MIXED = 2 };
+
+// Interior 32 x 32 accumulator tile T = tn * TM + tm of a wave whose whole tile lies inside C and inside one batch:
+// no bounds checks.  FOLDED: the bias is already in the accumulator.  A lane owns row m0w + tm*32 + l31 and columns
+// tn*32 + qd*8 + hi*4 + {0..3}, qd = 0..3.
+template <int BN, bool OUT_F32, int T>
+OSK_DEV void tile_interior(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool folded, int gelu, const float4* bq,
+                           const float4* gq) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int tn = T / TM, tm = T % TM;
+  const int m = m0w + tm * 32 + l31;
+  const int b = m / p.crpb, l = m - b * p.crpb;
+  const int64_t roff = b * p.cbs + (int64_t)l * p.crs;
+  uint2 rv[4];
+  if (p.gate) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      rv[qd] = *reinterpret_cast<const uint2*>(p.res + roff + n0w + tn * 32 + qd * 8 + hi * 4);
+  }
+  float acc[16];
+  read_acc<BN, T>(acc);
+  if (!folded && p.bias) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      acc[qd * 4 + 0] += bq[qd].x; acc[qd * 4 + 1] += bq[qd].y; acc[qd * 4 + 2] += bq[qd].z; acc[qd * 4 + 3] += bq[qd].w;
+    }
+  }
+  if (gelu == GELU_ALL) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = gelu_tanh(acc[i]);
+  } else if (gelu == GELU_MIXED) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0w + tn * 32 + (i >> 2) * 8 + hi * 4 + (i & 3);
+      const float g = gelu_tanh(acc[i]);
+      acc[i] = n >= p.gelu_from ? g : acc[i];
+    }
+  }
+  if (p.gate) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      acc[qd * 4 + 0] = bf16_lo(rv[qd].x) + gq[qd].x * acc[qd * 4 + 0];
+      acc[qd * 4 + 1] = bf16_hi(rv[qd].x) + gq[qd].y * acc[qd * 4 + 1];
+      acc[qd * 4 + 2] = bf16_lo(rv[qd].y) + gq[qd].z * acc[qd * 4 + 2];
+      acc[qd * 4 + 3] = bf16_hi(rv[qd].y) + gq[qd].w * acc[qd * 4 + 3];
+    }
+  }
+  if constexpr (OUT_F32) {
+    float* crow = reinterpret_cast<float*>(p.C) + roff + n0w + tn * 32 + hi * 4;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      *reinterpret_cast<float4*>(crow + qd * 8) = make_float4(acc[qd * 4], acc[qd * 4 + 1], acc[qd * 4 + 2], acc[qd * 4 + 3]);
+  } else {
+    uint2 packed[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      packed[qd].x = pack_bf16x2(acc[qd * 4 + 0], acc[qd * 4 + 1]);
+      packed[qd].y = pack_bf16x2(acc[qd * 4 + 2], acc[qd * 4 + 3]);
+    }
+    // the partner lane (other half-wave, same row) holds the other 4 columns of every 8-column block: one
+    // v_permlane32_swap per dword gives the lower half-wave the whole block qd and the upper one the whole block qd + 1
+    unsigned short* crow = reinterpret_cast<unsigned short*>(p.C) + roff + n0w + tn * 32;
+    const bool wide = (((uintptr_t)crow) & 15) == 0;
+#pragma unroll
+    for (int qd = 0; qd < 4; qd += 2) {
+      if (wide) {
+        auto sx = __builtin_amdgcn_permlane32_swap(packed[qd].x, packed[qd + 1].x, false, false);
+        auto sy = __builtin_amdgcn_permlane32_swap(packed[qd].y, packed[qd + 1].y, false, false);
+        *reinterpret_cast<uint4*>(crow + (qd + hi) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      } else {
+        *reinterpret_cast<uint2*>(crow + qd * 8 + hi * 4) = packed[qd];
+        *reinterpret_cast<uint2*>(crow + (qd + 1) * 8 + hi * 4) = packed[qd + 1];
+      }
+    }
+  }
+}
+
+// edge tiles: per-element bounds checks (rows >= M were computed on clamped copies of row M-1 and are dropped)
+template <int BN, bool OUT_F32, int T>
+OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool folded) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int tn = T / TM, tm = T % TM;
+  float acc[16];
+  read_acc<BN, T>(acc);
+  const int m = m0w + tm * 32 + l31;
+  if (m >= p.M) return;
+  const int b = m / p.crpb, l = m - b * p.crpb;
+  const int64_t roff = b * p.cbs + (int64_t)l * p.crs;
+  const float* grow = p.gate ? p.gate + b * p.gbs : nullptr;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const int n = n0w + tn * 32 + qd * 8 + hi * 4;
+    for (int j = 0; j < 4 && n + j < p.N; ++j) {
+      float t = acc[qd * 4 + j];
+      if (!folded && p.bias) t += p.bias[n + j];
+      if (n + j >= p.gelu_from) t = gelu_tanh(t);
+      if (grow) t = bf16_bits_to_f32(p.res[roff + n + j]) + grow[n + j] * t;
+      if constexpr (OUT_F32) reinterpret_cast<float*>(p.C)[roff + n + j] = t;
+      else reinterpret_cast<unsigned short*>(p.C)[roff + n + j] = f32_to_bf16_bits(t);
+    }
+  }
+}
+
+template <int BN, bool OUT_F32, int... Ts>
+OSK_DEV void epilogue_tn(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded,
+                         std::integer_sequence<int, Ts...>) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int tn = ((Ts, ...)) / TM;   // all Ts share tn
+  if (interior) {
+    const int nf = n0w + tn * 32;        // wave-uniform: GELU for none / all / some of this tile's 32 columns
+    const int gelu = nf >= p.gelu_from ? GELU_ALL : (nf + 32 <= p.gelu_from ? GELU_NONE : GELU_MIXED);
+    float4 bq[4], gq[4];
+    const int b = m0w / p.crpb;          // an interior wave tile lies inside one batch
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int n = nf + qd * 8 + hi * 4;
+      if (!folded && p.bias) bq[qd] = *reinterpret_cast<const float4*>(p.bias + n);
+      if (p.gate) gq[qd] = *reinterpret_cast<const float4*>(p.gate + b * p.gbs + n);
+    }
+    (tile_interior<BN, OUT_F32, Ts>(p, m0w, n0w, l31, hi, folded, gelu, bq, gq), ...);
+  } else {
+    (tile_edge<BN, OUT_F32, Ts>(p, m0w, n0w, l31, hi, folded), ...);
+  }
+}
+
+template <int BN, bool OUT_F32>
+OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  if constexpr (TM == 4) {
+    epilogue_tn<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, 0, 1, 2, 3>{});
+    epilogue_tn<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, 4, 5, 6, 7>{});
+  } else {
+    epilogue_tn<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, 0, 1>{});
+    epilogue_tn<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, 2, 3>{});
+  }
+}
+
+template <int BN, bool OUT_F32>
+__global__ void __launch_bounds__(512, 2) gemm256p_kernel(const GemmParams p) {
+  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
+  constexpr int WN = BN / (TN * 32);           // waves along N (4 or 2); waves along M = 8 / WN
+  constexpr int W_BASE = BN == 256 ? OSKG256_W_BASE : OSKG128_W_BASE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int nbm = (p.M + 255) / 256, nbn = (p.N + BN - 1) / BN;
+  const int ntiles = nbm * nbn;
+  const int grp = p.group > 0 ? p.group : 1;
+  const int per_group = grp * nbn;
+  // tile order of gemm256.hip: every XCD owns a contiguous range of the list; inside it groups of `grp` row bands,
+  // N-major within a group.  Iteration i of this workgroup is list position blockIdx.x + i * gridDim.x (gridDim.x is a
+  // multiple of 8 whenever a workgroup has more than one tile, so a workgroup stays inside its XCD's range).
+  auto tile_of = [&](int it, int& m0, int& n0) {
+    const int tile = xcd_remap(it, ntiles);
+    const int g = tile / per_group, r = tile - g * per_group;
+    const int rows_here = nbm - g * grp < grp ? nbm - g * grp : grp;
+    const int bn = r / rows_here, bm = g * grp + (r - bn * rows_here);
+    m0 = bm * 256;
+    n0 = bn * BN;
+  };
+  // LDS-DMA sources: instruction j = wave + 8 i covers tile rows [8 j, 8 j + 8); byte offsets from the tensor bases
+  const int srow8 = lane >> 3, spos = lane & 7;
+  auto offsets = [&](int m0, int n0, unsigned* aoff, unsigned* woff) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (wave + 8 * i) * 8 + srow8;
+      const int c = spos ^ ((r >> 1) & 7);
+      int m = m0 + r;
+      m = m < p.M ? m : p.M - 1;
+      const int b = m / p.arpb, l = m - b * p.arpb;
+      aoff[i] = (unsigned)((b * p.abs_ + (int64_t)l * p.ars) * 2 + c * 16);
+      int n = n0 + (r < BN ? r : 0);
+      n = n < p.N ? n : p.N - 1;
+      woff[i] = (unsigned)((int64_t)n * p.wrs * 2 + c * 16);
+    }
+  };
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned sz0 = (unsigned)((hi ^ ((l31 >> 1) & 7)) << 4);   // k-sub-step ks: ^ (ks << 5) inside the asm
+  const unsigned faA0 = lds_base + (wm * TM * 32 + l31) * 128 + sz0;
+  const unsigned faW0 = lds_base + W_BASE + (wn * TN * 32 + l31) * 128 + sz0;
+  const uint64_t abase = rfl64((uint64_t)(uintptr_t)p.A), wbase = rfl64((uint64_t)(uintptr_t)p.W);
+  const uint64_t bbase = rfl64((uint64_t)(uintptr_t)p.bias);
+  const unsigned nk = rfl((unsigned)(p.K / 64));
+  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + W_BASE + wave * 1024);
+
+  // Per tile the per-lane source offsets of this tile and of the next one are recomputed (a few hundred VALU
+  // instructions against ~40k cycles of K loop) instead of being carried across the epilogue: nothing but wave-uniform
+  // scalars stays live there.
+  unsigned prefetched = 0;
+  for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
+    const int itn = it + (int)gridDim.x;
+    const bool has_next = itn < ntiles;
+    int m0, n0, m0n, n0n;
+    tile_of(it, m0, n0);
+    tile_of(has_next ? itn : it, m0n, n0n);
+    unsigned aoff[4], woff[4], aoffn[4], woffn[4];
+    offsets(m0, n0, aoff, woff);
+    offsets(m0n, n0n, aoffn, woffn);
+    const int m0w = m0 + wm * TM * 32, n0w = n0 + wn * TN * 32;
+    const bool folded = p.bias != nullptr && n0w + TN * 32 <= p.N;                 // wave-uniform
+    const unsigned boff = (unsigned)((n0w + hi * 4) * 4);
+    const unsigned flags = rfl(prefetched | (has_next ? 2u : 0u) | (folded ? 4u : 0u));
+
+#define OSKP_OPERANDS                                                                                              \
+  ::"v"(faA0), "v"(faW0), "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(woff[0]), "v"(woff[1]),       \
+      "v"(woff[2]), "v"(woff[3]), "v"(aoffn[0]), "v"(aoffn[1]), "v"(aoffn[2]), "v"(aoffn[3]), "v"(woffn[0]),         \
+      "v"(woffn[1]), "v"(woffn[2]), "v"(woffn[3]), "v"(boff), "s"(abase), "s"(wbase), "s"(bbase), "s"(nk), "s"(adst), \
+      "s"(wdst), "s"(flags)
+    if constexpr (BN == 256) {
+      asm volatile(
+#include "gemm256p_body_n256.inc"
+          OSKP_OPERANDS : OSKP256_CLOBBERS);
+    } else {
+      asm volatile(
+#include "gemm256p_body_n128.inc"
+          OSKP_OPERANDS : OSKP128_CLOBBERS);
+    }
+
+    const int b_first = m0w / p.crpb, b_last = (m0w + TM * 32 - 1) / p.crpb;
+    const bool interior = m0w + TM * 32 <= p.M && n0w + TN * 32 <= p.N && b_first == b_last;  // wave-uniform
+    epilogue_all<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded);
+    prefetched = 1;
+  }
+}
+
+template <int BN, bool OUT_F32>
+int launch_one(const GemmParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  static int n_cu = 0;
+  constexpr int SMEM = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;
+  auto kernel = gemm256p_kernel<BN, OUT_F32>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+    if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+    n_cu -= n_cu % 8;    // the tile walk keeps a workgroup inside one XCD's range only for a grid that is a multiple of 8
+    if (n_cu < 8) n_cu = 8;
+    attr_set = true;
+  }
+  const int ntiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+  const int grid = ntiles < n_cu ? ntiles : n_cu;   // one workgroup per CU (LDS: 128 KiB of 160)
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), SMEM, st, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int launch_gemm256p(const GemmParams& p, int bn, int out_f32, hipStream_t st) {
+  if (bn == 256) return out_f32 ? launch_one<256, true>(p, st) : launch_one<256, false>(p, st);
+  return out_f32 ? launch_one<128, true>(p, st) : launch_one<128, false>(p, st);
+}
+
+}  // namespace osk_gemm

@@ -262,7 +262,9 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
       bool use_old = cold < (bn == 256 ? c256 : c128);
       if (gv == 2) { bn = 256; use_old = false; }
       if (gv == 3) { bn = 128; use_old = false; }
-      if (!use_old) return osk_gemm::launch_gemm256(p, bn, out_f32, st);
+      // persistent-workgroup form (gemm256p.hip) unless OSK_GEMM_PERSIST=0 (round-1 kernel, kept for A/B runs)
+      static const bool persist = [] { const char* e = getenv("OSK_GEMM_PERSIST"); return !e || atoi(e) != 0; }();
+      if (!use_old) return persist ? osk_gemm::launch_gemm256p(p, bn, out_f32, st) : osk_gemm::launch_gemm256(p, bn, out_f32, st);
     }
   }
   const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);

@@ -27,6 +27,8 @@ struct GemmParams {
 // gemm256.hip: 256 x {256,128} x 64 tiles, 8 waves, hand-scheduled (generated) K loop
 bool gemm256_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
 int launch_gemm256(const GemmParams& p, int bn, int out_f32, hipStream_t st);
+// gemm256p.hip: the same tiles walked by one persistent workgroup per CU (cross-tile prefetch, bias-initialised accumulators)
+int launch_gemm256p(const GemmParams& p, int bn, int out_f32, hipStream_t st);
 // the same kernel on OCP e4m3 operands (A, W point at bytes; strides in elements = bytes)
 bool gemm256_fp8_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
 int launch_gemm256_fp8(const GemmParams& p, int bn, int out_f32, hipStream_t st);

@@ -60,11 +60,14 @@ OSK_DEV float wave_max(float v) {
 }
 
 OSK_DEV float gelu_tanh(float x) {
-  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2 u)
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2 u) == x / (1 + 2^(-2 log2(e) u)):
+  // two multiplies, one fma, v_exp_f32, one add, v_rcp_f32, one multiply (1-ulp transcendentals: the result is
+  // rounded to bf16 by the caller).  x -> -inf: 2^(+inf) = inf, rcp = 0, result -0; x -> +inf: x.
+  const float t = x * __builtin_fmaf(0.044715f, x * x, 1.0f);
+  const float e = __builtin_amdgcn_exp2f(t * (-2.0f * 0.7978845608028654f * 1.4426950408889634f));
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-OSK_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
+OSK_DEV float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 
 // Bijective XCD-aware remap of a 1-D block id (block b is observed on XCD b % 8): give every XCD a
 // contiguous range of logical tiles so neighbouring tiles share that XCD's private 4 MiB L2.

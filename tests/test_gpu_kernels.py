@@ -125,6 +125,56 @@ def test_gemm_large_tile_epilogues_and_views(hip_lib):
     bf16_ulp_close(yj[:, :Lt].float().cpu(), _gemm_ref(x[:, :Lt], wt, None).float().bfloat16().float(), abs_=3e-3)
 
 
+# The persistent-workgroup kernel (gemm256p.hip) only differs from a one-tile-per-workgroup launch when a workgroup owns
+# SEVERAL tiles (more tiles than CUs): cross-tile LDS-DMA prefetch at the end of a K loop, prefetched entry, bias-initialised
+# accumulators per tile.  Shapes with 2-5 tiles per workgroup: one / two / odd K-step counts, ragged M and N edges, batch
+# boundaries inside tiles, GELU starting inside a 32-column tile, the gate epilogue, f32 output, both tile widths.
+@pytest.mark.parametrize("M_L,N,K,gelu_from,gated", [
+    ((3, 5000), 2304, 192, 1000, False),     # 59 x 9 = 531 tiles; GELU from a column that is not a multiple of 32
+    ((3, 9000), 1152, 256, None, True),      # 106 x 5 tiles (last N tile half empty), gate * x + residual
+    ((1, 40000), 512, 64, None, False),      # one K step per tile (157 x 2 tiles)
+    ((2, 20000), 640, 128, 384, False),      # two K steps, BN = 128 path (N % 256 != 0), GELU from a tile boundary
+    ((1, 33000), 1000, 320, None, True),     # ragged N (1000), ragged M, odd K-step count, gated
+])
+def test_gemm_persistent_multi_tile(hip_lib, M_L, N, K, gelu_from, gated):
+    B, L = M_L
+    a = rnd("a", (B, L, K), seed=31)
+    w = rnd("w", (N, K), std=K ** -0.5, seed=32)
+    bias = rnd("b", (N,), std=0.3, dtype=torch.float32, seed=33)
+    res = gate = None
+    out = torch.empty(B, L, N, dtype=BF, device=DEV)
+    kw = {}
+    if gated:
+        res = rnd("r", (B, L, N), seed=34)
+        gate = rnd("g", (B, N), std=0.5, dtype=torch.float32, seed=35)
+        out.copy_(res)
+        kw = dict(res=out, gate=gate, gate_batch_stride=gate.stride(0))
+    hip_lib.gemm(a, w, bias, out, gelu_from=gelu_from, **kw)
+    # reference on the GPU in f32 (operands are bf16-exact, so f32 accumulation is the only difference from f64)
+    v = (a.float().reshape(B * L, K) @ w.float().T + bias).reshape(B, L, N)
+    if gelu_from is not None:
+        v = torch.cat([v[..., :gelu_from], torch.nn.functional.gelu(v[..., gelu_from:], approximate="tanh")], -1)
+    if gated:
+        v = res.float() + gate[:, None, :] * v
+    bf16_ulp_close(out.float().cpu(), v.bfloat16().float().cpu(), rel=2 ** -7, abs_=3e-3)
+    outs = []
+    for _ in range(3):
+        o = torch.empty(B, L, N, dtype=BF, device=DEV)
+        if gated:
+            o.copy_(res)
+            hip_lib.gemm(a, w, bias, o, gelu_from=gelu_from, res=o, gate=gate, gate_batch_stride=gate.stride(0))
+        else:
+            hip_lib.gemm(a, w, bias, o, gelu_from=gelu_from)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(out, o) for o in outs), "persistent GEMM: run-to-run difference (cross-tile prefetch race?)"
+    if not gated:
+        o32 = torch.empty(B, L, N, dtype=torch.float32, device=DEV)
+        hip_lib.gemm(a, w, None, o32)
+        ref32 = (a.float().reshape(B * L, K) @ w.float().T).reshape(B, L, N)
+        assert (o32 - ref32).abs().max().item() <= 1e-3 * max(1.0, ref32.abs().max().item())
+
+
 def test_gemm_is_transpose_detecting(hip_lib):
     """A = I block, asymmetric W: C must equal W^T rows exactly (guide: A=I-check with asymmetric B)."""
     K = N = 128

@@ -176,6 +176,196 @@ def gen(c):
     return L
 
 
+PERS_OPERANDS = ["faA0", "faW0", "aoff0", "aoff1", "aoff2", "aoff3", "woff0", "woff1", "woff2", "woff3",
+                 "aoffn0", "aoffn1", "aoffn2", "aoffn3", "woffn0", "woffn1", "woffn2", "woffn3", "boff",
+                 "abase", "wbase", "bias", "nk", "adst", "wdst", "flags"]
+POP = {n: "%%%d" % i for i, n in enumerate(PERS_OPERANDS)}
+S_PFLAGS, S_PBIAS = 52, 54          # flags; bias base (pair)
+PERS_S_LAST = 55
+PF_PREFETCHED, PF_HAS_NEXT, PF_BIAS = 0, 1, 2   # flag bits
+
+
+def gen_pers(c):
+    """K loop of gen() for a PERSISTENT workgroup (csrc/gemm256p.hip): the asm statement is executed once per output
+    tile of the workgroup's tile list, and the fixed costs of a tile move off the matrix pipe's critical path:
+      * exit: after the last barrier both LDS stages are free -> the LDS-DMA of the NEXT tile's K steps 0 and 1 (per-lane
+        source offsets aoffn / woffn) is issued in the shadows of the trailing k-sub-step, so it lands while the wrapper
+        runs this tile's epilogue (flags bit 1 = there is a next tile);
+      * entry: flags bit 0 = stages 0 / 1 are already in flight (issued by the previous tile's exit): no load prologue;
+      * the accumulators start from the bias (flags bit 2; 16 f32 per 32-column tile and lane, loaded once per tile
+        into the idle fragment registers) instead of zero, so the epilogue of an un-gated Linear issues no load at all.
+    The fragment addresses of k-sub-steps 1..3 are faX0 ^ (ks << 5) (the XOR swizzle only touches address bits 4..6)."""
+    assert not c.FP8
+    L = []
+    e = lambda t: L.append("  " + t)
+    lab = lambda n: L.append(".Lp%s_%s_%%=:" % (c.tag, n))
+    ref = lambda n: ".Lp%s_%s_%%=" % (c.tag, n)
+    VX = c.V0 + c.VN                       # 6 derived fragment addresses: A ks 1..3, W ks 1..3
+    fa = {("A", 0): POP["faA0"], ("W", 0): POP["faW0"]}
+    for ks in range(1, 4):
+        fa[("A", ks)] = vr(VX + ks - 1)
+        fa[("W", ks)] = vr(VX + 3 + ks - 1)
+
+    def reads(stage, ks, fset):
+        out = []
+        for tm in range(c.TM):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, tm), 4), fa[("A", ks)], stage * c.A_STAGE + tm * 4096))
+        for tn in range(c.TN):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, c.TM + tn), 4), fa[("W", ks)], stage * c.W_STAGE + tn * 4096))
+        return out
+
+    def mfmas(fset):
+        out = []
+        for tn in range(c.TN):
+            for tm in range(c.TM):
+                acc = ar((tn * c.TM + tm) * 16, 16)
+                out.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, c.TM + tn), 4), vr(c.frag(fset, tm), 4), acc))
+        return out
+
+    def dma(stage, nxt=False):
+        sfx = "n" if nxt else ""
+        out = []
+        for i in range(c.NA):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (POP["aoff%s%d" % (sfx, i)], S_AB, S_AB + 1)))
+        for i in range(c.NW):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * 8192),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (POP["woff%s%d" % (sfx, i)], S_WB, S_WB + 1)))
+        return out
+
+    def advance():
+        return ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
+                "s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK),
+                "s_cselect_b32 s%d, 128, 0" % S_STEP,
+                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL),
+                "s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1),
+                "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1)]
+
+    def plain(pieces):
+        for m0w, d in pieces:
+            e(m0w); e("s_nop 0"); e(d)
+
+    # ---- setup
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, POP["abase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, POP["wbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_PBIAS, S_PBIAS + 1, POP["bias"]))
+    e("s_mov_b32 s%d, %s" % (S_NK, POP["nk"]))
+    e("s_mov_b32 s%d, %s" % (S_ADST, POP["adst"]))
+    e("s_mov_b32 s%d, %s" % (S_WDST, POP["wdst"]))
+    e("s_mov_b32 s%d, %s" % (S_PFLAGS, POP["flags"]))
+    e("s_mov_b32 s%d, 0" % S_T)
+    e("s_mov_b32 s%d, 0" % S_KL)
+    for ks in range(1, 4):
+        e("v_xor_b32_e32 %s, %d, %s" % (fa[("A", ks)], ks << 5, POP["faA0"]))
+        e("v_xor_b32_e32 %s, %d, %s" % (fa[("W", ks)], ks << 5, POP["faW0"]))
+    # ---- entry: K step 0 -> stage 0 unless the previous tile's exit already fetched it
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_PREFETCHED))
+    e("s_cbranch_scc1 %s" % ref("have0"))
+    plain(dma(0))
+    lab("have0")
+    for a in advance():
+        e(a)
+    # bias of this lane's accumulator columns -> the idle fragment registers (consumed before the first fragment read)
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_BIAS))
+    e("s_cbranch_scc0 %s" % ref("nobias"))
+    for tn in range(c.TN):
+        for qd in range(4):
+            e("global_load_dwordx4 %s, %s, s[%d:%d] offset:%d" % (vr(c.V0 + (tn * 4 + qd) * 4, 4), POP["boff"], S_PBIAS, S_PBIAS + 1,
+                                                                   (tn * 32 + qd * 8) * 4))
+    lab("nobias")
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_PREFETCHED))
+    e("s_cbranch_scc1 %s" % ref("have1"))
+    plain(dma(1))
+    lab("have1")
+    for a in advance():
+        e(a)
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_BIAS))
+    e("s_cbranch_scc0 %s" % ref("zero"))
+    for tn in range(c.TN):
+        for tm in range(c.TM):
+            for r in range(16):
+                e("v_accvgpr_write_b32 %s, %s" % (ar((tn * c.TM + tm) * 16 + r), vr(c.V0 + tn * 16 + r)))
+    e("s_branch %s" % ref("inited"))
+    lab("zero")
+    for r in range(c.NACC):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    lab("inited")
+    e("s_nop 1")
+    for r in reads(0, 0, 0):
+        e(r)
+    e("s_branch %s" % ref("entry0"))
+
+    for k in range(2):
+        cur = k
+        lab("step%d" % k)
+        for r in reads(cur, 0, 0):
+            e(r)
+        mf = mfmas(1)
+        pieces = dma(cur ^ 1)
+        e(pieces[0][0])
+        for i, m in enumerate(mf):
+            e(m)
+            if i < len(pieces):
+                e(pieces[i][1])
+                if i + 1 < len(pieces):
+                    e(pieces[i + 1][0])
+        plain(pieces[len(mf):])
+        for a in advance():
+            e(a)
+        lab("entry%d" % k)
+        for ks in range(3):
+            fset = ks % 2
+            e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(fset)
+            rd = reads(cur, ks + 1, fset ^ 1)
+            for i, m in enumerate(mf):
+                e(m)
+                if i < len(rd):
+                    e(rd[i])
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_barrier")
+        e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
+        e("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NK))
+        e("s_cbranch_scc0 %s" % ref("exit"))
+        if k == 1:
+            e("s_branch %s" % ref("step0"))
+    lab("exit")
+    # both stages are free now (every fragment of the last K step is in registers): fetch the next tile's first two K steps
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_HAS_NEXT))
+    e("s_cbranch_scc0 %s" % ref("last"))
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, POP["abase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, POP["wbase"]))
+    mf = mfmas(1)
+    pieces = dma(0, nxt=True)
+    e(pieces[0][0])
+    for i, m in enumerate(mf):
+        e(m)
+        if i < len(pieces):
+            e(pieces[i][1])
+            if i + 1 < len(pieces):
+                e(pieces[i + 1][0])
+    plain(pieces[len(mf):])
+    e("s_cmp_gt_u32 s%d, 1" % S_NK)                      # K step 1 exists?  (else stage 1 re-fetches step 0: harmless)
+    e("s_cselect_b32 s%d, 128, 0" % S_STEP)
+    e("s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP))
+    e("s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1))
+    e("s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP))
+    e("s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1))
+    plain(dma(1, nxt=True))
+    e("s_branch %s" % ref("end"))
+    lab("last")
+    for m in mfmas(1):
+        e(m)
+    lab("end")
+    e("s_nop 15")
+    e("s_nop 15")
+    return L
+
+
 def gen_fp8(c):
     """K loop of the fp8 (OCP e4m3) GEMM: the SAME tile, LDS image (128-byte rows = 128 K elements now), LDS-DMA
     loaders and operands as gen(); one v_mfma_f32_32x32x64_f8f6f4 (64 cycles, 2x the bf16 MAC rate) consumes what
@@ -616,6 +806,15 @@ def main():
             cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 12)] + ['"a%d"' % i for i in range(c.NACC)] + \
                     ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
             f.write("#define %sCONV_CLOBBERS %s\n" % (P, ", ".join(cclob)))
+        with open(os.path.join(args.out, "gemm256p_body_n%d.inc" % bn), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile K loop, persistent workgroup.\n" % bn)
+            for ln in gen_pers(c):
+                f.write('"%s\\n"\n' % ln)
+        with open(os.path.join(args.out, "gemm256p_regs_n%d.inc" % bn), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
+            pclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 6)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                    ['"s%d"' % i for i in range(S_FIRST, PERS_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+            f.write("#define OSKP%d_CLOBBERS %s\n" % (bn, ", ".join(pclob)))
         with open(os.path.join(args.out, "conv256_body_n%d.inc" % bn), "w") as f:
             f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile, whole K axis (all filter taps).\n" % bn)
             for ln in gen_conv(c):
