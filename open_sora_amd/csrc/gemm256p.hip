@@ -16,7 +16,7 @@
 // round-1 kernel at the K = 1152 shapes.
 //
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 2*M*N*K.
-#include "gemm_params.h"
+#include "gemm_epilogue.h"
 #include "gemm256_regs_n256.inc"
 #include "gemm256_regs_n128.inc"
 #include "gemm256p_regs_n256.inc"
@@ -52,144 +52,18 @@ OSK_DEV void read_acc(float* v16) {
   }
 }
 
-enum { GELU_NONE = 0, GELU_ALL = 1, GELU_MIXED = 2 };
+template <int BN>
+struct Geo {
+  static constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  static constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
+  template <int T>
+  OSK_DEV static void read(float* v16) { read_acc<BN, T>(v16); }
+};
 
-// Interior 32 x 32 accumulator tile T = tn * TM + tm of a wave whose whole tile lies inside C and inside one batch:
-// no bounds checks.  FOLDED: the bias is already in the accumulator.  A lane owns row m0w + tm*32 + l31 and columns
-// tn*32 + qd*8 + hi*4 + {0..3}, qd = 0..3.
-template <int BN, bool OUT_F32, int T>
-OSK_DEV void tile_interior(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool folded, int gelu, const float4* bq,
-                           const float4* gq) {
-  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
-  constexpr int tn = T / TM, tm = T % TM;
-  const int m = m0w + tm * 32 + l31;
-  const int b = m / p.crpb, l = m - b * p.crpb;
-  const int64_t roff = b * p.cbs + (int64_t)l * p.crs;
-  uint2 rv[4];
-  if (p.gate) {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd)
-      rv[qd] = *reinterpret_cast<const uint2*>(p.res + roff + n0w + tn * 32 + qd * 8 + hi * 4);
-  }
-  float acc[16];
-  read_acc<BN, T>(acc);
-  if (!folded && p.bias) {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      acc[qd * 4 + 0] += bq[qd].x; acc[qd * 4 + 1] += bq[qd].y; acc[qd * 4 + 2] += bq[qd].z; acc[qd * 4 + 3] += bq[qd].w;
-    }
-  }
-  if (gelu == GELU_ALL) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = gelu_tanh(acc[i]);
-  } else if (gelu == GELU_MIXED) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int n = n0w + tn * 32 + (i >> 2) * 8 + hi * 4 + (i & 3);
-      const float g = gelu_tanh(acc[i]);
-      acc[i] = n >= p.gelu_from ? g : acc[i];
-    }
-  }
-  if (p.gate) {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      acc[qd * 4 + 0] = bf16_lo(rv[qd].x) + gq[qd].x * acc[qd * 4 + 0];
-      acc[qd * 4 + 1] = bf16_hi(rv[qd].x) + gq[qd].y * acc[qd * 4 + 1];
-      acc[qd * 4 + 2] = bf16_lo(rv[qd].y) + gq[qd].z * acc[qd * 4 + 2];
-      acc[qd * 4 + 3] = bf16_hi(rv[qd].y) + gq[qd].w * acc[qd * 4 + 3];
-    }
-  }
-  if constexpr (OUT_F32) {
-    float* crow = reinterpret_cast<float*>(p.C) + roff + n0w + tn * 32 + hi * 4;
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd)
-      *reinterpret_cast<float4*>(crow + qd * 8) = make_float4(acc[qd * 4], acc[qd * 4 + 1], acc[qd * 4 + 2], acc[qd * 4 + 3]);
-  } else {
-    uint2 packed[4];
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      packed[qd].x = pack_bf16x2(acc[qd * 4 + 0], acc[qd * 4 + 1]);
-      packed[qd].y = pack_bf16x2(acc[qd * 4 + 2], acc[qd * 4 + 3]);
-    }
-    // the partner lane (other half-wave, same row) holds the other 4 columns of every 8-column block: one
-    // v_permlane32_swap per dword gives the lower half-wave the whole block qd and the upper one the whole block qd + 1
-    unsigned short* crow = reinterpret_cast<unsigned short*>(p.C) + roff + n0w + tn * 32;
-    const bool wide = (((uintptr_t)crow) & 15) == 0;
-#pragma unroll
-    for (int qd = 0; qd < 4; qd += 2) {
-      if (wide) {
-        auto sx = __builtin_amdgcn_permlane32_swap(packed[qd].x, packed[qd + 1].x, false, false);
-        auto sy = __builtin_amdgcn_permlane32_swap(packed[qd].y, packed[qd + 1].y, false, false);
-        *reinterpret_cast<uint4*>(crow + (qd + hi) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-      } else {
-        *reinterpret_cast<uint2*>(crow + qd * 8 + hi * 4) = packed[qd];
-        *reinterpret_cast<uint2*>(crow + (qd + 1) * 8 + hi * 4) = packed[qd + 1];
-      }
-    }
-  }
-}
-
-// edge tiles: per-element bounds checks (rows >= M were computed on clamped copies of row M-1 and are dropped)
-template <int BN, bool OUT_F32, int T>
-OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool folded) {
-  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
-  constexpr int tn = T / TM, tm = T % TM;
-  float acc[16];
-  read_acc<BN, T>(acc);
-  const int m = m0w + tm * 32 + l31;
-  if (m >= p.M) return;
-  const int b = m / p.crpb, l = m - b * p.crpb;
-  const int64_t roff = b * p.cbs + (int64_t)l * p.crs;
-  const float* grow = p.gate ? p.gate + b * p.gbs : nullptr;
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const int n = n0w + tn * 32 + qd * 8 + hi * 4;
-    for (int j = 0; j < 4 && n + j < p.N; ++j) {
-      float t = acc[qd * 4 + j];
-      if (!folded && p.bias) t += p.bias[n + j];
-      if (n + j >= p.gelu_from) t = gelu_tanh(t);
-      if (grow) t = bf16_bits_to_f32(p.res[roff + n + j]) + grow[n + j] * t;
-      if constexpr (OUT_F32) reinterpret_cast<float*>(p.C)[roff + n + j] = t;
-      else reinterpret_cast<unsigned short*>(p.C)[roff + n + j] = f32_to_bf16_bits(t);
-    }
-  }
-}
-
-template <int BN, bool OUT_F32, int... Ts>
-OSK_DEV void epilogue_tn(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded,
-                         std::integer_sequence<int, Ts...>) {
-  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
-  constexpr int tn = ((Ts, ...)) / TM;   // all Ts share tn
-  if (interior) {
-    const int nf = n0w + tn * 32;        // wave-uniform: GELU for none / all / some of this tile's 32 columns
-    const int gelu = nf >= p.gelu_from ? GELU_ALL : (nf + 32 <= p.gelu_from ? GELU_NONE : GELU_MIXED);
-    float4 bq[4], gq[4];
-    const int b = m0w / p.crpb;          // an interior wave tile lies inside one batch
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int n = nf + qd * 8 + hi * 4;
-      if (!folded && p.bias) bq[qd] = *reinterpret_cast<const float4*>(p.bias + n);
-      if (p.gate) gq[qd] = *reinterpret_cast<const float4*>(p.gate + b * p.gbs + n);
-    }
-    (tile_interior<BN, OUT_F32, Ts>(p, m0w, n0w, l31, hi, folded, gelu, bq, gq), ...);
-  } else {
-    (tile_edge<BN, OUT_F32, Ts>(p, m0w, n0w, l31, hi, folded), ...);
-  }
-}
-
-template <int BN, bool OUT_F32>
-OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded) {
-  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
-  if constexpr (TM == 4) {
-    epilogue_tn<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, 0, 1, 2, 3>{});
-    epilogue_tn<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, 4, 5, 6, 7>{});
-  } else {
-    epilogue_tn<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, 0, 1>{});
-    epilogue_tn<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, 2, 3>{});
-  }
-}
-
-template <int BN, bool OUT_F32>
+// SCHED: K-step schedule of the generated body (tools/gen_gemm_asm.py::gen_pers): 0 = the round-1 order (fragment reads
+// of a new stage issued in a block right behind the barrier, one prefetch read per MFMA shadow), 1 = matrix pipe first
+// (the trailing sub-step starts behind the barrier, reads two per shadow at the head of every sub-step)
+template <int BN, bool OUT_F32, int SCHED>
 __global__ void __launch_bounds__(512, 2) gemm256p_kernel(const GemmParams p) {
   constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
@@ -265,29 +139,37 @@ __global__ void __launch_bounds__(512, 2) gemm256p_kernel(const GemmParams p) {
       "v"(woff[2]), "v"(woff[3]), "v"(aoffn[0]), "v"(aoffn[1]), "v"(aoffn[2]), "v"(aoffn[3]), "v"(woffn[0]),         \
       "v"(woffn[1]), "v"(woffn[2]), "v"(woffn[3]), "v"(boff), "s"(abase), "s"(wbase), "s"(bbase), "s"(nk), "s"(adst), \
       "s"(wdst), "s"(flags)
-    if constexpr (BN == 256) {
+    if constexpr (BN == 256 && SCHED == 1) {
       asm volatile(
-#include "gemm256p_body_n256.inc"
+#include "gemm256p_body_n256_s1.inc"
           OSKP_OPERANDS : OSKP256_CLOBBERS);
+    } else if constexpr (BN == 256) {
+      asm volatile(
+#include "gemm256p_body_n256_s0.inc"
+          OSKP_OPERANDS : OSKP256_CLOBBERS);
+    } else if constexpr (SCHED == 1) {
+      asm volatile(
+#include "gemm256p_body_n128_s1.inc"
+          OSKP_OPERANDS : OSKP128_CLOBBERS);
     } else {
       asm volatile(
-#include "gemm256p_body_n128.inc"
+#include "gemm256p_body_n128_s0.inc"
           OSKP_OPERANDS : OSKP128_CLOBBERS);
     }
 
     const int b_first = m0w / p.crpb, b_last = (m0w + TM * 32 - 1) / p.crpb;
     const bool interior = m0w + TM * 32 <= p.M && n0w + TN * 32 <= p.N && b_first == b_last;  // wave-uniform
-    epilogue_all<BN, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded);
+    epi::epilogue_all<Geo<BN>, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded);
     prefetched = 1;
   }
 }
 
-template <int BN, bool OUT_F32>
+template <int BN, bool OUT_F32, int SCHED>
 int launch_one(const GemmParams& p, hipStream_t st) {
   static bool attr_set = false;
   static int n_cu = 0;
   constexpr int SMEM = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;
-  auto kernel = gemm256p_kernel<BN, OUT_F32>;
+  auto kernel = gemm256p_kernel<BN, OUT_F32, SCHED>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
@@ -307,8 +189,16 @@ int launch_one(const GemmParams& p, hipStream_t st) {
 }  // namespace
 
 int launch_gemm256p(const GemmParams& p, int bn, int out_f32, hipStream_t st) {
-  if (bn == 256) return out_f32 ? launch_one<256, true>(p, st) : launch_one<256, false>(p, st);
-  return out_f32 ? launch_one<128, true>(p, st) : launch_one<128, false>(p, st);
+  // OSK_GEMM_SCHED: 0 / 1 for both tile widths (A/B runs); default: schedule 1 for the 256-wide tile, 0 for the 128-wide one
+  // (its 4-MFMA sub-steps leave no head shadows for paired reads)
+  static const int forced = [] { const char* e = getenv("OSK_GEMM_SCHED"); return e ? atoi(e) : -1; }();
+  const int sched = forced >= 0 ? forced : (bn == 256 ? 1 : 0);
+  if (bn == 256) {
+    if (sched == 1) return out_f32 ? launch_one<256, true, 1>(p, st) : launch_one<256, false, 1>(p, st);
+    return out_f32 ? launch_one<256, true, 0>(p, st) : launch_one<256, false, 0>(p, st);
+  }
+  if (sched == 1) return out_f32 ? launch_one<128, true, 1>(p, st) : launch_one<128, false, 1>(p, st);
+  return out_f32 ? launch_one<128, true, 0>(p, st) : launch_one<128, false, 0>(p, st);
 }
 
 }  // namespace osk_gemm

@@ -264,6 +264,9 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
       if (gv == 3) { bn = 128; use_old = false; }
       // persistent-workgroup form (gemm256p.hip) unless OSK_GEMM_PERSIST=0 (round-1 kernel, kept for A/B runs)
       static const bool persist = [] { const char* e = getenv("OSK_GEMM_PERSIST"); return !e || atoi(e) != 0; }();
+      // 256-wide tiles: the 4-wave layout (gemm256w.hip: 128 x 128 wave tiles) unless OSK_GEMM_W4=0
+      static const bool w4 = [] { const char* e = getenv("OSK_GEMM_W4"); return !e || atoi(e) != 0; }();
+      if (!use_old && persist && w4 && bn == 256) return osk_gemm::launch_gemm256w(p, out_f32, st);
       if (!use_old) return persist ? osk_gemm::launch_gemm256p(p, bn, out_f32, st) : osk_gemm::launch_gemm256(p, bn, out_f32, st);
     }
   }

@@ -185,7 +185,7 @@ PERS_S_LAST = 55
 PF_PREFETCHED, PF_HAS_NEXT, PF_BIAS = 0, 1, 2   # flag bits
 
 
-def gen_pers(c):
+def gen_pers(c, sched=0):
     """K loop of gen() for a PERSISTENT workgroup (csrc/gemm256p.hip): the asm statement is executed once per output
     tile of the workgroup's tile list, and the fixed costs of a tile move off the matrix pipe's critical path:
       * exit: after the last barrier both LDS stages are free -> the LDS-DMA of the NEXT tile's K steps 0 and 1 (per-lane
@@ -281,8 +281,15 @@ def gen_pers(c):
     e("s_cbranch_scc1 %s" % ref("have1"))
     plain(dma(1))
     lab("have1")
-    for a in advance():
-        e(a)
+    if sched == 0:
+        for a in advance():
+            e(a)
+    else:
+        # schedule 1 enters the loop at entry0, whose first shadows carry the LAST LDS-DMA pieces of the stage-1 fetch
+        # (re-issued here: same bytes to the same LDS rows, harmless) followed by the pointer advance: set up M0 for them
+        pcs = dma(1)
+        n_trail = c.TM * c.TN - (c.NFRAG + 1) // 2
+        e(pcs[n_trail][0])
     e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_BIAS))
     e("s_cbranch_scc0 %s" % ref("zero"))
     for tn in range(c.TN):
@@ -299,9 +306,7 @@ def gen_pers(c):
         e(r)
     e("s_branch %s" % ref("entry0"))
 
-    for k in range(2):
-        cur = k
-        lab("step%d" % k)
+    def step_sched0(cur):
         for r in reads(cur, 0, 0):
             e(r)
         mf = mfmas(1)
@@ -316,7 +321,7 @@ def gen_pers(c):
         plain(pieces[len(mf):])
         for a in advance():
             e(a)
-        lab("entry%d" % k)
+        lab("entry%d" % cur)
         for ks in range(3):
             fset = ks % 2
             e("s_waitcnt lgkmcnt(0)")
@@ -326,6 +331,56 @@ def gen_pers(c):
                 e(m)
                 if i < len(rd):
                     e(rd[i])
+
+    def step_sched1(cur):
+        """matrix pipe first: the trailing k-sub-step (fragments in registers) starts right behind the barrier, the
+        fragment reads of the new stage ride in its first shadows TWO per shadow (they have the rest of the trailing
+        sub-step to land), then one LDS-DMA piece per shadow; every later sub-step also issues its prefetch reads two per
+        shadow at its head, so a fragment has most of a sub-step of slack before the lgkmcnt wait that guards it."""
+        mf = mfmas(1)
+        rd = reads(cur, 0, 0)
+        pieces = dma(cur ^ 1)
+        npair = (len(rd) + 1) // 2
+        slots = [[] for _ in range(len(mf) + c.TM * c.TN)]      # shadows of the trailing sub-step, then of sub-step 0
+        for i in range(npair):
+            slots[i] += rd[2 * i: 2 * i + 2]
+        e(pieces[0][0])
+        for j, (m0w, d) in enumerate(pieces):
+            slots[npair + j].append(d)
+            if j + 1 < len(pieces):
+                slots[npair + j].append(pieces[j + 1][0])
+        for i, m in enumerate(mf):
+            e(m)
+            for x in slots[i]:
+                e(x)
+        lab("entry%d" % cur)
+        carry = slots[len(mf):]                                 # LDS-DMA pieces that did not fit behind the reads
+        for ks in range(3):
+            fset = ks % 2
+            e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(fset)
+            rd = reads(cur, ks + 1, fset ^ 1)
+            sh = [[] for _ in mf]
+            first = 0
+            if ks == 0:
+                for i, x in enumerate(carry):
+                    if x:
+                        sh[i] += x
+                        first = i + 1
+            for i in range((len(rd) + 1) // 2):
+                sh[min(first + i, len(mf) - 1)] += rd[2 * i: 2 * i + 2]
+            for i, m in enumerate(mf):
+                e(m)
+                for x in sh[i]:
+                    e(x)
+            if ks == 0:
+                for a in advance():     # only now: the carried LDS-DMA pieces above still address THIS fetch's K step
+                    e(a)
+
+    for k in range(2):
+        cur = k
+        lab("step%d" % k)
+        (step_sched1 if sched == 1 else step_sched0)(cur)
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         e("s_barrier")
         e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
@@ -356,6 +411,263 @@ def gen_pers(c):
     e("s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP))
     e("s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1))
     plain(dma(1, nxt=True))
+    e("s_branch %s" % ref("end"))
+    lab("last")
+    for m in mfmas(1):
+        e(m)
+    lab("end")
+    e("s_nop 15")
+    e("s_nop 15")
+    return L
+
+
+class Cfg4:
+    """4 waves (one per SIMD, the whole 512-register file each), 2 x 2 over a 256 x 256 x 64 tile: wave tile 128 x 128 =
+    4 x 4 MFMA tiles in 256 accumulator AGPRs.  A k-sub-step reads 8 fragments for 16 MFMAs (the 8-wave layouts: 6 for 8):
+    a third less LDS read traffic per flop, half the waves per barrier."""
+
+    def __init__(self):
+        self.BN, self.FP8 = 256, False
+        self.TM, self.TN = 4, 4
+        self.NA, self.NW = 8, 8                 # LDS-DMA instructions per wave and stage (32 KiB / 4 waves / 1 KiB)
+        self.DMA_STRIDE = 4096                  # LDS bytes between a wave's consecutive LDS-DMA instructions (4 waves x 1 KiB)
+        self.A_STAGE, self.W_STAGE = 32768, 32768
+        self.W_BASE = 65536
+        self.SMEM = self.W_BASE + 2 * self.W_STAGE
+        self.NACC = 256
+        self.NFRAG = 8
+        self.FW = 4
+        self.V0 = 128                           # asm-owned VGPRs: v128.. (two fragment sets = 64, then 6 addresses)
+        self.VN = 2 * self.NFRAG * self.FW
+        self.tag = "w256"
+
+    def frag(self, fset, idx):
+        return self.V0 + (fset * self.NFRAG + idx) * self.FW
+
+
+W4_OPERANDS = ["faA0", "faW0"] + ["aoff%d" % i for i in range(8)] + ["woff%d" % i for i in range(8)] + \
+              ["boff", "abase", "wbase", "bias", "nk", "adst", "wdst", "flags", "dA", "dW", "aoffp", "woffp"]
+WOP = {n: "%%%d" % i for i, n in enumerate(W4_OPERANDS)}
+S_DA, S_DW, S_PFA, S_PFW = 56, 57, 58, 60
+W4_S_LAST = 61
+
+
+def gen_w4(c, pf=0, abl=0):
+    """Persistent-workgroup K loop (see gen_pers) for the 4-wave layout of Cfg4.  Differences: 16 MFMAs, 8 fragment
+    reads and 16 LDS-DMA pieces per k-sub-step / K step and wave, placed "matrix pipe first" (schedule 1 of gen_pers:
+    behind a barrier the trailing sub-step starts at once, reads ride two per shadow at the head of a sub-step, one
+    LDS-DMA piece per shadow behind them); the next tile's source offsets are this tile's plus a wave-uniform byte
+    delta (dA, dW: valid when both tiles are interior -- the wrapper clears flags bit 1 otherwise), computed into the
+    idle fragment registers at the exit."""
+    L = []
+    e = lambda t: L.append("  " + t)
+    lab = lambda n: L.append(".L%s_%s_%%=:" % (c.tag, n))
+    ref = lambda n: ".L%s_%s_%%=" % (c.tag, n)
+    VX = c.V0 + c.VN
+    fa = {("A", 0): WOP["faA0"], ("W", 0): WOP["faW0"]}
+    for ks in range(1, 4):
+        fa[("A", ks)] = vr(VX + ks - 1)
+        fa[("W", ks)] = vr(VX + 3 + ks - 1)
+    NM = c.TM * c.TN
+
+    def reads(stage, ks, fset):
+        out = []
+        for tm in range(c.TM):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, tm), 4), fa[("A", ks)], stage * c.A_STAGE + tm * 4096))
+        for tn in range(c.TN):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, c.TM + tn), 4), fa[("W", ks)], stage * c.W_STAGE + tn * 4096))
+        return out
+
+    def mfmas(fset):
+        out = []
+        for tn in range(c.TN):
+            for tm in range(c.TM):
+                acc = ar((tn * c.TM + tm) * 16, 16)
+                out.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, c.TM + tn), 4), vr(c.frag(fset, tm), 4), acc))
+        return out
+
+    def dma(stage, aregs=None, wregs=None):
+        aregs = aregs or [WOP["aoff%d" % i] for i in range(c.NA)]
+        wregs = wregs or [WOP["woff%d" % i] for i in range(c.NW)]
+        out = []
+        for i in range(c.NA):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * c.DMA_STRIDE),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (aregs[i], S_AB, S_AB + 1)))
+        for i in range(c.NW):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * c.DMA_STRIDE),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (wregs[i], S_WB, S_WB + 1)))
+        return out
+
+    def advance():
+        return ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
+                "s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK),
+                "s_cselect_b32 s%d, 128, 0" % S_STEP,
+                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL),
+                "s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1),
+                "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1)]
+
+    def plain(pieces):
+        for m0w, d in pieces:
+            e(m0w); e("s_nop 0"); e(d)
+
+    N_TRAIL = NM - (c.NFRAG + 1) // 2          # LDS-DMA pieces issued in the trailing sub-step; the rest ride in sub-step 0
+
+    # ---- setup
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, WOP["abase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, WOP["wbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_PBIAS, S_PBIAS + 1, WOP["bias"]))
+    e("s_mov_b32 s%d, %s" % (S_NK, WOP["nk"]))
+    e("s_mov_b32 s%d, %s" % (S_ADST, WOP["adst"]))
+    e("s_mov_b32 s%d, %s" % (S_WDST, WOP["wdst"]))
+    e("s_mov_b32 s%d, %s" % (S_PFLAGS, WOP["flags"]))
+    e("s_mov_b32 s%d, %s" % (S_DA, WOP["dA"]))
+    e("s_mov_b32 s%d, %s" % (S_DW, WOP["dW"]))
+    e("s_mov_b32 s%d, 0" % S_T)
+    e("s_mov_b32 s%d, 0" % S_KL)
+    for ks in range(1, 4):
+        e("v_xor_b32_e32 %s, %d, %s" % (fa[("A", ks)], ks << 5, WOP["faA0"]))
+        e("v_xor_b32_e32 %s, %d, %s" % (fa[("W", ks)], ks << 5, WOP["faW0"]))
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_PREFETCHED))
+    e("s_cbranch_scc1 %s" % ref("have0"))
+    plain(dma(0))
+    lab("have0")
+    for a in advance():
+        e(a)
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_BIAS))
+    e("s_cbranch_scc0 %s" % ref("nobias"))
+    for tn in range(c.TN):
+        for qd in range(4):
+            e("global_load_dwordx4 %s, %s, s[%d:%d] offset:%d" % (vr(c.V0 + (tn * 4 + qd) * 4, 4), WOP["boff"], S_PBIAS, S_PBIAS + 1,
+                                                                   (tn * 32 + qd * 8) * 4))
+    lab("nobias")
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_PREFETCHED))
+    e("s_cbranch_scc1 %s" % ref("have1"))
+    plain(dma(1))
+    lab("have1")
+    e(dma(1)[N_TRAIL][0])                      # M0 for the pieces entry0 (re-)issues before it advances the pointers
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_BIAS))
+    e("s_cbranch_scc0 %s" % ref("zero"))
+    for tn in range(c.TN):
+        for tm in range(c.TM):
+            for r in range(16):
+                e("v_accvgpr_write_b32 %s, %s" % (ar((tn * c.TM + tm) * 16 + r), vr(c.V0 + tn * 16 + r)))
+    e("s_branch %s" % ref("inited"))
+    lab("zero")
+    for r in range(c.NACC):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    lab("inited")
+    e("s_nop 1")
+    for r in reads(0, 0, 0):
+        e(r)
+    e("s_branch %s" % ref("entry0"))
+
+    def step(cur):
+        mf = mfmas(1)
+        rd = reads(cur, 0, 0)
+        pieces = dma(cur ^ 1)
+        npair = (len(rd) + 1) // 2
+        slots = [[] for _ in range(2 * NM)]
+        for i in range(npair):
+            slots[i] += rd[2 * i: 2 * i + 2]
+        e(pieces[0][0])
+        for j, (m0w, d) in enumerate(pieces):
+            slots[npair + j].append(d)
+            if j + 1 < len(pieces):
+                slots[npair + j].append(pieces[j + 1][0])
+        for i, m in enumerate(mf):
+            e(m)
+            for x in slots[i]:
+                e(x)
+        lab("entry%d" % cur)
+        carry = slots[NM:]
+        for ks in range(3):
+            fset = ks % 2
+            e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(fset)
+            rd = reads(cur, ks + 1, fset ^ 1)
+            sh = [[] for _ in mf]
+            first = 0
+            if ks == 0:
+                for i, x in enumerate(carry):
+                    if x:
+                        sh[i] += x
+                        first = i + 1
+            for i in range((len(rd) + 1) // 2):
+                sh[min(first + i, len(mf) - 1)] += rd[2 * i: 2 * i + 2]
+            for i, m in enumerate(mf):
+                e(m)
+                for x in sh[i]:
+                    e(x)
+            if ks == 0:
+                for a in advance():
+                    e(a)
+                if pf:
+                    # L2 software prefetch: touch one dword per 128-byte line of the A / W slices of the K step AFTER the
+                    # one the loaders now point at (lane = row: aoffp / woffp), two K steps before its LDS-DMA is issued,
+                    # so that fetch finds its lines in L2 instead of waiting for the fabric inside the barrier's vmcnt.
+                    # These two loads are the youngest VMEM operations of the step: the barrier waits vmcnt(2).
+                    VD = c.V0 + c.VN + 6
+                    e("s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL))
+                    e("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK))
+                    e("s_cselect_b32 s%d, 128, 0" % S_STEP)
+                    e("s_add_u32 s%d, s%d, s%d" % (S_PFA, S_AB, S_STEP))
+                    e("s_addc_u32 s%d, s%d, 0" % (S_PFA + 1, S_AB + 1))
+                    e("s_add_u32 s%d, s%d, s%d" % (S_PFW, S_WB, S_STEP))
+                    e("s_addc_u32 s%d, s%d, 0" % (S_PFW + 1, S_WB + 1))
+                    e("global_load_dword %s, %s, s[%d:%d]" % (vr(VD), WOP["aoffp"], S_PFA, S_PFA + 1))
+                    e("global_load_dword %s, %s, s[%d:%d]" % (vr(VD + 1), WOP["woffp"], S_PFW, S_PFW + 1))
+
+    for k in range(2):
+        lab("step%d" % k)
+        step(k)
+        # abl (timing ablations, WRONG RESULTS, tools only): bit 0 = no LDS-DMA wait at the barrier, bit 1 = no barrier
+        if abl & 1:
+            e("s_waitcnt lgkmcnt(0)")
+        else:
+            e("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (2 if pf else 0))
+        if not abl & 2:
+            e("s_barrier")
+        e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
+        e("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NK))
+        e("s_cbranch_scc0 %s" % ref("exit"))
+        if k == 1:
+            e("s_branch %s" % ref("step0"))
+    lab("exit")
+    if abl:
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_HAS_NEXT))
+    e("s_cbranch_scc0 %s" % ref("last"))
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, WOP["abase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, WOP["wbase"]))
+    # next tile's per-lane source offsets into fragment set 0 (its last MFMAs were issued before the barrier)
+    an = [vr(c.V0 + i) for i in range(c.NA)]
+    wn = [vr(c.V0 + c.NA + i) for i in range(c.NW)]
+    for i in range(c.NA):
+        e("v_add_u32_e32 %s, s%d, %s" % (an[i], S_DA, WOP["aoff%d" % i]))
+    for i in range(c.NW):
+        e("v_add_u32_e32 %s, s%d, %s" % (wn[i], S_DW, WOP["woff%d" % i]))
+    mf = mfmas(1)
+    pieces = dma(0, an, wn)
+    e(pieces[0][0])
+    for i, m in enumerate(mf):
+        e(m)
+        if i < len(pieces):
+            e(pieces[i][1])
+            if i + 1 < len(pieces):
+                e(pieces[i + 1][0])
+    plain(pieces[len(mf):])
+    e("s_cmp_gt_u32 s%d, 1" % S_NK)
+    e("s_cselect_b32 s%d, 128, 0" % S_STEP)
+    e("s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP))
+    e("s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1))
+    e("s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP))
+    e("s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1))
+    plain(dma(1, an, wn))
     e("s_branch %s" % ref("end"))
     lab("last")
     for m in mfmas(1):
@@ -784,6 +1096,7 @@ def gen_conv(c):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
+    ap.add_argument("--ablations", action="store_true", help="also emit the timing-only ablation bodies of the 4-wave GEMM")
     args = ap.parse_args()
     for bn in (256, 128):
         c = Cfg(bn)
@@ -806,10 +1119,11 @@ def main():
             cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 12)] + ['"a%d"' % i for i in range(c.NACC)] + \
                     ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
             f.write("#define %sCONV_CLOBBERS %s\n" % (P, ", ".join(cclob)))
-        with open(os.path.join(args.out, "gemm256p_body_n%d.inc" % bn), "w") as f:
-            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile K loop, persistent workgroup.\n" % bn)
-            for ln in gen_pers(c):
-                f.write('"%s\\n"\n' % ln)
+        for sched in (0, 1):
+            with open(os.path.join(args.out, "gemm256p_body_n%d_s%d.inc" % (bn, sched)), "w") as f:
+                f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile K loop, persistent workgroup, schedule %d.\n" % (bn, sched))
+                for ln in gen_pers(c, sched):
+                    f.write('"%s\\n"\n' % ln)
         with open(os.path.join(args.out, "gemm256p_regs_n%d.inc" % bn), "w") as f:
             f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
             pclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 6)] + ['"a%d"' % i for i in range(c.NACC)] + \
@@ -823,6 +1137,27 @@ def main():
             f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile, one K segment (filter tap).\n" % bn)
             for ln in gen_segment(c):
                 f.write('"%s\\n"\n' % ln)
+    c = Cfg4()
+    if args.ablations:   # timing-only experiments for tools/: never committed, never shipped
+        for abl in (1, 2, 3):
+            with open(os.path.join(args.out, "gemm256w_body_abl%d.inc" % abl), "w") as f:
+                f.write("// GENERATED by tools/gen_gemm_asm.py --ablations -- timing experiment, WRONG RESULTS.\n")
+                for ln in gen_w4(c, 0, abl):
+                    f.write('"%s\\n"\n' % ln)
+    for pf in (0, 1):
+        with open(os.path.join(args.out, "gemm256w_body_pf%d.inc" % pf), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup%s.\n"
+                    % (", L2 software prefetch" if pf else ""))
+            for ln in gen_w4(c, pf):
+                f.write('"%s\\n"\n' % ln)
+    with open(os.path.join(args.out, "gemm256w_regs.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
+        f.write("#define OSKW_SMEM %d\n#define OSKW_W_BASE %d\n#define OSKW_TM %d\n#define OSKW_TN %d\n" % (c.SMEM, c.W_BASE, c.TM, c.TN))
+        clob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 8)] + ['"a%d"' % i for i in range(c.NACC)] + \
+               ['"s%d"' % i for i in range(S_FIRST, W4_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+        f.write("#define OSKW_CLOBBERS %s\n" % ", ".join(clob))
+        for t in range(c.TM * c.TN):
+            f.write("#define OSKW_AR%d %s\n" % (t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
     for bn in (256, 128):
         c = Cfg(bn, fp8=True)
         with open(os.path.join(args.out, "gemm256_fp8_body_n%d.inc" % bn), "w") as f:
