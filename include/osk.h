@@ -246,6 +246,13 @@ int osk_groupnorm_apply_ndhwc_bf16(const void* x, const double* sums, const floa
 int osk_masked_softmax_f32_bf16(const float* scores, int64_t ld_scores, void* probs, int64_t ld_probs,
                                 int Sq, int Sk, int keys_per_frame, float scale, void* stream);
 
+/* ---- tile cross-fade of the tiled VAE paths, in place in b (f32 math, one rounding):
+ *   b[o, e, i] = a[o, Da - extent + e, i] * (1 - e/extent) + b[o, e, i] * (e/extent),  e < extent
+ * replaces blend_v / blend_h / blend_t (hunyuan_vae/autoencoder_kl_causal_3d.py:360-382; a Python loop of `extent`
+ * slice assignments there).  a, b: contiguous bf16 viewed as [outer, Da | Db, inner] along the blended axis
+ * (NCTHW tiles: blend_t -> outer B*C, inner H*W; blend_v -> outer B*C*T, inner W; blend_h -> outer B*C*T*H, inner 1). */
+int osk_blend_bf16(const void* a, void* b, int64_t outer, int Da, int Db, int extent, int64_t inner, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

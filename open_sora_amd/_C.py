@@ -50,6 +50,7 @@ SIGNATURES = {
     "osk_groupnorm_stats_ndhwc_bf16": [_vp, _i32, _i64, _i32, _i32, _vp, _vp],
     "osk_groupnorm_apply_ndhwc_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _vp],
     "osk_masked_softmax_f32_bf16": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
+    "osk_blend_bf16": [_vp, _vp, _i64, _i32, _i32, _i32, _i64, _vp],
 }
 
 
@@ -410,3 +411,23 @@ def masked_softmax(scores: torch.Tensor, probs: torch.Tensor, Sk: int, keys_per_
     _check(lib.osk_masked_softmax_f32_bf16(scores.data_ptr(), scores.stride(0), probs.data_ptr(), probs.stride(0), Sq,
                                            Sk, keys_per_frame, scale, _stream()), "osk_masked_softmax_f32_bf16")
     return probs
+
+
+def blend(a: torch.Tensor, b: torch.Tensor, extent: int, dim: int) -> torch.Tensor:
+    """tile cross-fade along `dim`, written into b: the last `extent` slices of a fade into the first `extent` of b.
+    a, b: contiguous bf16 tensors that agree in every other dimension."""
+    dim = dim % b.ndim
+    extent = min(a.shape[dim], b.shape[dim], extent)
+    if extent == 0:
+        return b
+    assert a.dtype == b.dtype == torch.bfloat16 and a.is_contiguous() and b.is_contiguous()
+    assert a.shape[:dim] == b.shape[:dim] and a.shape[dim + 1:] == b.shape[dim + 1:], (a.shape, b.shape, dim)
+    outer = 1
+    for s_ in b.shape[:dim]:
+        outer *= s_
+    inner = 1
+    for s_ in b.shape[dim + 1:]:
+        inner *= s_
+    _check(lib.osk_blend_bf16(a.data_ptr(), b.data_ptr(), outer, a.shape[dim], b.shape[dim], extent, inner, _stream()),
+           "osk_blend_bf16")
+    return b

@@ -414,6 +414,7 @@ class AutoencoderKLCausal3D(nn.Module):
         sample_size = config.sample_size[0] if isinstance(config.sample_size, (list, tuple)) else config.sample_size
         self.tile_latent_min_size = int(sample_size / (2 ** (len(config.block_out_channels) - 1)))
         self.tile_overlap_factor = config.tile_overlap_factor
+        self._tile_group = None   # enable_tile_parallel(): process group the tiles of a tiled encode / decode are spread over
 
     # ---- switches (autoencoder_kl_causal_3d.py:148-190)
     def enable_temporal_tiling(self, use_tiling: bool = True):
@@ -513,19 +514,16 @@ class AutoencoderKLCausal3D(nn.Module):
             out.append((input_size[i] - 1) // self.spatial_compression_ratio + 1)
         return out
 
-    # ---- tiling (autoencoder_kl_causal_3d.py:360-552): same loops; the cross-fades are vectorised device ops
+    # ---- tiling (autoencoder_kl_causal_3d.py:360-552): the reference's loops; a cross-fade is ONE kernel launch
+    # (osk_blend_bf16, f32 math, in place in b) instead of `extent` slice assignments
     @staticmethod
     def _blend(a: Tensor, b: Tensor, extent: int, dim: int) -> Tensor:
-        extent = min(a.shape[dim], b.shape[dim], extent)
-        if extent == 0:
-            return b
-        shape = [1] * b.ndim
-        shape[dim] = extent
-        w = (torch.arange(extent, device=b.device, dtype=torch.float32) / extent).view(shape)
-        ia, ib = [slice(None)] * b.ndim, [slice(None)] * b.ndim
-        ia[dim] = slice(a.shape[dim] - extent, a.shape[dim])
-        ib[dim] = slice(0, extent)
-        b[tuple(ib)] = (a[tuple(ia)].float() * (1 - w) + b[tuple(ib)].float() * w).to(b.dtype)
+        if b.dtype == BF16 and a.dtype == BF16 and a.is_contiguous() and b.is_contiguous():
+            return _ops().blend(a, b, extent, dim)
+        # other dtypes / strided tiles (a caller's own tensors): round-trip through contiguous bf16 copies, written back into b
+        bb = b.to(BF16).contiguous()
+        _ops().blend(a.to(BF16).contiguous(), bb, extent, dim)
+        b.copy_(bb)
         return b
 
     def blend_v(self, a, b, blend_extent):
@@ -537,9 +535,57 @@ class AutoencoderKLCausal3D(nn.Module):
     def blend_t(self, a, b, blend_extent):
         return self._blend(a, b, blend_extent, -3)
 
-    def _spatial_tiles(self, fn, x, tile, stride, blend_extent, row_limit):
-        rows = [[fn(x[..., i: i + tile, j: j + tile]) for j in range(0, x.shape[-1], stride)]
-                for i in range(0, x.shape[-2], stride)]
+    # ---- tile parallelism (SURVEY.md section 8(e) "VAE": the tiles of the reference's own tiled encode / decode are
+    # independent units): with a process group set, every rank runs fn on the tiles i % P == rank and the results are
+    # exchanged by one broadcast per tile from its owner (RCCL over xGMI; each tile's pixels cross a link once per
+    # receiver); the blends and the assembly are replicated, so every rank returns the whole tensor.
+    def enable_tile_parallel(self, group=None):
+        import torch.distributed as dist
+
+        self._tile_group = group if group is not None else dist.group.WORLD
+        return self
+
+    def disable_tile_parallel(self):
+        self._tile_group = None
+
+    def _map_tiles(self, fn, tiles, out_shape):
+        """[fn(t) for t in tiles], the calls spread over the ranks of the tile group (when one is set and there is more
+        than one tile).  out_shape(t) -> shape of fn(t) (needed by the ranks that do not compute it)."""
+        group = getattr(self, "_tile_group", None)
+        if group is None or len(tiles) < 2:
+            return [fn(t) for t in tiles]
+        import torch.distributed as dist
+
+        P, rank = dist.get_world_size(group), dist.get_rank(group)
+        if P == 1:
+            return [fn(t) for t in tiles]
+        outs = []
+        for i, t in enumerate(tiles):
+            owner = i % P
+            if owner == rank:
+                o = fn(t).contiguous()
+            else:
+                o = torch.empty(out_shape(t), dtype=t.dtype, device=t.device)
+            outs.append(o)
+        for i, o in enumerate(outs):   # after all local tiles are queued: the broadcasts overlap the remaining compute
+            dist.broadcast(o, src=dist.get_global_rank(group, i % P), group=group)
+        return outs
+
+    def _moments_shape(self, t):
+        B, _, T, H, W = t.shape
+        lt, lh, lw = self.get_latent_size((T, H, W))
+        return (B, 2 * self.z_channels, lt, lh, lw)
+
+    def _decoded_shape(self, t):
+        B, _, T, H, W = t.shape
+        return (B, self.config.out_channels, 1 + self.time_compression_ratio * (T - 1) if T > 1 else 1,
+                H * self.spatial_compression_ratio, W * self.spatial_compression_ratio)
+
+    def _spatial_tiles(self, fn, x, tile, stride, blend_extent, row_limit, out_shape=None):
+        coords = [(i, j) for i in range(0, x.shape[-2], stride) for j in range(0, x.shape[-1], stride)]
+        flat = self._map_tiles(fn, [x[..., i: i + tile, j: j + tile] for i, j in coords], out_shape)
+        ncol = len(range(0, x.shape[-1], stride))
+        rows = [flat[r * ncol: (r + 1) * ncol] for r in range(len(flat) // ncol)]
         out_rows = []
         for i, row in enumerate(rows):
             out_row = []
@@ -556,20 +602,22 @@ class AutoencoderKLCausal3D(nn.Module):
         ov = self.tile_overlap_factor
         be = int(self.tile_latent_min_size * ov)
         m = self._spatial_tiles(self._moments, x, self.tile_sample_min_size, int(self.tile_sample_min_size * (1 - ov)),
-                                be, self.tile_latent_min_size - be)
+                                be, self.tile_latent_min_size - be, self._moments_shape)
         return m if return_moments else DiagonalGaussianDistribution(m)
 
     def spatial_tiled_decode(self, z: Tensor) -> Tensor:
         ov = self.tile_overlap_factor
         be = int(self.tile_sample_min_size * ov)
         return self._spatial_tiles(self._decode_core, z, self.tile_latent_min_size,
-                                   int(self.tile_latent_min_size * (1 - ov)), be, self.tile_sample_min_size - be)
+                                   int(self.tile_latent_min_size * (1 - ov)), be, self.tile_sample_min_size - be,
+                                   self._decoded_shape)
 
-    def _temporal_tiles(self, fn, x, tile, stride, blend_extent, t_limit):
-        row = []
-        for i in range(0, x.shape[2], stride):
-            t = fn(x[:, :, i: i + tile + 1])
-            row.append(t[:, :, 1:] if i > 0 else t)
+    def _temporal_tiles(self, fn, x, tile, stride, blend_extent, t_limit, out_shape=None, spread=False):
+        starts = list(range(0, x.shape[2], stride))
+        chunks = [x[:, :, i: i + tile + 1] for i in starts]
+        # spread = the chunks themselves are the parallel units (no spatial tiling inside fn: that level spreads otherwise)
+        outs = self._map_tiles(fn, chunks, out_shape) if spread else [fn(c) for c in chunks]
+        row = [t[:, :, 1:].contiguous() if k > 0 else t for k, t in enumerate(outs)]   # contiguous: blended in place
         out = []
         for i, t in enumerate(row):
             if i > 0:
@@ -588,8 +636,9 @@ class AutoencoderKLCausal3D(nn.Module):
             return self._moments(t)
 
         be = int(self.tile_latent_min_tsize * ov)
+        inner_spatial = self.use_spatial_tiling and (x.shape[-1] > self.tile_sample_min_size or x.shape[-2] > self.tile_sample_min_size)
         m = self._temporal_tiles(enc, x, self.tile_sample_min_tsize, int(self.tile_sample_min_tsize * (1 - ov)), be,
-                                 self.tile_latent_min_tsize - be)
+                                 self.tile_latent_min_tsize - be, self._moments_shape, spread=not inner_spatial)
         return DiagonalGaussianDistribution(m)
 
     def temporal_tiled_decode(self, z: Tensor) -> Tensor:
@@ -601,8 +650,9 @@ class AutoencoderKLCausal3D(nn.Module):
             return self._decode_core(t)
 
         be = int(self.tile_sample_min_tsize * ov)
+        inner_spatial = self.use_spatial_tiling and (z.shape[-1] > self.tile_latent_min_size or z.shape[-2] > self.tile_latent_min_size)
         return self._temporal_tiles(dec, z, self.tile_latent_min_tsize, int(self.tile_latent_min_tsize * (1 - ov)), be,
-                                    self.tile_sample_min_tsize - be)
+                                    self.tile_sample_min_tsize - be, self._decoded_shape, spread=not inner_spatial)
 
 
 def CausalVAE3D_HUNYUAN(from_pretrained: str = None, device_map="cuda", torch_dtype: torch.dtype = BF16, **kwargs):

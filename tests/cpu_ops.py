@@ -339,3 +339,20 @@ def masked_softmax(scores, probs, Sk, keys_per_frame, scale):
     probs.zero_()
     probs[:, :Sk] = torch.softmax(s, -1).to(probs.dtype)
     return probs
+
+
+def blend(a, b, extent, dim):
+    """osk_blend_bf16: f32 cross-fade written into b, one rounding"""
+    dim = dim % b.ndim
+    extent = min(a.shape[dim], b.shape[dim], extent)
+    if extent == 0:
+        return b
+    assert a.is_contiguous() and b.is_contiguous()
+    shape = [1] * b.ndim
+    shape[dim] = extent
+    w = (torch.arange(extent, dtype=torch.float32) / extent).view(shape)
+    ia, ib = [slice(None)] * b.ndim, [slice(None)] * b.ndim
+    ia[dim] = slice(a.shape[dim] - extent, a.shape[dim])
+    ib[dim] = slice(0, extent)
+    b[tuple(ib)] = (a[tuple(ia)].float() * (1 - w) + b[tuple(ib)].float() * w).to(b.dtype)
+    return b

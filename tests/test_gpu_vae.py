@@ -261,3 +261,32 @@ def test_full_size_encode_decode_properties(hip_lib):
         za = m.encode(x2[:1], sample_posterior=False)
         zb = m.encode(x2[1:], sample_posterior=False)
         assert (z2 - torch.cat((za, zb))).abs().max() <= 2.0 ** -6 * z2.abs().max()
+
+
+@pytest.mark.parametrize("dim,shape_a,shape_b,extent", [
+    (-2, (1, 3, 5, 24, 40), (1, 3, 5, 20, 40), 8),      # blend_v (vector path: inner = W = 40)
+    (-1, (2, 16, 3, 12, 10), (2, 16, 3, 12, 7), 4),     # blend_h (scalar path: inner = 1)
+    (-3, (1, 4, 9, 6, 12), (1, 4, 7, 6, 12), 2),        # blend_t
+    (-1, (1, 3, 2, 8, 3), (1, 3, 2, 8, 16), 8),         # extent clipped to a's width (3)
+])
+def test_blend_kernel_vs_reference_formula(hip_lib, dim, shape_a, shape_b, extent):
+    """osk_blend_bf16 vs blend_v / blend_h / blend_t (autoencoder_kl_causal_3d.py:360-382) evaluated in f64:
+    b[.., y, ..] = a[.., -e + y, ..] (1 - y/e) + b[.., y, ..] (y/e), in place, untouched outside the seam."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    a = torch.randn(*shape_a, device=DEV, generator=g).to(BF)
+    b = torch.randn(*shape_b, device=DEV, generator=g).to(BF)
+    b0 = b.clone()
+    out = hip_lib.blend(a, b, extent, dim)
+    assert out.data_ptr() == b.data_ptr()
+    e = min(a.shape[dim], b.shape[dim], extent)
+    ref = b0.double().cpu()
+    a64 = a.double().cpu()
+    for y in range(e):
+        ia, ib = [slice(None)] * 5, [slice(None)] * 5
+        ia[dim], ib[dim] = a.shape[dim] - e + y, y
+        ref[tuple(ib)] = a64[tuple(ia)] * (1 - y / e) + b0.double().cpu()[tuple(ib)] * (y / e)
+    err = (b.double().cpu() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-6).all(), err.max()
+    rest = [slice(None)] * 5
+    rest[dim] = slice(e, None)
+    assert torch.equal(b[tuple(rest)], b0[tuple(rest)])
