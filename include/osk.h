@@ -246,6 +246,18 @@ int osk_groupnorm_apply_ndhwc_bf16(const void* x, const double* sums, const floa
 int osk_masked_softmax_f32_bf16(const float* scores, int64_t ld_scores, void* probs, int64_t ld_probs,
                                 int Sq, int Sk, int keys_per_frame, float scale, void* stream);
 
+/* ---- flash attention of the causal VAE's mid block: ONE head of dimension 512, frame-causal mask
+ *   out[i] = softmax_j(scale * q[i].k[j]) v[j]  over keys j with  j / keys_per_frame <= i / keys_per_frame   (+ bias_v)
+ * replaces diffusers Attention + prepare_causal_attention_mask inside UNetMidBlockCausal3D
+ * (hunyuan_vae/unet_causal_3d_blocks.py:52-60,312-351): no S x S mask, no S x S score matrix in memory.
+ * q, k, out: bf16 [B, S, 512] views (batch / row strides in elements, rows contiguous); vt: bf16 V^T [B][512][ld]
+ * (natural key order, ld >= round_up(S, 32), ZERO beyond S) -- the layout the V projection GEMM V^T = W_v x^T writes;
+ * bias_v f32 [512] | NULL is added after normalisation (softmax rows sum to one).  keys_per_frame = 0: no mask. */
+int osk_attention_hd512_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride, const void* k,
+                                 int64_t k_batch_stride, int64_t k_row_stride, const void* vt, int64_t vt_batch_stride,
+                                 int64_t vt_row_stride, const float* bias_v, void* out, int64_t out_batch_stride,
+                                 int64_t out_row_stride, int B, int S, int keys_per_frame, float scale, void* stream);
+
 /* ---- tile cross-fade of the tiled VAE paths, in place in b (f32 math, one rounding):
  *   b[o, e, i] = a[o, Da - extent + e, i] * (1 - e/extent) + b[o, e, i] * (e/extent),  e < extent
  * replaces blend_v / blend_h / blend_t (hunyuan_vae/autoencoder_kl_causal_3d.py:360-382; a Python loop of `extent`

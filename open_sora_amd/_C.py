@@ -51,6 +51,8 @@ SIGNATURES = {
     "osk_groupnorm_apply_ndhwc_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _vp],
     "osk_masked_softmax_f32_bf16": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_blend_bf16": [_vp, _vp, _i64, _i32, _i32, _i32, _i64, _vp],
+    "osk_attention_hd512_fwd_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
+                                     _i32, _f32, _vp],
 }
 
 
@@ -431,3 +433,16 @@ def blend(a: torch.Tensor, b: torch.Tensor, extent: int, dim: int) -> torch.Tens
     _check(lib.osk_blend_bf16(a.data_ptr(), b.data_ptr(), outer, a.shape[dim], b.shape[dim], extent, inner, _stream()),
            "osk_blend_bf16")
     return b
+
+
+def attention_hd512(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, bias_v, out: torch.Tensor, keys_per_frame: int,
+                    scale: float) -> torch.Tensor:
+    """the VAE mid block's one-head attention: q, k, out bf16 [B, S, 512] views; vt bf16 [B, 512, ld] (natural key order,
+    zero beyond S, ld >= round_up(S, 32)); bias_v f32 [512] | None; frame-causal over groups of keys_per_frame keys."""
+    B, S, C = q.shape
+    assert C == 512 and vt.shape[1] == 512 and vt.stride(2) == 1 and q.stride(2) == 1 and k.stride(2) == 1 and out.stride(2) == 1
+    _check(lib.osk_attention_hd512_fwd_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                                            vt.data_ptr(), vt.stride(0), vt.stride(1), _p(bias_v), out.data_ptr(),
+                                            out.stride(0), out.stride(1), B, S, keys_per_frame, scale, _stream()),
+           "osk_attention_hd512_fwd_bf16")
+    return out

@@ -274,13 +274,13 @@ def _resnet(blk: ResnetBlockCausal3D, x: Tensor) -> Tensor:
 def _mid_attention(att: Attention, x: Tensor) -> Tensor:
     """UNetMidBlockCausal3D attention branch (unet_causal_3d_blocks.py:345-351): GroupNorm -> q,k,v (one head of
     dim C) -> frame-causal softmax(q k^T / sqrt(C)) v -> out proj + residual.  NDHWC == token-major: no rearrange.
-    QK^T and PV run on the MFMA GEMM kernel (scores f32), the mask is a predicate inside the softmax kernel.
-    P V + b_v == P (V + 1 b_v^T) because softmax rows sum to one: the V bias is added by the PV GEMM epilogue."""
+    C = 512 (every shipped width): osk_attention_hd512_fwd_bf16 -- scores stay in registers, the mask is a predicate, one
+    launch for the whole batch.  Other widths (test geometries): QK^T and P.V as GEMMs around the masked-softmax kernel.
+    P V + b_v == P (V + 1 b_v^T) because softmax rows sum to one: the V bias is added after the product either way."""
     o = _ops()
     B, T, H, W, C = x.shape
     S, n_hw = T * H * W, H * W
     Sp = (S + 63) // 64 * 64
-    S4 = (S + 3) // 4 * 4
     wq, bq = _plan(att.to_q, "lin")
     wk, bk = _plan(att.to_k, "lin")
     wv, bv = _plan(att.to_v, "lin")
@@ -288,13 +288,26 @@ def _mid_attention(att: Attention, x: Tensor) -> Tensor:
     hn = _gn(att.group_norm, x, False).view(B, S, C)
     tok = x.view(B, S, C)
     out = torch.empty_like(tok)
+    ones = torch.ones(C, dtype=torch.float32, device=x.device)
+    if C == 512:
+        q = torch.empty(B, S, C, dtype=BF16, device=x.device)
+        k = torch.empty_like(q)
+        att_o = torch.empty_like(q)
+        vt = torch.zeros(B, C, Sp, dtype=BF16, device=x.device)
+        o.gemm(hn, wq, bq, q)
+        o.gemm(hn, wk, bk, k)
+        for b in range(B):
+            o.gemm(wv.view(1, C, C), hn[b], None, vt[b: b + 1, :, :S])     # V^T [C, S] = Wv hn^T
+        o.attention_hd512(q, k, vt, bv, att_o, n_hw, C ** -0.5)
+        o.gemm(att_o, wo, bo, out, res=tok, gate=ones, gate_batch_stride=0)
+        return out.view(B, T, H, W, C)
+    S4 = (S + 3) // 4 * 4
     q = torch.empty(1, S, C, dtype=BF16, device=x.device)
     k = torch.empty_like(q)
     att_o = torch.empty_like(q)
     vt = torch.zeros(1, C, Sp, dtype=BF16, device=x.device)
     scores = torch.empty(1, S, S4, dtype=torch.float32, device=x.device)
     probs = torch.empty(S, Sp, dtype=BF16, device=x.device)
-    ones = torch.ones(C, dtype=torch.float32, device=x.device)
     for b in range(B):
         hb = hn[b: b + 1]
         o.gemm(hb, wq, bq, q)

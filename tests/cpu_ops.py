@@ -356,3 +356,20 @@ def blend(a, b, extent, dim):
     ib[dim] = slice(0, extent)
     b[tuple(ib)] = (a[tuple(ia)].float() * (1 - w) + b[tuple(ib)].float() * w).to(b.dtype)
     return b
+
+
+def attention_hd512(q, k, vt, bias_v, out, keys_per_frame, scale):
+    """osk_attention_hd512_fwd_bf16: f32 frame-causal softmax(q k^T scale) v (+ bias), P rounded to bf16 before P.V"""
+    B, S, C = q.shape
+    f = torch.arange(S) // (keys_per_frame if keys_per_frame > 0 else S)
+    mask = f[None, :] > f[:, None]
+    for b in range(B):
+        s_ = (q[b].float() @ k[b].float().T) * scale
+        s_ = s_.masked_fill(mask, float("-inf"))
+        m = s_.amax(-1, keepdim=True)
+        e = torch.exp(s_ - m)
+        o = (e.to(torch.bfloat16).float() @ vt[b, :, :S].float().T) / e.sum(-1, keepdim=True)
+        if bias_v is not None:
+            o = o + bias_v.float()
+        out[b].copy_(o.to(out.dtype))
+    return out

@@ -290,3 +290,34 @@ def test_blend_kernel_vs_reference_formula(hip_lib, dim, shape_a, shape_b, exten
     rest = [slice(None)] * 5
     rest[dim] = slice(e, None)
     assert torch.equal(b[tuple(rest)], b0[tuple(rest)])
+
+
+@pytest.mark.parametrize("B,T,hw,masked", [(1, 3, 64, True), (2, 5, 37, True), (1, 1, 300, True), (1, 4, 96, False), (1, 9, 256, True)])
+def test_attention_hd512_vs_f64(hip_lib, B, T, hw, masked):
+    """osk_attention_hd512_fwd_bf16 (one head of dim 512, frame-causal) against an f64 softmax(q k^T / sqrt(512) + mask) v + b
+    with the reference's mask rule (unet_causal_3d_blocks.py:52-60: key frame <= query frame); ragged S (not a multiple of
+    the 32-key tile / 128-query block), batch, strided q / k views, no-mask mode."""
+    S, C = T * hw, 512
+    Sp = (S + 63) // 64 * 64
+    g = torch.Generator(device=DEV).manual_seed(S + B)
+    qk = torch.randn(B, S, 2 * C, device=DEV, generator=g).to(BF)          # q, k as column views of one buffer
+    q, k = qk[:, :, :C], qk[:, :, C:]
+    v = torch.randn(B, S, C, device=DEV, generator=g).to(BF)
+    vt = torch.zeros(B, C, Sp, dtype=BF, device=DEV)
+    vt[:, :, :S] = v.transpose(1, 2)
+    bias = torch.randn(C, device=DEV, generator=g) * 0.1
+    out = torch.empty(B, S, C, dtype=BF, device=DEV)
+    # scores of O(1) spread so that the softmax is neither flat nor one-hot
+    scale = 4.0 * C ** -0.5
+    hip_lib.attention_hd512(q, k, vt, bias, out, hw if masked else 0, scale)
+    s = torch.einsum("bqc,bkc->bqk", q.double(), k.double()) * scale
+    if masked:
+        f = torch.arange(S, device=DEV) // hw
+        s = s.masked_fill(f[None, None, :] > f[None, :, None], float("-inf"))
+    ref = torch.softmax(s, -1) @ v.double() + bias.double()
+    err = (out.double() - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 2.0 ** -7      # P is rounded to bf16 before P.V, the output once more
+    assert torch.isfinite(out.float()).all() and (err <= tol).all(), (err.max().item(), (err / tol).max().item())
+    out2 = torch.empty_like(out)
+    hip_lib.attention_hd512(q, k, vt, bias, out2, hw if masked else 0, scale)
+    assert torch.equal(out, out2)
