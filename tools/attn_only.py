@@ -19,7 +19,7 @@ if pv8:
     _C.v_transpose_fp8(v, sv, vt8, H, hd)
 for _ in range(3):
     if pv8:
-        _C.attention_fwd_pv8(q, k, vt8, sv, out, H, hd, hd ** -0.5)
+        _C.attention_fwd_pv8(q, k, vt8, sv, out, H, hd, hd ** -0.5, workspace=_C.attention_workspace(out.device))
     else:
-        _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5)
+        _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5, workspace=_C.attention_workspace(out.device))   # as the model calls it: tail split + merge
 torch.cuda.synchronize()

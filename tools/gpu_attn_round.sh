@@ -28,13 +28,22 @@ for vm in ${PMC_VARIANTS:-}; do v=${vm%%:*}; m=${vm##*:}
   done
   python - "$P" <<'PY' | tee $P/summary.txt
 import csv, glob, collections, sys
+import re
 for f in sorted(glob.glob(sys.argv[1] + "/p*/*counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "attn" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        print(f"{k:32s} per-launch avg {sum(v)/len(v):.6g}  (n={len(v)})")
+            kn = re.search(r"(attn_\w+)", r["Kernel_Name"]).group(1)      # attn_asm72_kernel / attn_merge_kernel separately
+            agg[(kn, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (kn, k), v in sorted(agg.items()):
+        print(f"{kn:22s} {k:32s} per-launch avg {sum(v)/len(v):.6g}  (n={len(v)})")
+for f in sorted(glob.glob(sys.argv[1] + "/p1/*kernel_trace.csv")):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "attn" in r["Kernel_Name"]:
+            d[re.search(r"(attn_\w+)", r["Kernel_Name"]).group(1)].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    for kn, v in d.items():
+        print(f"{kn:22s} duration (profiled pass 1) avg {sum(v)/len(v)/1e3:.1f} us  (n={len(v)})")
 PY
   rm -rf $P/p*/  # raw per-dispatch csvs are large; the summary is what is kept
 done
