@@ -258,12 +258,14 @@ _ATTN_WS: dict = {}
 
 
 def attention_workspace(device) -> torch.Tensor:
-    """per-device workspace for the tail split of osk_attention_fwd_ws_bf16 (allocated once, reused by every launch on
-    the device's compute stream: launches are stream-ordered, the merge kernel of one has consumed it before the next)."""
-    key = str(device)
+    """workspace for the tail split of osk_attention_fwd_ws_bf16, one per (device, stream): launches are ordered within a
+    stream (the merge kernel of one launch has consumed the buffer before the next launch writes it), not across
+    streams.  Allocated once per key, reused by every launch."""
+    dev = torch.device(device)
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
     ws = _ATTN_WS.get(key)
     if ws is None:
-        ws = _ATTN_WS[key] = torch.empty(lib.osk_attention_workspace_bytes(), dtype=torch.uint8, device=device)
+        ws = _ATTN_WS[key] = torch.empty(lib.osk_attention_workspace_bytes(), dtype=torch.uint8, device=dev)
     return ws
 
 

@@ -37,8 +37,7 @@ _OPS = _C
 
 def set_ops_for_testing(ops) -> None:
     global _OPS
-    _OPS = ops
-    _WS_CACHE.clear()
+    _OPS = ops     # workspaces are keyed on id(_OPS): buffers made for another kernel table are not reused
 
 
 def ops():
@@ -408,17 +407,26 @@ class _Workspace:
         return self.y.view(self.B, self.L, 3 * D + R)
 
 
-_WS_CACHE: dict = {}
+def _stream_key(device) -> int:
+    """identity of the stream the kernels of this call are enqueued on (0 on the CPU emulation used by tests)"""
+    return torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
 
 
-def _workspace(B, L_txt, L_img, D, R, H, hd, device) -> _Workspace:
-    key = (B, L_txt, L_img, D, R, H, hd, str(device))
-    ws = _WS_CACHE.get(key)
+def _workspace(owner, B, L_txt, L_img, D, R, H, hd, device) -> _Workspace:
+    """Activation buffers of one (geometry, device, STREAM), owned by `owner` (the model, or the block a stand-alone
+    processor call runs on): two models, or one model driven from two streams, never share buffers -- launches are only
+    ordered within a stream.  Allocated once per key and reused by every block and step; at most 4 geometries are kept."""
+    cache = getattr(owner, "_osk_ws_cache", None)
+    if cache is None:
+        cache = {}
+        object.__setattr__(owner, "_osk_ws_cache", cache)
+    key = (B, L_txt, L_img, D, R, H, hd, str(device), _stream_key(device), id(_OPS))
+    ws = cache.get(key)
     if ws is None:
-        if len(_WS_CACHE) > 4:
-            _WS_CACHE.clear()
+        if len(cache) >= 4:
+            cache.clear()
         ws = _Workspace(B, L_txt, L_img, D, R, H, hd, device)
-        _WS_CACHE[key] = ws
+        cache[key] = ws
     return ws
 
 
@@ -599,7 +607,7 @@ class HipDoubleStreamBlockProcessor:
         B, Li, _ = img.shape
         Lt = txt.shape[1]
         R = plan.img_mlp[0].shape[0]
-        ws = _workspace(B, Lt, Li, D, R, H, hd, img.device)
+        ws = _workspace(attn, B, Lt, Li, D, R, H, hd, img.device)
         cos, sin, mode = _pe_to_cos_sin(pe, hd)
         mod, cols = _run_modulation(vec.float().contiguous(), plan.mod_layers, D)
         ws.x[:, Lt:].copy_(img)
@@ -617,7 +625,7 @@ class HipSingleStreamBlockProcessor:
         plan = plan_single(attn)
         B, L, _ = x.shape
         R = plan.w1.shape[0] - 3 * D
-        ws = _workspace(B, 0, L, D, R, H, hd, x.device)
+        ws = _workspace(attn, B, 0, L, D, R, H, hd, x.device)
         cos, sin, mode = _pe_to_cos_sin(pe, hd)
         mod, cols = _run_modulation(vec.float().contiguous(), plan.mod_layers, D)
         ws.x.copy_(x)
@@ -791,7 +799,7 @@ class MMDiTModel(nn.Module):
             if cond is not None:
                 cond = cond[:, i0:i1]
         Li, Lt = img.shape[1], txt.shape[1]
-        ws = _workspace(B, Lt, Li, D, R, H, hd, dev)
+        ws = _workspace(self, B, Lt, Li, D, R, H, hd, dev)
         # --- img_in (+cond_in): concatenated K-padded A operand
         if Li:
             Kp = p["in_w"].shape[1]

@@ -77,7 +77,7 @@ class SeqPar:
 
     # ------------------------------------------------------------------ K/V exchange
     def _buffers(self, B: int, Lloc: int, H: int, hd: int, device):
-        key = (B, Lloc, H, hd, str(device))
+        key = (B, Lloc, H, hd, str(device), mmdit._stream_key(device))
         b = self._bufs.get(key)
         if b is None:
             if len(self._bufs) > 2:
@@ -89,7 +89,7 @@ class SeqPar:
         return b
 
     def _buffers8(self, B: int, Lloc: int, H: int, hd: int, device):
-        key = ("pv8", B, Lloc, H, hd, str(device))
+        key = ("pv8", B, Lloc, H, hd, str(device), mmdit._stream_key(device))
         b = self._bufs.get(key)
         if b is None:
             if len(self._bufs) > 2:
@@ -148,7 +148,7 @@ class SeqPar:
 
     # ------------------------------------------------------------------ head-parallel exchange (all-to-all)
     def _heads_buffers(self, B: int, Lloc: int, H: int, hd: int, device):
-        key = ("heads", B, Lloc, H, hd, str(device))
+        key = ("heads", B, Lloc, H, hd, str(device), mmdit._stream_key(device))
         b = self._bufs.get(key)
         if b is None:
             if len(self._bufs) > 2:

@@ -201,3 +201,31 @@ def test_checkpoint_load_and_rope_convention_on_gpu(hip_lib, tmp_path):
     with torch.inference_mode():
         out_half = m_half(**inp)
     assert_parity(out_half, truth, ref_bf16, "MMDiT, permuted checkpoint + liger RoPE convention")
+
+
+def test_two_models_and_two_streams_do_not_share_workspaces(hip_lib):
+    """Workspaces are owned per model and per stream (round 1 kept one process-global workspace per
+    geometry): two models of the same geometry driven concurrently from two streams, and ONE model driven from two
+    streams with different inputs, must reproduce their sequential results bit for bit."""
+    cfg, B, T, h, w, L_txt = configs.GOLDEN["hd72_eager_split"]
+    m1, m2 = _build(cfg), _build(cfg)
+    with torch.no_grad():
+        for p_ in m2.parameters():
+            p_.mul_(1.25)
+    inp1 = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF, device="cuda")
+    inp2 = {k: (v if "ids" in k else (v * 0.5).to(v.dtype)) for k, v in inp1.items()}
+    with torch.inference_mode():
+        ref = [m1(**inp1).clone(), m2(**inp2).clone(), m1(**inp2).clone()]
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for _ in range(3):     # a few rounds so that the launches really interleave
+            with torch.cuda.stream(s1):
+                a = m1(**inp1)
+            with torch.cuda.stream(s2):
+                b = m2(**inp2)
+                c = m1(**inp2)
+            torch.cuda.synchronize()
+            assert torch.equal(a, ref[0]) and torch.equal(b, ref[1]) and torch.equal(c, ref[2])
+    ws1 = {id(v) for v in m1._osk_ws_cache.values()}
+    ws2 = {id(v) for v in m2._osk_ws_cache.values()}
+    assert len(ws1) >= 2 and not (ws1 & ws2)
