@@ -45,14 +45,32 @@ OSK_DEV void read_acc(float* v16) {
   }
 }
 
-// bias + residual + bf16 store of one 32 x 32 accumulator tile T = tn * TM + tm (lane: voxel m, 4 channels per quad)
+// Tile row -> output voxel (linear index over [B, To, Ho, Wo]).
+//   linear (brick = 0): row r of M-tile bm is voxel 256 bm + r: a tile is a run of 256 voxels along W.
+//   brick  (brick = 1, Ho % 16 == 0 and Wo % 16 == 0): M-tile bm = (spatial brick, frame) with the FRAME index fastest;
+//     a tile is the 16 x 16 spatial brick of ONE frame.  The tiles an XCD runs at a time (consecutive list positions)
+//     are then the successive frames of one spatial brick: the three time taps of a causal 3 x 3 x 3 filter re-read
+//     frames that a neighbouring tile is reading right now (private-L2 hits) instead of planes fetched a whole frame of
+//     tiles ago -- with linear tiles every input plane came over the fabric three times (round 1: 3.75 x the
+//     algorithmic bytes); the in-plane halo of a 16 x 16 brick is 27 % instead of 200 % of a one-row tile's.
+OSK_DEV int tile_row_to_voxel(const ConvParams& p, int bm, int r) {
+  if (!p.brick) return bm * 256 + r;
+  const int t = bm % p.To, sb = bm / p.To;
+  const int nwb = p.Wo >> 4, nhb = p.Ho >> 4;
+  const int wb = sb % nwb, q = sb / nwb;
+  const int hb = q % nhb, b = q / nhb;
+  return ((b * p.To + t) * p.Ho + hb * 16 + (r >> 4)) * p.Wo + wb * 16 + (r & 15);
+}
+
+// bias + residual + bf16 store of one 32 x 32 accumulator tile T = tn * TM + tm (lane: voxel m, 4 channels per quad);
+// r0w = first tile row of this wave
 template <int BN, int T>
-OSK_DEV void epilogue_tile(const ConvParams& p, int m0w, int n0w, int l31, int hi) {
+OSK_DEV void epilogue_tile(const ConvParams& p, int bm, int r0w, int n0w, int l31, int hi) {
   constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   constexpr int tn = T / TM, tm = T % TM;
   float acc[16];
   read_acc<BN, T>(acc);
-  const int m = m0w + tm * 32 + l31;
+  const int m = tile_row_to_voxel(p, bm, r0w + tm * 32 + l31);
   if (m >= p.M) return;
   const int64_t roff = (int64_t)m * p.Cout;
   const bool vec_ok = (p.Cout & 3) == 0;
@@ -117,8 +135,8 @@ OSK_DEV void epilogue_tile(const ConvParams& p, int m0w, int n0w, int l31, int h
 }
 
 template <int BN, int... Ts>
-OSK_DEV void epilogue_all(const ConvParams& p, int m0w, int n0w, int l31, int hi, std::integer_sequence<int, Ts...>) {
-  (epilogue_tile<BN, Ts>(p, m0w, n0w, l31, hi), ...);
+OSK_DEV void epilogue_all(const ConvParams& p, int bm, int r0w, int n0w, int l31, int hi, std::integer_sequence<int, Ts...>) {
+  (epilogue_tile<BN, Ts>(p, bm, r0w, n0w, l31, hi), ...);
 }
 
 template <int BN>
@@ -225,7 +243,7 @@ __global__ void __launch_bounds__(512, 2) conv256_kernel(const ConvParams p) {
     for (int i = 0; i < 4; ++i) aoffc[i] = aoffn[i];
   }
 
-  epilogue_all<BN>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
+  epilogue_all<BN>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});   // (linear tiles: the launcher clears p.brick)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -254,7 +272,7 @@ __global__ void __launch_bounds__(512, 2) conv256t_kernel(const ConvParams p) {
   // ---- offset table: thread -> tile row tid % 256, taps tid / 256, + 2, + 4, ...
   {
     const int r = tid & 255;
-    int m = m0 + r;
+    int m = tile_row_to_voxel(p, bm, r);
     m = m < p.M ? m : p.M - 1;
     const int wo = m % p.Wo;
     int q = m / p.Wo;
@@ -327,7 +345,7 @@ __global__ void __launch_bounds__(512, 2) conv256t_kernel(const ConvParams p) {
 #include "conv256_body_n128.inc"
         OSKCT_OPERANDS : OSKG128_CONV_CLOBBERS);
   }
-  epilogue_all<BN>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
+  epilogue_all<BN>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
 }
 
 template <int BN, bool TABLE_VERSION>
@@ -353,8 +371,15 @@ bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes) {
 }
 
 // variant 1: one asm segment per filter tap (conv256_kernel); otherwise the single-call table version
-int launch_conv256(const ConvParams& p, int variant, hipStream_t st) {
+int launch_conv256(const ConvParams& p0, int variant, hipStream_t st) {
+  ConvParams p = p0;
+  p.brick = 0;
   if (variant == 1) return p.Cout >= 256 ? launch_one<256, false>(p, st) : launch_one<128, false>(p, st);
+  // OSK_CONV_BRICK=1: 16 x 16 spatial bricks in frame-fastest order instead of linear 256-voxel runs.  Measured (round 2,
+  // profiles/r02_pmc_gemm_conv.txt): parity-green, same time (69.4 vs 69.0 ms per VAE encode+decode) and 12 % MORE fabric-side
+  // reads (49.3 vs 43.8 GB) -- the short 16-voxel row segments cost more than the time-tap reuse saves -- so it stays off.
+  static const bool brick = [] { const char* e = getenv("OSK_CONV_BRICK"); return e && atoi(e) != 0; }();
+  p.brick = brick && (p.Ho % 16 == 0) && (p.Wo % 16 == 0) ? 1 : 0;
   return p.Cout >= 256 ? launch_one<256, true>(p, st) : launch_one<128, true>(p, st);
 }
 

@@ -18,6 +18,7 @@ struct ConvParams {
   int lg_cpt, ntaps, nk;
   int M;
   int64_t wrs;
+  int brick = 0;      // conv256t: 1 = a tile is a 16 x 16 spatial brick of one frame, tiles ordered frame-fastest (conv3d_256.hip)
 };
 
 

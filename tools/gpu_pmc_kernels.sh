@@ -9,16 +9,21 @@ run() {  # name, counters, command...
 }
 run vae_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
 run vae_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
-run dit_fetch "FETCH_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline
-run dit_write "WRITE_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline
+if [ -n "$PMC_LINEAR_CONV" ]; then   # the round-1 tile mapping of conv256t for comparison
+  OSK_CONV_BRICK=0 run vaelin_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
+  OSK_CONV_BRICK=0 run vaelin_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
+fi
+run dit_fetch "FETCH_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-b1
+run dit_write "WRITE_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-b1
 python - "$O" <<'PY' | tee $O/summary.txt
 import csv, glob, collections, sys
 for f in sorted(glob.glob(sys.argv[1] + "/*/*counter_collection.csv")):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        key = next((k for k in ("conv256t_kernel", "conv256_kernel", "conv3d_kernel", "gemm256_kernel", "gemm_bf16_kernel",
-                                "attn_asm72_kernel", "gn_stats", "gn_apply") if k in n), None)
+        key = next((k for k in ("conv256t_kernel", "conv256_kernel", "conv3d_kernel", "gemm256w_kernel", "gemm256p_kernel",
+                                "gemm256_kernel", "gemm_bf16_kernel", "attn_asm72_kernel", "attn_hd512_kernel", "gn_stats",
+                                "gn_apply", "qknorm_rope", "ln_modulate", "v_transpose") if k in n), None)
         if key:
             agg[(key, r["Counter_Name"])][0] += float(r["Counter_Value"])
             agg[(key, r["Counter_Name"])][1] += 1
