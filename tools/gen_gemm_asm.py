@@ -449,10 +449,11 @@ W4_OPERANDS = ["faA0", "faW0"] + ["aoff%d" % i for i in range(8)] + ["woff%d" % 
               ["boff", "abase", "wbase", "bias", "nk", "adst", "wdst", "flags", "dA", "dW", "aoffp", "woffp"]
 WOP = {n: "%%%d" % i for i, n in enumerate(W4_OPERANDS)}
 S_DA, S_DW, S_PFA, S_PFW = 56, 57, 58, 60
-W4_S_LAST = 61
+S_RA, S_RW, S_KOFF = 64, 68, 72          # buffer resources of A and W (4 SGPRs each), K-step byte offset (dmak = 1)
+W4_S_LAST = 72
 
 
-def gen_w4(c, pf=0, abl=0):
+def gen_w4(c, pf=0, abl=0, dmak=0, spread=1, rd_per=2):
     """Persistent-workgroup K loop (see gen_pers) for the 4-wave layout of Cfg4.  Differences: 16 MFMAs, 8 fragment
     reads and 16 LDS-DMA pieces per k-sub-step / K step and wave, placed "matrix pipe first" (schedule 1 of gen_pers:
     behind a barrier the trailing sub-step starts at once, reads ride two per shadow at the head of a sub-step, one
@@ -486,27 +487,35 @@ def gen_w4(c, pf=0, abl=0):
                 out.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, c.TM + tn), 4), vr(c.frag(fset, tm), 4), acc))
         return out
 
-    def dma(stage, aregs=None, wregs=None):
+    # dmak: which LDS-DMA instruction fetches the tiles.  0 = global_load_lds_dwordx4 (FLAT encoding: 32-bit lane offset +
+    # 64-bit scalar base that the loop advances), 1 = buffer_load_dwordx4 ... offen lds (MUBUF: lane offset + buffer
+    # resource + ONE scalar K offset that the loop advances) -- the form hipBLASLt's kernels use.
+    def dma(stage, aregs=None, wregs=None, koff=None):
         aregs = aregs or [WOP["aoff%d" % i] for i in range(c.NA)]
         wregs = wregs or [WOP["woff%d" % i] for i in range(c.NW)]
+        ko = "s%d" % S_KOFF if koff is None else koff
         out = []
         for i in range(c.NA):
-            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * c.DMA_STRIDE),
-                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (aregs[i], S_AB, S_AB + 1)))
+            ld = ("buffer_load_dwordx4 %s, s[%d:%d], %s offen lds" % (aregs[i], S_RA, S_RA + 3, ko)) if dmak else \
+                 ("global_load_lds_dwordx4 %s, s[%d:%d]" % (aregs[i], S_AB, S_AB + 1))
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * c.DMA_STRIDE), ld))
         for i in range(c.NW):
-            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * c.DMA_STRIDE),
-                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (wregs[i], S_WB, S_WB + 1)))
+            ld = ("buffer_load_dwordx4 %s, s[%d:%d], %s offen lds" % (wregs[i], S_RW, S_RW + 3, ko)) if dmak else \
+                 ("global_load_lds_dwordx4 %s, s[%d:%d]" % (wregs[i], S_WB, S_WB + 1))
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * c.DMA_STRIDE), ld))
         return out
 
     def advance():
-        return ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
+        head = ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
                 "s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK),
                 "s_cselect_b32 s%d, 128, 0" % S_STEP,
-                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL),
-                "s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP),
-                "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1),
-                "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
-                "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1)]
+                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL)]
+        if dmak:
+            return head + ["s_add_u32 s%d, s%d, s%d" % (S_KOFF, S_KOFF, S_STEP)]
+        return head + ["s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP),
+                       "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1),
+                       "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
+                       "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1)]
 
     def plain(pieces):
         for m0w, d in pieces:
@@ -524,6 +533,13 @@ def gen_w4(c, pf=0, abl=0):
     e("s_mov_b32 s%d, %s" % (S_PFLAGS, WOP["flags"]))
     e("s_mov_b32 s%d, %s" % (S_DA, WOP["dA"]))
     e("s_mov_b32 s%d, %s" % (S_DW, WOP["dW"]))
+    if dmak:   # raw buffer resources: base, stride 0, num_records 2^32 - 1 bytes, gfx9 data-format word
+        for rs, base in ((S_RA, WOP["abase"]), (S_RW, WOP["wbase"])):
+            e("s_mov_b64 s[%d:%d], %s" % (rs, rs + 1, base))
+            e("s_and_b32 s%d, s%d, 0xffff" % (rs + 1, rs + 1))
+            e("s_mov_b32 s%d, -1" % (rs + 2))
+            e("s_mov_b32 s%d, 0x00020000" % (rs + 3))
+        e("s_mov_b32 s%d, 0" % S_KOFF)
     e("s_mov_b32 s%d, 0" % S_T)
     e("s_mov_b32 s%d, 0" % S_KL)
     for ks in range(1, 4):
@@ -548,7 +564,10 @@ def gen_w4(c, pf=0, abl=0):
     e("s_cbranch_scc1 %s" % ref("have1"))
     plain(dma(1))
     lab("have1")
-    e(dma(1)[N_TRAIL][0])                      # M0 for the pieces entry0 (re-)issues before it advances the pointers
+    if spread > 1:
+        e(dma(1)[(NM + spread - 1) // spread][0])   # first piece whose shadow lies behind entry0
+    else:
+        e(dma(1)[N_TRAIL][0])                  # M0 for the pieces entry0 (re-)issues before it advances the pointers
     e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_BIAS))
     e("s_cbranch_scc0 %s" % ref("zero"))
     for tn in range(c.TN):
@@ -565,7 +584,49 @@ def gen_w4(c, pf=0, abl=0):
         e(r)
     e("s_branch %s" % ref("entry0"))
 
+    def step_spread(cur):
+        """spread > 1: one LDS-DMA piece every `spread` MFMA shadows from the trailing sub-step onwards (instead of one
+        per shadow in 16 consecutive shadows); fragment reads two per shadow in the first free shadows of each
+        sub-step.  The issue window is the trailing sub-step + sub-steps 0 and 1: the last pieces still have sub-step 2
+        to land before the barrier's vmcnt(0)."""
+        pieces = dma(cur ^ 1)
+        nsh = 3 * NM                                            # shadows of: trailing sub-step, sub-step 0, sub-step 1
+        slots = [[] for _ in range(4 * NM)]
+        dma_slots = [spread * j for j in range(len(pieces))]
+        assert dma_slots[-1] < nsh, "every piece must be issued before sub-step 2"
+        e(pieces[0][0])
+        for j, (m0w, d) in enumerate(pieces):
+            slots[dma_slots[j]].append(d)
+            if j + 1 < len(pieces):
+                slots[dma_slots[j]].append(pieces[j + 1][0])
+        last = dma_slots[-1]
+        # fragment reads: sub-step g's fragments are read during the sub-step before it (index: 0 = trailing)
+        for blk, (ks, fset) in enumerate(((0, 0), (1, 1), (2, 0), (3, 1))):
+            rd = reads(cur, ks, fset)
+            if rd_per == 1:      # one read per shadow, in the first shadows of the sub-step (a shadow may also carry an LDS-DMA piece)
+                for i, r in enumerate(rd):
+                    slots[blk * NM + i].insert(0, r)
+                continue
+            free = [i for i in range(blk * NM, (blk + 1) * NM - 3) if i not in dma_slots]
+            for i in range((len(rd) + rd_per - 1) // rd_per):
+                slots[free[i]] += rd[rd_per * i: rd_per * i + rd_per]
+        for blk in range(4):
+            if blk == 1:
+                lab("entry%d" % cur)
+            if blk >= 1:
+                e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(1 if blk % 2 == 0 else 0)                # trailing: set 1, sub-step 0: set 0, 1: set 1, 2: set 0
+            for i, m in enumerate(mf):
+                e(m)
+                for x in slots[blk * NM + i]:
+                    e(x)
+                if blk * NM + i == last:
+                    for a in advance():
+                        e(a)
+
     def step(cur):
+        if spread > 1:
+            return step_spread(cur)
         mf = mfmas(1)
         rd = reads(cur, 0, 0)
         pieces = dma(cur ^ 1)
@@ -606,6 +667,7 @@ def gen_w4(c, pf=0, abl=0):
                 for a in advance():
                     e(a)
                 if pf:
+                    assert not dmak
                     # L2 software prefetch: touch one dword per 128-byte line of the A / W slices of the K step AFTER the
                     # one the loaders now point at (lane = row: aoffp / woffp), two K steps before its LDS-DMA is issued,
                     # so that fetch finds its lines in L2 instead of waiting for the fabric inside the barrier's vmcnt.
@@ -652,7 +714,7 @@ def gen_w4(c, pf=0, abl=0):
     for i in range(c.NW):
         e("v_add_u32_e32 %s, s%d, %s" % (wn[i], S_DW, WOP["woff%d" % i]))
     mf = mfmas(1)
-    pieces = dma(0, an, wn)
+    pieces = dma(0, an, wn, koff="0")
     e(pieces[0][0])
     for i, m in enumerate(mf):
         e(m)
@@ -663,11 +725,12 @@ def gen_w4(c, pf=0, abl=0):
     plain(pieces[len(mf):])
     e("s_cmp_gt_u32 s%d, 1" % S_NK)
     e("s_cselect_b32 s%d, 128, 0" % S_STEP)
-    e("s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP))
-    e("s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1))
-    e("s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP))
-    e("s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1))
-    plain(dma(1, an, wn))
+    if not dmak:
+        e("s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP))
+        e("s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1))
+        e("s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP))
+        e("s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1))
+    plain(dma(1, an, wn, koff="s%d" % S_STEP))
     e("s_branch %s" % ref("end"))
     lab("last")
     for m in mfmas(1):
@@ -1144,6 +1207,19 @@ def main():
                 f.write("// GENERATED by tools/gen_gemm_asm.py --ablations -- timing experiment, WRONG RESULTS.\n")
                 for ln in gen_w4(c, 0, abl):
                     f.write('"%s\\n"\n' % ln)
+    with open(os.path.join(args.out, "gemm256w_body_spread2r1.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, one LDS-DMA piece per 2 MFMA shadows, one fragment read per shadow.\n")
+        for ln in gen_w4(c, 0, 0, 0, 2, 1):
+            f.write('"%s\\n"\n' % ln)
+    for sp in (2, 3):
+        with open(os.path.join(args.out, "gemm256w_body_spread%d.inc" % sp), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, one LDS-DMA piece per %d MFMA shadows.\n" % sp)
+            for ln in gen_w4(c, 0, 0, 0, sp):
+                f.write('"%s\\n"\n' % ln)
+    with open(os.path.join(args.out, "gemm256w_body_buf.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, buffer_load ... lds tile fetch.\n")
+        for ln in gen_w4(c, 0, 0, 1):
+            f.write('"%s\\n"\n' % ln)
     for pf in (0, 1):
         with open(os.path.join(args.out, "gemm256w_body_pf%d.inc" % pf), "w") as f:
             f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup%s.\n"
