@@ -471,6 +471,10 @@ def fixup(st, L, sx, init):
 
 
 # ------------------------------------------------------------------------------------------ body
+DMAGAP = 1     # LDS-DMA items: one per DMAGAP MFMA shadows (set by --exp dmagapN for the experimental variant)
+DMACOST = 12   # issue cycles a shadow's filler budget is charged for an LDS-DMA item
+
+
 def body(st, L, k, safe):
     """iteration with ring slot parity k: SC = scores of tile t (k == 0: set A), SN receives tile t+1"""
     NU = L.NU
@@ -484,18 +488,19 @@ def body(st, L, k, safe):
     # -- trailing P.V MFMAs of tile t-1 (the last two fragment pairs were read before the barrier); in their shadows the
     #    first LDS-DMA pieces of K(t+2) -> slot cur and V(t+1) -> slot cur^1 (M0 write BEFORE the MFMA: no s_nop)
     pieces = [("k", i) for i in range(nslot(L, "k") - 1)] + [("v", i) for i in range(nslot(L, "v") - 1)]
-    pieces = pieces[:L.NTRAIL]
+    pieces = pieces[:(L.NTRAIL + DMAGAP - 1) // DMAGAP]
     done = {"k": sum(1 for w, _ in pieces if w == "k"), "v": sum(1 for w, _ in pieces if w == "v")}
 
     def piece(pc, part):
         (k_dma if pc[0] == "k" else v_dma)(st, L, cur if pc[0] == "k" else cur ^ 1, pc[1], part)
 
     for n in range(L.NTRAIL):
-        if n < len(pieces):
-            piece(pieces[n], 1)
+        pn = n // DMAGAP if n % DMAGAP == 0 else len(pieces)
+        if pn < len(pieces):
+            piece(pieces[pn], 1)
         pv_mfma(st, L, (L.G.NPV - L.NTP) * NU + n)
-        if n < len(pieces):
-            piece(pieces[n], 2)
+        if pn < len(pieces):
+            piece(pieces[pn], 2)
     # -- decision: did some score of tile t exceed the reference by more than 2^THR (VCC from the previous body)?
     st.emit("s_cbranch_vccnz .L@@_rare%d" % k)
     st.label(".L@@_entry%d" % k)
@@ -503,11 +508,11 @@ def body(st, L, k, safe):
     # -- remaining LDS-DMA work, one item per shadow right after the entry point: (emitter, cycles)
     later = []
     for i in range(done["k"], nslot(L, "k") - 1):
-        later.append((lambda i=i: k_dma(st, L, cur, i), 12))
-    later.append((lambda: dma_last(st, L, "k", cur, uid), 12))
+        later.append((lambda i=i: k_dma(st, L, cur, i), DMACOST))
+    later.append((lambda: dma_last(st, L, "k", cur, uid), DMACOST))
     for i in range(done["v"], nslot(L, "v") - 1):
-        later.append((lambda i=i: v_dma(st, L, cur ^ 1, i), 12))
-    later.append((lambda: dma_last(st, L, "v", cur ^ 1, uid), 12))
+        later.append((lambda i=i: v_dma(st, L, cur ^ 1, i), DMACOST))
+    later.append((lambda: dma_last(st, L, "v", cur ^ 1, uid), DMACOST))
     if not L.PV8:   # pv8: the ones / key-validity row arrives with the V^T tile itself
         later.append((lambda: ones_row(st, L, cur ^ 1), 8))   # before the V^T loader moves on: S_VRG is tile t+1's
     later.append((lambda: advance(st, "k", uid), 28))
@@ -557,7 +562,7 @@ def body(st, L, k, safe):
             elif pair + L.RD < L.G.NPV:
                 v_read(st, L, cur, pair + L.RD, ("v", pair + L.RD))
                 used += 8 if L.PV8 else 4
-        if later:
+        if later and n % DMAGAP == 0:
             fn, cyc = later.pop(0)
             fn()
             used += cyc
@@ -693,9 +698,16 @@ def main():
     for hd, nu, pv8 in layouts:
         L = Layout(nu, hd, pv8)
         exp_safe = args.exp == "safe"
-        exp_ab = frozenset() if exp_safe else frozenset(args.exp.split("+"))
+        exp_gap = args.exp.startswith("dmagap")    # "dmagap2" / "dmagap2c30": a SCHEDULE variant (correct results), not an ablation
+        exp_ab = frozenset() if (exp_safe or exp_gap) else frozenset(args.exp.split("+"))
         for vi, (safe, ablate) in enumerate([(False, frozenset()), (exp_safe, exp_ab)]):
+            global DMAGAP, DMACOST
+            DMAGAP, DMACOST = 1, 12
+            if vi == 1 and exp_gap:
+                spec = args.exp[len("dmagap"):].split("c")
+                DMAGAP, DMACOST = int(spec[0]), int(spec[1]) if len(spec) > 1 else 12
             st = generate(L, safe, ablate)
+            DMAGAP, DMACOST = 1, 12
             if args.table == nu and args.hd == hd and vi == 0 and args.pv8 == pv8:
                 gap = []
                 for kind, text in st.table:
@@ -709,7 +721,8 @@ def main():
             with open(os.path.join(args.out, "attention_asm%s_n%d_v%d.inc" % (tagof(hd, pv8), nu, vi)), "w") as f:
                 f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d%s, layout NU=%d, variant %d: %s\n" %
                         (hd, ", fp8 P.V" if pv8 else "", nu, vi,
-                         "production" if vi == 0 else ("hazard-padded (debug)" if safe else "timing ablation " + "+".join(sorted(ablate)))))
+                         "production" if vi == 0 else ("hazard-padded (debug)" if safe else
+                                                       ("schedule experiment " + args.exp if exp_gap else "timing ablation " + "+".join(sorted(ablate))))))
                 for ln in st.lines:
                     f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%dv%d" % (tagof(hd, pv8), nu, vi)))
     # register / operand contract for the wrapper
