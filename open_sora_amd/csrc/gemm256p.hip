@@ -139,7 +139,11 @@ __global__ void __launch_bounds__(512, 2) gemm256p_kernel(const GemmParams p) {
       "v"(woff[2]), "v"(woff[3]), "v"(aoffn[0]), "v"(aoffn[1]), "v"(aoffn[2]), "v"(aoffn[3]), "v"(woffn[0]),         \
       "v"(woffn[1]), "v"(woffn[2]), "v"(woffn[3]), "v"(boff), "s"(abase), "s"(wbase), "s"(bbase), "s"(nk), "s"(adst), \
       "s"(wdst), "s"(flags)
-    if constexpr (BN == 256 && SCHED == 1) {
+    if constexpr (BN == 256 && SCHED == 2) {
+      asm volatile(
+#include "gemm256p_body_n256_s2.inc"
+          OSKP_OPERANDS : OSKP256_CLOBBERS);
+    } else if constexpr (BN == 256 && SCHED == 1) {
       asm volatile(
 #include "gemm256p_body_n256_s1.inc"
           OSKP_OPERANDS : OSKP256_CLOBBERS);
@@ -189,15 +193,17 @@ int launch_one(const GemmParams& p, hipStream_t st) {
 }  // namespace
 
 int launch_gemm256p(const GemmParams& p, int bn, int out_f32, hipStream_t st) {
-  // OSK_GEMM_SCHED: 0 / 1 for both tile widths (A/B runs); default: schedule 1 for the 256-wide tile, 0 for the 128-wide one
-  // (its 4-MFMA sub-steps leave no head shadows for paired reads)
+  // OSK_GEMM_SCHED: 0 / 1 / 2 (A/B runs); default: schedule 2 (schedule 1 with the LDS-DMA instructions one per two MFMA
+  // shadows: +2..4 % measured, profiles/r02_gemm_experiments.md) for the 256-wide tile, 0 for the 128-wide one (its 4-MFMA
+  // sub-steps leave no head shadows for paired reads)
   static const int forced = [] { const char* e = getenv("OSK_GEMM_SCHED"); return e ? atoi(e) : -1; }();
-  const int sched = forced >= 0 ? forced : (bn == 256 ? 1 : 0);
+  const int sched = forced >= 0 ? forced : (bn == 256 ? 2 : 0);
   if (bn == 256) {
+    if (sched == 2) return out_f32 ? launch_one<256, true, 2>(p, st) : launch_one<256, false, 2>(p, st);
     if (sched == 1) return out_f32 ? launch_one<256, true, 1>(p, st) : launch_one<256, false, 1>(p, st);
     return out_f32 ? launch_one<256, true, 0>(p, st) : launch_one<256, false, 0>(p, st);
   }
-  if (sched == 1) return out_f32 ? launch_one<128, true, 1>(p, st) : launch_one<128, false, 1>(p, st);
+  if (sched >= 1) return out_f32 ? launch_one<128, true, 1>(p, st) : launch_one<128, false, 1>(p, st);
   return out_f32 ? launch_one<128, true, 0>(p, st) : launch_one<128, false, 0>(p, st);
 }
 

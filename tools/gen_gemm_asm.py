@@ -285,10 +285,10 @@ def gen_pers(c, sched=0):
         for a in advance():
             e(a)
     else:
-        # schedule 1 enters the loop at entry0, whose first shadows carry the LAST LDS-DMA pieces of the stage-1 fetch
+        # schedules 1 / 2 enter the loop at entry0, whose first shadows carry the LAST LDS-DMA pieces of the stage-1 fetch
         # (re-issued here: same bytes to the same LDS rows, harmless) followed by the pointer advance: set up M0 for them
         pcs = dma(1)
-        n_trail = c.TM * c.TN - (c.NFRAG + 1) // 2
+        n_trail = (c.TM * c.TN + 1) // 2 if sched == 2 else c.TM * c.TN - (c.NFRAG + 1) // 2
         e(pcs[n_trail][0])
     e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_BIAS))
     e("s_cbranch_scc0 %s" % ref("zero"))
@@ -377,10 +377,43 @@ def gen_pers(c, sched=0):
                 for a in advance():     # only now: the carried LDS-DMA pieces above still address THIS fetch's K step
                     e(a)
 
+    def step_sched2(cur):
+        """schedule 1 with the LDS-DMA pieces one per TWO shadows over the trailing sub-step and sub-step 0 (see gen_w4:
+        an LDS-DMA instruction holds the issue port for several MFMA shadows)"""
+        NM = c.TM * c.TN
+        pieces = dma(cur ^ 1)
+        dma_slots = [2 * j for j in range(len(pieces))]
+        assert dma_slots[-1] < 2 * NM
+        slots = [[] for _ in range(4 * NM)]
+        e(pieces[0][0])
+        for j, (m0w, d) in enumerate(pieces):
+            slots[dma_slots[j]].append(d)
+            if j + 1 < len(pieces):
+                slots[dma_slots[j]].append(pieces[j + 1][0])
+        last = dma_slots[-1]
+        for blk, (ks, fset) in enumerate(((0, 0), (1, 1), (2, 0), (3, 1))):
+            rd = reads(cur, ks, fset)
+            free = [i for i in range(blk * NM, (blk + 1) * NM - 1) if i not in dma_slots]
+            for i in range((len(rd) + 1) // 2):
+                slots[free[i]] += rd[2 * i: 2 * i + 2]
+        for blk in range(4):
+            if blk == 1:
+                lab("entry%d" % cur)
+            if blk >= 1:
+                e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(1 if blk % 2 == 0 else 0)
+            for i, m in enumerate(mf):
+                e(m)
+                for x in slots[blk * NM + i]:
+                    e(x)
+                if blk * NM + i == last:
+                    for a in advance():
+                        e(a)
+
     for k in range(2):
         cur = k
         lab("step%d" % k)
-        (step_sched1 if sched == 1 else step_sched0)(cur)
+        (step_sched2 if sched == 2 else (step_sched1 if sched == 1 else step_sched0))(cur)
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         e("s_barrier")
         e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
@@ -1182,7 +1215,7 @@ def main():
             cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 12)] + ['"a%d"' % i for i in range(c.NACC)] + \
                     ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
             f.write("#define %sCONV_CLOBBERS %s\n" % (P, ", ".join(cclob)))
-        for sched in (0, 1):
+        for sched in (0, 1, 2) if bn == 256 else (0, 1):
             with open(os.path.join(args.out, "gemm256p_body_n%d_s%d.inc" % (bn, sched)), "w") as f:
                 f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile K loop, persistent workgroup, schedule %d.\n" % (bn, sched))
                 for ln in gen_pers(c, sched):
