@@ -194,7 +194,7 @@ def bench_vae(args, dev):
     rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "kernel_traffic.json")
     if os.path.exists(rec_path) and (T, S) == (33, 256):
         for rec in json.load(open(rec_path)):
-            if rec["kernel"].startswith("conv256t_kernel"):
+            if rec["kernel"].startswith("conv256"):   # the latest record wins
                 traffic, traffic_src = rec["hbm_bytes_per_step"], rec["source"]
     res = {
         "metric": "vae_video_frames_per_sec (encode + decode; ms per encode+decode in ms_per_step)",
@@ -205,9 +205,9 @@ def bench_vae(args, dev):
                    "flops_encode": enc_f, "flops_decode": dec_f},
         "step_tflops": round((enc_f + dec_f) / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round((enc_f + dec_f) / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        # all conv launches of one encode + decode: conv256t_kernel (conv3d_256.hip) where Cin % 128 == 0, Cout >= 128,
-        # conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers
-        "roofline": {"bound": "mfma", "kernel": "conv256t_kernel + conv3d_kernel (by layer shape)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+        # all conv launches of one encode + decode: conv3d_256.hip where Cin % 128 == 0 (conv256w_kernel for Cout >= 256,
+        # conv256t_kernel<128> for Cout = 128), conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers
+        "roofline": {"bound": "mfma", "kernel": "conv256w_kernel + conv256t_kernel + conv3d_kernel (by layer shape)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_source": traffic_src,
                      "launches": len(prof) // args.steps, "total_conv_ms_per_step": round(conv_ms, 3)},

@@ -14,6 +14,8 @@
 #include "conv_params.h"
 #include "gemm256_regs_n256.inc"
 #include "gemm256_regs_n128.inc"
+#include "gemm256w_regs.inc"
+#include <type_traits>
 
 namespace osk_conv {
 namespace {
@@ -26,9 +28,11 @@ OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) 
       "=v"(v16[8]), "=v"(v16[9]), "=v"(v16[10]), "=v"(v16[11]), "=v"(v16[12]), "=v"(v16[13]), "=v"(v16[14]),          \
       "=v"(v16[15])
 
-template <int BN, int T>
-OSK_DEV void read_acc(float* v16) {
-  if constexpr (BN == 256) {
+// accumulator layouts: TM x TN MFMA tiles per wave, tile T = tn * TM + tm in AGPRs [16 T, 16 T + 16)
+struct Lay256 {   // 8 waves, 256 x 256 tile, wave tile 128 x 64
+  static constexpr int TM = OSKG256_TM, TN = OSKG256_TN;
+  template <int T>
+  OSK_DEV void read(float* v16) {
     if constexpr (T == 0) asm volatile(OSKG256_AR0 : OSKC_OUT16);
     else if constexpr (T == 1) asm volatile(OSKG256_AR1 : OSKC_OUT16);
     else if constexpr (T == 2) asm volatile(OSKG256_AR2 : OSKC_OUT16);
@@ -37,13 +41,42 @@ OSK_DEV void read_acc(float* v16) {
     else if constexpr (T == 5) asm volatile(OSKG256_AR5 : OSKC_OUT16);
     else if constexpr (T == 6) asm volatile(OSKG256_AR6 : OSKC_OUT16);
     else asm volatile(OSKG256_AR7 : OSKC_OUT16);
-  } else {
+  }
+};
+struct Lay128 {   // 8 waves, 256 x 128 tile, wave tile 64 x 64
+  static constexpr int TM = OSKG128_TM, TN = OSKG128_TN;
+  template <int T>
+  OSK_DEV void read(float* v16) {
     if constexpr (T == 0) asm volatile(OSKG128_AR0 : OSKC_OUT16);
     else if constexpr (T == 1) asm volatile(OSKG128_AR1 : OSKC_OUT16);
     else if constexpr (T == 2) asm volatile(OSKG128_AR2 : OSKC_OUT16);
     else asm volatile(OSKG128_AR3 : OSKC_OUT16);
   }
-}
+};
+struct LayW {     // 4 waves, 256 x 256 tile, wave tile 128 x 128
+  static constexpr int TM = OSKW_TM, TN = OSKW_TN;
+  template <int T>
+  OSK_DEV void read(float* v16) {
+    if constexpr (T == 0) asm volatile(OSKW_AR0 : OSKC_OUT16);
+    else if constexpr (T == 1) asm volatile(OSKW_AR1 : OSKC_OUT16);
+    else if constexpr (T == 2) asm volatile(OSKW_AR2 : OSKC_OUT16);
+    else if constexpr (T == 3) asm volatile(OSKW_AR3 : OSKC_OUT16);
+    else if constexpr (T == 4) asm volatile(OSKW_AR4 : OSKC_OUT16);
+    else if constexpr (T == 5) asm volatile(OSKW_AR5 : OSKC_OUT16);
+    else if constexpr (T == 6) asm volatile(OSKW_AR6 : OSKC_OUT16);
+    else if constexpr (T == 7) asm volatile(OSKW_AR7 : OSKC_OUT16);
+    else if constexpr (T == 8) asm volatile(OSKW_AR8 : OSKC_OUT16);
+    else if constexpr (T == 9) asm volatile(OSKW_AR9 : OSKC_OUT16);
+    else if constexpr (T == 10) asm volatile(OSKW_AR10 : OSKC_OUT16);
+    else if constexpr (T == 11) asm volatile(OSKW_AR11 : OSKC_OUT16);
+    else if constexpr (T == 12) asm volatile(OSKW_AR12 : OSKC_OUT16);
+    else if constexpr (T == 13) asm volatile(OSKW_AR13 : OSKC_OUT16);
+    else if constexpr (T == 14) asm volatile(OSKW_AR14 : OSKC_OUT16);
+    else asm volatile(OSKW_AR15 : OSKC_OUT16);
+  }
+};
+template <int BN>
+using LayOf = std::conditional_t<BN == 256, Lay256, Lay128>;
 
 // Tile row -> output voxel (linear index over [B, To, Ho, Wo]).
 //   linear (brick = 0): row r of M-tile bm is voxel 256 bm + r: a tile is a run of 256 voxels along W.
@@ -62,14 +95,50 @@ OSK_DEV int tile_row_to_voxel(const ConvParams& p, int bm, int r) {
   return ((b * p.To + t) * p.Ho + hb * 16 + (r >> 4)) * p.Wo + wb * 16 + (r & 15);
 }
 
+// LDS offset table [tap][256 tile rows]: byte offset of the voxel that filter tap reads for that output row
+// (thread -> row tid % 256, taps tid / 256, + tap_stride, ...)
+OSK_DEV void build_tap_table(const ConvParams& p, int bm, int tid, int tap_stride, unsigned* table) {
+  const int r = tid & 255;
+  int m = tile_row_to_voxel(p, bm, r);
+  m = m < p.M ? m : p.M - 1;
+  const int wo = m % p.Wo;
+  int q = m / p.Wo;
+  const int ho = q % p.Ho;
+  q /= p.Ho;
+  const int to = q % p.To;
+  const int b = q / p.To;
+  const int HW = p.H * p.W;
+  const unsigned cin_bytes = (unsigned)p.Cin * 2;
+  for (int tap = tid >> 8; tap < p.ntaps; tap += tap_stride) {
+    int dt = 0, dh = 0, dw = 0;
+    if (p.ks == 3) {
+      dt = tap / 9;
+      const int r9 = tap - dt * 9;
+      dh = r9 / 3;
+      dw = r9 - dh * 3;
+    }
+    // clamp = replicate / causal padding, shift = nearest upsample (frame 0 is spatial-only)
+    int tu = to * p.st + dt - (p.ks - 1);
+    tu = tu < 0 ? 0 : (tu > p.Tu - 1 ? p.Tu - 1 : tu);
+    const int ts = p.up_t ? (tu == 0 ? 0 : 1 + ((tu - 1) >> 1)) : tu;
+    int hu = ho * p.sh + dh - (p.ks >> 1);
+    hu = hu < 0 ? 0 : (hu > p.Hu - 1 ? p.Hu - 1 : hu);
+    const int hs = p.up_hw ? (hu >> 1) : hu;
+    int wu = wo * p.sw + dw - (p.ks >> 1);
+    wu = wu < 0 ? 0 : (wu > p.Wu - 1 ? p.Wu - 1 : wu);
+    const int ws = p.up_hw ? (wu >> 1) : wu;
+    table[tap * 256 + r] = (unsigned)((b * p.T + ts) * HW + hs * p.W + ws) * cin_bytes;
+  }
+}
+
 // bias + residual + bf16 store of one 32 x 32 accumulator tile T = tn * TM + tm (lane: voxel m, 4 channels per quad);
 // r0w = first tile row of this wave
-template <int BN, int T>
+template <class Lay, int T>
 OSK_DEV void epilogue_tile(const ConvParams& p, int bm, int r0w, int n0w, int l31, int hi) {
-  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
+  constexpr int TM = Lay::TM;
   constexpr int tn = T / TM, tm = T % TM;
   float acc[16];
-  read_acc<BN, T>(acc);
+  Lay::template read<T>(acc);
   const int m = tile_row_to_voxel(p, bm, r0w + tm * 32 + l31);
   if (m >= p.M) return;
   const int64_t roff = (int64_t)m * p.Cout;
@@ -134,9 +203,9 @@ OSK_DEV void epilogue_tile(const ConvParams& p, int bm, int r0w, int n0w, int l3
   }
 }
 
-template <int BN, int... Ts>
+template <class Lay, int... Ts>
 OSK_DEV void epilogue_all(const ConvParams& p, int bm, int r0w, int n0w, int l31, int hi, std::integer_sequence<int, Ts...>) {
-  (epilogue_tile<BN, Ts>(p, bm, r0w, n0w, l31, hi), ...);
+  (epilogue_tile<Lay, Ts>(p, bm, r0w, n0w, l31, hi), ...);
 }
 
 template <int BN>
@@ -243,7 +312,7 @@ __global__ void __launch_bounds__(512, 2) conv256_kernel(const ConvParams p) {
     for (int i = 0; i < 4; ++i) aoffc[i] = aoffn[i];
   }
 
-  epilogue_all<BN>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});   // (linear tiles: the launcher clears p.brick)
+  epilogue_all<LayOf<BN>>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});   // (linear tiles: the launcher clears p.brick)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -269,41 +338,7 @@ __global__ void __launch_bounds__(512, 2) conv256t_kernel(const ConvParams p) {
   const int bm = tile / nbn, bn = tile - bm * nbn;
   const int m0 = bm * 256, n0 = bn * BN;
 
-  // ---- offset table: thread -> tile row tid % 256, taps tid / 256, + 2, + 4, ...
-  {
-    const int r = tid & 255;
-    int m = tile_row_to_voxel(p, bm, r);
-    m = m < p.M ? m : p.M - 1;
-    const int wo = m % p.Wo;
-    int q = m / p.Wo;
-    const int ho = q % p.Ho;
-    q /= p.Ho;
-    const int to = q % p.To;
-    const int b = q / p.To;
-    const int HW = p.H * p.W;
-    const unsigned cin_bytes = (unsigned)p.Cin * 2;
-    unsigned* table = reinterpret_cast<unsigned*>(smem + TABLE);
-    for (int tap = tid >> 8; tap < p.ntaps; tap += 2) {
-      int dt = 0, dh = 0, dw = 0;
-      if (p.ks == 3) {
-        dt = tap / 9;
-        const int r9 = tap - dt * 9;
-        dh = r9 / 3;
-        dw = r9 - dh * 3;
-      }
-      // clamp = replicate / causal padding, shift = nearest upsample (frame 0 is spatial-only)
-      int tu = to * p.st + dt - (p.ks - 1);
-      tu = tu < 0 ? 0 : (tu > p.Tu - 1 ? p.Tu - 1 : tu);
-      const int ts = p.up_t ? (tu == 0 ? 0 : 1 + ((tu - 1) >> 1)) : tu;
-      int hu = ho * p.sh + dh - (p.ks >> 1);
-      hu = hu < 0 ? 0 : (hu > p.Hu - 1 ? p.Hu - 1 : hu);
-      const int hs = p.up_hw ? (hu >> 1) : hu;
-      int wu = wo * p.sw + dw - (p.ks >> 1);
-      wu = wu < 0 ? 0 : (wu > p.Wu - 1 ? p.Wu - 1 : wu);
-      const int ws = p.up_hw ? (wu >> 1) : wu;
-      table[tap * 256 + r] = (unsigned)((b * p.T + ts) * HW + hs * p.W + ws) * cin_bytes;
-    }
-  }
+  build_tap_table(p, bm, tid, 2, reinterpret_cast<unsigned*>(smem + TABLE));
   __syncthreads();
 
   // ---- LDS-DMA row slots of this lane: instruction j = wave + 8 i covers tile rows [8 j, 8 j + 8)
@@ -345,7 +380,71 @@ __global__ void __launch_bounds__(512, 2) conv256t_kernel(const ConvParams p) {
 #include "conv256_body_n128.inc"
         OSKCT_OPERANDS : OSKG128_CONV_CLOBBERS);
   }
-  epilogue_all<BN>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
+  epilogue_all<LayOf<BN>>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 4-wave form of conv256t_kernel<256> (Cout >= 256): one wave per SIMD with the whole register file, wave tile 128 x 128
+// (gemm256w.hip's layout: a third less LDS read traffic per flop), K loop conv256w_body.inc = the table-driven loop above
+// with the LDS-DMA instructions one per two MFMA shadows (what bounded the GEMM: profiles/r02_gemm_experiments.md).
+__global__ void __launch_bounds__(256, 1) conv256w_kernel(const ConvParams p) {
+  constexpr int TM = OSKW_TM, TN = OSKW_TN, BN = 256;
+  constexpr int TABLE = OSKW_SMEM;   // the table sits behind the two stages
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int nbm = (p.M + 255) / 256, nbn = (p.Cout + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int n0 = bn * BN;
+
+  build_tap_table(p, bm, tid, 1, reinterpret_cast<unsigned*>(smem + TABLE));
+  __syncthreads();
+
+  // ---- LDS-DMA row slots of this lane: instruction j = wave + 4 i (i = 0..7) covers tile rows [8 j, 8 j + 8); the swizzle
+  // key (r >> 1) & 7 of row r = 8 (wave + 4 i) + lane / 8 does not depend on i
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int srow8 = lane >> 3, spos = lane & 7;
+  const int r0 = wave * 8 + srow8;
+  const int c = spos ^ ((r0 >> 1) & 7);
+  const unsigned chk = (unsigned)(c * 16);
+  const unsigned arow0 = lds_base + TABLE + r0 * 4;
+  unsigned woff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int n = n0 + r0 + 32 * i;
+    n = n < p.Cout ? n : p.Cout - 1;
+    woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
+  }
+  const unsigned sz0 = (unsigned)((hi ^ ((l31 >> 1) & 7)) << 4);
+  const unsigned faA0 = lds_base + (wm * TM * 32 + l31) * 128 + sz0;
+  const unsigned faW0 = lds_base + OSKW_W_BASE + (wn * TN * 32 + l31) * 128 + sz0;
+  const uint64_t xbase = rfl64((uint64_t)(uintptr_t)p.x), wbase = rfl64((uint64_t)(uintptr_t)p.w);
+  const unsigned nkt = rfl((unsigned)(p.Cin / 64)), nk = rfl((unsigned)(p.ntaps * (p.Cin / 64)));
+  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + OSKW_W_BASE + wave * 1024);
+  asm volatile(
+#include "conv256w_body.inc"
+      ::"v"(faA0), "v"(faW0), "v"(arow0), "v"(chk), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]),
+      "v"(woff[5]), "v"(woff[6]), "v"(woff[7]), "s"(xbase), "s"(wbase), "s"(nk), "s"(nkt), "s"(adst), "s"(wdst)
+      : OSKW_CONV_CLOBBERS);
+  epilogue_all<LayW>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
+}
+
+int launch_w(const ConvParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int SMEM = OSKW_SMEM + 27 * 1024;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv256w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int nblk = ((p.M + 255) / 256) * ((p.Cout + 255) / 256);
+  hipLaunchKernelGGL(conv256w_kernel, dim3(nblk), dim3(256), SMEM, st, p);
+  return (int)hipGetLastError();
 }
 
 template <int BN, bool TABLE_VERSION>
@@ -380,7 +479,10 @@ int launch_conv256(const ConvParams& p0, int variant, hipStream_t st) {
   // reads (49.3 vs 43.8 GB) -- the short 16-voxel row segments cost more than the time-tap reuse saves -- so it stays off.
   static const bool brick = [] { const char* e = getenv("OSK_CONV_BRICK"); return e && atoi(e) != 0; }();
   p.brick = brick && (p.Ho % 16 == 0) && (p.Wo % 16 == 0) ? 1 : 0;
-  return p.Cout >= 256 ? launch_one<256, true>(p, st) : launch_one<128, true>(p, st);
+  // OSK_CONV_W4=0: the 8-wave kernel for Cout >= 256 too (A/B runs)
+  static const bool w4 = [] { const char* e = getenv("OSK_CONV_W4"); return !e || atoi(e) != 0; }();
+  if (p.Cout >= 256) return w4 ? launch_w(p, st) : launch_one<256, true>(p, st);
+  return launch_one<128, true>(p, st);
 }
 
 }  // namespace osk_conv

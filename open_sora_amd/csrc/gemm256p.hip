@@ -57,7 +57,7 @@ struct Geo {
   static constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   static constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
   template <int T>
-  OSK_DEV static void read(float* v16) { read_acc<BN, T>(v16); }
+  OSK_DEV void read(float* v16) { read_acc<BN, T>(v16); }
 };
 
 // SCHED: K-step schedule of the generated body (tools/gen_gemm_asm.py::gen_pers): 0 = the round-1 order (fragment reads

@@ -32,7 +32,7 @@ OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) 
 struct GeoW {
   static constexpr int TM = OSKW_TM, TN = OSKW_TN;
   template <int T>
-  OSK_DEV static void read(float* v16) {
+  OSK_DEV void read(float* v16) {
     if constexpr (T == 0) asm volatile(OSKW_AR0 : OSKW_OUT16);
     else if constexpr (T == 1) asm volatile(OSKW_AR1 : OSKW_OUT16);
     else if constexpr (T == 2) asm volatile(OSKW_AR2 : OSKW_OUT16);

@@ -1188,6 +1188,181 @@ def gen_conv(c):
     e("s_nop 15")
     return L
 
+CW_OPERANDS = ["faA0", "faW0", "arow0", "chk"] + ["woff%d" % i for i in range(8)] + ["xbase", "wbase", "nk", "nkt", "adst", "wdst"]
+CWOP = {n: "%%%d" % i for i, n in enumerate(CW_OPERANDS)}
+
+
+def gen_conv_w4(c, spread=2):
+    """gen_conv on the 4-wave layout of Cfg4 with gen_w4's spread schedule: the whole K axis (all filter taps) of the
+    implicit-GEMM convolution in one call, wave tile 128 x 128, one LDS-DMA piece per `spread` MFMA shadows.  A wave's 8
+    activation pieces cover tile rows 8 (wave + 4 i) + lane / 8: their voxel offsets sit 128 bytes apart in the LDS table
+    row of the tap (one address register + immediate offsets), and the swizzled channel-chunk offset is the same for all
+    8 (the row's swizzle key (r >> 1) & 7 does not depend on i).  Per K step: pieces A0..A7 in the trailing sub-step,
+    W0..W7 in sub-step 0, then the loaders advance, sub-step 1 re-reads the table for the step they now point at and
+    sub-step 2 adds the chunk offset (by then this step's pieces have long read their address registers)."""
+    L = []
+    e = lambda t: L.append("  " + t)
+    lab = lambda n: L.append(".Lcw_%s_%%=:" % n)
+    ref = lambda n: ".Lcw_%s_%%=" % n
+    VX = c.V0 + c.VN
+    fa = {("A", 0): CWOP["faA0"], ("W", 0): CWOP["faW0"]}
+    for ks in range(1, 4):
+        fa[("A", ks)] = vr(VX + ks - 1)
+        fa[("W", ks)] = vr(VX + 3 + ks - 1)
+    VA = VX + 6                # table address of the tap being fetched
+    VR = VA + 1                # 8 raw table entries
+    VO = VR + c.NA             # 8 offsets of the step being fetched
+    NM = c.TM * c.TN
+
+    def reads(stage, ks, fset):
+        out = []
+        for tm in range(c.TM):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, tm), 4), fa[("A", ks)], stage * c.A_STAGE + tm * 4096))
+        for tn in range(c.TN):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, c.TM + tn), 4), fa[("W", ks)], stage * c.W_STAGE + tn * 4096))
+        return out
+
+    def mfmas(fset):
+        out = []
+        for tn in range(c.TN):
+            for tm in range(c.TM):
+                acc = ar((tn * c.TM + tm) * 16, 16)
+                out.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, c.TM + tn), 4), vr(c.frag(fset, tm), 4), acc))
+        return out
+
+    def dma(stage):
+        out = []
+        for i in range(c.NA):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * c.DMA_STRIDE),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (vr(VO + i), S_AB, S_AB + 1)))
+        for i in range(c.NW):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * c.DMA_STRIDE),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (CWOP["woff%d" % i], S_WB, S_WB + 1)))
+        return out
+
+    def table_reads():
+        return ["v_add_u32_e32 %s, s%d, %s" % (vr(VA), S_TAPOFF, CWOP["arow0"])] + \
+               ["ds_read_b32 %s, %s offset:%d" % (vr(VR + i), vr(VA), i * 128) for i in range(c.NA)]
+
+    def table_adds():
+        return ["v_add_u32_e32 %s, %s, %s" % (vr(VO + i), vr(VR + i), CWOP["chk"]) for i in range(c.NA)]
+
+    def advance():     # gen_conv's: tap-major K axis, clamp at the end
+        return ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
+                "s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK),
+                "s_cselect_b32 s%d, 128, 0" % S_STEP,
+                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL),
+                "s_cselect_b32 s%d, 1, 0" % S_TMP,
+                "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1),
+                "s_add_u32 s%d, s%d, s%d" % (S_SIT, S_SIT, S_TMP),
+                "s_cmp_ge_u32 s%d, s%d" % (S_SIT, S_NKT),
+                "s_cselect_b32 s%d, 0, s%d" % (S_SIT, S_SIT),
+                "s_cselect_b32 s%d, 1024, 0" % S_STEP,
+                "s_add_u32 s%d, s%d, s%d" % (S_TAPOFF, S_TAPOFF, S_STEP),
+                "s_lshl_b32 s%d, s%d, 7" % (S_STEP, S_SIT),
+                "s_add_u32 s%d, s%d, s%d" % (S_AB, S_XB2, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_XB2 + 1)]
+
+    def plain(pieces):
+        for m0w, d in pieces:
+            e(m0w); e("s_nop 0"); e(d)
+
+    # ---- setup
+    e("s_mov_b64 s[%d:%d], %s" % (S_XB2, S_XB2 + 1, CWOP["xbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, CWOP["xbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, CWOP["wbase"]))
+    e("s_mov_b32 s%d, %s" % (S_NK, CWOP["nk"]))
+    e("s_mov_b32 s%d, %s" % (S_NKT, CWOP["nkt"]))
+    e("s_mov_b32 s%d, %s" % (S_ADST, CWOP["adst"]))
+    e("s_mov_b32 s%d, %s" % (S_WDST, CWOP["wdst"]))
+    for sreg in (S_T, S_KL, S_SIT, S_TAPOFF):
+        e("s_mov_b32 s%d, 0" % sreg)
+    for ks in range(1, 4):
+        e("v_xor_b32_e32 %s, %d, %s" % (fa[("A", ks)], ks << 5, CWOP["faA0"]))
+        e("v_xor_b32_e32 %s, %d, %s" % (fa[("W", ks)], ks << 5, CWOP["faW0"]))
+    for r in range(c.NACC):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    for t in table_reads():
+        e(t)
+    e("s_waitcnt lgkmcnt(0)")
+    for t in table_adds():
+        e(t)
+    e("s_nop 1")
+    plain(dma(0))
+    for a in advance():
+        e(a)
+    for t in table_reads():
+        e(t)
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")     # stage 0 landed AND its DMA has consumed the offset registers
+    for t in table_adds():
+        e(t)
+    e("s_barrier")
+    e("s_nop 1")
+    plain(dma(1))                          # entry0 re-issues the W pieces (same step, same data), then advances
+    first_entry_piece = (NM + spread - 1) // spread
+    assert first_entry_piece >= c.NA, "entry0 must not re-issue activation pieces (their offsets would be stale)"
+    e(dma(1)[first_entry_piece][0])
+    for r in reads(0, 0, 0):
+        e(r)
+    e("s_branch %s" % ref("entry0"))
+
+    def step(cur):
+        pieces = dma(cur ^ 1)
+        slots = [[] for _ in range(4 * NM)]
+        dma_slots = [spread * j for j in range(len(pieces))]
+        assert dma_slots[-1] < 2 * NM
+        e(pieces[0][0])
+        for j, (m0w, d) in enumerate(pieces):
+            slots[dma_slots[j]].append(d)
+            if j + 1 < len(pieces):
+                slots[dma_slots[j]].append(pieces[j + 1][0])
+        last = dma_slots[-1]
+        for blk, (ks, fset) in enumerate(((0, 0), (1, 1), (2, 0), (3, 1))):
+            rd = reads(cur, ks, fset)
+            free = [i for i in range(blk * NM, (blk + 1) * NM - 3) if i not in dma_slots]
+            for i in range((len(rd) + 1) // 2):
+                slots[free[i]] += rd[2 * i: 2 * i + 2]
+        tr = table_reads()                                     # sub-step 1, behind its fragment reads
+        base = 2 * NM + (c.NFRAG + 1) // 2
+        slots[base] += tr[:3]
+        for i in range(3, len(tr), 2):
+            slots[base + 1 + (i - 3) // 2] += tr[i: i + 2]
+        ta = table_adds()                                      # sub-step 2, behind its fragment reads
+        base = 3 * NM + (c.NFRAG + 1) // 2
+        for i, t in enumerate(ta):
+            slots[base + i].append(t)
+        for blk in range(4):
+            if blk == 1:
+                lab("entry%d" % cur)
+            if blk >= 1:
+                e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(1 if blk % 2 == 0 else 0)
+            for i, m in enumerate(mf):
+                e(m)
+                for x in slots[blk * NM + i]:
+                    e(x)
+                if blk * NM + i == last:
+                    for a in advance():
+                        e(a)
+
+    for k in range(2):
+        lab("step%d" % k)
+        step(k)
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_barrier")
+        e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
+        e("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NK))
+        e("s_cbranch_scc0 %s" % ref("exit"))
+        if k == 1:
+            e("s_branch %s" % ref("step0"))
+    lab("exit")
+    for m in mfmas(1):
+        e(m)
+    e("s_nop 15")
+    e("s_nop 15")
+    return L
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -1259,12 +1434,19 @@ def main():
                     % (", L2 software prefetch" if pf else ""))
             for ln in gen_w4(c, pf):
                 f.write('"%s\\n"\n' % ln)
+    with open(os.path.join(args.out, "conv256w_body.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), whole K axis (all filter taps), one LDS-DMA piece per 2 MFMA shadows.\n")
+        for ln in gen_conv_w4(c, 2):
+            f.write('"%s\\n"\n' % ln)
     with open(os.path.join(args.out, "gemm256w_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
         f.write("#define OSKW_SMEM %d\n#define OSKW_W_BASE %d\n#define OSKW_TM %d\n#define OSKW_TN %d\n" % (c.SMEM, c.W_BASE, c.TM, c.TN))
         clob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 8)] + ['"a%d"' % i for i in range(c.NACC)] + \
                ['"s%d"' % i for i in range(S_FIRST, W4_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
         f.write("#define OSKW_CLOBBERS %s\n" % ", ".join(clob))
+        cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 6 + 1 + 2 * c.NA)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+        f.write("#define OSKW_CONV_CLOBBERS %s\n" % ", ".join(cclob))
         for t in range(c.TM * c.TN):
             f.write("#define OSKW_AR%d %s\n" % (t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
     for bn in (256, 128):
