@@ -8,10 +8,13 @@
 //
 // Layout (the conventions of attention_fwd.hip): both products are issued "swapped" on v_mfma_f32_32x32x16_bf16 so a
 // lane owns ONE query column:  S^T[key][q] = K[key][:] . Q^T  and  O^T[d][q] += V^T[d][key] . P^T.
-// Workgroup = 4 waves (one per SIMD) x 32 queries; key tile = 32 keys.  The 512 output dims are produced in TWO passes
-// of 256 (O^T = 8 row tiles x 16 = 128 accumulators per pass; with Q's 32 k-steps x 4 = 128 registers a one-pass
-// kernel needs 256 + 128 + working registers and spills): the second pass recomputes QK^T and the softmax statistics
-// bit-identically -- 1.5x the MFMAs of a kernel that is 0.3 % of the VAE's work, for no scratch traffic.
+// Workgroup = 4 waves (one per SIMD) x 32 queries; key tile = 32 keys.  The 512 output dims are produced in TWO halves
+// of 256 (O^T = 8 row tiles x 16 = 128 accumulators per half; with Q's 32 k-steps x 4 = 128 registers a one-pass
+// kernel needs 256 + 128 + working registers and spills): each half recomputes QK^T and the softmax statistics
+// bit-identically -- 1.5x the MFMAs of a kernel that is 0.3 % of the VAE's work, for no scratch traffic.  The halves are
+// separate workgroups (blockIdx.z): at 33 x 256 x 256 the launch is 72 query blocks -- a quarter of the chip -- and its
+// time is the chain of 288 key tiles of the last frame's query block, so the second half costs nothing when it runs
+// beside the first (1.52 -> 0.8 ms); query blocks are launched last-frame-first (longest chain first).
 //   LDS: K tile [32 keys][1 KiB] + V^T half tile [256 dims][64 B], double buffered (96 KiB), filled by LDS-DMA
 //        (global_load_lds_dwordx4) with source-side XOR swizzles: K chunk ^ (key & 15), V^T chunk ^ ((dim >> 2) & 3)
 //        -> conflict-free ds_read_b128 fragment reads for both row strides.
@@ -57,7 +60,8 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.y;
-  const int q0 = blockIdx.x * QB;
+  const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QB;   // longest key range first
+  const int pass = blockIdx.z;
   const int qi = q0 + wave * QW + l31;
   const int qc = qi < p.S ? qi : p.S - 1;
 
@@ -103,7 +107,6 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
   };
 
   const unsigned ksw = (unsigned)(l31 & 15), vsw = (unsigned)((l31 >> 2) & 3);
-  for (int pass = 0; pass < NPASS; ++pass) {
   f32x16_t o[NDT];
 #pragma unroll
   for (int d = 0; d < NDT; ++d)
@@ -194,8 +197,6 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
         *reinterpret_cast<uint2*>(orow + dim) = u;
       }
   }
-  __syncthreads();   // the next pass refills buffer 0 while slower waves may still read this pass's last tile
-  }  // pass
 }
 
 }  // namespace
@@ -227,7 +228,7 @@ extern "C" int osk_attention_hd512_fwd_bf16(const void* q, int64_t q_batch_strid
   p.out = (unsigned short*)out; p.obs = out_batch_stride; p.ors = out_row_stride;
   p.S = S; p.kpf = keys_per_frame;
   p.scale_log2 = scale * 1.4426950408889634f;
-  dim3 grid((S + QB - 1) / QB, B), block(256);
+  dim3 grid((S + QB - 1) / QB, B, NPASS), block(256);
   hipLaunchKernelGGL(attn_hd512_kernel, grid, block, SMEM, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
