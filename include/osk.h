@@ -227,6 +227,22 @@ int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, int W, int 
                                  int stride_t, int stride_h, int stride_w, int up_t, int up_hw,
                                  const void* res, void* out, int To, int Ho, int Wo, void* stream);
 
+/* ---- the same convolution + the GroupNorm statistics of its OUTPUT in the epilogue: the first half of the nn.GroupNorm
+ * that consumes this tensor next (ResnetBlockCausal3D.norm2 after conv1, the next block's norm1 / Attention.group_norm /
+ * conv_norm_out after conv2 + residual or a Down/Upsample conv: unet_causal_3d_blocks.py:247-259) without the extra
+ * read of the tensor that osk_groupnorm_stats_ndhwc_bf16 costs.
+ *   gn_sums f64 [B, gn_groups, 2], ZEROED BY THE CALLER; on return (stream order) it holds what
+ *   osk_groupnorm_stats_ndhwc_bf16(out, ...) would (sums of the bf16-rounded outputs; f32 partials per 256-voxel tile,
+ *   f64 atomics across tiles) -- feed it to osk_groupnorm_apply_ndhwc_bf16.
+ * Only the large-tile kernels carry this epilogue: returns OSK_EUNSUPPORTED -- and launches NOTHING -- unless
+ * Cin % 128 == 0, Cout >= 128, Cout % 32 == 0, Cout / gn_groups in {4, 8, 16}, >= 256 output voxels and
+ * (B == 1 or To*Ho*Wo % 256 == 0); the caller then runs the plain conv + osk_groupnorm_stats_ndhwc_bf16. */
+int osk_causal_conv3d_gn_ndhwc_bf16(const void* x, int B, int T, int H, int W, int Cin,
+                                    const void* w, int64_t w_row_stride, const float* bias, int Cout, int ksize,
+                                    int stride_t, int stride_h, int stride_w, int up_t, int up_hw,
+                                    const void* res, void* out, int To, int Ho, int Wo,
+                                    double* gn_sums, int gn_groups, void* stream);
+
 /* ---- GroupNorm statistics: sums[b][g] = (sum, sum of squares) in f64 over S voxels x C/G channels.
  * first half of nn.GroupNorm(32, C, eps=1e-6) (unet_causal_3d_blocks.py:216,218; vae.py:115,229; diffusers
  * Attention.group_norm).  x bf16 [B, S, C]; sums f64 [B, G, 2] (zeroed inside, on the stream).  C in

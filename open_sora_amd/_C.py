@@ -47,6 +47,8 @@ SIGNATURES = {
     "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
     "osk_causal_conv3d_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                      _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
+    "osk_causal_conv3d_gn_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
+                                        _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "osk_groupnorm_stats_ndhwc_bf16": [_vp, _i32, _i64, _i32, _i32, _vp, _vp],
     "osk_groupnorm_apply_ndhwc_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _vp],
     "osk_masked_softmax_f32_bf16": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
@@ -74,6 +76,9 @@ def _load() -> C.CDLL:
 
 
 lib = _load()
+
+
+OSK_EUNSUPPORTED = -2   # csrc/osk_common.h
 
 
 def _check(status: int, what: str) -> None:
@@ -369,9 +374,12 @@ def conv_out_dims(T: int, H: int, W: int, stride=(1, 1, 1), up=(False, False)):
 
 
 def causal_conv3d(x: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, ksize: int, stride=(1, 1, 1),
-                  up=(False, False), res=None) -> torch.Tensor:
+                  up=(False, False), res=None, gn_sums: torch.Tensor | None = None) -> torch.Tensor:
     """x bf16 [B, T, H, W, Cin] contiguous; w bf16 [Cout, Kpad] (tap-major, channel-minor, zero padded);
-    bias f32 [Cout] | None; out bf16 [B, To, Ho, Wo, Cout] contiguous; res like out | None."""
+    bias f32 [Cout] | None; out bf16 [B, To, Ho, Wo, Cout] contiguous; res like out | None.
+    gn_sums (f64 [B, G, 2], zeroed by the caller): also accumulate the GroupNorm statistics of `out` in the conv's
+    epilogue; the return value is then (out, fused).  The kernels that carry that epilogue do not take every shape: when
+    they do not, the plain conv runs, gn_sums stays untouched and fused is False (the consumer runs groupnorm_stats)."""
     B, T, H, W, Cin = x.shape
     Cout = w.shape[0]
     To, Ho, Wo = conv_out_dims(T, H, W, stride, up)
@@ -381,13 +389,23 @@ def causal_conv3d(x: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, ksi
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _check(lib.osk_causal_conv3d_ndhwc_bf16(x.data_ptr(), B, T, H, W, Cin, w.data_ptr(), w.stride(0), _p(bias), Cout,
-                                            ksize, stride[0], stride[1], stride[2], int(up[0]), int(up[1]), _p(res),
-                                            out.data_ptr(), To, Ho, Wo, _stream()), "osk_causal_conv3d_ndhwc_bf16")
+    fused = False
+    if gn_sums is not None:
+        assert gn_sums.dtype == torch.float64 and gn_sums.is_contiguous() and gn_sums.shape[0] == B and gn_sums.shape[2] == 2
+        rc = lib.osk_causal_conv3d_gn_ndhwc_bf16(x.data_ptr(), B, T, H, W, Cin, w.data_ptr(), w.stride(0), _p(bias), Cout,
+                                                 ksize, stride[0], stride[1], stride[2], int(up[0]), int(up[1]), _p(res),
+                                                 out.data_ptr(), To, Ho, Wo, gn_sums.data_ptr(), gn_sums.shape[1], _stream())
+        fused = rc == 0
+        if rc != 0 and rc != OSK_EUNSUPPORTED:
+            _check(rc, "osk_causal_conv3d_gn_ndhwc_bf16")
+    if not fused:
+        _check(lib.osk_causal_conv3d_ndhwc_bf16(x.data_ptr(), B, T, H, W, Cin, w.data_ptr(), w.stride(0), _p(bias), Cout,
+                                                ksize, stride[0], stride[1], stride[2], int(up[0]), int(up[1]), _p(res),
+                                                out.data_ptr(), To, Ho, Wo, _stream()), "osk_causal_conv3d_ndhwc_bf16")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * Cin * Cout * ksize ** 3 * B * To * Ho * Wo))
-    return out
+    return out if gn_sums is None else (out, fused)
 
 
 def groupnorm_stats(x: torch.Tensor, G: int, sums: torch.Tensor) -> torch.Tensor:

@@ -221,10 +221,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_kernel(const ConvParams p) {
 
 }  // namespace
 
-extern "C" int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, int W, int Cin, const void* w,
-                                            int64_t w_row_stride, const float* bias, int Cout, int ksize,
-                                            int stride_t, int stride_h, int stride_w, int up_t, int up_hw,
-                                            const void* res, void* out, int To, int Ho, int Wo, void* stream) {
+static int conv_entry(const void* x, int B, int T, int H, int W, int Cin, const void* w, int64_t w_row_stride,
+                      const float* bias, int Cout, int ksize, int stride_t, int stride_h, int stride_w, int up_t, int up_hw,
+                      const void* res, void* out, int To, int Ho, int Wo, double* gn_sums, int gn_groups, void* stream) {
   if (!x || !w || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return OSK_EINVAL;
   if (ksize != 1 && ksize != 3) return OSK_EUNSUPPORTED;
   if (stride_t < 1 || stride_h < 1 || stride_w < 1 || stride_t > 2 || stride_h > 2 || stride_w > 2) return OSK_EINVAL;
@@ -262,12 +261,35 @@ extern "C" int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, 
     // 1 the per-tap segment version
     static const int cv = [] { const char* e = getenv("OSK_CONV_VARIANT"); return e ? atoi(e) : -1; }();
     const int64_t x_bytes = (int64_t)B * T * H * W * Cin * 2;
-    if (cv != 0 && osk_conv::conv256_supported(p, x_bytes, (int64_t)Cout * w_row_stride * 2))
-      return osk_conv::launch_conv256(p, cv, s);
+    const bool big = cv != 0 && osk_conv::conv256_supported(p, x_bytes, (int64_t)Cout * w_row_stride * 2);
+    if (gn_sums) {   // fused statistics live in the large-tile kernels' epilogue only; nothing is launched otherwise
+      p.gn_sums = gn_sums;
+      p.gn_G = gn_groups;
+      if (!big || !osk_conv::conv256_gn_supported(p)) return OSK_EUNSUPPORTED;
+    }
+    if (big) return osk_conv::launch_conv256(p, cv, s);
   }
   const int nblk = ((p.M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
   dim3 grid(nblk), block(256);
   if (Cin % 64 == 0) hipLaunchKernelGGL((conv3d_kernel<true>), grid, block, SMEM_BYTES, s, p);
   else hipLaunchKernelGGL((conv3d_kernel<false>), grid, block, SMEM_BYTES, s, p);
   return (int)hipGetLastError();
+}
+
+extern "C" int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, int W, int Cin, const void* w,
+                                            int64_t w_row_stride, const float* bias, int Cout, int ksize,
+                                            int stride_t, int stride_h, int stride_w, int up_t, int up_hw,
+                                            const void* res, void* out, int To, int Ho, int Wo, void* stream) {
+  return conv_entry(x, B, T, H, W, Cin, w, w_row_stride, bias, Cout, ksize, stride_t, stride_h, stride_w, up_t, up_hw, res, out,
+                    To, Ho, Wo, nullptr, 0, stream);
+}
+
+extern "C" int osk_causal_conv3d_gn_ndhwc_bf16(const void* x, int B, int T, int H, int W, int Cin, const void* w,
+                                               int64_t w_row_stride, const float* bias, int Cout, int ksize,
+                                               int stride_t, int stride_h, int stride_w, int up_t, int up_hw,
+                                               const void* res, void* out, int To, int Ho, int Wo, double* gn_sums,
+                                               int gn_groups, void* stream) {
+  if (!gn_sums || gn_groups <= 0 || ((uintptr_t)gn_sums & 7)) return OSK_EINVAL;
+  return conv_entry(x, B, T, H, W, Cin, w, w_row_stride, bias, Cout, ksize, stride_t, stride_h, stride_w, up_t, up_hw, res, out,
+                    To, Ho, Wo, gn_sums, gn_groups, stream);
 }

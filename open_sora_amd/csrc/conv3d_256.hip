@@ -133,15 +133,68 @@ OSK_DEV void build_tap_table(const ConvParams& p, int bm, int tid, int tap_strid
 
 // bias + residual + bf16 store of one 32 x 32 accumulator tile T = tn * TM + tm (lane: voxel m, 4 channels per quad);
 // r0w = first tile row of this wave
-template <class Lay, int T>
-OSK_DEV void epilogue_tile(const ConvParams& p, int bm, int r0w, int n0w, int l31, int hi) {
+// fused GroupNorm statistics: a lane's partial (sum, sum of squares) of its voxel rows for the four 4-channel quads
+// (channels nstrip + 8 qd + 4 hi + j) of the 32-column strip being walked, accumulated over the strip's TM row tiles
+struct GnAcc {
+  float s[4], q[4];
+};
+
+typedef __bf16 gn_bf16x2_t __attribute__((ext_vector_type(2)));
+
+// two packed bf16 pairs = 4 rounded outputs: v_dot2c_f32_bf16 accumulates a pair's sum (against {1, 1}) or sum of squares
+// in one instruction (bf16 x bf16 products are exact in f32)
+OSK_DEV void gn_add(GnAcc& a, int qd, unsigned lo_hi0, unsigned lo_hi1) {
+  const gn_bf16x2_t p0 = __builtin_bit_cast(gn_bf16x2_t, lo_hi0), p1 = __builtin_bit_cast(gn_bf16x2_t, lo_hi1);
+  const gn_bf16x2_t one = __builtin_bit_cast(gn_bf16x2_t, 0x3f803f80u);
+  a.s[qd] = __builtin_amdgcn_fdot2_f32_bf16(p0, one, a.s[qd], false);
+  a.s[qd] = __builtin_amdgcn_fdot2_f32_bf16(p1, one, a.s[qd], false);
+  a.q[qd] = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, a.q[qd], false);
+  a.q[qd] = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, a.q[qd], false);
+}
+
+// sum over the 32 lanes of a half-wave, in every lane: four DPP adds inside a row of 16 (quad swaps, half mirror, mirror:
+// one VALU instruction each, no LDS crossbar) and one cross-row exchange
+OSK_DEV float half_wave_sum(float v) {
+#define OSKC_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+  OSKC_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  OSKC_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  OSKC_DPP_ADD(0x141);   // row_half_mirror
+  OSKC_DPP_ADD(0x140);   // row_mirror
+#undef OSKC_DPP_ADD
+  return v + __shfl_xor(v, 16, 64);
+}
+
+// end of a strip: reduce over the 32 voxel lanes of each half-wave, then LDS float atomics into the tile's per-group slots
+// ls[2 * (group - first group of the tile) + {0, 1}]
+OSK_DEV void gn_flush(const ConvParams& p, GnAcc& a, int nstrip, int n0, int l31, int hi, float* ls) {
+  const int cpg = p.Cout / p.gn_G;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const float s = half_wave_sum(a.s[qd]), q = half_wave_sum(a.q[qd]);
+    if (l31 == 0) {
+      const int n = nstrip + qd * 8 + hi * 4;
+      if (n < p.Cout) {
+        const int gl = n / cpg - n0 / cpg;
+        atomicAdd(ls + 2 * gl, s);
+        atomicAdd(ls + 2 * gl + 1, q);
+      }
+    }
+    a.s[qd] = 0.f;
+    a.q[qd] = 0.f;
+  }
+}
+
+// bias + residual + bf16 store of one 32 x 32 accumulator tile T = tn * TM + tm (lane: voxel m, 4 channels per quad);
+// r0w = first tile row of this wave; GN: accumulate the fused GroupNorm statistics (wave-uniform template switch)
+template <class Lay, int T, bool GN>
+OSK_DEV void epilogue_tile(const ConvParams& p, int bm, int r0w, int n0, int n0w, int l31, int hi, GnAcc& ga, float* ls) {
   constexpr int TM = Lay::TM;
   constexpr int tn = T / TM, tm = T % TM;
   float acc[16];
   Lay::template read<T>(acc);
   const int m = tile_row_to_voxel(p, bm, r0w + tm * 32 + l31);
-  if (m >= p.M) return;
-  const int64_t roff = (int64_t)m * p.Cout;
+  const bool valid = m < p.M;
+  const int64_t roff = (int64_t)(valid ? m : 0) * p.Cout;
   const bool vec_ok = (p.Cout & 3) == 0;
   // whole 32-channel strip inside Cout and the row 16-byte aligned (Cout % 8 == 0): pair the half-waves and store 16 B
   // (v_permlane32_swap per dword: the lower half-wave takes the whole 8-channel block qd, the upper one block qd + 1)
@@ -164,48 +217,86 @@ OSK_DEV void epilogue_tile(const ConvParams& p, int bm, int r0w, int n0w, int l3
       }
       packed[qd].x = pack_bf16x2(v[0], v[1]);
       packed[qd].y = pack_bf16x2(v[2], v[3]);
+      if constexpr (GN) {
+        if (valid) gn_add(ga, qd, packed[qd].x, packed[qd].y);
+      }
     }
 #pragma unroll
     for (int qd = 0; qd < 4; qd += 2) {
       auto sx = __builtin_amdgcn_permlane32_swap(packed[qd].x, packed[qd + 1].x, false, false);
       auto sy = __builtin_amdgcn_permlane32_swap(packed[qd].y, packed[qd + 1].y, false, false);
-      *reinterpret_cast<uint4*>(p.out + roff + nstrip + (qd + hi) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      if (valid) *reinterpret_cast<uint4*>(p.out + roff + nstrip + (qd + hi) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     }
-    return;
-  }
+  } else {
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const int n = n0w + tn * 32 + qd * 8 + hi * 4;
-    if (n >= p.Cout) continue;
-    float v[4];
+    for (int qd = 0; qd < 4; ++qd) {
+      const int n = n0w + tn * 32 + qd * 8 + hi * 4;
+      if (n >= p.Cout || !valid) continue;
+      float v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = acc[qd * 4 + j];
-    if (vec_ok && n + 3 < p.Cout) {
-      if (p.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
-      if (p.res) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
-        v[0] += bf16_lo(rv.x); v[1] += bf16_hi(rv.x); v[2] += bf16_lo(rv.y); v[3] += bf16_hi(rv.y);
-      }
-      uint2 o;
-      o.x = pack_bf16x2(v[0], v[1]);
-      o.y = pack_bf16x2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(p.out + roff + n) = o;
-    } else {
-      for (int j = 0; j < 4 && n + j < p.Cout; ++j) {
-        float t = v[j] + (p.bias ? p.bias[n + j] : 0.f);
-        if (p.res) t += bf16_bits_to_f32(p.res[roff + n + j]);
-        p.out[roff + n + j] = f32_to_bf16_bits(t);
+      for (int j = 0; j < 4; ++j) v[j] = acc[qd * 4 + j];
+      if (vec_ok && n + 3 < p.Cout) {
+        if (p.bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if (p.res) {
+          const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+          v[0] += bf16_lo(rv.x); v[1] += bf16_hi(rv.x); v[2] += bf16_lo(rv.y); v[3] += bf16_hi(rv.y);
+        }
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p.out + roff + n) = o;
+        if constexpr (GN) gn_add(ga, qd, o.x, o.y);
+      } else {
+        for (int j = 0; j < 4 && n + j < p.Cout; ++j) {
+          float t = v[j] + (p.bias ? p.bias[n + j] : 0.f);
+          if (p.res) t += bf16_bits_to_f32(p.res[roff + n + j]);
+          p.out[roff + n + j] = f32_to_bf16_bits(t);
+        }
       }
     }
   }
+  if constexpr (GN && tm == TM - 1) gn_flush(p, ga, nstrip, n0, l31, hi, ls);
 }
 
-template <class Lay, int... Ts>
-OSK_DEV void epilogue_all(const ConvParams& p, int bm, int r0w, int n0w, int l31, int hi, std::integer_sequence<int, Ts...>) {
-  (epilogue_tile<Lay, Ts>(p, bm, r0w, n0w, l31, hi), ...);
+template <class Lay, bool GN, int... Ts>
+OSK_DEV void epilogue_tiles(const ConvParams& p, int bm, int r0w, int n0, int n0w, int l31, int hi, float* ls,
+                            std::integer_sequence<int, Ts...>) {
+  GnAcc ga;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ga.s[i] = ga.q[i] = 0.f;
+  (epilogue_tile<Lay, Ts, GN>(p, bm, r0w, n0, n0w, l31, hi, ga, ls), ...);
+}
+
+// The whole workgroup calls this after its K loop (LDS is quiescent: every stage read and every LDS-DMA write was waited
+// for before the loop's last barrier).  BN = channels per workgroup tile, n0 = its first channel.
+// With p.gn_sums: the tile's per-group (sum, sum of squares) are collected in LDS floats (<= 256 voxels x 16 channels per
+// slot), then ONE f64 atomic per (group, statistic) and tile goes to sums[b][g] -- the tile lies inside one batch item
+// (conv256_gn_supported).
+template <class Lay, int BN>
+OSK_DEV void epilogue_all(const ConvParams& p, int bm, int r0w, int n0, int n0w, int l31, int hi, unsigned char* smem) {
+  constexpr auto seq = std::make_integer_sequence<int, Lay::TM * Lay::TN>{};
+  if (!p.gn_sums) {
+    epilogue_tiles<Lay, false>(p, bm, r0w, n0, n0w, l31, hi, nullptr, seq);
+    return;
+  }
+  float* ls = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x;
+  const int cpg = p.Cout / p.gn_G;
+  int nch = p.Cout - n0;
+  nch = nch < BN ? nch : BN;
+  const int nslots = 2 * (nch / cpg);              // <= 2 * 256 / 4 = 128
+  if (tid < nslots) ls[tid] = 0.f;
+  __syncthreads();
+  epilogue_tiles<Lay, true>(p, bm, r0w, n0, n0w, l31, hi, ls, seq);
+  __syncthreads();
+  if (tid < nslots) {
+    const int m = tile_row_to_voxel(p, bm, 0);
+    const int b = m / (p.To * p.Ho * p.Wo);
+    atomicAdd(p.gn_sums + ((int64_t)b * p.gn_G + n0 / cpg) * 2 + tid, (double)ls[tid]);
+  }
 }
 
 template <int BN>
@@ -312,7 +403,7 @@ __global__ void __launch_bounds__(512, 2) conv256_kernel(const ConvParams p) {
     for (int i = 0; i < 4; ++i) aoffc[i] = aoffn[i];
   }
 
-  epilogue_all<LayOf<BN>>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});   // (linear tiles: the launcher clears p.brick)
+  epilogue_all<LayOf<BN>, BN>(p, bm, wm * TM * 32, n0, n0 + wn * TN * 32, l31, hi, smem);   // (linear tiles: the launcher clears p.brick)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -380,7 +471,7 @@ __global__ void __launch_bounds__(512, 2) conv256t_kernel(const ConvParams p) {
 #include "conv256_body_n128.inc"
         OSKCT_OPERANDS : OSKG128_CONV_CLOBBERS);
   }
-  epilogue_all<LayOf<BN>>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
+  epilogue_all<LayOf<BN>, BN>(p, bm, wm * TM * 32, n0, n0 + wn * TN * 32, l31, hi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -431,7 +522,7 @@ __global__ void __launch_bounds__(256, 1) conv256w_kernel(const ConvParams p) {
       ::"v"(faA0), "v"(faW0), "v"(arow0), "v"(chk), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]),
       "v"(woff[5]), "v"(woff[6]), "v"(woff[7]), "s"(xbase), "s"(wbase), "s"(nk), "s"(nkt), "s"(adst), "s"(wdst)
       : OSKW_CONV_CLOBBERS);
-  epilogue_all<LayW>(p, bm, wm * TM * 32, n0 + wn * TN * 32, l31, hi, std::make_integer_sequence<int, TM * TN>{});
+  epilogue_all<LayW, BN>(p, bm, wm * TM * 32, n0, n0 + wn * TN * 32, l31, hi, smem);
 }
 
 int launch_w(const ConvParams& p, hipStream_t st) {
@@ -467,6 +558,16 @@ int launch_one(const ConvParams& p, hipStream_t st) {
 // 32-bit per-lane byte offsets: both tensors must span < 4 GiB; whole K steps per tap in pairs: Cin % 128 == 0
 bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes) {
   return p.Cin % 128 == 0 && p.Cout >= 128 && p.M >= 256 && x_bytes < (int64_t)0xFFFFFFFF && w_bytes < (int64_t)0xFFFFFFFF;
+}
+
+// fused GroupNorm statistics: whole groups inside a 32-column strip quad structure (4, 8 or 16 channels per group), every
+// workgroup tile inside one batch item (a tile is 256 consecutive voxels)
+bool conv256_gn_supported(const ConvParams& p) {
+  if (p.gn_G <= 0 || p.Cout % p.gn_G || p.Cout % 32) return false;
+  const int cpg = p.Cout / p.gn_G;
+  if (cpg != 4 && cpg != 8 && cpg != 16) return false;
+  const int64_t per_b = (int64_t)p.To * p.Ho * p.Wo;
+  return p.B == 1 || per_b % 256 == 0;
 }
 
 // variant 1: one asm segment per filter tap (conv256_kernel); otherwise the single-call table version

@@ -19,11 +19,16 @@ struct ConvParams {
   int M;
   int64_t wrs;
   int brick = 0;      // conv256t: 1 = a tile is a 16 x 16 spatial brick of one frame, tiles ordered frame-fastest (conv3d_256.hip)
+  // fused GroupNorm statistics of the OUTPUT (conv3d_256.hip only): sums[b][g] += (sum y, sum y^2) over the bf16-rounded
+  // outputs of group g (gn_G groups of Cout / gn_G adjacent channels); null = off
+  double* gn_sums = nullptr;
+  int gn_G = 0;
 };
 
 
 // conv3d_256.hip: 256 voxels x {256,128} channels x 64 tile, 8 waves, one hand-scheduled asm K segment per filter tap
 bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes);
+bool conv256_gn_supported(const ConvParams& p);   // the fused-statistics epilogue takes this output geometry
 int launch_conv256(const ConvParams& p, int variant, hipStream_t st);
 
 }  // namespace osk_conv

@@ -247,28 +247,40 @@ def _plan(mod, kind):
     return p
 
 
-def _conv(mod, x: Tensor, up=(False, False), res: Tensor | None = None) -> Tensor:
+def _conv(mod, x: Tensor, up=(False, False), res: Tensor | None = None, gn: int = 0) -> Tensor:
+    """gn = G > 0: the output feeds an nn.GroupNorm(G, ...) next -- its statistics are taken in the conv's epilogue
+    (osk_causal_conv3d_gn_ndhwc_bf16) and travel with the tensor (`_osk_gn`) to `_gn`, which then skips its read pass."""
     p = _plan(mod, "conv")
     B, T, H, W, C = x.shape
     assert C == p.cin_p, (C, p.cin_p)
     To, Ho, Wo = _ops().conv_out_dims(T, H, W, p.stride, up)
     out = torch.empty(B, To, Ho, Wo, p.cout, dtype=BF16, device=x.device)
+    if gn and p.cout % gn == 0:
+        sums = torch.zeros(B, gn, 2, dtype=torch.float64, device=x.device)
+        _, fused = _ops().causal_conv3d(x, p.w, p.b, out, p.k, p.stride, up, res, gn_sums=sums)
+        if fused:
+            out._osk_gn = (gn, sums)
+        return out
     return _ops().causal_conv3d(x, p.w, p.b, out, p.k, p.stride, up, res)
 
 
 def _gn(mod: nn.GroupNorm, x: Tensor, silu: bool) -> Tensor:
     gamma, beta, G, eps = _plan(mod, "gn")
-    sums = torch.empty(x.shape[0], G, 2, dtype=torch.float64, device=x.device)
-    _ops().groupnorm_stats(x, G, sums)
+    have = getattr(x, "_osk_gn", None)
+    if have is not None and have[0] == G:
+        sums = have[1]
+    else:
+        sums = torch.empty(x.shape[0], G, 2, dtype=torch.float64, device=x.device)
+        _ops().groupnorm_stats(x, G, sums)
     return _ops().groupnorm_apply(x, sums, gamma, beta, torch.empty_like(x), G, eps, silu)
 
 
 def _resnet(blk: ResnetBlockCausal3D, x: Tensor) -> Tensor:
     """ResnetBlockCausal3D.forward (unet_causal_3d_blocks.py:247-259); the residual add rides in conv2's epilogue."""
-    h = _conv(blk.conv1, _gn(blk.norm1, x, True))
+    h = _conv(blk.conv1, _gn(blk.norm1, x, True), gn=blk.norm2.num_groups)
     h = _gn(blk.norm2, h, True)
     sc = x if blk.conv_shortcut is None else _conv(blk.conv_shortcut, x)
-    return _conv(blk.conv2, h, res=sc)
+    return _conv(blk.conv2, h, res=sc, gn=blk.norm1.num_groups)   # the next consumer is a GroupNorm of the same grouping
 
 
 def _mid_attention(att: Attention, x: Tensor) -> Tensor:
@@ -341,19 +353,21 @@ def _to_ncthw(x: Tensor, dtype) -> Tensor:
 
 def run_encoder(enc: EncoderCausal3D, x: Tensor) -> Tensor:
     """EncoderCausal3D.forward (vae.py:128-155) on NDHWC input (channels padded to 8)."""
-    h = _conv(enc.conv_in, x)
+    G = enc.conv_norm_out.num_groups
+    h = _conv(enc.conv_in, x, gn=G)
     for blk in enc.down_blocks:
         for r in blk.resnets:
             h = _resnet(r, h)
         if blk.downsamplers is not None:
-            h = _conv(blk.downsamplers[0].conv, h)
+            h = _conv(blk.downsamplers[0].conv, h, gn=G)
     h = _mid(enc.mid_block, h)
     return _conv(enc.conv_out, _gn(enc.conv_norm_out, h, True))
 
 
 def run_decoder(dec: DecoderCausal3D, z: Tensor) -> Tensor:
     """DecoderCausal3D.forward (vae.py:246-277); the nearest upsample is folded into the upsampler conv."""
-    h = _conv(dec.conv_in, z)
+    G = dec.conv_norm_out.num_groups
+    h = _conv(dec.conv_in, z, gn=G)
     h = _mid(dec.mid_block, h)
     for blk in dec.up_blocks:
         for r in blk.resnets:
@@ -361,7 +375,7 @@ def run_decoder(dec: DecoderCausal3D, z: Tensor) -> Tensor:
         if blk.upsamplers is not None:
             ft, fh, fw = blk.upsamplers[0].upsample_factor
             assert fh == fw and fh in (1, 2) and ft in (1, 2)
-            h = _conv(blk.upsamplers[0].conv, h, up=(ft == 2, fh == 2))
+            h = _conv(blk.upsamplers[0].conv, h, up=(ft == 2, fh == 2), gn=G)
     return _conv(dec.conv_out, _gn(dec.conv_norm_out, h, True))
 
 

@@ -285,7 +285,7 @@ def conv_out_dims(T, H, W, stride=(1, 1, 1), up=(False, False)):
     return (Tu - 1) // stride[0] + 1, (Hu - 1) // stride[1] + 1, (Wu - 1) // stride[2] + 1
 
 
-def causal_conv3d(x, w, bias, out, ksize, stride=(1, 1, 1), up=(False, False), res=None):
+def causal_conv3d(x, w, bias, out, ksize, stride=(1, 1, 1), up=(False, False), res=None, gn_sums=None):
     B, T, H, W, Cin = x.shape
     Cout = w.shape[0]
     taps = ksize ** 3
@@ -302,6 +302,9 @@ def causal_conv3d(x, w, bias, out, ksize, stride=(1, 1, 1), up=(False, False), r
     if res is not None:
         y = y + res.float()
     out.copy_(y.to(out.dtype))
+    if gn_sums is not None:      # the fused-statistics contract: gn_sums arrives zeroed and is ACCUMULATED into
+        gn_sums += groupnorm_stats(out, gn_sums.shape[1], torch.empty_like(gn_sums))
+        return out, True
     return out
 
 

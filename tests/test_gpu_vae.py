@@ -93,6 +93,55 @@ def test_causal_conv3d(hip_lib, case):
     tol = 2.0 ** -8 * ref.abs() + 1e-3 * float(ref.abs().max())
     assert torch.isfinite(got).all() and (err <= tol).all(), f"max err {err.max():.3e} (ref max {ref.abs().max():.3e})"
 
+GN_FUSED_CASES = [
+    # Cin, Cout, k, stride, up, B, T, H, W, residual, G, expect_fused
+    (128, 128, 3, (1, 1, 1), (False, False), 1, 3, 20, 18, True, 32, True),    # 128-wide 8-wave tile, 4 channels per group, ragged M
+    (128, 256, 3, (1, 2, 2), (False, False), 2, 2, 32, 32, True, 32, True),    # 4-wave tile, 8 per group, 2 batch items (256 | To Ho Wo)
+    (256, 512, 3, (1, 1, 1), (True, True), 1, 2, 7, 9, False, 32, True),       # 16 per group, upsample folded in, two N tiles
+    (128, 384, 1, (1, 1, 1), (False, False), 1, 4, 9, 9, False, 48, True),     # ragged N for the 256-wide tile (256 + 128), 8 per group
+    (128, 256, 3, (1, 1, 1), (False, False), 2, 3, 10, 11, False, 32, False),  # a 256-voxel tile would straddle the batch items
+    (64, 128, 3, (1, 1, 1), (False, False), 1, 3, 12, 12, False, 32, False),   # Cin % 128 != 0: small-tile kernel, no fused epilogue
+    (128, 160, 3, (1, 1, 1), (False, False), 1, 3, 12, 12, False, 32, False),  # 5 channels per group
+]
+
+
+@pytest.mark.parametrize("case", GN_FUSED_CASES, ids=lambda c: f"{c[0]}to{c[1]}k{c[2]}B{c[5]}G{c[10]}")
+def test_conv_fused_groupnorm_statistics(hip_lib, case):
+    """osk_causal_conv3d_gn_ndhwc_bf16: same output bits as the plain conv, and gn_sums == the statistics of that output
+    (f64 sums of the bf16 values; the kernel's per-tile partials are f32: relative 1e-5); shapes the fused epilogue does
+    not take report fused = False, leave gn_sums untouched and still run the conv."""
+    ci, co, k, stride, up, B, T, H, W, with_res, G, expect = case
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(B, T, H, W, ci, generator=g, device=DEV).to(BF)
+    w = _pack_w(torch.randn(co, ci, k, k, k, generator=g, device=DEV).cpu() * (ci * k ** 3) ** -0.5, ci)
+    b = (torch.randn(co, generator=g, device=DEV) * 0.1 + 0.3).float()
+    To, Ho, Wo = hip_lib.conv_out_dims(T, H, W, stride, up)
+    res = torch.randn(B, To, Ho, Wo, co, generator=g, device=DEV).to(BF) if with_res else None
+    plain = torch.empty(B, To, Ho, Wo, co, dtype=BF, device=DEV)
+    hip_lib.causal_conv3d(x, w, b, plain, k, stride, up, res)
+    out = torch.full_like(plain, float("nan"))
+    sums = torch.zeros(B, G, 2, dtype=torch.float64, device=DEV)
+    out2, fused = hip_lib.causal_conv3d(x, w, b, out, k, stride, up, res, gn_sums=sums)
+    assert fused == expect
+    assert torch.equal(out2.view(torch.int16), plain.view(torch.int16))
+    if not fused:
+        assert float(sums.abs().sum()) == 0.0
+        return
+    xf = plain.double().reshape(B, -1, G, co // G)
+    exact = torch.stack((xf.sum((1, 3)), (xf * xf).sum((1, 3))), -1)
+    n = xf.shape[1] * xf.shape[3]
+    scale = torch.stack((xf.abs().sum((1, 3)), (xf * xf).sum((1, 3))), -1)      # cancellation-free magnitude of each sum
+    assert ((sums - exact).abs() <= 2e-5 * scale + 1e-9).all(), ((sums - exact).abs() / scale).max()
+    if co & (co - 1) == 0:     # the stand-alone statistics kernel (power-of-two channel counts) agrees
+        ref = torch.zeros_like(sums)
+        hip_lib.groupnorm_stats(plain, G, ref)
+        assert ((ref - exact).abs() <= 2e-5 * scale + 1e-9).all()
+    # what the consumer computes from it: mean and rstd of every (batch, group)
+    mean, mean_x = sums[..., 0] / n, exact[..., 0] / n
+    var, var_x = sums[..., 1] / n - mean ** 2, exact[..., 1] / n - mean_x ** 2
+    assert torch.allclose(mean, mean_x, rtol=0, atol=2e-5 * float(plain.float().abs().max()))
+    assert torch.allclose(var, var_x, rtol=1e-4, atol=1e-6)
+
 
 def test_conv3d_rejects_bad_arguments(hip_lib):
     x = torch.zeros(1, 2, 4, 4, 24, dtype=BF, device=DEV)
