@@ -116,6 +116,19 @@ def cfg1_line(dev, budget_s):
             out = model(**ginp)
         torch.cuda.synchronize()
         gpu_ms = (time.perf_counter() - t0) / n * 1e3
+        # the same forward replayed from a hipGraph (sampling.I2VDenoiser.denoise(hip_graph=True) does this per denoise
+        # step): is this small model launch-bound?  (measured: no -- same time)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out_g = model(**ginp)
+        graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            graph.replay()
+        torch.cuda.synchronize()
+        gpu_graph_ms = (time.perf_counter() - t0) / n * 1e3
+        graph_same = bool(torch.equal(out_g, out))
         t0 = time.perf_counter()
         truth = O.forward(sd, cfg, **inp)                       # warm-up (thread pool, allocator) and the parity reference
         t_first = time.perf_counter() - t0
@@ -130,7 +143,8 @@ def cfg1_line(dev, budget_s):
     fl = configs.flops_per_forward(cfg, 1, 4096, 512)
     return {"workload": "MMDiT-S (hidden 384, 6x64, 4+8 blocks) single forward, latent 1x128x128, L=4608, B=1",
             "cpu_ms": round(cpu_ms, 1), "cpu_timed_forwards": max(1, len(times)), "cpu_tflops": round(fl / cpu_ms / 1e9, 3),
-            "cores": ncores, "kind": "port", "gpu_ms": round(gpu_ms, 3), "rel_l2_gpu_vs_cpu_fp32": round(rel, 5)}
+            "cores": ncores, "kind": "port", "gpu_ms": round(gpu_ms, 3), "gpu_hipgraph_ms": round(gpu_graph_ms, 3),
+            "hipgraph_bit_identical": graph_same, "rel_l2_gpu_vs_cpu_fp32": round(rel, 5)}
 
 
 def vae_cpu_baseline(budget_s):

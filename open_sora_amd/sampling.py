@@ -92,7 +92,14 @@ def prepare_ids(bs: int, t: int, h: int, w: int, n_txt: int, device, dtype, patc
 class I2VDenoiser:
     """sampling.py:158-245.  `denoise(model, img=..., timesteps=[...], guidance=..., guidance_img=..., masks=...,
     masked_ref=..., img_ids=..., txt=..., txt_ids=..., y_vec=..., [text_osci, image_osci, scale_temporal_osci,
-    patch_size, sigma_min])` with img/txt/... already tripled (cond | uncond | uncond_2)."""
+    patch_size, sigma_min])` with img/txt/... already tripled (cond | uncond | uncond_2).
+
+    Not in the reference: `hip_graph=True` replays the model forward of steps 1.. from a hipGraph captured after step 0
+    (every entry point of the library is capturable: no allocation, no synchronisation; the per-step inputs -- the
+    latent triple and the timestep vector -- live in fixed buffers).  Same results bit for bit.  Measured on this host:
+    no gain at either end -- the XL step's ~540 launches hide behind 150 ms of kernels, and even the S model's 2.6 ms
+    forward replays in the same 2.6 ms (`bench.py`: cpu_baseline.cfg1.gpu_hipgraph_ms) -- so it is off by default and
+    meant for hosts whose Python dispatch is slower than the GPU."""
 
     def denoise(self, model, **kwargs) -> Tensor:
         img = kwargs.pop("img")
@@ -106,6 +113,7 @@ class I2VDenoiser:
         image_osci = kwargs.pop("image_osci", False)
         scale_temporal_osci = kwargs.pop("scale_temporal_osci", False)
         patch_size = kwargs.pop("patch_size", 2)
+        hip_graph = bool(kwargs.pop("hip_graph", False))
 
         n3 = img.shape[0]
         n = n3 // 3
@@ -120,10 +128,20 @@ class I2VDenoiser:
         x = img[:n].to(torch.bfloat16, copy=True).contiguous()
         x_next = torch.empty_like(x)
         img3 = torch.empty(n3, *x.shape[1:], device=dev, dtype=dt)
+        t_vec = torch.empty(n3, dtype=dt, device=dev)
+        graph, pred = None, None
         for i, (t_curr, t_prev) in enumerate(zip(timesteps[:-1], timesteps[1:])):
-            t_vec = torch.full((n3,), t_curr, dtype=dt, device=dev)
+            t_vec.fill_(t_curr)
             img3.view(3, *x.shape).copy_(x.unsqueeze(0).expand(3, *x.shape))
-            pred = model(img=img3, **kwargs, cond=cond3, timesteps=t_vec, guidance=guidance_vec)
+            if graph is not None:
+                graph.replay()                    # writes the captured `pred`
+            else:
+                pred = model(img=img3, **kwargs, cond=cond3, timesteps=t_vec, guidance=guidance_vec)
+                if hip_graph and i == 0 and len(timesteps) > 2:
+                    # step 0 ran eagerly (it built the plans and workspaces); capture the same call for the rest
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        pred_g = model(img=img3, **kwargs, cond=cond3, timesteps=t_vec, guidance=guidance_vec)
             text_gs = get_oscillation_gs(guidance, i) if text_osci else guidance
             image_gs = get_oscillation_gs(guidance_img, i) if image_osci else guidance_img
             gvec = None
@@ -135,6 +153,8 @@ class I2VDenoiser:
             _ops().cfg_euler(pred.to(torch.bfloat16).contiguous(), x, x_next, float(text_gs), float(image_gs),
                              float(t_prev - t_curr), gvec)
             x, x_next = x_next, x
+            if graph is not None:
+                pred = pred_g                     # from now on the forward's output is the captured tensor
         return x.to(dt)
 
     def prepare_guidance(self, text: list, optional_models: dict, device, dtype, **kwargs):

@@ -216,6 +216,36 @@ def test_i2v_denoise_loop_on_gpu_vs_oracle(hip_lib, osci):
     assert ours.shape == truth.shape == (n, T * (Hh // 2) * (Ww // 2), 64)
     assert_parity(ours, truth, ref, f"I2VDenoiser.denoise, 3 steps on the GPU [{'osci' if osci else 'const'}]")
 
+def test_i2v_denoise_loop_hipgraph_replay_is_bit_identical(hip_lib):
+    """I2VDenoiser.denoise(hip_graph=True): step 0 eager, the model forward of steps 1.. replayed from a hipGraph captured
+    after it (fixed input buffers, the timestep vector refilled in place): the same latent bit for bit as the eager loop,
+    with oscillating guidance (the scalars of the CFG / Euler kernel change per step and stay outside the graph)."""
+    from open_sora_amd import mmdit, sampling
+
+    cfg, sd = _sampler_case()
+    model = mmdit.Flux(device_map=DEV, torch_dtype=BF, **cfg)
+    model.load_state_dict({k: v.to(DEV, BF) for k, v in sd.items()}, strict=True)
+    n, T, Hh, Ww, Lt = 1, 3, 12, 8, 32
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn(n, 16, T, Hh, Ww, generator=g)
+    masks = torch.zeros(n, 1, T, Hh, Ww)
+    masks[:, :, 0] = 1
+    masked_ref = torch.randn(n, 16, T, Hh, Ww, generator=g) * masks
+    txt = torch.randn(3 * n, Lt, cfg["context_in_dim"], generator=g) * 0.2
+    y_vec = torch.randn(3 * n, cfg["vec_in_dim"], generator=g)
+    img_ids, txt_ids = S.grid_ids(3 * n, T, Hh // 2, Ww // 2, Lt, torch.float32)
+    ts = sampling.get_schedule(6, (Hh // 2) * (Ww // 2), T)
+    c = lambda t: t.to(DEV, BF)
+    args = dict(img=c(S.pack(z)).repeat(3, 1, 1), masks=c(masks), masked_ref=c(masked_ref), img_ids=c(img_ids),
+                txt=c(txt), txt_ids=c(txt_ids), y_vec=c(y_vec), timesteps=ts, guidance=7.5, guidance_img=3.0,
+                text_osci=True, image_osci=True, scale_temporal_osci=True)
+    with torch.inference_mode():
+        eager = sampling.I2VDenoiser().denoise(model, **dict(args))
+        graphed = sampling.I2VDenoiser().denoise(model, hip_graph=True, **dict(args))
+        torch.cuda.synchronize()
+    assert torch.isfinite(eager.float()).all()
+    assert torch.equal(eager, graphed)
+
 
 class _T5:
     def __call__(self, prompt, added_tokens=0, seq_align=1):
