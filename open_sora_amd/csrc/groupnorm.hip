@@ -137,16 +137,26 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const unsigned short* __r
     }
     return pack8(v);
   };
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto ld = [&](int64_t rw) -> uint4 {
+    const u32x4* p = reinterpret_cast<const u32x4*>(xb + rw * C + c * 8);
+    const u32x4 v = __builtin_nontemporal_load(p);   // streamed once: +7 % stand-alone on the 0.5 - 1 GB tensors, +0.15 % on the VAE
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
+  auto st = [&](int64_t rw, const uint4& v) {
+    u32x4* p = reinterpret_cast<u32x4*>(ob + rw * C + c * 8);
+    const u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, p);
+  };
   int64_t row = row0 + r;
-  for (; row + 3 * rpp < row1; row += 4 * rpp) {   // 4 independent loads in flight per lane, then 4 stores
+  for (; row + 3 * rpp < row1; row += 4 * rpp) {   // 4 independent loads in flight per lane, then 4 stores (8: no gain)
     uint4 u[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const uint4*>(xb + (row + i * rpp) * C + c * 8);
+    for (int i = 0; i < 4; ++i) u[i] = ld(row + i * rpp);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(ob + (row + i * rpp) * C + c * 8) = one(u[i]);
+    for (int i = 0; i < 4; ++i) st(row + i * rpp, one(u[i]));
   }
-  for (; row < row1; row += rpp)
-    *reinterpret_cast<uint4*>(ob + row * C + c * 8) = one(*reinterpret_cast<const uint4*>(xb + row * C + c * 8));
+  for (; row < row1; row += rpp) st(row, one(ld(row)));
 }
 
 // ---------------------------------------------------------------------------------------------
