@@ -425,9 +425,11 @@ __global__ void __launch_bounds__(512, 2) conv256t_kernel(const ConvParams p) {
   const int hi = lane >> 5, l31 = lane & 31;
 
   const int nbm = (p.M + 255) / 256, nbn = (p.Cout + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+  const int ntiles = nbm * nbn;
+  for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {   // persistent (see conv256w_kernel)
+  const int tile = xcd_remap(it, ntiles);
   const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int m0 = bm * 256, n0 = bn * BN;
+  const int n0 = bn * BN;
 
   build_tap_table(p, bm, tid, 2, reinterpret_cast<unsigned*>(smem + TABLE));
   __syncthreads();
@@ -472,6 +474,7 @@ __global__ void __launch_bounds__(512, 2) conv256t_kernel(const ConvParams p) {
         OSKCT_OPERANDS : OSKG128_CONV_CLOBBERS);
   }
   epilogue_all<LayOf<BN>, BN>(p, bm, wm * TM * 32, n0, n0 + wn * TN * 32, l31, hi, smem);
+  }   // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -488,8 +491,12 @@ __global__ void __launch_bounds__(256, 1) conv256w_kernel(const ConvParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int hi = lane >> 5, l31 = lane & 31;
 
+  // persistent: one workgroup per CU (155 KB of LDS) walks the tile list with stride gridDim.x -- a one-tile workgroup's
+  // successor cannot be dispatched before it retires, so every tile paid a dispatch gap on top of its serial prologue
   const int nbm = (p.M + 255) / 256, nbn = (p.Cout + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+  const int ntiles = nbm * nbn;
+  for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
+  const int tile = xcd_remap(it, ntiles);
   const int bm = tile / nbn, bn = tile - bm * nbn;
   const int n0 = bn * BN;
 
@@ -523,6 +530,20 @@ __global__ void __launch_bounds__(256, 1) conv256w_kernel(const ConvParams p) {
       "v"(woff[5]), "v"(woff[6]), "v"(woff[7]), "s"(xbase), "s"(wbase), "s"(nk), "s"(nkt), "s"(adst), "s"(wdst)
       : OSKW_CONV_CLOBBERS);
   epilogue_all<LayW, BN>(p, bm, wm * TM * 32, n0, n0 + wn * TN * 32, l31, hi, smem);
+  }   // tile loop (the next tile's table build ends in a barrier: nobody refills stage 0 while the statistics slots are read)
+}
+
+// grid of the persistent kernels: one workgroup per CU (a multiple of 8, so that the XCD remap of the tile list keeps a
+// workgroup inside one XCD's range); OSK_CONV_PERSIST=0: one workgroup per tile (A/B runs)
+int persistent_grid(int ntiles) {
+  static const bool on = [] { const char* e = getenv("OSK_CONV_PERSIST"); return !e || atoi(e) != 0; }();
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    n -= n % 8;
+    return n < 8 ? 8 : n;
+  }();
+  return on && ntiles > n_cu ? n_cu : ntiles;
 }
 
 int launch_w(const ConvParams& p, hipStream_t st) {
@@ -534,7 +555,7 @@ int launch_w(const ConvParams& p, hipStream_t st) {
     attr_set = true;
   }
   const int nblk = ((p.M + 255) / 256) * ((p.Cout + 255) / 256);
-  hipLaunchKernelGGL(conv256w_kernel, dim3(nblk), dim3(256), SMEM, st, p);
+  hipLaunchKernelGGL(conv256w_kernel, dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
   return (int)hipGetLastError();
 }
 
@@ -549,7 +570,7 @@ int launch_one(const ConvParams& p, hipStream_t st) {
     attr_set = true;
   }
   const int nblk = ((p.M + 255) / 256) * ((p.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL(kernel, dim3(nblk), dim3(512), SMEM, st, p);
+  hipLaunchKernelGGL(kernel, dim3(TABLE_VERSION ? persistent_grid(nblk) : nblk), dim3(512), SMEM, st, p);
   return (int)hipGetLastError();
 }
 
