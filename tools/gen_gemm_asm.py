@@ -646,12 +646,16 @@ def gen_w4(c, pf=0, abl=0, dmak=0, spread=1, rd_per=2):
         for blk in range(4):
             if blk == 1:
                 lab("entry%d" % cur)
-            if blk >= 1:
+            if blk >= 1 and not abl & 4:                        # abl bit 2: no wait for the fragment reads (timing only)
                 e("s_waitcnt lgkmcnt(0)")
             mf = mfmas(1 if blk % 2 == 0 else 0)                # trailing: set 1, sub-step 0: set 0, 1: set 1, 2: set 0
             for i, m in enumerate(mf):
                 e(m)
                 for x in slots[blk * NM + i]:
+                    if abl & 8 and x.startswith("ds_read"):      # abl bit 3: no fragment reads at all (timing only)
+                        continue
+                    if abl & 16 and ("global_load_lds" in x or x.startswith("s_add_u32 m0")):   # bit 4: no LDS-DMA in the loop
+                        continue
                     e(x)
                 if blk * NM + i == last:
                     for a in advance():
@@ -1410,10 +1414,10 @@ def main():
                 f.write('"%s\\n"\n' % ln)
     c = Cfg4()
     if args.ablations:   # timing-only experiments for tools/: never committed, never shipped
-        for abl in (1, 2, 3):
+        for abl in (1, 2, 3, 4, 8, 12, 15, 16, 24, 31):     # on the default (spread 2) schedule
             with open(os.path.join(args.out, "gemm256w_body_abl%d.inc" % abl), "w") as f:
                 f.write("// GENERATED by tools/gen_gemm_asm.py --ablations -- timing experiment, WRONG RESULTS.\n")
-                for ln in gen_w4(c, 0, abl):
+                for ln in gen_w4(c, 0, abl, 0, 2):
                     f.write('"%s\\n"\n' % ln)
     with open(os.path.join(args.out, "gemm256w_body_spread2r1.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, one LDS-DMA piece per 2 MFMA shadows, one fragment read per shadow.\n")
