@@ -1,0 +1,176 @@
+// The 4-wave persistent bf16 GEMM of gemm256w.hip on v_mfma_f32_16x16x32_bf16:  C = epi(A[M,K] @ W[N,K]^T + bias)
+//
+// Same 256 x 256 x 64 workgroup tile, LDS image, LDS-DMA loaders, tile walk, cross-tile prefetch and bias-initialised
+// accumulators; the wave tile 128 x 128 is 8 x 8 accumulator tiles of 16 x 16 (4 AGPRs each) and a K step is two sub-steps of
+// K = 32.  Why a second MFMA shape (profiles/r02_gemm_experiments.md, "what the K loop's time is made of"): every kernel of
+// this library runs at the board's 1.4 kW cap, so time ~ energy per flop; with gemm256w's loop otherwise unchanged, issuing the
+// same flops as 16x16x32 MFMAs (4 accumulator registers written per 16 matrix cycles instead of 16 per 32) measured +5-7 %.
+// A fragment is 16 rows x 32 k: lane l reads row l % 16, 16-byte chunk (l / 16) + 4 s of the swizzled 128-byte LDS row --
+// conflict-free for ds_read_b128's lane groups ({0-3, 12-15, 20-27}, ...: the 8 chunk ^ key values of a group are distinct).
+// Operands are swapped (first = weight fragment): a lane owns output row l % 16 and channels 4 (l / 16) .. + 3 of each tile.
+// K loop: tools/gen_gemm_asm.py::gen_x4; epilogue: gemm_epilogue16.h.
+//
+// Roofline: MFMA bf16.  Algorithmic FLOPs = 2*M*N*K.
+#include "gemm_epilogue16.h"
+#include "gemm256x_regs.inc"
+
+namespace osk_gemm {
+namespace {
+
+OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v); }
+
+#define OSKX_OUT4 "=v"(v4[0]), "=v"(v4[1]), "=v"(v4[2]), "=v"(v4[3])
+
+struct GeoX {
+  static constexpr int NB = OSKX_NB;
+  template <int T>
+  OSK_DEV void read(float* v4) {
+#define OSKX_CASE(t) else if constexpr (T == t) asm volatile(OSKX_AR##t : OSKX_OUT4)
+    if constexpr (T < 0) {}
+    OSKX_CASE(0); OSKX_CASE(1); OSKX_CASE(2); OSKX_CASE(3); OSKX_CASE(4); OSKX_CASE(5); OSKX_CASE(6); OSKX_CASE(7);
+    OSKX_CASE(8); OSKX_CASE(9); OSKX_CASE(10); OSKX_CASE(11); OSKX_CASE(12); OSKX_CASE(13); OSKX_CASE(14); OSKX_CASE(15);
+    OSKX_CASE(16); OSKX_CASE(17); OSKX_CASE(18); OSKX_CASE(19); OSKX_CASE(20); OSKX_CASE(21); OSKX_CASE(22); OSKX_CASE(23);
+    OSKX_CASE(24); OSKX_CASE(25); OSKX_CASE(26); OSKX_CASE(27); OSKX_CASE(28); OSKX_CASE(29); OSKX_CASE(30); OSKX_CASE(31);
+    OSKX_CASE(32); OSKX_CASE(33); OSKX_CASE(34); OSKX_CASE(35); OSKX_CASE(36); OSKX_CASE(37); OSKX_CASE(38); OSKX_CASE(39);
+    OSKX_CASE(40); OSKX_CASE(41); OSKX_CASE(42); OSKX_CASE(43); OSKX_CASE(44); OSKX_CASE(45); OSKX_CASE(46); OSKX_CASE(47);
+    OSKX_CASE(48); OSKX_CASE(49); OSKX_CASE(50); OSKX_CASE(51); OSKX_CASE(52); OSKX_CASE(53); OSKX_CASE(54); OSKX_CASE(55);
+    OSKX_CASE(56); OSKX_CASE(57); OSKX_CASE(58); OSKX_CASE(59); OSKX_CASE(60); OSKX_CASE(61); OSKX_CASE(62); OSKX_CASE(63);
+#undef OSKX_CASE
+  }
+};
+
+template <bool OUT_F32>
+__global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmParams p) {
+  constexpr int WT = OSKX_NB * 16, BN = 256;   // wave tile side
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q4 = lane >> 4, l15 = lane & 15;
+
+  const int nbm = (p.M + 255) / 256, nbn = (p.N + BN - 1) / BN;
+  const int ntiles = nbm * nbn;
+  const int grp = p.group > 0 ? p.group : 1;
+  const int per_group = grp * nbn;
+  auto tile_of = [&](int it, int& m0, int& n0) {      // tile order of gemm256.hip / gemm256p.hip
+    const int tile = xcd_remap(it, ntiles);
+    const int g = tile / per_group, r = tile - g * per_group;
+    const int rows_here = nbm - g * grp < grp ? nbm - g * grp : grp;
+    const int bn = r / rows_here, bm = g * grp + (r - bn * rows_here);
+    m0 = bm * 256;
+    n0 = bn * BN;
+  };
+  // LDS-DMA sources: instruction j = wave + 4 i (i = 0..7) covers tile rows [8 j, 8 j + 8); byte offsets from the bases
+  const int srow8 = lane >> 3, spos = lane & 7;
+  auto offsets = [&](int m0, int n0, unsigned* aoff, unsigned* woff) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = (wave + 4 * i) * 8 + srow8;
+      const int c = spos ^ ((r >> 1) & 7);
+      int m = m0 + r;
+      m = m < p.M ? m : p.M - 1;
+      const int b = m / p.arpb, l = m - b * p.arpb;
+      aoff[i] = (unsigned)((b * p.abs_ + (int64_t)l * p.ars) * 2 + c * 16);
+      int n = n0 + r;
+      n = n < p.N ? n : p.N - 1;
+      woff[i] = (unsigned)((int64_t)n * p.wrs * 2 + c * 16);
+    }
+  };
+  // a tile whose 256 A rows lie inside M and inside one batch, and whose 256 W rows lie inside N: its per-lane source
+  // offsets are an affine function of (m0, n0), so the next tile's are this tile's plus a wave-uniform delta
+  auto affine = [&](int m0, int n0) {
+    return m0 + 256 <= p.M && n0 + 256 <= p.N && m0 / p.arpb == (m0 + 255) / p.arpb;
+  };
+  auto a_origin = [&](int m0) -> int64_t {
+    const int b = m0 / p.arpb, l = m0 - b * p.arpb;
+    return (b * p.abs_ + (int64_t)l * p.ars) * 2;
+  };
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  // fragment row l15 of a 16-row block, 16-byte chunk q4 (k 8 q4 .. + 7 of the sub-step's 32) under the row's swizzle key
+  const unsigned sz0 = (unsigned)((q4 ^ ((l15 >> 1) & 7)) << 4);
+  const unsigned faA0 = lds_base + (wm * WT + l15) * 128 + sz0;
+  const unsigned faW0 = lds_base + OSKX_W_BASE + (wn * WT + l15) * 128 + sz0;
+  const uint64_t abase = rfl64((uint64_t)(uintptr_t)p.A), wbase = rfl64((uint64_t)(uintptr_t)p.W);
+  const uint64_t bbase = rfl64((uint64_t)(uintptr_t)p.bias);
+  const unsigned nk = rfl((unsigned)(p.K / 64));
+  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + OSKX_W_BASE + wave * 1024);
+
+  unsigned prefetched = 0;
+  for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
+    const int itn = it + (int)gridDim.x;
+    int m0, n0, m0n = 0, n0n = 0;
+    tile_of(it, m0, n0);
+    bool has_next = itn < ntiles;
+    unsigned dA = 0, dW = 0;
+    if (has_next) {
+      tile_of(itn, m0n, n0n);
+      // cross-tile prefetch only between two affine tiles (edge tiles start with their own cold fetch)
+      has_next = affine(m0, n0) && affine(m0n, n0n);
+      dA = (unsigned)(a_origin(m0n) - a_origin(m0));
+      dW = (unsigned)(((int64_t)n0n - n0) * p.wrs * 2);
+    }
+    unsigned aoff[8], woff[8];
+    offsets(m0, n0, aoff, woff);
+    const int m0w = m0 + wm * WT, n0w = n0 + wn * WT;
+    const bool folded = p.bias != nullptr && n0w + WT <= p.N;                 // wave-uniform
+    const unsigned boff = (unsigned)((n0w + q4 * 4) * 4);
+    const unsigned flags = rfl(prefetched | (has_next ? 2u : 0u) | (folded ? 4u : 0u));
+    const unsigned dAs = rfl(dA), dWs = rfl(dW);
+
+    // prefetch lanes: lane l of wave w touches row 64 w + l of the A tile and of the W tile (one dword per 128-byte line)
+    unsigned aoffp, woffp;
+    {
+      int m = m0 + wave * 64 + lane;
+      m = m < p.M ? m : p.M - 1;
+      const int b = m / p.arpb, l = m - b * p.arpb;
+      aoffp = (unsigned)((b * p.abs_ + (int64_t)l * p.ars) * 2);
+      int n = n0 + wave * 64 + lane;
+      n = n < p.N ? n : p.N - 1;
+      woffp = (unsigned)((int64_t)n * p.wrs * 2);
+    }
+#define OSKW_OPERANDS                                                                                               \
+  ::"v"(faA0), "v"(faW0), "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(aoff[4]), "v"(aoff[5]),          \
+      "v"(aoff[6]), "v"(aoff[7]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]), "v"(woff[5]),  \
+      "v"(woff[6]), "v"(woff[7]), "v"(boff), "s"(abase), "s"(wbase), "s"(bbase), "s"(nk), "s"(adst), "s"(wdst),        \
+      "s"(flags), "s"(dAs), "s"(dWs), "v"(aoffp), "v"(woffp)
+    asm volatile(
+#include "gemm256x_body.inc"
+        OSKW_OPERANDS : OSKX_CLOBBERS);
+
+    const int b_first = m0w / p.crpb, b_last = (m0w + WT - 1) / p.crpb;
+    const bool interior = m0w + WT <= p.M && n0w + WT <= p.N && b_first == b_last;  // wave-uniform
+    epi16::epilogue_all<GeoX, OUT_F32>(p, m0w, n0w, l15, q4, interior, folded);
+    prefetched = has_next ? 1u : 0u;
+  }
+}
+
+template <bool OUT_F32>
+int launch_one(const GemmParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  static int n_cu = 0;
+  auto kernel = gemm256x_kernel<OUT_F32>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OSKX_SMEM);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+    if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+    n_cu -= n_cu % 8;    // the tile walk keeps a workgroup inside one XCD's range only for a grid that is a multiple of 8
+    if (n_cu < 8) n_cu = 8;
+    attr_set = true;
+  }
+  const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const int grid = ntiles < n_cu ? ntiles : n_cu;   // one workgroup per CU (LDS: 128 KiB of 160)
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), OSKX_SMEM, st, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int launch_gemm256x(const GemmParams& p, int out_f32, hipStream_t st) {
+  return out_f32 ? launch_one<true>(p, st) : launch_one<false>(p, st);
+}
+
+}  // namespace osk_gemm

@@ -1,0 +1,138 @@
+// Fused epilogue of gemm256x.hip: gemm_epilogue.h's bias / GELU-tanh / gate * x + residual / bf16 or f32 store on the
+// accumulator layout of v_mfma_f32_16x16x32_bf16 with swapped operands: of every 16 x 16 tile (J = column block, I = row
+// block) a lane owns output row 16 I + l15 (l15 = lane % 16) and the 4 consecutive columns 16 J + 4 q4 .. + 3 (q4 = lane / 16).
+// Geo supplies NB (16-blocks per wave tile side) and read<T>(float[4]) = the 4 accumulator registers of tile T = J * NB + I.
+#pragma once
+#include "gemm_epilogue.h"
+
+namespace osk_gemm {
+namespace epi16 {
+
+using epi::GELU_ALL;
+using epi::GELU_MIXED;
+using epi::GELU_NONE;
+
+// one interior tile up to (not including) the store: acc[4] -> final values
+template <class Geo, int T>
+OSK_DEV void tile_values(const GemmParams& p, int64_t roff, int n, bool folded, int gelu, const float4& bq, const float4& gq,
+                         float* acc) {
+  uint2 rv = make_uint2(0, 0);
+  if (p.gate) rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+  Geo::template read<T>(acc);
+  if (!folded && p.bias) {
+    acc[0] += bq.x; acc[1] += bq.y; acc[2] += bq.z; acc[3] += bq.w;
+  }
+  if (gelu == GELU_ALL) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = gelu_tanh(acc[i]);
+  } else if (gelu == GELU_MIXED) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float g = gelu_tanh(acc[i]);
+      acc[i] = n + i >= p.gelu_from ? g : acc[i];
+    }
+  }
+  if (p.gate) {
+    acc[0] = bf16_lo(rv.x) + gq.x * acc[0];
+    acc[1] = bf16_hi(rv.x) + gq.y * acc[1];
+    acc[2] = bf16_lo(rv.y) + gq.z * acc[2];
+    acc[3] = bf16_hi(rv.y) + gq.w * acc[3];
+  }
+}
+
+// Interior: the pair of row blocks (I, I + 1) of column block J.  bf16: v_permlane16_swap turns the two tiles' 8-byte pieces
+// into 16-byte stores -- the lanes of an even 16-lane row keep tile I and take their right neighbour row's 4 columns, the
+// odd rows take tile I + 1: lane (q4, l15) stores 8 columns (16 J + 8 (q4 / 2) ..) of output row 16 (I + (q4 & 1)) + l15.
+template <class Geo, bool OUT_F32, int J, int I>
+OSK_DEV void pair_interior(const GemmParams& p, const int64_t* rowoff, int n0w, int q4, bool folded, int gelu, const float4& bq,
+                           const float4& gq) {
+  constexpr int NB = Geo::NB;
+  const int n = n0w + J * 16 + q4 * 4;
+  const int64_t roff[2] = {rowoff[I], rowoff[I + 1]};
+  float a0[4], a1[4];
+  tile_values<Geo, J * NB + I>(p, roff[0], n, folded, gelu, bq, gq, a0);
+  tile_values<Geo, J * NB + I + 1>(p, roff[1], n, folded, gelu, bq, gq, a1);
+  if constexpr (OUT_F32) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + roff[0] + n) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + roff[1] + n) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+  } else {
+    const uint2 p0 = make_uint2(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]));
+    const uint2 p1 = make_uint2(pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3]));
+    unsigned short* c = reinterpret_cast<unsigned short*>(p.C);
+    const bool wide = ((((uintptr_t)c) & 15) == 0) && ((p.crs & 7) == 0) && ((p.cbs & 7) == 0) && ((n0w & 7) == 0);   // wave-uniform
+    if (wide) {
+      // swap(vdst = tile I, src = tile I + 1): [0] = {I.row0, (I+1).row0, I.row2, (I+1).row2}, [1] = {I.row1, (I+1).row1, I.row3, (I+1).row3}
+      auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+      auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+      const int64_t ro = (q4 & 1) ? roff[1] : roff[0];
+      *reinterpret_cast<uint4*>(c + ro + n0w + J * 16 + (q4 >> 1) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+    } else {
+      *reinterpret_cast<uint2*>(c + roff[0] + n) = p0;
+      *reinterpret_cast<uint2*>(c + roff[1] + n) = p1;
+    }
+  }
+}
+
+// edge tiles: per-element bounds checks (rows >= M were computed on clamped copies of row M-1 and are dropped)
+template <class Geo, bool OUT_F32, int T>
+OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded) {
+  constexpr int NB = Geo::NB;
+  constexpr int J = T / NB, I = T % NB;
+  float acc[4];
+  Geo::template read<T>(acc);
+  const int m = m0w + I * 16 + l15;
+  if (m >= p.M) return;
+  const int b = m / p.crpb, l = m - b * p.crpb;
+  const int64_t roff = b * p.cbs + (int64_t)l * p.crs;
+  const float* grow = p.gate ? p.gate + b * p.gbs : nullptr;
+  const int n = n0w + J * 16 + q4 * 4;
+  for (int j = 0; j < 4 && n + j < p.N; ++j) {
+    float t = acc[j];
+    if (!folded && p.bias) t += p.bias[n + j];
+    if (n + j >= p.gelu_from) t = gelu_tanh(t);
+    if (grow) t = bf16_bits_to_f32(p.res[roff + n + j]) + grow[n + j] * t;
+    if constexpr (OUT_F32) reinterpret_cast<float*>(p.C)[roff + n + j] = t;
+    else reinterpret_cast<unsigned short*>(p.C)[roff + n + j] = f32_to_bf16_bits(t);
+  }
+}
+
+template <class Geo, bool OUT_F32, int J, int... Is>
+OSK_DEV void col_block(const GemmParams& p, const int64_t* rowoff, int m0w, int n0w, int l15, int q4, bool interior, bool folded,
+                       std::integer_sequence<int, Is...>) {
+  constexpr int NB = Geo::NB;
+  if (interior) {
+    const int nf = n0w + J * 16;          // wave-uniform: GELU for none / all / some of this block's 16 columns
+    const int gelu = nf >= p.gelu_from ? GELU_ALL : (nf + 16 <= p.gelu_from ? GELU_NONE : GELU_MIXED);
+    const int n = nf + q4 * 4;
+    const int b = m0w / p.crpb;           // an interior wave tile lies inside one batch
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), gq = bq;
+    if (!folded && p.bias) bq = *reinterpret_cast<const float4*>(p.bias + n);
+    if (p.gate) gq = *reinterpret_cast<const float4*>(p.gate + b * p.gbs + n);
+    (pair_interior<Geo, OUT_F32, J, 2 * Is>(p, rowoff, n0w, q4, folded, gelu, bq, gq), ...);   // Is = 0 .. NB/2 - 1
+  } else {
+    (tile_edge<Geo, OUT_F32, J * NB + 2 * Is>(p, m0w, n0w, l15, q4, folded), ...);
+    (tile_edge<Geo, OUT_F32, J * NB + 2 * Is + 1>(p, m0w, n0w, l15, q4, folded), ...);
+  }
+}
+
+template <class Geo, bool OUT_F32, int... Js>
+OSK_DEV void cols(const GemmParams& p, const int64_t* rowoff, int m0w, int n0w, int l15, int q4, bool interior, bool folded,
+                  std::integer_sequence<int, Js...>) {
+  (col_block<Geo, OUT_F32, Js>(p, rowoff, m0w, n0w, l15, q4, interior, folded, std::make_integer_sequence<int, Geo::NB / 2>{}), ...);
+}
+
+// the whole 128 x 128 wave tile, column block by column block (bias / gate vectors are loaded once per block)
+template <class Geo, bool OUT_F32>
+OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool interior, bool folded) {
+  // element offsets of this lane's NB output rows (an interior wave tile lies inside one batch: one division for all of them)
+  int64_t rowoff[Geo::NB];
+  if (interior) {
+    const int b = m0w / p.crpb, l0 = m0w - b * p.crpb + l15;
+#pragma unroll
+    for (int i = 0; i < Geo::NB; ++i) rowoff[i] = b * p.cbs + (int64_t)(l0 + 16 * i) * p.crs;
+  }
+  cols<Geo, OUT_F32>(p, rowoff, m0w, n0w, l15, q4, interior, folded, std::make_integer_sequence<int, Geo::NB>{});
+}
+
+}  // namespace epi16
+}  // namespace osk_gemm

@@ -31,6 +31,7 @@ int launch_gemm256(const GemmParams& p, int bn, int out_f32, hipStream_t st);
 int launch_gemm256p(const GemmParams& p, int bn, int out_f32, hipStream_t st);
 // gemm256w.hip: the persistent walk with 4 waves per workgroup (one per SIMD, 128 x 128 wave tiles, 256 accumulator AGPRs)
 int launch_gemm256w(const GemmParams& p, int out_f32, hipStream_t st);
+int launch_gemm256x(const GemmParams& p, int out_f32, hipStream_t st);   // gemm256x.hip: the same on v_mfma_f32_16x16x32_bf16
 // the same kernel on OCP e4m3 operands (A, W point at bytes; strides in elements = bytes)
 bool gemm256_fp8_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
 int launch_gemm256_fp8(const GemmParams& p, int bn, int out_f32, hipStream_t st);

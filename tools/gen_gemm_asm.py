@@ -517,6 +517,13 @@ def gen_w4(c, pf=0, abl=0, dmak=0, spread=1, rd_per=2):
         for tn in range(c.TN):
             for tm in range(c.TM):
                 acc = ar((tn * c.TM + tm) * 16, 16)
+                if abl & 32:   # bit 5 (timing only): the same flops as TWO v_mfma_f32_16x16x32_bf16 on 4-register accumulators
+                    b0 = (tn * c.TM + tm) * 16
+                    f2 = fset ^ 1 if abl & 64 else fset      # bit 6: the second MFMA takes its operands from the other fragment set
+                    out.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s\\n  v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (
+                        ar(b0, 4), vr(c.frag(fset, c.TM + tn), 4), vr(c.frag(fset, tm), 4), ar(b0, 4),
+                        ar(b0 + 4, 4), vr(c.frag(f2, c.TM + tn), 4), vr(c.frag(f2, tm), 4), ar(b0 + 4, 4)))
+                    continue
                 out.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, c.TM + tn), 4), vr(c.frag(fset, tm), 4), acc))
         return out
 
@@ -768,6 +775,218 @@ def gen_w4(c, pf=0, abl=0, dmak=0, spread=1, rd_per=2):
         e("s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP))
         e("s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1))
     plain(dma(1, an, wn, koff="s%d" % S_STEP))
+    e("s_branch %s" % ref("end"))
+    lab("last")
+    for m in mfmas(1):
+        e(m)
+    lab("end")
+    e("s_nop 15")
+    e("s_nop 15")
+    return L
+
+class Cfg4x:
+    """Cfg4's 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16: 8 x 8 accumulator tiles of 16 x 16 (4 registers each, the
+    same 256 AGPRs), a K step = TWO sub-steps of K = 32.  A fragment is 16 rows x 32 k -- one ds_read_b128 per lane (row
+    l % 16, k group l / 16) out of the SAME LDS image (rows of 128 bytes, 16-byte chunk c of row r at (c ^ ((r >> 1) & 7))):
+    conflict-free for this lane map too.  Why (profiles/r02_gemm_experiments.md): with the K loop otherwise unchanged, issuing
+    the same flops as 16x16x32 instead of 32x32x16 MFMAs is worth +5-7 % at the board's power cap (4 accumulator registers
+    written per 16 matrix cycles instead of 16 per 32)."""
+
+    def __init__(self):
+        self.BN = 256
+        self.NB = 8                             # 16-row / 16-column blocks per wave tile side
+        self.NA, self.NW = 8, 8
+        self.DMA_STRIDE = 4096
+        self.A_STAGE, self.W_STAGE = 32768, 32768
+        self.W_BASE = 65536
+        self.SMEM = self.W_BASE + 2 * self.W_STAGE
+        self.NACC = 256
+        self.NFRAG = 16                         # 8 activation + 8 weight fragments per sub-step
+        self.FW = 4
+        self.V0 = 96                            # asm-owned VGPRs: v96.. (two fragment sets = 128, then 2 addresses)
+        self.VN = 2 * self.NFRAG * self.FW
+        self.tag = "x256"
+
+    def frag(self, fset, idx):
+        return self.V0 + (fset * self.NFRAG + idx) * self.FW
+
+
+def gen_x4(c, spread=4, rd_per=1):
+    """gen_w4's persistent-workgroup K loop (same operands, same LDS-DMA side, same cross-tile prefetch and bias-initialised
+    accumulators) for Cfg4x.  Per K step and wave: 128 MFMAs of 16 cycles in two blocks of 64 -- the trailing sub-step (k 32..63
+    of the previous K step, fragment set 1) and sub-step 0 (set 0) --, 16 fragment reads per block two per shadow at its head,
+    the 16 LDS-DMA pieces one per `spread` shadows of the trailing block (the time spacing of gen_w4's one per two 32-cycle
+    shadows)."""
+    L = []
+    e = lambda t: L.append("  " + t)
+    lab = lambda n: L.append(".L%s_%s_%%=:" % (c.tag, n))
+    ref = lambda n: ".L%s_%s_%%=" % (c.tag, n)
+    VX = c.V0 + c.VN
+    fa = {("A", 0): WOP["faA0"], ("W", 0): WOP["faW0"], ("A", 1): vr(VX), ("W", 1): vr(VX + 1)}
+    NB = c.NB
+    NM = NB * NB
+
+    def reads(stage, s32, fset):
+        out = []
+        for i in range(NB):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, i), 4), fa[("A", s32)], stage * c.A_STAGE + i * 2048))
+        for j in range(NB):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, NB + j), 4), fa[("W", s32)], stage * c.W_STAGE + j * 2048))
+        return out
+
+    def mfmas(fset):
+        # swapped operands: first = weight fragment (D rows = 16 output channels), second = activation fragment (D columns =
+        # 16 output rows): a lane owns output row l % 16 and channels 4 (l / 16) .. + 3 of every 16 x 16 tile
+        out = []
+        for j in range(NB):
+            for i in range(NB):
+                acc = ar((j * NB + i) * 4, 4)
+                out.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, NB + j), 4), vr(c.frag(fset, i), 4), acc))
+        return out
+
+    def dma(stage, aregs=None, wregs=None):
+        aregs = aregs or [WOP["aoff%d" % i] for i in range(c.NA)]
+        wregs = wregs or [WOP["woff%d" % i] for i in range(c.NW)]
+        out = []
+        for i in range(c.NA):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * c.DMA_STRIDE),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (aregs[i], S_AB, S_AB + 1)))
+        for i in range(c.NW):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * c.DMA_STRIDE),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (wregs[i], S_WB, S_WB + 1)))
+        return out
+
+    def advance():
+        return ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
+                "s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK),
+                "s_cselect_b32 s%d, 128, 0" % S_STEP,
+                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL),
+                "s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1),
+                "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1)]
+
+    def plain(pieces):
+        for m0w, d in pieces:
+            e(m0w); e("s_nop 0"); e(d)
+
+    # ---- setup
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, WOP["abase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, WOP["wbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_PBIAS, S_PBIAS + 1, WOP["bias"]))
+    e("s_mov_b32 s%d, %s" % (S_NK, WOP["nk"]))
+    e("s_mov_b32 s%d, %s" % (S_ADST, WOP["adst"]))
+    e("s_mov_b32 s%d, %s" % (S_WDST, WOP["wdst"]))
+    e("s_mov_b32 s%d, %s" % (S_PFLAGS, WOP["flags"]))
+    e("s_mov_b32 s%d, %s" % (S_DA, WOP["dA"]))
+    e("s_mov_b32 s%d, %s" % (S_DW, WOP["dW"]))
+    e("s_mov_b32 s%d, 0" % S_T)
+    e("s_mov_b32 s%d, 0" % S_KL)
+    e("v_xor_b32_e32 %s, 64, %s" % (fa[("A", 1)], WOP["faA0"]))     # k 32..63: 16-byte chunk index + 4 = ^ 4 under the swizzle
+    e("v_xor_b32_e32 %s, 64, %s" % (fa[("W", 1)], WOP["faW0"]))
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_PREFETCHED))
+    e("s_cbranch_scc1 %s" % ref("have0"))
+    plain(dma(0))
+    lab("have0")
+    for a in advance():
+        e(a)
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_BIAS))
+    e("s_cbranch_scc0 %s" % ref("nobias"))
+    for j in range(NB):   # bias of this lane's 4 channels of column block j -> the idle fragment registers
+        e("global_load_dwordx4 %s, %s, s[%d:%d] offset:%d" % (vr(c.V0 + j * 4, 4), WOP["boff"], S_PBIAS, S_PBIAS + 1, j * 64))
+    lab("nobias")
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_PREFETCHED))
+    e("s_cbranch_scc1 %s" % ref("have1"))
+    plain(dma(1))
+    lab("have1")
+    assert spread * (c.NA + c.NW - 1) < NM, "all pieces are issued in the trailing block: entry0 re-issues none"
+    for a in advance():
+        e(a)
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_BIAS))
+    e("s_cbranch_scc0 %s" % ref("zero"))
+    for j in range(NB):
+        for i in range(NB):
+            for r in range(4):
+                e("v_accvgpr_write_b32 %s, %s" % (ar((j * NB + i) * 4 + r), vr(c.V0 + j * 4 + r)))
+    e("s_branch %s" % ref("inited"))
+    lab("zero")
+    for r in range(c.NACC):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    lab("inited")
+    e("s_nop 1")
+    for r in reads(0, 0, 0):
+        e(r)
+    e("s_branch %s" % ref("entry0"))
+
+    def step(cur):
+        pieces = dma(cur ^ 1)
+        slots = [[] for _ in range(2 * NM)]
+        dma_slots = [spread * j for j in range(len(pieces))]
+        e(pieces[0][0])
+        for j, (m0w, d) in enumerate(pieces):
+            slots[dma_slots[j]].append(d)
+            if j + 1 < len(pieces):
+                slots[dma_slots[j]].append(pieces[j + 1][0])
+        last = dma_slots[-1]
+        for blk, (s32, fset) in enumerate(((0, 0), (1, 1))):
+            rd = reads(cur, s32, fset)
+            free = [i for i in range(blk * NM, (blk + 1) * NM) if i not in dma_slots]
+            for i in range((len(rd) + rd_per - 1) // rd_per):      # a ds_read_b128 costs ~9 cycles of a 16-cycle shadow
+                slots[free[i]] += rd[rd_per * i: rd_per * i + rd_per]
+        for blk in range(2):
+            if blk == 1:
+                lab("entry%d" % cur)
+                e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(1 if blk == 0 else 0)
+            for i, m in enumerate(mf):
+                e(m)
+                for x in slots[blk * NM + i]:
+                    e(x)
+                if blk * NM + i == last:
+                    for a in advance():
+                        e(a)
+
+    for k in range(2):
+        lab("step%d" % k)
+        step(k)
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_barrier")
+        e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
+        e("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NK))
+        e("s_cbranch_scc0 %s" % ref("exit"))
+        if k == 1:
+            e("s_branch %s" % ref("step0"))
+    lab("exit")
+    e("s_bitcmp1_b32 s%d, %d" % (S_PFLAGS, PF_HAS_NEXT))
+    e("s_cbranch_scc0 %s" % ref("last"))
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, WOP["abase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, WOP["wbase"]))
+    # next tile's per-lane source offsets into fragment set 0 (its last MFMAs were issued before the barrier)
+    an = [vr(c.V0 + i) for i in range(c.NA)]
+    wn = [vr(c.V0 + c.NA + i) for i in range(c.NW)]
+    for i in range(c.NA):
+        e("v_add_u32_e32 %s, s%d, %s" % (an[i], S_DA, WOP["aoff%d" % i]))
+    for i in range(c.NW):
+        e("v_add_u32_e32 %s, s%d, %s" % (wn[i], S_DW, WOP["woff%d" % i]))
+    mf = mfmas(1)
+    pieces = dma(0, an, wn)
+    e(pieces[0][0])
+    for i, m in enumerate(mf):
+        e(m)
+        if i % spread == 0 and i // spread < len(pieces):
+            k = i // spread
+            e(pieces[k][1])
+            if k + 1 < len(pieces):
+                e(pieces[k + 1][0])
+    e("s_cmp_gt_u32 s%d, 1" % S_NK)
+    e("s_cselect_b32 s%d, 128, 0" % S_STEP)
+    e("s_add_u32 s%d, s%d, s%d" % (S_AB, S_AB, S_STEP))
+    e("s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_AB + 1))
+    e("s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP))
+    e("s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1))
+    plain(dma(1, an, wn))
     e("s_branch %s" % ref("end"))
     lab("last")
     for m in mfmas(1):
@@ -1414,7 +1633,7 @@ def main():
                 f.write('"%s\\n"\n' % ln)
     c = Cfg4()
     if args.ablations:   # timing-only experiments for tools/: never committed, never shipped
-        for abl in (1, 2, 3, 4, 8, 12, 15, 16, 24, 31):     # on the default (spread 2) schedule
+        for abl in (1, 2, 3, 4, 8, 12, 15, 16, 24, 31, 32, 56, 96):     # on the default (spread 2) schedule
             with open(os.path.join(args.out, "gemm256w_body_abl%d.inc" % abl), "w") as f:
                 f.write("// GENERATED by tools/gen_gemm_asm.py --ablations -- timing experiment, WRONG RESULTS.\n")
                 for ln in gen_w4(c, 0, abl, 0, 2):
@@ -1453,6 +1672,19 @@ def main():
         f.write("#define OSKW_CONV_CLOBBERS %s\n" % ", ".join(cclob))
         for t in range(c.TM * c.TN):
             f.write("#define OSKW_AR%d %s\n" % (t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
+    cx = Cfg4x()
+    with open(os.path.join(args.out, "gemm256x_body.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, persistent workgroup.\n")
+        for ln in gen_x4(cx):
+            f.write('"%s\\n"\n' % ln)
+    with open(os.path.join(args.out, "gemm256x_regs.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
+        f.write("#define OSKX_SMEM %d\n#define OSKX_W_BASE %d\n#define OSKX_NB %d\n" % (cx.SMEM, cx.W_BASE, cx.NB))
+        clob = ['"v%d"' % i for i in range(cx.V0, cx.V0 + cx.VN + 2)] + ['"a%d"' % i for i in range(cx.NACC)] + \
+               ['"s%d"' % i for i in range(S_FIRST, W4_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+        f.write("#define OSKX_CLOBBERS %s\n" % ", ".join(clob))
+        for t in range(cx.NB * cx.NB):
+            f.write("#define OSKX_AR%d %s\n" % (t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 4 + i) for i in range(4))))
     for bn in (256, 128):
         c = Cfg(bn, fp8=True)
         with open(os.path.join(args.out, "gemm256_fp8_body_n%d.inc" % bn), "w") as f:
