@@ -266,9 +266,9 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
       static const bool persist = [] { const char* e = getenv("OSK_GEMM_PERSIST"); return !e || atoi(e) != 0; }();
       // 256-wide tiles: the 4-wave layout (gemm256w.hip: 128 x 128 wave tiles) unless OSK_GEMM_W4=0
       static const bool w4 = [] { const char* e = getenv("OSK_GEMM_W4"); return !e || atoi(e) != 0; }();
-      // OSK_GEMM_X=1 (opt-in): the 4-wave kernel on v_mfma_f32_16x16x32_bf16 (gemm256x.hip).  Parity-green; K step 1-6 % shorter,
-      // per-tile fixed cost 1-4 us higher: +3 % at K >= 4608, -2..-9 % at K = 1152 (profiles/r02_gemm_experiments.md)
-      static const bool x16 = [] { const char* e = getenv("OSK_GEMM_X"); return e && atoi(e) != 0; }();
+      // ... on v_mfma_f32_16x16x32_bf16 (gemm256x.hip: +7-13 % at the XL shapes over the 32x32x16 form, gemm256w.hip, which
+      // OSK_GEMM_X=0 selects for A/B runs)
+      static const bool x16 = [] { const char* e = getenv("OSK_GEMM_X"); return !e || atoi(e) != 0; }();
       if (!use_old && persist && w4 && bn == 256 && x16) return osk_gemm::launch_gemm256x(p, out_f32, st);
       if (!use_old && persist && w4 && bn == 256) return osk_gemm::launch_gemm256w(p, out_f32, st);
       if (!use_old) return persist ? osk_gemm::launch_gemm256p(p, bn, out_f32, st) : osk_gemm::launch_gemm256(p, bn, out_f32, st);

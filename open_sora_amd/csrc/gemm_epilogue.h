@@ -149,6 +149,7 @@ OSK_DEV void epilogue_cols(const GemmParams& p, int m0w, int n0w, int l31, int h
 // the whole wave tile: column block by column block (column vectors -- bias, gate -- are loaded once per block)
 template <class Geo, bool OUT_F32>
 OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded) {
+  if (m0w >= p.M || n0w >= p.N) return;   // the whole wave tile lies outside C (ragged last tile row / column): wave-uniform
   epilogue_cols<Geo, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::make_integer_sequence<int, Geo::TN>{});
 }
 

@@ -12,27 +12,25 @@ using epi::GELU_ALL;
 using epi::GELU_MIXED;
 using epi::GELU_NONE;
 
-// one interior tile up to (not including) the store: acc[4] -> final values
-template <class Geo, int T>
-OSK_DEV void tile_values(const GemmParams& p, int64_t roff, int n, bool folded, int gelu, const float4& bq, const float4& gq,
-                         float* acc) {
+// one interior tile up to (not including) the store: acc[4] -> final values.  Interior tiles never add the bias here: the
+// accumulators started from it (an interior wave tile has all its columns inside N, which is the kernel's "folded" condition).
+// GATE and the tile's GELU class are compile-time / hoisted: 64 tiles per wave make every per-tile branch count.
+template <class Geo, int T, bool GATE, int GELU>
+OSK_DEV void tile_values(const GemmParams& p, int64_t roff, int n, const float4& gq, float* acc) {
   uint2 rv = make_uint2(0, 0);
-  if (p.gate) rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+  if constexpr (GATE) rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
   Geo::template read<T>(acc);
-  if (!folded && p.bias) {
-    acc[0] += bq.x; acc[1] += bq.y; acc[2] += bq.z; acc[3] += bq.w;
-  }
-  if (gelu == GELU_ALL) {
+  if constexpr (GELU == GELU_ALL) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = gelu_tanh(acc[i]);
-  } else if (gelu == GELU_MIXED) {
+  } else if constexpr (GELU == GELU_MIXED) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float g = gelu_tanh(acc[i]);
       acc[i] = n + i >= p.gelu_from ? g : acc[i];
     }
   }
-  if (p.gate) {
+  if constexpr (GATE) {
     acc[0] = bf16_lo(rv.x) + gq.x * acc[0];
     acc[1] = bf16_hi(rv.x) + gq.y * acc[1];
     acc[2] = bf16_lo(rv.y) + gq.z * acc[2];
@@ -43,33 +41,23 @@ OSK_DEV void tile_values(const GemmParams& p, int64_t roff, int n, bool folded, 
 // Interior: the pair of row blocks (I, I + 1) of column block J.  bf16: v_permlane16_swap turns the two tiles' 8-byte pieces
 // into 16-byte stores -- the lanes of an even 16-lane row keep tile I and take their right neighbour row's 4 columns, the
 // odd rows take tile I + 1: lane (q4, l15) stores 8 columns (16 J + 8 (q4 / 2) ..) of output row 16 (I + (q4 & 1)) + l15.
-template <class Geo, bool OUT_F32, int J, int I>
-OSK_DEV void pair_interior(const GemmParams& p, const int64_t* rowoff, int n0w, int q4, bool folded, int gelu, const float4& bq,
-                           const float4& gq) {
+// (The caller routes outputs that are not 16-byte addressable to the edge path.)
+template <class Geo, bool OUT_F32, bool GATE, int GELU, int J, int I>
+OSK_DEV void pair_interior(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4& gq) {
   constexpr int NB = Geo::NB;
   const int n = n0w + J * 16 + q4 * 4;
-  const int64_t roff[2] = {rowoff[I], rowoff[I + 1]};
   float a0[4], a1[4];
-  tile_values<Geo, J * NB + I>(p, roff[0], n, folded, gelu, bq, gq, a0);
-  tile_values<Geo, J * NB + I + 1>(p, roff[1], n, folded, gelu, bq, gq, a1);
+  tile_values<Geo, J * NB + I, GATE, GELU>(p, rowoff[I], n, gq, a0);
+  tile_values<Geo, J * NB + I + 1, GATE, GELU>(p, rowoff[I + 1], n, gq, a1);
   if constexpr (OUT_F32) {
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + roff[0] + n) = make_float4(a0[0], a0[1], a0[2], a0[3]);
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + roff[1] + n) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + rowoff[I] + n) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + rowoff[I + 1] + n) = make_float4(a1[0], a1[1], a1[2], a1[3]);
   } else {
-    const uint2 p0 = make_uint2(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]));
-    const uint2 p1 = make_uint2(pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3]));
-    unsigned short* c = reinterpret_cast<unsigned short*>(p.C);
-    const bool wide = ((((uintptr_t)c) & 15) == 0) && ((p.crs & 7) == 0) && ((p.cbs & 7) == 0) && ((n0w & 7) == 0);   // wave-uniform
-    if (wide) {
-      // swap(vdst = tile I, src = tile I + 1): [0] = {I.row0, (I+1).row0, I.row2, (I+1).row2}, [1] = {I.row1, (I+1).row1, I.row3, (I+1).row3}
-      auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
-      auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
-      const int64_t ro = (q4 & 1) ? roff[1] : roff[0];
-      *reinterpret_cast<uint4*>(c + ro + n0w + J * 16 + (q4 >> 1) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-    } else {
-      *reinterpret_cast<uint2*>(c + roff[0] + n) = p0;
-      *reinterpret_cast<uint2*>(c + roff[1] + n) = p1;
-    }
+    // swap(vdst = tile I, src = tile I + 1): [0] = {I.row0, (I+1).row0, I.row2, (I+1).row2}, [1] = {I.row1, (I+1).row1, I.row3, (I+1).row3}
+    auto sx = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a1[0], a1[1]), false, false);
+    auto sy = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[2], a1[3]), false, false);
+    // storeoff[I / 2] = element offset of this lane's output row 16 (I + (q4 & 1)) + l15, + its 8-column half (q4 / 2)
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.C) + storeoff[I / 2] + n0w + J * 16) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
   }
 }
 
@@ -96,42 +84,56 @@ OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, b
   }
 }
 
-template <class Geo, bool OUT_F32, int J, int... Is>
-OSK_DEV void col_block(const GemmParams& p, const int64_t* rowoff, int m0w, int n0w, int l15, int q4, bool interior, bool folded,
+template <class Geo, bool OUT_F32, bool GATE, int GELU, int J, int... Is>
+OSK_DEV void col_pairs(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4& gq,
                        std::integer_sequence<int, Is...>) {
-  constexpr int NB = Geo::NB;
-  if (interior) {
-    const int nf = n0w + J * 16;          // wave-uniform: GELU for none / all / some of this block's 16 columns
-    const int gelu = nf >= p.gelu_from ? GELU_ALL : (nf + 16 <= p.gelu_from ? GELU_NONE : GELU_MIXED);
-    const int n = nf + q4 * 4;
-    const int b = m0w / p.crpb;           // an interior wave tile lies inside one batch
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), gq = bq;
-    if (!folded && p.bias) bq = *reinterpret_cast<const float4*>(p.bias + n);
-    if (p.gate) gq = *reinterpret_cast<const float4*>(p.gate + b * p.gbs + n);
-    (pair_interior<Geo, OUT_F32, J, 2 * Is>(p, rowoff, n0w, q4, folded, gelu, bq, gq), ...);   // Is = 0 .. NB/2 - 1
-  } else {
-    (tile_edge<Geo, OUT_F32, J * NB + 2 * Is>(p, m0w, n0w, l15, q4, folded), ...);
-    (tile_edge<Geo, OUT_F32, J * NB + 2 * Is + 1>(p, m0w, n0w, l15, q4, folded), ...);
-  }
+  (pair_interior<Geo, OUT_F32, GATE, GELU, J, 2 * Is>(p, rowoff, storeoff, n0w, q4, gq), ...);   // Is = 0 .. NB/2 - 1
 }
 
-template <class Geo, bool OUT_F32, int... Js>
-OSK_DEV void cols(const GemmParams& p, const int64_t* rowoff, int m0w, int n0w, int l15, int q4, bool interior, bool folded,
-                  std::integer_sequence<int, Js...>) {
-  (col_block<Geo, OUT_F32, Js>(p, rowoff, m0w, n0w, l15, q4, interior, folded, std::make_integer_sequence<int, Geo::NB / 2>{}), ...);
+template <class Geo, bool OUT_F32, bool GATE, int J>
+OSK_DEV void col_block(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int m0w, int n0w, int q4) {
+  constexpr auto seq = std::make_integer_sequence<int, Geo::NB / 2>{};
+  const int nf = n0w + J * 16;            // wave-uniform: GELU for none / all / some of this block's 16 columns
+  float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (GATE) gq = *reinterpret_cast<const float4*>(p.gate + (m0w / p.crpb) * p.gbs + nf + q4 * 4);   // one batch per interior wave tile
+  if (nf + 16 <= p.gelu_from) col_pairs<Geo, OUT_F32, GATE, GELU_NONE, J>(p, rowoff, storeoff, n0w, q4, gq, seq);
+  else if (nf >= p.gelu_from) col_pairs<Geo, OUT_F32, GATE, GELU_ALL, J>(p, rowoff, storeoff, n0w, q4, gq, seq);
+  else col_pairs<Geo, OUT_F32, GATE, GELU_MIXED, J>(p, rowoff, storeoff, n0w, q4, gq, seq);
 }
 
-// the whole 128 x 128 wave tile, column block by column block (bias / gate vectors are loaded once per block)
+template <class Geo, bool OUT_F32, bool GATE, int... Js>
+OSK_DEV void cols_interior(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int m0w, int n0w, int q4,
+                           std::integer_sequence<int, Js...>) {
+  (col_block<Geo, OUT_F32, GATE, Js>(p, rowoff, storeoff, m0w, n0w, q4), ...);
+}
+
+template <class Geo, bool OUT_F32, int... Ts>
+OSK_DEV void tiles_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded, std::integer_sequence<int, Ts...>) {
+  (tile_edge<Geo, OUT_F32, Ts>(p, m0w, n0w, l15, q4, folded), ...);
+}
+
+// the whole 128 x 128 wave tile
 template <class Geo, bool OUT_F32>
 OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool interior, bool folded) {
-  // element offsets of this lane's NB output rows (an interior wave tile lies inside one batch: one division for all of them)
-  int64_t rowoff[Geo::NB];
-  if (interior) {
-    const int b = m0w / p.crpb, l0 = m0w - b * p.crpb + l15;
-#pragma unroll
-    for (int i = 0; i < Geo::NB; ++i) rowoff[i] = b * p.cbs + (int64_t)(l0 + 16 * i) * p.crs;
+  constexpr int NB = Geo::NB;
+  if (m0w >= p.M || n0w >= p.N) return;   // the whole wave tile lies outside C (ragged last tile row / column): wave-uniform
+  // the fast path stores 16 bytes per lane (bf16) / reads 8-byte residual pieces: C, its strides and the tile origin must allow it
+  const bool wide = OUT_F32 || (((((uintptr_t)p.C) & 15) == 0) && ((p.crs & 7) == 0) && ((p.cbs & 7) == 0));
+  if (!interior || !wide || (p.bias && !folded)) {
+    tiles_edge<Geo, OUT_F32>(p, m0w, n0w, l15, q4, folded, std::make_integer_sequence<int, NB * NB>{});
+    return;
   }
-  cols<Geo, OUT_F32>(p, rowoff, m0w, n0w, l15, q4, interior, folded, std::make_integer_sequence<int, Geo::NB>{});
+  // element offsets of this lane's NB output rows (an interior wave tile lies inside one batch: one division for all of them),
+  // and of the NB / 2 rows it STORES after the lane-row exchange
+  int64_t rowoff[NB], storeoff[NB / 2];
+  const int b = m0w / p.crpb, l0 = m0w - b * p.crpb + l15;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) rowoff[i] = b * p.cbs + (int64_t)(l0 + 16 * i) * p.crs;
+#pragma unroll
+  for (int i = 0; i < NB / 2; ++i) storeoff[i] = ((q4 & 1) ? rowoff[2 * i + 1] : rowoff[2 * i]) + (q4 >> 1) * 8;
+  constexpr auto js = std::make_integer_sequence<int, NB>{};
+  if (p.gate) cols_interior<Geo, OUT_F32, true>(p, rowoff, storeoff, m0w, n0w, q4, js);
+  else cols_interior<Geo, OUT_F32, false>(p, rowoff, storeoff, m0w, n0w, q4, js);
 }
 
 }  // namespace epi16

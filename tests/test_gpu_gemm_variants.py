@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = {
-    "x16 (gemm256x.hip: v_mfma_f32_16x16x32_bf16)": {"OSK_GEMM_X": "1"},
+    "4-wave persistent on 32x32x16 MFMAs (gemm256w.hip)": {"OSK_GEMM_X": "0"},
     "8-wave persistent, schedule 2 (gemm256p.hip)": {"OSK_GEMM_W4": "0"},
     "round-1 one-tile-per-workgroup kernel (gemm256.hip)": {"OSK_GEMM_PERSIST": "0"},
 }
