@@ -15,6 +15,7 @@
 #include "gemm256_regs_n256.inc"
 #include "gemm256_regs_n128.inc"
 #include "gemm256w_regs.inc"
+#include "gemm256x_regs.inc"
 #include <type_traits>
 
 namespace osk_conv {
@@ -533,6 +534,234 @@ __global__ void __launch_bounds__(256, 1) conv256w_kernel(const ConvParams p) {
   }   // tile loop (the next tile's table build ends in a barrier: nobody refills stage 0 while the statistics slots are read)
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// conv256w_kernel on v_mfma_f32_16x16x32_bf16 (gemm256x.hip's compute side: at the board's power cap the 16x16x32 stream is the
+// cheaper one per flop, profiles/r02_gemm_experiments.md): 8 x 8 accumulator tiles of 16 x 16 per wave, the same LDS image read
+// through a 16-row x 32-k lane map, K loop conv256x_body.inc (tools/gen_gemm_asm.py::gen_conv_x4).  Of every 16 x 16 tile
+// (J = channel block, I = voxel block) a lane owns voxel row 16 I + l15 and channels 16 J + 4 q4 .. + 3.
+#define OSKCX_OUT4 "=v"(v4[0]), "=v"(v4[1]), "=v"(v4[2]), "=v"(v4[3])
+template <int T>
+OSK_DEV void read_x(float* v4) {
+#define OSKCX_CASE(t) else if constexpr (T == t) asm volatile(OSKX_AR##t : OSKCX_OUT4)
+  if constexpr (T < 0) {}
+  OSKCX_CASE(0); OSKCX_CASE(1); OSKCX_CASE(2); OSKCX_CASE(3); OSKCX_CASE(4); OSKCX_CASE(5); OSKCX_CASE(6); OSKCX_CASE(7);
+  OSKCX_CASE(8); OSKCX_CASE(9); OSKCX_CASE(10); OSKCX_CASE(11); OSKCX_CASE(12); OSKCX_CASE(13); OSKCX_CASE(14); OSKCX_CASE(15);
+  OSKCX_CASE(16); OSKCX_CASE(17); OSKCX_CASE(18); OSKCX_CASE(19); OSKCX_CASE(20); OSKCX_CASE(21); OSKCX_CASE(22); OSKCX_CASE(23);
+  OSKCX_CASE(24); OSKCX_CASE(25); OSKCX_CASE(26); OSKCX_CASE(27); OSKCX_CASE(28); OSKCX_CASE(29); OSKCX_CASE(30); OSKCX_CASE(31);
+  OSKCX_CASE(32); OSKCX_CASE(33); OSKCX_CASE(34); OSKCX_CASE(35); OSKCX_CASE(36); OSKCX_CASE(37); OSKCX_CASE(38); OSKCX_CASE(39);
+  OSKCX_CASE(40); OSKCX_CASE(41); OSKCX_CASE(42); OSKCX_CASE(43); OSKCX_CASE(44); OSKCX_CASE(45); OSKCX_CASE(46); OSKCX_CASE(47);
+  OSKCX_CASE(48); OSKCX_CASE(49); OSKCX_CASE(50); OSKCX_CASE(51); OSKCX_CASE(52); OSKCX_CASE(53); OSKCX_CASE(54); OSKCX_CASE(55);
+  OSKCX_CASE(56); OSKCX_CASE(57); OSKCX_CASE(58); OSKCX_CASE(59); OSKCX_CASE(60); OSKCX_CASE(61); OSKCX_CASE(62); OSKCX_CASE(63);
+#undef OSKCX_CASE
+}
+
+// sum over the 16 lanes of a lane row, in every lane (the DPP half of half_wave_sum)
+OSK_DEV float row16_sum(float v) {
+#define OSKC_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+  OSKC_DPP_ADD(0xB1);
+  OSKC_DPP_ADD(0x4E);
+  OSKC_DPP_ADD(0x141);
+  OSKC_DPP_ADD(0x140);
+#undef OSKC_DPP_ADD
+  return v;
+}
+
+// fast path of one pair of voxel blocks (I, I + 1) of channel block J: whole 16-channel block inside Cout, rows 16-byte
+// addressable.  RES / GN are compile-time, bias arrives as a register quad: 64 tiles per wave make per-tile branches count.
+template <bool RES, bool GN, int J, int I>
+OSK_DEV void pair_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid,
+                    int n, int ncol, const float4& bq, float& gs, float& gq) {
+  float a0[4], a1[4];
+  uint2 r0 = make_uint2(0, 0), r1 = r0;
+  if constexpr (RES) {
+    r0 = *reinterpret_cast<const uint2*>(p.res + rowoff[I] + n);        // rows beyond M read row 0 (clamped offsets)
+    r1 = *reinterpret_cast<const uint2*>(p.res + rowoff[I + 1] + n);
+  }
+  read_x<J * OSKX_NB + I>(a0);
+  read_x<J * OSKX_NB + I + 1>(a1);
+  a0[0] += bq.x; a0[1] += bq.y; a0[2] += bq.z; a0[3] += bq.w;
+  a1[0] += bq.x; a1[1] += bq.y; a1[2] += bq.z; a1[3] += bq.w;
+  if constexpr (RES) {
+    a0[0] += bf16_lo(r0.x); a0[1] += bf16_hi(r0.x); a0[2] += bf16_lo(r0.y); a0[3] += bf16_hi(r0.y);
+    a1[0] += bf16_lo(r1.x); a1[1] += bf16_hi(r1.x); a1[2] += bf16_lo(r1.y); a1[3] += bf16_hi(r1.y);
+  }
+  const unsigned x0 = pack_bf16x2(a0[0], a0[1]), y0 = pack_bf16x2(a0[2], a0[3]);
+  const unsigned x1 = pack_bf16x2(a1[0], a1[1]), y1 = pack_bf16x2(a1[2], a1[3]);
+  if constexpr (GN) {
+    const gn_bf16x2_t one = __builtin_bit_cast(gn_bf16x2_t, 0x3f803f80u);
+    if (valid[I]) {
+      const gn_bf16x2_t u = __builtin_bit_cast(gn_bf16x2_t, x0), v = __builtin_bit_cast(gn_bf16x2_t, y0);
+      gs = __builtin_amdgcn_fdot2_f32_bf16(u, one, gs, false); gs = __builtin_amdgcn_fdot2_f32_bf16(v, one, gs, false);
+      gq = __builtin_amdgcn_fdot2_f32_bf16(u, u, gq, false);   gq = __builtin_amdgcn_fdot2_f32_bf16(v, v, gq, false);
+    }
+    if (valid[I + 1]) {
+      const gn_bf16x2_t u = __builtin_bit_cast(gn_bf16x2_t, x1), v = __builtin_bit_cast(gn_bf16x2_t, y1);
+      gs = __builtin_amdgcn_fdot2_f32_bf16(u, one, gs, false); gs = __builtin_amdgcn_fdot2_f32_bf16(v, one, gs, false);
+      gq = __builtin_amdgcn_fdot2_f32_bf16(u, u, gq, false);   gq = __builtin_amdgcn_fdot2_f32_bf16(v, v, gq, false);
+    }
+  }
+  // v_permlane16_swap(tile I, tile I + 1): even lane rows end up with tile I's 8 channels 8 (q4 / 2) .., odd rows with tile I + 1's
+  auto sx = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
+  auto sy = __builtin_amdgcn_permlane16_swap(y0, y1, false, false);
+  if (svalid[I / 2]) *reinterpret_cast<uint4*>(p.out + storeoff[I / 2] + ncol) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+}
+
+template <bool RES, bool GN, int J, int... Is>
+OSK_DEV void col_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid, int n0,
+                   int n0w, int l15, int q4, float* ls, std::integer_sequence<int, Is...>) {
+  const int ncol = n0w + J * 16;          // first channel of the block (wave-uniform), n = this lane's first channel
+  const int n = ncol + q4 * 4;
+  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + n);
+  float gs = 0.f, gq = 0.f;
+  (pair_x<RES, GN, J, 2 * Is>(p, rowoff, valid, storeoff, svalid, n, ncol, bq, gs, gq), ...);
+  if constexpr (GN) {
+    gs = row16_sum(gs);
+    gq = row16_sum(gq);
+    if (l15 == 0) {
+      const int cpg = p.Cout / p.gn_G;
+      const int gl = n / cpg - n0 / cpg;
+      atomicAdd(ls + 2 * gl, gs);
+      atomicAdd(ls + 2 * gl + 1, gq);
+    }
+  }
+}
+
+template <bool RES, bool GN, int... Js>
+OSK_DEV void cols_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid, int n0,
+                    int n0w, int l15, int q4, float* ls, std::integer_sequence<int, Js...>) {
+  // channel blocks beyond Cout (ragged last tile column: Cout % 256 == 128) are skipped: wave-uniform
+  ((n0w + Js * 16 < p.Cout ? col_x<RES, GN, Js>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls,
+                                                 std::make_integer_sequence<int, OSKX_NB / 2>{})
+                            : (void)0), ...);
+}
+
+// generic path of one tile (any Cout, any alignment): per-element bounds checks, no statistics
+template <int T>
+OSK_DEV void tile_x_generic(const ConvParams& p, int bm, int r0w, int n0w, int l15, int q4) {
+  constexpr int J = T / OSKX_NB, I = T % OSKX_NB;
+  float acc[4];
+  read_x<T>(acc);
+  const int m = tile_row_to_voxel(p, bm, r0w + I * 16 + l15);
+  if (m >= p.M) return;
+  const int64_t roff = (int64_t)m * p.Cout;
+  const int n = n0w + J * 16 + q4 * 4;
+  for (int j = 0; j < 4 && n + j < p.Cout; ++j) {
+    float t = acc[j] + (p.bias ? p.bias[n + j] : 0.f);
+    if (p.res) t += bf16_bits_to_f32(p.res[roff + n + j]);
+    p.out[roff + n + j] = f32_to_bf16_bits(t);
+  }
+}
+template <int... Ts>
+OSK_DEV void tiles_x_generic(const ConvParams& p, int bm, int r0w, int n0w, int l15, int q4, std::integer_sequence<int, Ts...>) {
+  (tile_x_generic<Ts>(p, bm, r0w, n0w, l15, q4), ...);
+}
+
+// the whole workgroup calls this after its K loop (see epilogue_all): BN = 256 channels per workgroup tile from n0
+OSK_DEV void epilogue_all_x(const ConvParams& p, int bm, int r0w, int n0, int n0w, int l15, int q4, unsigned char* smem) {
+  constexpr int NB = OSKX_NB;
+  const bool fast = (p.Cout & 15) == 0 && ((((uintptr_t)p.out) & 15) == 0) && (!p.res || (((uintptr_t)p.res) & 7) == 0) &&
+                    (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
+  float* ls = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x;
+  int nslots = 0;
+  if (p.gn_sums) {   // conv256_gn_supported(): Cout % 32 == 0 -> the fast path
+    const int cpg = p.Cout / p.gn_G;
+    int nch = p.Cout - n0;
+    nch = nch < 256 ? nch : 256;
+    nslots = 2 * (nch / cpg);
+    if (tid < nslots) ls[tid] = 0.f;
+    __syncthreads();
+  }
+  if (n0w < p.Cout) {                      // wave tiles entirely beyond Cout have nothing to store
+    if (!fast) {
+      tiles_x_generic(p, bm, r0w, n0w, l15, q4, std::make_integer_sequence<int, NB * NB>{});
+    } else {
+      // element offsets of this lane's NB voxel rows (rows beyond M: clamped to row 0 for loads, masked for stores and
+      // statistics) and of the NB / 2 rows it STORES after the lane-row exchange (+ its 8-channel half)
+      int64_t rowoff[NB], storeoff[NB / 2];
+      bool valid[NB], svalid[NB / 2];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int m = tile_row_to_voxel(p, bm, r0w + i * 16 + l15);
+        valid[i] = m < p.M;
+        rowoff[i] = (int64_t)(valid[i] ? m : 0) * p.Cout;
+      }
+#pragma unroll
+      for (int i = 0; i < NB / 2; ++i) {
+        storeoff[i] = ((q4 & 1) ? rowoff[2 * i + 1] : rowoff[2 * i]) + (q4 >> 1) * 8;
+        svalid[i] = (q4 & 1) ? valid[2 * i + 1] : valid[2 * i];
+      }
+      constexpr auto js = std::make_integer_sequence<int, NB>{};
+      if (p.gn_sums) {
+        if (p.res) cols_x<true, true>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
+        else cols_x<false, true>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
+      } else {
+        if (p.res) cols_x<true, false>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
+        else cols_x<false, false>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
+      }
+    }
+  }
+  if (p.gn_sums) {
+    __syncthreads();
+    if (tid < nslots) {
+      const int m = tile_row_to_voxel(p, bm, 0);
+      const int b = m / (p.To * p.Ho * p.Wo);
+      atomicAdd(p.gn_sums + ((int64_t)b * p.gn_G + n0 / (p.Cout / p.gn_G)) * 2 + tid, (double)ls[tid]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256, 1) conv256x_kernel(const ConvParams p) {
+  constexpr int WT = OSKX_NB * 16, BN = 256;
+  constexpr int TABLE = OSKX_SMEM;   // the table sits behind the two stages
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q4 = lane >> 4, l15 = lane & 15;
+
+  const int nbm = (p.M + 255) / 256, nbn = (p.Cout + BN - 1) / BN;
+  const int ntiles = nbm * nbn;
+  for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {   // persistent (see conv256w_kernel)
+  const int tile = xcd_remap(it, ntiles);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int n0 = bn * BN;
+
+  build_tap_table(p, bm, tid, 1, reinterpret_cast<unsigned*>(smem + TABLE));
+  __syncthreads();
+
+  // ---- LDS-DMA side: exactly conv256w_kernel's (same LDS image)
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int srow8 = lane >> 3, spos = lane & 7;
+  const int r0 = wave * 8 + srow8;
+  const int c = spos ^ ((r0 >> 1) & 7);
+  const unsigned chk = (unsigned)(c * 16);
+  const unsigned arow0 = lds_base + TABLE + r0 * 4;
+  unsigned woff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int n = n0 + r0 + 32 * i;
+    n = n < p.Cout ? n : p.Cout - 1;
+    woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
+  }
+  // ---- fragment side: row l15 of a 16-row block, 16-byte chunk q4 (k 8 q4 .. + 7 of the sub-step's 32) under the row's swizzle key
+  const unsigned sz0 = (unsigned)((q4 ^ ((l15 >> 1) & 7)) << 4);
+  const unsigned faA0 = lds_base + (wm * WT + l15) * 128 + sz0;
+  const unsigned faW0 = lds_base + OSKX_W_BASE + (wn * WT + l15) * 128 + sz0;
+  const uint64_t xbase = rfl64((uint64_t)(uintptr_t)p.x), wbase = rfl64((uint64_t)(uintptr_t)p.w);
+  const unsigned nkt = rfl((unsigned)(p.Cin / 64)), nk = rfl((unsigned)(p.ntaps * (p.Cin / 64)));
+  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + OSKX_W_BASE + wave * 1024);
+  asm volatile(
+#include "conv256x_body.inc"
+      ::"v"(faA0), "v"(faW0), "v"(arow0), "v"(chk), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]),
+      "v"(woff[5]), "v"(woff[6]), "v"(woff[7]), "s"(xbase), "s"(wbase), "s"(nk), "s"(nkt), "s"(adst), "s"(wdst)
+      : OSKX_CONV_CLOBBERS);
+  epilogue_all_x(p, bm, wm * WT, n0, n0 + wn * WT, l15, q4, smem);
+  }   // tile loop
+}
+
 // grid of the persistent kernels: one workgroup per CU (a multiple of 8, so that the XCD remap of the tile list keeps a
 // workgroup inside one XCD's range); OSK_CONV_PERSIST=0: one workgroup per tile (A/B runs)
 int persistent_grid(int ntiles) {
@@ -544,6 +773,19 @@ int persistent_grid(int ntiles) {
     return n < 8 ? 8 : n;
   }();
   return on && ntiles > n_cu ? n_cu : ntiles;
+}
+
+int launch_x(const ConvParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int SMEM = OSKX_SMEM + 27 * 1024;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv256x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int nblk = ((p.M + 255) / 256) * ((p.Cout + 255) / 256);
+  hipLaunchKernelGGL(conv256x_kernel, dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
+  return (int)hipGetLastError();
 }
 
 int launch_w(const ConvParams& p, hipStream_t st) {
@@ -603,6 +845,10 @@ int launch_conv256(const ConvParams& p0, int variant, hipStream_t st) {
   p.brick = brick && (p.Ho % 16 == 0) && (p.Wo % 16 == 0) ? 1 : 0;
   // OSK_CONV_W4=0: the 8-wave kernel for Cout >= 256 too (A/B runs)
   static const bool w4 = [] { const char* e = getenv("OSK_CONV_W4"); return !e || atoi(e) != 0; }();
+  // the 4-wave kernel on v_mfma_f32_16x16x32_bf16 (conv256x_kernel: VAE encode + decode 64.5 -> 62.2 ms); OSK_CONV_X=0 = the
+  // 32x32x16 form (conv256w_kernel) for A/B runs
+  static const bool x16 = [] { const char* e = getenv("OSK_CONV_X"); return !e || atoi(e) != 0; }();
+  if (p.Cout >= 256 && w4 && x16) return launch_x(p, st);
   if (p.Cout >= 256) return w4 ? launch_w(p, st) : launch_one<256, true>(p, st);
   return launch_one<128, true>(p, st);
 }

@@ -1586,6 +1586,168 @@ def gen_conv_w4(c, spread=2):
     e("s_nop 15")
     return L
 
+def gen_conv_x4(c, spread=4):
+    """gen_conv_w4 (table-driven implicit-GEMM convolution, whole K axis in one call, 4 waves) on Cfg4x's compute side: 128
+    v_mfma_f32_16x16x32_bf16 per K step in two blocks of 64 (gen_x4).  Per K step: the 8 activation + 8 weight LDS-DMA pieces one
+    per `spread` shadows of the trailing block, then the loaders advance; the other block re-reads the offset table behind its
+    fragment reads for the step they now point at, and the chunk offset is added behind the end-of-step wait (this step's
+    pieces have long read their address registers)."""
+    L = []
+    e = lambda t: L.append("  " + t)
+    lab = lambda n: L.append(".Lcx_%s_%%=:" % n)
+    ref = lambda n: ".Lcx_%s_%%=" % n
+    VX = c.V0 + c.VN
+    fa = {("A", 0): CWOP["faA0"], ("W", 0): CWOP["faW0"], ("A", 1): vr(VX), ("W", 1): vr(VX + 1)}
+    VA = VX + 2                # table address of the tap being fetched
+    VR = VA + 1                # 8 raw table entries
+    VO = VR + c.NA             # 8 offsets of the step being fetched
+    NB = c.NB
+    NM = NB * NB
+
+    def reads(stage, s32, fset):
+        out = []
+        for i in range(NB):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, i), 4), fa[("A", s32)], stage * c.A_STAGE + i * 2048))
+        for j in range(NB):
+            out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, NB + j), 4), fa[("W", s32)], stage * c.W_STAGE + j * 2048))
+        return out
+
+    def mfmas(fset):
+        out = []
+        for j in range(NB):
+            for i in range(NB):
+                acc = ar((j * NB + i) * 4, 4)
+                out.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, NB + j), 4), vr(c.frag(fset, i), 4), acc))
+        return out
+
+    def dma(stage):
+        out = []
+        for i in range(c.NA):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_ADST, stage * c.A_STAGE + i * c.DMA_STRIDE),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (vr(VO + i), S_AB, S_AB + 1)))
+        for i in range(c.NW):
+            out.append(("s_add_u32 m0, s%d, %d" % (S_WDST, stage * c.W_STAGE + i * c.DMA_STRIDE),
+                        "global_load_lds_dwordx4 %s, s[%d:%d]" % (CWOP["woff%d" % i], S_WB, S_WB + 1)))
+        return out
+
+    def table_reads():
+        return ["v_add_u32_e32 %s, s%d, %s" % (vr(VA), S_TAPOFF, CWOP["arow0"])] + \
+               ["ds_read_b32 %s, %s offset:%d" % (vr(VR + i), vr(VA), i * 128) for i in range(c.NA)]
+
+    def table_adds():
+        return ["v_add_u32_e32 %s, %s, %s" % (vr(VO + i), vr(VR + i), CWOP["chk"]) for i in range(c.NA)]
+
+    def advance():     # gen_conv's: tap-major K axis, clamp at the end
+        return ["s_add_u32 s%d, s%d, 1" % (S_TMP, S_KL),
+                "s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NK),
+                "s_cselect_b32 s%d, 128, 0" % S_STEP,
+                "s_cselect_b32 s%d, s%d, s%d" % (S_KL, S_TMP, S_KL),
+                "s_cselect_b32 s%d, 1, 0" % S_TMP,
+                "s_add_u32 s%d, s%d, s%d" % (S_WB, S_WB, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_WB + 1, S_WB + 1),
+                "s_add_u32 s%d, s%d, s%d" % (S_SIT, S_SIT, S_TMP),
+                "s_cmp_ge_u32 s%d, s%d" % (S_SIT, S_NKT),
+                "s_cselect_b32 s%d, 0, s%d" % (S_SIT, S_SIT),
+                "s_cselect_b32 s%d, 1024, 0" % S_STEP,
+                "s_add_u32 s%d, s%d, s%d" % (S_TAPOFF, S_TAPOFF, S_STEP),
+                "s_lshl_b32 s%d, s%d, 7" % (S_STEP, S_SIT),
+                "s_add_u32 s%d, s%d, s%d" % (S_AB, S_XB2, S_STEP),
+                "s_addc_u32 s%d, s%d, 0" % (S_AB + 1, S_XB2 + 1)]
+
+    def plain(pieces):
+        for m0w, d in pieces:
+            e(m0w); e("s_nop 0"); e(d)
+
+    # ---- setup
+    e("s_mov_b64 s[%d:%d], %s" % (S_XB2, S_XB2 + 1, CWOP["xbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_AB, S_AB + 1, CWOP["xbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, CWOP["wbase"]))
+    e("s_mov_b32 s%d, %s" % (S_NK, CWOP["nk"]))
+    e("s_mov_b32 s%d, %s" % (S_NKT, CWOP["nkt"]))
+    e("s_mov_b32 s%d, %s" % (S_ADST, CWOP["adst"]))
+    e("s_mov_b32 s%d, %s" % (S_WDST, CWOP["wdst"]))
+    for sreg in (S_T, S_KL, S_SIT, S_TAPOFF):
+        e("s_mov_b32 s%d, 0" % sreg)
+    e("v_xor_b32_e32 %s, 64, %s" % (fa[("A", 1)], CWOP["faA0"]))
+    e("v_xor_b32_e32 %s, 64, %s" % (fa[("W", 1)], CWOP["faW0"]))
+    for r in range(c.NACC):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    for t in table_reads():
+        e(t)
+    e("s_waitcnt lgkmcnt(0)")
+    for t in table_adds():
+        e(t)
+    e("s_nop 1")
+    plain(dma(0))
+    for a in advance():
+        e(a)
+    for t in table_reads():
+        e(t)
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")     # stage 0 landed AND its DMA has consumed the offset registers
+    for t in table_adds():
+        e(t)
+    e("s_barrier")
+    e("s_nop 1")
+    plain(dma(1))
+    assert spread * (c.NA + c.NW - 1) < NM, "all pieces are issued in the trailing block: entry0 re-issues none"
+    for a in advance():
+        e(a)
+    for r in reads(0, 0, 0):
+        e(r)
+    e("s_branch %s" % ref("entry0"))
+
+    def step(cur):
+        pieces = dma(cur ^ 1)
+        slots = [[] for _ in range(2 * NM)]
+        dma_slots = [spread * j for j in range(len(pieces))]
+        e(pieces[0][0])
+        for j, (m0w, d) in enumerate(pieces):
+            slots[dma_slots[j]].append(d)
+            if j + 1 < len(pieces):
+                slots[dma_slots[j]].append(pieces[j + 1][0])
+        last = dma_slots[-1]
+        for blk, (s32, fset) in enumerate(((0, 0), (1, 1))):
+            rd = reads(cur, s32, fset)
+            free = [i for i in range(blk * NM, (blk + 1) * NM) if i not in dma_slots]
+            for i, r in enumerate(rd):
+                slots[free[i]].append(r)
+        tr = table_reads()                                     # block 1, behind its fragment reads
+        base = NM + 2 * NB
+        slots[base] += tr[:3]
+        for i in range(3, len(tr), 2):
+            slots[base + 1 + (i - 3) // 2] += tr[i: i + 2]
+        for blk in range(2):
+            if blk == 1:
+                lab("entry%d" % cur)
+                e("s_waitcnt lgkmcnt(0)")
+            mf = mfmas(1 if blk == 0 else 0)
+            for i, m in enumerate(mf):
+                e(m)
+                for x in slots[blk * NM + i]:
+                    e(x)
+                if blk * NM + i == last:
+                    for a in advance():
+                        e(a)
+
+    for k in range(2):
+        lab("step%d" % k)
+        step(k)
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        for t in table_adds():             # offsets of the step the loaders point at: this step's pieces were issued a block ago
+            e(t)
+        e("s_barrier")
+        e("s_add_u32 s%d, s%d, 1" % (S_T, S_T))
+        e("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NK))
+        e("s_cbranch_scc0 %s" % ref("exit"))
+        if k == 1:
+            e("s_branch %s" % ref("step0"))
+    lab("exit")
+    for m in mfmas(1):
+        e(m)
+    e("s_nop 15")
+    e("s_nop 15")
+    return L
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -1677,12 +1839,19 @@ def main():
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, persistent workgroup.\n")
         for ln in gen_x4(cx):
             f.write('"%s\\n"\n' % ln)
+    with open(os.path.join(args.out, "conv256x_body.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, whole K axis (all filter taps).\n")
+        for ln in gen_conv_x4(cx):
+            f.write('"%s\\n"\n' % ln)
     with open(os.path.join(args.out, "gemm256x_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
         f.write("#define OSKX_SMEM %d\n#define OSKX_W_BASE %d\n#define OSKX_NB %d\n" % (cx.SMEM, cx.W_BASE, cx.NB))
         clob = ['"v%d"' % i for i in range(cx.V0, cx.V0 + cx.VN + 2)] + ['"a%d"' % i for i in range(cx.NACC)] + \
                ['"s%d"' % i for i in range(S_FIRST, W4_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
         f.write("#define OSKX_CLOBBERS %s\n" % ", ".join(clob))
+        cclob = ['"v%d"' % i for i in range(cx.V0, cx.V0 + cx.VN + 2 + 1 + 2 * cx.NA)] + ['"a%d"' % i for i in range(cx.NACC)] + \
+                ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+        f.write("#define OSKX_CONV_CLOBBERS %s\n" % ", ".join(cclob))
         for t in range(cx.NB * cx.NB):
             f.write("#define OSKX_AR%d %s\n" % (t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 4 + i) for i in range(4))))
     for bn in (256, 128):
