@@ -219,9 +219,9 @@ def bench_vae(args, dev):
                    "flops_encode": enc_f, "flops_decode": dec_f},
         "step_tflops": round((enc_f + dec_f) / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round((enc_f + dec_f) / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        # all conv launches of one encode + decode: conv3d_256.hip where Cin % 128 == 0 (conv256w_kernel for Cout >= 256,
-        # conv256t_kernel<128> for Cout = 128), conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers
-        "roofline": {"bound": "mfma", "kernel": "conv256w_kernel + conv256t_kernel + conv3d_kernel (by layer shape)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+        # all conv launches of one encode + decode: conv3d_256.hip where Cin % 128 == 0 (conv256x_kernel<8> for Cout >= 256,
+        # conv256x_kernel<4> for Cout = 128), conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers
+        "roofline": {"bound": "mfma", "kernel": "conv256x_kernel + conv3d_kernel (by layer shape)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_source": traffic_src,
                      "launches": len(prof) // args.steps, "total_conv_ms_per_step": round(conv_ms, 3)},

@@ -657,9 +657,11 @@ OSK_DEV void tiles_x_generic(const ConvParams& p, int bm, int r0w, int n0w, int 
   (tile_x_generic<Ts>(p, bm, r0w, n0w, l15, q4), ...);
 }
 
-// the whole workgroup calls this after its K loop (see epilogue_all): BN = 256 channels per workgroup tile from n0
+// the whole workgroup calls this after its K loop (see epilogue_all): NBJ = 16-channel blocks per wave (8: 256 channels per
+// workgroup tile from n0, 4: 128)
+template <int NBJ>
 OSK_DEV void epilogue_all_x(const ConvParams& p, int bm, int r0w, int n0, int n0w, int l15, int q4, unsigned char* smem) {
-  constexpr int NB = OSKX_NB;
+  constexpr int NB = OSKX_NB, BN = 32 * NBJ;
   const bool fast = (p.Cout & 15) == 0 && ((((uintptr_t)p.out) & 15) == 0) && (!p.res || (((uintptr_t)p.res) & 7) == 0) &&
                     (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
   float* ls = reinterpret_cast<float*>(smem);
@@ -668,14 +670,14 @@ OSK_DEV void epilogue_all_x(const ConvParams& p, int bm, int r0w, int n0, int n0
   if (p.gn_sums) {   // conv256_gn_supported(): Cout % 32 == 0 -> the fast path
     const int cpg = p.Cout / p.gn_G;
     int nch = p.Cout - n0;
-    nch = nch < 256 ? nch : 256;
+    nch = nch < BN ? nch : BN;
     nslots = 2 * (nch / cpg);
     if (tid < nslots) ls[tid] = 0.f;
     __syncthreads();
   }
   if (n0w < p.Cout) {                      // wave tiles entirely beyond Cout have nothing to store
     if (!fast) {
-      tiles_x_generic(p, bm, r0w, n0w, l15, q4, std::make_integer_sequence<int, NB * NB>{});
+      tiles_x_generic(p, bm, r0w, n0w, l15, q4, std::make_integer_sequence<int, NB * NBJ>{});
     } else {
       // element offsets of this lane's NB voxel rows (rows beyond M: clamped to row 0 for loads, masked for stores and
       // statistics) and of the NB / 2 rows it STORES after the lane-row exchange (+ its 8-channel half)
@@ -692,7 +694,7 @@ OSK_DEV void epilogue_all_x(const ConvParams& p, int bm, int r0w, int n0, int n0
         storeoff[i] = ((q4 & 1) ? rowoff[2 * i + 1] : rowoff[2 * i]) + (q4 >> 1) * 8;
         svalid[i] = (q4 & 1) ? valid[2 * i + 1] : valid[2 * i];
       }
-      constexpr auto js = std::make_integer_sequence<int, NB>{};
+      constexpr auto js = std::make_integer_sequence<int, NBJ>{};
       if (p.gn_sums) {
         if (p.res) cols_x<true, true>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
         else cols_x<false, true>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
@@ -712,9 +714,10 @@ OSK_DEV void epilogue_all_x(const ConvParams& p, int bm, int r0w, int n0, int n0
   }
 }
 
+template <int NBJ>
 __global__ void __launch_bounds__(256, 1) conv256x_kernel(const ConvParams p) {
-  constexpr int WT = OSKX_NB * 16, BN = 256;
-  constexpr int TABLE = OSKX_SMEM;   // the table sits behind the two stages
+  constexpr int WT = OSKX_NB * 16, WTN = NBJ * 16, BN = 32 * NBJ;        // wave tile WT voxels x WTN channels, 2 x 2 waves
+  constexpr int TABLE = NBJ == 8 ? OSKX_SMEM : OSKX128_SMEM;             // the table sits behind the two stages
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -739,26 +742,33 @@ __global__ void __launch_bounds__(256, 1) conv256x_kernel(const ConvParams p) {
   const int c = spos ^ ((r0 >> 1) & 7);
   const unsigned chk = (unsigned)(c * 16);
   const unsigned arow0 = lds_base + TABLE + r0 * 4;
-  unsigned woff[8];
+  unsigned woff[8];                        // NBJ LDS-DMA pieces per wave cover the BN weight rows (slots beyond NBJ: unused copies)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    int n = n0 + r0 + 32 * i;
+    int n = n0 + r0 + 32 * (i & (NBJ - 1));
     n = n < p.Cout ? n : p.Cout - 1;
     woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
   }
   // ---- fragment side: row l15 of a 16-row block, 16-byte chunk q4 (k 8 q4 .. + 7 of the sub-step's 32) under the row's swizzle key
   const unsigned sz0 = (unsigned)((q4 ^ ((l15 >> 1) & 7)) << 4);
   const unsigned faA0 = lds_base + (wm * WT + l15) * 128 + sz0;
-  const unsigned faW0 = lds_base + OSKX_W_BASE + (wn * WT + l15) * 128 + sz0;
+  const unsigned faW0 = lds_base + OSKX_W_BASE + (wn * WTN + l15) * 128 + sz0;
   const uint64_t xbase = rfl64((uint64_t)(uintptr_t)p.x), wbase = rfl64((uint64_t)(uintptr_t)p.w);
   const unsigned nkt = rfl((unsigned)(p.Cin / 64)), nk = rfl((unsigned)(p.ntaps * (p.Cin / 64)));
   const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + OSKX_W_BASE + wave * 1024);
-  asm volatile(
-#include "conv256x_body.inc"
-      ::"v"(faA0), "v"(faW0), "v"(arow0), "v"(chk), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]),
+#define OSKCX_OPERANDS                                                                                               \
+  ::"v"(faA0), "v"(faW0), "v"(arow0), "v"(chk), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]), \
       "v"(woff[5]), "v"(woff[6]), "v"(woff[7]), "s"(xbase), "s"(wbase), "s"(nk), "s"(nkt), "s"(adst), "s"(wdst)
-      : OSKX_CONV_CLOBBERS);
-  epilogue_all_x(p, bm, wm * WT, n0, n0 + wn * WT, l15, q4, smem);
+  if constexpr (NBJ == 8) {
+    asm volatile(
+#include "conv256x_body.inc"
+        OSKCX_OPERANDS : OSKX_CONV_CLOBBERS);
+  } else {
+    asm volatile(
+#include "conv256x_body_n128.inc"
+        OSKCX_OPERANDS : OSKX128_CONV_CLOBBERS);
+  }
+  epilogue_all_x<NBJ>(p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
   }   // tile loop
 }
 
@@ -775,16 +785,17 @@ int persistent_grid(int ntiles) {
   return on && ntiles > n_cu ? n_cu : ntiles;
 }
 
+template <int NBJ>
 int launch_x(const ConvParams& p, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int SMEM = OSKX_SMEM + 27 * 1024;
+  constexpr int BN = 32 * NBJ, SMEM = (NBJ == 8 ? OSKX_SMEM : OSKX128_SMEM) + 27 * 1024;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv256x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv256x_kernel<NBJ>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int nblk = ((p.M + 255) / 256) * ((p.Cout + 255) / 256);
-  hipLaunchKernelGGL(conv256x_kernel, dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
+  const int nblk = ((p.M + 255) / 256) * ((p.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL(conv256x_kernel<NBJ>, dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
   return (int)hipGetLastError();
 }
 
@@ -848,7 +859,11 @@ int launch_conv256(const ConvParams& p0, int variant, hipStream_t st) {
   // the 4-wave kernel on v_mfma_f32_16x16x32_bf16 (conv256x_kernel: VAE encode + decode 64.5 -> 62.2 ms); OSK_CONV_X=0 = the
   // 32x32x16 form (conv256w_kernel) for A/B runs
   static const bool x16 = [] { const char* e = getenv("OSK_CONV_X"); return !e || atoi(e) != 0; }();
-  if (p.Cout >= 256 && w4 && x16) return launch_x(p, st);
+  if (p.Cout >= 256 && w4 && x16) return launch_x<8>(p, st);
+  // Cout < 256: the 4-wave 256 x 128 tile of the same kernel (VAE encode + decode 62.8 -> 61.6 ms); OSK_CONV_X128=0 = the 8-wave
+  // conv256t_kernel<128> for A/B runs
+  static const bool x128 = [] { const char* e = getenv("OSK_CONV_X128"); return !e || atoi(e) != 0; }();
+  if (p.Cout < 256 && x128) return launch_x<4>(p, st);
   if (p.Cout >= 256) return w4 ? launch_w(p, st) : launch_one<256, true>(p, st);
   return launch_one<128, true>(p, st);
 }

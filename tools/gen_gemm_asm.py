@@ -792,20 +792,21 @@ class Cfg4x:
     the same flops as 16x16x32 instead of 32x32x16 MFMAs is worth +5-7 % at the board's power cap (4 accumulator registers
     written per 16 matrix cycles instead of 16 per 32)."""
 
-    def __init__(self):
-        self.BN = 256
-        self.NB = 8                             # 16-row / 16-column blocks per wave tile side
-        self.NA, self.NW = 8, 8
+    def __init__(self, nbj=8):
+        self.NB = 8                             # 16-row blocks per wave tile (128 rows)
+        self.NBJ = nbj                          # 16-column blocks per wave tile: 8 (256-wide workgroup tile) or 4 (128-wide)
+        self.BN = 32 * nbj
+        self.NA, self.NW = 8, nbj
         self.DMA_STRIDE = 4096
-        self.A_STAGE, self.W_STAGE = 32768, 32768
+        self.A_STAGE, self.W_STAGE = 32768, 4096 * nbj
         self.W_BASE = 65536
         self.SMEM = self.W_BASE + 2 * self.W_STAGE
-        self.NACC = 256
-        self.NFRAG = 16                         # 8 activation + 8 weight fragments per sub-step
+        self.NACC = 32 * nbj
+        self.NFRAG = 8 + nbj                    # activation + weight fragments per sub-step
         self.FW = 4
-        self.V0 = 96                            # asm-owned VGPRs: v96.. (two fragment sets = 128, then 2 addresses)
+        self.V0 = 96                            # asm-owned VGPRs: v96.. (two fragment sets, then the address registers)
         self.VN = 2 * self.NFRAG * self.FW
-        self.tag = "x256"
+        self.tag = "x%d" % self.BN
 
     def frag(self, fset, idx):
         return self.V0 + (fset * self.NFRAG + idx) * self.FW
@@ -1594,27 +1595,27 @@ def gen_conv_x4(c, spread=4):
     pieces have long read their address registers)."""
     L = []
     e = lambda t: L.append("  " + t)
-    lab = lambda n: L.append(".Lcx_%s_%%=:" % n)
-    ref = lambda n: ".Lcx_%s_%%=" % n
+    lab = lambda n: L.append(".Lc%s_%s_%%=:" % (c.tag, n))
+    ref = lambda n: ".Lc%s_%s_%%=" % (c.tag, n)
     VX = c.V0 + c.VN
     fa = {("A", 0): CWOP["faA0"], ("W", 0): CWOP["faW0"], ("A", 1): vr(VX), ("W", 1): vr(VX + 1)}
     VA = VX + 2                # table address of the tap being fetched
     VR = VA + 1                # 8 raw table entries
     VO = VR + c.NA             # 8 offsets of the step being fetched
-    NB = c.NB
-    NM = NB * NB
+    NB, NBJ = c.NB, c.NBJ
+    NM = NB * NBJ
 
     def reads(stage, s32, fset):
         out = []
         for i in range(NB):
             out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, i), 4), fa[("A", s32)], stage * c.A_STAGE + i * 2048))
-        for j in range(NB):
+        for j in range(NBJ):
             out.append("ds_read_b128 %s, %s offset:%d" % (vr(c.frag(fset, NB + j), 4), fa[("W", s32)], stage * c.W_STAGE + j * 2048))
         return out
 
     def mfmas(fset):
         out = []
-        for j in range(NB):
+        for j in range(NBJ):
             for i in range(NB):
                 acc = ar((j * NB + i) * 4, 4)
                 out.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc, vr(c.frag(fset, NB + j), 4), vr(c.frag(fset, i), 4), acc))
@@ -1689,9 +1690,12 @@ def gen_conv_x4(c, spread=4):
     e("s_barrier")
     e("s_nop 1")
     plain(dma(1))
-    assert spread * (c.NA + c.NW - 1) < NM, "all pieces are issued in the trailing block: entry0 re-issues none"
-    for a in advance():
-        e(a)
+    first_entry_piece = (NM + spread - 1) // spread
+    if first_entry_piece >= c.NA + c.NW:       # every piece is issued in the trailing block: entry0 re-issues none
+        for a in advance():
+            e(a)
+    else:                                      # entry0 re-issues the pieces whose shadows lie behind it (same step, same offsets,
+        e(dma(1)[first_entry_piece][0])        # same data: the activation offsets are still this step's), then advances
     for r in reads(0, 0, 0):
         e(r)
     e("s_branch %s" % ref("entry0"))
@@ -1711,8 +1715,10 @@ def gen_conv_x4(c, spread=4):
             free = [i for i in range(blk * NM, (blk + 1) * NM) if i not in dma_slots]
             for i, r in enumerate(rd):
                 slots[free[i]].append(r)
-        tr = table_reads()                                     # block 1, behind its fragment reads
-        base = NM + 2 * NB
+        tr = table_reads()                                     # block 1, behind its fragment reads and the loaders' advance
+        used = [i for i in range(NM, 2 * NM) if slots[i]]
+        base = max(used[-1], last) + 1
+        assert base + 4 < 2 * NM
         slots[base] += tr[:3]
         for i in range(3, len(tr), 2):
             slots[base + 1 + (i - 3) // 2] += tr[i: i + 2]
@@ -1843,8 +1849,16 @@ def main():
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, whole K axis (all filter taps).\n")
         for ln in gen_conv_x4(cx):
             f.write('"%s\\n"\n' % ln)
+    cx128 = Cfg4x(4)
+    with open(os.path.join(args.out, "conv256x_body_n128.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 128 x 64 tile, 4 waves x (128 x 64) on v_mfma_f32_16x16x32_bf16, whole K axis (all filter taps).\n")
+        for ln in gen_conv_x4(cx128):
+            f.write('"%s\\n"\n' % ln)
     with open(os.path.join(args.out, "gemm256x_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
+        cclob = ['"v%d"' % i for i in range(cx128.V0, cx128.V0 + cx128.VN + 2 + 1 + 2 * cx128.NA)] + ['"a%d"' % i for i in range(cx128.NACC)] + \
+                ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+        f.write("#define OSKX128_SMEM %d\n#define OSKX128_CONV_CLOBBERS %s\n" % (cx128.SMEM, ", ".join(cclob)))
         f.write("#define OSKX_SMEM %d\n#define OSKX_W_BASE %d\n#define OSKX_NB %d\n" % (cx.SMEM, cx.W_BASE, cx.NB))
         clob = ['"v%d"' % i for i in range(cx.V0, cx.V0 + cx.VN + 2)] + ['"a%d"' % i for i in range(cx.NACC)] + \
                ['"s%d"' % i for i in range(S_FIRST, W4_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']

@@ -21,7 +21,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/*/*counter_collection.csv")):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        key = next((k for k in ("conv256w_kernel", "conv256t_kernel", "conv256_kernel", "conv3d_kernel", "gemm256w_kernel", "gemm256p_kernel",
+        key = next((k for k in ("conv256x_kernel", "conv256w_kernel", "conv256t_kernel", "gemm256x_kernel", "conv256_kernel", "conv3d_kernel", "gemm256w_kernel", "gemm256p_kernel",
                                 "gemm256_kernel", "gemm_bf16_kernel", "attn_asm72_kernel", "attn_hd512_kernel", "gn_stats",
                                 "gn_apply", "qknorm_rope", "ln_modulate", "v_transpose") if k in n), None)
         if key:
