@@ -82,7 +82,12 @@ def _worker(rank, world, port, name, geom, q, mode, fp8):
             assert model._sp is not None and sp.P == world
             outs = [model(**inp).float().cpu() for _ in range(2)]
             seqpar.disable(model)
-        assert torch.equal(outs[0], outs[1]), "sequence-parallel forward is not repeatable"
+        if not torch.equal(outs[0], outs[1]):
+            d = (outs[0] - outs[1]).abs()
+            bad = (d > 0).nonzero()
+            raise AssertionError(f"sequence-parallel forward is not repeatable: {int((d > 0).sum())} of {d.numel()} elements differ, "
+                                 f"max |diff| {float(d.max()):.3e} (max |out| {float(outs[0].abs().max()):.3e}), first at {bad[0].tolist()}, "
+                                 f"last at {bad[-1].tolist()}, finite {bool(torch.isfinite(outs[1]).all())}")
         q.put((rank, single.numpy(), outs[0].numpy()))
     except BaseException:
         import traceback
