@@ -606,34 +606,51 @@ OSK_DEV void pair_x(const ConvParams& p, const int64_t* rowoff, const bool* vali
   if (svalid[I / 2]) *reinterpret_cast<uint4*>(p.out + storeoff[I / 2] + ncol) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
 }
 
-template <bool RES, bool GN, int J, int... Is>
-OSK_DEV void col_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid, int n0,
-                   int n0w, int l15, int q4, float* ls, std::integer_sequence<int, Is...>) {
-  const int ncol = n0w + J * 16;          // first channel of the block (wave-uniform), n = this lane's first channel
-  const int n = ncol + q4 * 4;
-  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + n);
-  float gs = 0.f, gq = 0.f;
-  (pair_x<RES, GN, J, 2 * Is>(p, rowoff, valid, storeoff, svalid, n, ncol, bq, gs, gq), ...);
+// all channel blocks J of one pair of voxel blocks, back to back: consecutive stores fill a voxel row's 32-byte pieces left to
+// right (with the channel block outermost the pieces of one 64-byte sector left four stores apart: +30 % fabric-side writes).
+// FULL: every channel block of the wave tile lies inside Cout (no per-block test)
+template <bool RES, bool GN, bool FULL, int I, int... Js>
+OSK_DEV void rowpair_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid,
+                       int n0w, int q4, const float4* bq, float* gs, float* gq, std::integer_sequence<int, Js...>) {
+  ((FULL || n0w + Js * 16 < p.Cout
+        ? pair_x<RES, GN, Js, I>(p, rowoff, valid, storeoff, svalid, n0w + Js * 16 + q4 * 4, n0w + Js * 16, bq[Js], gs[Js], gq[Js])
+        : (void)0), ...);
+}
+
+template <bool RES, bool GN, bool FULL, int NBJ, int... Is>
+OSK_DEV void tile_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid, int n0,
+                    int n0w, int l15, int q4, float* ls, std::integer_sequence<int, Is...>) {
+  float4 bq[NBJ];
+  float gs[NBJ], gq[NBJ];
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) {
+    bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gs[j] = gq[j] = 0.f;
+    const int n = n0w + j * 16 + q4 * 4;
+    if (p.bias && (FULL || n < p.Cout)) bq[j] = *reinterpret_cast<const float4*>(p.bias + n);
+  }
+  (rowpair_x<RES, GN, FULL, 2 * Is>(p, rowoff, valid, storeoff, svalid, n0w, q4, bq, gs, gq, std::make_integer_sequence<int, NBJ>{}), ...);
   if constexpr (GN) {
-    gs = row16_sum(gs);
-    gq = row16_sum(gq);
-    if (l15 == 0) {
-      const int cpg = p.Cout / p.gn_G;
-      const int gl = n / cpg - n0 / cpg;
-      atomicAdd(ls + 2 * gl, gs);
-      atomicAdd(ls + 2 * gl + 1, gq);
+    const int cpg = p.Cout / p.gn_G;
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      const int n = n0w + j * 16 + q4 * 4;
+      const float s = row16_sum(gs[j]), q = row16_sum(gq[j]);
+      if (l15 == 0 && (FULL || n < p.Cout)) {
+        const int gl = n / cpg - n0 / cpg;
+        atomicAdd(ls + 2 * gl, s);
+        atomicAdd(ls + 2 * gl + 1, q);
+      }
     }
   }
 }
 
-template <bool RES, bool GN, int... Js>
+template <bool RES, bool GN, int NBJ>
 OSK_DEV void cols_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid, int n0,
-                    int n0w, int l15, int q4, float* ls, std::integer_sequence<int, Js...>) {
-  // channel blocks beyond Cout (ragged last tile column: Cout % 256 == 128) are skipped: wave-uniform
-  ((n0w + Js * 16 < p.Cout ? col_x<RES, GN, Js>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls,
-                                                 std::make_integer_sequence<int, OSKX_NB / 2>{})
-                            : (void)0), ...);
+                    int n0w, int l15, int q4, float* ls) {
+  constexpr auto seq = std::make_integer_sequence<int, OSKX_NB / 2>{};
+  if (n0w + NBJ * 16 <= p.Cout) tile_x<RES, GN, true, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, seq);
+  else tile_x<RES, GN, false, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, seq);   // ragged last tile column
 }
 
 // generic path of one tile (any Cout, any alignment): per-element bounds checks, no statistics
@@ -694,13 +711,12 @@ OSK_DEV void epilogue_all_x(const ConvParams& p, int bm, int r0w, int n0, int n0
         storeoff[i] = ((q4 & 1) ? rowoff[2 * i + 1] : rowoff[2 * i]) + (q4 >> 1) * 8;
         svalid[i] = (q4 & 1) ? valid[2 * i + 1] : valid[2 * i];
       }
-      constexpr auto js = std::make_integer_sequence<int, NBJ>{};
       if (p.gn_sums) {
-        if (p.res) cols_x<true, true>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
-        else cols_x<false, true>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
+        if (p.res) cols_x<true, true, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
+        else cols_x<false, true, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
       } else {
-        if (p.res) cols_x<true, false>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
-        else cols_x<false, false>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, js);
+        if (p.res) cols_x<true, false, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
+        else cols_x<false, false, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
       }
     }
   }

@@ -84,27 +84,34 @@ OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, b
   }
 }
 
-template <class Geo, bool OUT_F32, bool GATE, int GELU, int J, int... Is>
-OSK_DEV void col_pairs(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4& gq,
-                       std::integer_sequence<int, Is...>) {
-  (pair_interior<Geo, OUT_F32, GATE, GELU, J, 2 * Is>(p, rowoff, storeoff, n0w, q4, gq), ...);   // Is = 0 .. NB/2 - 1
+// all column blocks J of one pair of row blocks, back to back: consecutive stores fill a row's 32-byte pieces left to right
+// (with the column block outermost, the pieces of one 64-byte sector left four stores apart: +20 % fabric-side write traffic)
+template <class Geo, bool OUT_F32, bool GATE, int GELU, int I, int... Js>
+OSK_DEV void row_pair(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4* gq,
+                      std::integer_sequence<int, Js...>) {
+  (pair_interior<Geo, OUT_F32, GATE, GELU, Js, I>(p, rowoff, storeoff, n0w, q4, gq[Js]), ...);
 }
 
-template <class Geo, bool OUT_F32, bool GATE, int J>
-OSK_DEV void col_block(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int m0w, int n0w, int q4) {
-  constexpr auto seq = std::make_integer_sequence<int, Geo::NB / 2>{};
-  const int nf = n0w + J * 16;            // wave-uniform: GELU for none / all / some of this block's 16 columns
-  float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (GATE) gq = *reinterpret_cast<const float4*>(p.gate + (m0w / p.crpb) * p.gbs + nf + q4 * 4);   // one batch per interior wave tile
-  if (nf + 16 <= p.gelu_from) col_pairs<Geo, OUT_F32, GATE, GELU_NONE, J>(p, rowoff, storeoff, n0w, q4, gq, seq);
-  else if (nf >= p.gelu_from) col_pairs<Geo, OUT_F32, GATE, GELU_ALL, J>(p, rowoff, storeoff, n0w, q4, gq, seq);
-  else col_pairs<Geo, OUT_F32, GATE, GELU_MIXED, J>(p, rowoff, storeoff, n0w, q4, gq, seq);
+template <class Geo, bool OUT_F32, bool GATE, int GELU, int... Is>
+OSK_DEV void tile_interior(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4* gq,
+                           std::integer_sequence<int, Is...>) {
+  (row_pair<Geo, OUT_F32, GATE, GELU, 2 * Is>(p, rowoff, storeoff, n0w, q4, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
 }
 
-template <class Geo, bool OUT_F32, bool GATE, int... Js>
-OSK_DEV void cols_interior(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int m0w, int n0w, int q4,
-                           std::integer_sequence<int, Js...>) {
-  (col_block<Geo, OUT_F32, GATE, Js>(p, rowoff, storeoff, m0w, n0w, q4), ...);
+template <class Geo, bool OUT_F32, bool GATE>
+OSK_DEV void cols_interior(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int m0w, int n0w, int q4) {
+  constexpr int NB = Geo::NB;
+  constexpr auto seq = std::make_integer_sequence<int, NB / 2>{};
+  float4 gq[NB];                          // gate of this lane's 4 channels of every column block (one batch per interior wave tile)
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    gq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (GATE) gq[j] = *reinterpret_cast<const float4*>(p.gate + (m0w / p.crpb) * p.gbs + n0w + j * 16 + q4 * 4);
+  }
+  // GELU class of the whole wave tile (wave-uniform): none / all / per element where the boundary cuts through it
+  if (n0w + NB * 16 <= p.gelu_from) tile_interior<Geo, OUT_F32, GATE, GELU_NONE>(p, rowoff, storeoff, n0w, q4, gq, seq);
+  else if (n0w >= p.gelu_from) tile_interior<Geo, OUT_F32, GATE, GELU_ALL>(p, rowoff, storeoff, n0w, q4, gq, seq);
+  else tile_interior<Geo, OUT_F32, GATE, GELU_MIXED>(p, rowoff, storeoff, n0w, q4, gq, seq);
 }
 
 template <class Geo, bool OUT_F32, int... Ts>
@@ -131,9 +138,8 @@ OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l15, int q4
   for (int i = 0; i < NB; ++i) rowoff[i] = b * p.cbs + (int64_t)(l0 + 16 * i) * p.crs;
 #pragma unroll
   for (int i = 0; i < NB / 2; ++i) storeoff[i] = ((q4 & 1) ? rowoff[2 * i + 1] : rowoff[2 * i]) + (q4 >> 1) * 8;
-  constexpr auto js = std::make_integer_sequence<int, NB>{};
-  if (p.gate) cols_interior<Geo, OUT_F32, true>(p, rowoff, storeoff, m0w, n0w, q4, js);
-  else cols_interior<Geo, OUT_F32, false>(p, rowoff, storeoff, m0w, n0w, q4, js);
+  if (p.gate) cols_interior<Geo, OUT_F32, true>(p, rowoff, storeoff, m0w, n0w, q4);
+  else cols_interior<Geo, OUT_F32, false>(p, rowoff, storeoff, m0w, n0w, q4);
 }
 
 }  // namespace epi16
