@@ -11,7 +11,7 @@
 // K loop: tools/gen_gemm_asm.py::gen_w4.  What round 2's counters say bounds it (profiles/r02_gemm_experiments.md): an LDS-DMA
 // instruction holds the wave's issue port far longer than an MFMA shadow (the guide: 60-185 cycles), so 16 of them in 16
 // consecutive shadows idle the matrix pipe behind each one; ONE PIECE PER TWO SHADOWS over the trailing sub-step and
-// sub-step 0 (gemm256w_body_spread2.inc, the default) gives +4..10 % -- the vendor kernel gets the same spacing from a
+// sub-step 0 (gemm256w_body_spread2.inc) gives +4..10 % -- the vendor kernel gets the same spacing from a
 // deeper pipeline (three barriers per K step).
 //
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 2*M*N*K.
@@ -52,8 +52,7 @@ struct GeoW {
   }
 };
 
-// PF: which generated K loop (see launch_gemm256w): 3 = one LDS-DMA piece per two MFMA shadows (the default)
-template <bool OUT_F32, int PF>
+template <bool OUT_F32>
 __global__ void __launch_bounds__(256, 1) gemm256w_kernel(const GemmParams p) {
   constexpr int TM = OSKW_TM, TN = OSKW_TN, BN = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -147,31 +146,9 @@ __global__ void __launch_bounds__(256, 1) gemm256w_kernel(const GemmParams p) {
       "v"(aoff[6]), "v"(aoff[7]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]), "v"(woff[5]),  \
       "v"(woff[6]), "v"(woff[7]), "v"(boff), "s"(abase), "s"(wbase), "s"(bbase), "s"(nk), "s"(adst), "s"(wdst),        \
       "s"(flags), "s"(dAs), "s"(dWs), "v"(aoffp), "v"(woffp)
-    if constexpr (PF == 1) {
-      asm volatile(
-#include "gemm256w_body_pf1.inc"
-          OSKW_OPERANDS : OSKW_CLOBBERS);
-    } else if constexpr (PF == 2) {
-      asm volatile(
-#include "gemm256w_body_buf.inc"
-          OSKW_OPERANDS : OSKW_CLOBBERS);
-    } else if constexpr (PF == 3) {
-      asm volatile(
+    asm volatile(
 #include "gemm256w_body_spread2.inc"
-          OSKW_OPERANDS : OSKW_CLOBBERS);
-    } else if constexpr (PF == 4) {
-      asm volatile(
-#include "gemm256w_body_spread3.inc"
-          OSKW_OPERANDS : OSKW_CLOBBERS);
-    } else if constexpr (PF == 5) {
-      asm volatile(
-#include "gemm256w_body_spread2r1.inc"
-          OSKW_OPERANDS : OSKW_CLOBBERS);
-    } else {
-      asm volatile(
-#include "gemm256w_body_pf0.inc"
-          OSKW_OPERANDS : OSKW_CLOBBERS);
-    }
+        OSKW_OPERANDS : OSKW_CLOBBERS);
 
     const int b_first = m0w / p.crpb, b_last = (m0w + TM * 32 - 1) / p.crpb;
     const bool interior = m0w + TM * 32 <= p.M && n0w + TN * 32 <= p.N && b_first == b_last;  // wave-uniform
@@ -180,11 +157,11 @@ __global__ void __launch_bounds__(256, 1) gemm256w_kernel(const GemmParams p) {
   }
 }
 
-template <bool OUT_F32, int PF>
+template <bool OUT_F32>
 int launch_one(const GemmParams& p, hipStream_t st) {
   static bool attr_set = false;
   static int n_cu = 0;
-  auto kernel = gemm256w_kernel<OUT_F32, PF>;
+  auto kernel = gemm256w_kernel<OUT_F32>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OSKW_SMEM);
     if (e != hipSuccess) return (int)e;
@@ -204,19 +181,9 @@ int launch_one(const GemmParams& p, hipStream_t st) {
 }  // namespace
 
 int launch_gemm256w(const GemmParams& p, int out_f32, hipStream_t st) {
-  // OSK_GEMM_PF selects the generated K loop (A/B runs; measurements in profiles/r02_gemm_experiments.md):
-  //   3 (default) one LDS-DMA piece per 2 MFMA shadows   0 one per shadow in 16 consecutive shadows (-4..10 %)
-  //   4 one per 3 shadows (the last pieces land late: worse at 8192^3)   5 = 3 with one fragment read per shadow (same)
-  //   1 = 0 + L2 software prefetch (-6 %)   2 = 0 with buffer_load ... lds instead of global_load_lds (same)
-  static const int pf = [] { const char* e = getenv("OSK_GEMM_PF"); return e ? atoi(e) : 3; }();
-  switch (pf) {
-    case 0: return out_f32 ? launch_one<true, 0>(p, st) : launch_one<false, 0>(p, st);
-    case 1: return out_f32 ? launch_one<true, 1>(p, st) : launch_one<false, 1>(p, st);
-    case 2: return out_f32 ? launch_one<true, 2>(p, st) : launch_one<false, 2>(p, st);
-    case 4: return out_f32 ? launch_one<true, 4>(p, st) : launch_one<false, 4>(p, st);
-    case 5: return out_f32 ? launch_one<true, 5>(p, st) : launch_one<false, 5>(p, st);
-    default: return out_f32 ? launch_one<true, 3>(p, st) : launch_one<false, 3>(p, st);
-  }
+  // one generated K loop: LDS-DMA one piece per 2 MFMA shadows.  The other schedules of round 2 (one per shadow -4..10 %, one per 3
+  // shadows, buffer_load ... lds, L2 software prefetch -6 %) are in profiles/r02_gemm_experiments.md and tools/gen_gemm_asm.py.
+  return out_f32 ? launch_one<true>(p, st) : launch_one<false>(p, st);
 }
 
 }  // namespace osk_gemm

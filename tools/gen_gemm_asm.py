@@ -1806,25 +1806,12 @@ def main():
                 f.write("// GENERATED by tools/gen_gemm_asm.py --ablations -- timing experiment, WRONG RESULTS.\n")
                 for ln in gen_w4(c, 0, abl, 0, 2):
                     f.write('"%s\\n"\n' % ln)
-    with open(os.path.join(args.out, "gemm256w_body_spread2r1.inc"), "w") as f:
-        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, one LDS-DMA piece per 2 MFMA shadows, one fragment read per shadow.\n")
-        for ln in gen_w4(c, 0, 0, 0, 2, 1):
+    # the 4-wave 32x32x16 kernel ships ONE body (LDS-DMA one piece per 2 shadows); the other schedules measured in round 2
+    # are generator options kept for experiments: gen_w4(c, pf=1) L2 prefetch, dmak=1 buffer_load ... lds, spread=1 / 3, rd_per=1
+    with open(os.path.join(args.out, "gemm256w_body_spread2.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, one LDS-DMA piece per 2 MFMA shadows.\n")
+        for ln in gen_w4(c, 0, 0, 0, 2):
             f.write('"%s\\n"\n' % ln)
-    for sp in (2, 3):
-        with open(os.path.join(args.out, "gemm256w_body_spread%d.inc" % sp), "w") as f:
-            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, one LDS-DMA piece per %d MFMA shadows.\n" % sp)
-            for ln in gen_w4(c, 0, 0, 0, sp):
-                f.write('"%s\\n"\n' % ln)
-    with open(os.path.join(args.out, "gemm256w_body_buf.inc"), "w") as f:
-        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, buffer_load ... lds tile fetch.\n")
-        for ln in gen_w4(c, 0, 0, 1):
-            f.write('"%s\\n"\n' % ln)
-    for pf in (0, 1):
-        with open(os.path.join(args.out, "gemm256w_body_pf%d.inc" % pf), "w") as f:
-            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup%s.\n"
-                    % (", L2 software prefetch" if pf else ""))
-            for ln in gen_w4(c, pf):
-                f.write('"%s\\n"\n' % ln)
     with open(os.path.join(args.out, "conv256w_body.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), whole K axis (all filter taps), one LDS-DMA piece per 2 MFMA shadows.\n")
         for ln in gen_conv_w4(c, 2):
