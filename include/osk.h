@@ -235,7 +235,7 @@ int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, int W, int 
  *   osk_groupnorm_stats_ndhwc_bf16(out, ...) would (sums of the bf16-rounded outputs; f32 partials per 256-voxel tile,
  *   f64 atomics across tiles) -- feed it to osk_groupnorm_apply_ndhwc_bf16.
  * Only the large-tile kernels carry this epilogue: returns OSK_EUNSUPPORTED -- and launches NOTHING -- unless
- * Cin % 128 == 0, Cout >= 128, Cout % 32 == 0, Cout / gn_groups in {4, 8, 16}, >= 256 output voxels and
+ * Cin % 128 == 0, Cout >= 128, Cout % 32 == 0, Cout / gn_groups in {4, 8, 16}, >= 256 output voxels, out 16-byte aligned and
  * (B == 1 or To*Ho*Wo % 256 == 0); the caller then runs the plain conv + osk_groupnorm_stats_ndhwc_bf16. */
 int osk_causal_conv3d_gn_ndhwc_bf16(const void* x, int B, int T, int H, int W, int Cin,
                                     const void* w, int64_t w_row_stride, const float* bias, int Cout, int ksize,

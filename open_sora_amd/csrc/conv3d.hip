@@ -265,7 +265,8 @@ static int conv_entry(const void* x, int B, int T, int H, int W, int Cin, const 
     if (gn_sums) {   // fused statistics live in the large-tile kernels' epilogue only; nothing is launched otherwise
       p.gn_sums = gn_sums;
       p.gn_G = gn_groups;
-      if (!big || !osk_conv::conv256_gn_supported(p)) return OSK_EUNSUPPORTED;
+      // (the statistics ride in the 16-byte-store path of the epilogue: the output must be 16-byte aligned)
+      if (!big || !osk_conv::conv256_gn_supported(p) || ((uintptr_t)out & 15)) return OSK_EUNSUPPORTED;
     }
     if (big) return osk_conv::launch_conv256(p, cv, s);
   }
