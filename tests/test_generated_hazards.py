@@ -10,7 +10,10 @@ and reports
   RAW-lds : a fragment read from a stage whose fill is still in flight,
   WAR-lds : an LDS-DMA fill issued into a stage that was read since the last barrier (a slower wave may still be reading it),
   M0      : an LDS-DMA instruction without a fresh M0 write, or directly behind it (the hardware needs one instruction between).
-The schedules are hand-designed in tools/gen_gemm_asm.py and validated on the GPU; this guards future edits of the generator
+LDS operations retire in order, so `s_waitcnt lgkmcnt(N)` retires all but the N most recent reads (the attention bodies count
+their waits).  The flash-attention bodies (tools/gen_attn_asm.py) get the register and M0 checks only: their K / V^T rings are
+not two symmetric stages.
+The schedules are hand-designed in tools/gen_*_asm.py and validated on the GPU; this guards future edits of the generators
 on a machine without one."""
 import glob
 import os
@@ -21,6 +24,7 @@ import pytest
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "open_sora_amd", "csrc")
 BODIES = sorted(p for p in glob.glob(os.path.join(CSRC, "*.inc"))
                 if ("_body" in p or "_segment" in p) and "attention" not in os.path.basename(p))
+ATTN_BODIES = sorted(p for p in glob.glob(os.path.join(CSRC, "attention_asm*_n*_v*.inc")))
 S_ADST, S_WDST = "s45", "s46"
 A_STAGE = 32768
 
@@ -49,10 +53,10 @@ def regs_of(tok):
     return []
 
 
-def lint(path):
+def lint(path, stages=True):
     ins = parse(path)
     labels = {t[:-1]: i for i, t in enumerate(ins) if t.endswith(":")}
-    w4_style = any(t.startswith("v_xor_b32") and t.rstrip().endswith("%0") for t in ins)
+    w4_style = any(t.startswith("v_xor_b32_e32") and t.rstrip().endswith("%0") for t in ins)
     cls = {"%0": "A", "%1": "W"} if w4_style else {**{"%%%d" % i: "A" for i in range(4)}, **{"%%%d" % i: "W" for i in range(4, 8)}}
     for t in ins:                                    # address registers derived by XOR inherit the operand class
         m = re.match(r"v_xor_b32_e32 (v\d+), \d+, (%\d+)", t)
@@ -76,14 +80,16 @@ def lint(path):
             out.append(i + 1)
         return out
 
-    # state: (pending_lds regs, pending_dma stages, dma_landed_locally, read_since_barrier, m0, m0_age)
-    empty = (frozenset(), frozenset(), frozenset(), frozenset(), None, 9)
+    # state: (LDS reads in flight: tuple of destination sets in issue order, pending_dma stages, dma_landed_locally,
+    #         read_since_barrier, m0, m0_age)
+    empty = ((), frozenset(), frozenset(), frozenset(), None, 9)
     state_in = {0: empty}
     work = [0]
     errors = set()
 
     def step(i, st):
-        pend, dma, landed, rsb, m0, age = st
+        pq, dma, landed, rsb, m0, age = st
+        pend = set().union(*pq) if pq else set()
         t = ins[i]
         if t.endswith(":"):
             return st
@@ -93,25 +99,25 @@ def lint(path):
             dst = regs_of(args[0])
             addr = args[1].split()[0]
             off = int(re.search(r"offset:(\d+)", t).group(1)) if "offset:" in t else 0
-            if op == "ds_read_b128":
+            if op == "ds_read_b128" and stages:
                 assert addr in cls, (path, t)
                 key = (cls[addr], stage_of(cls[addr], off))
                 if key in dma or key in landed:
                     errors.add(("RAW-lds", i, t))
                 rsb = rsb | {key}
-            pend = pend | set(dst)
             for r in regs_of(addr):
-                if r in pend - set(dst):
+                if r in pend:
                     errors.add(("RAW-reg", i, t))
-        elif op == "s_add_u32" and args[0] == "m0":
-            base, imm = args[1], int(args[2])
-            m0 = ("A" if base == S_ADST else "W", stage_of("A" if base == S_ADST else "W", imm))
+            pq = pq + (frozenset(dst),)
+        elif op in ("s_add_u32", "s_mov_b32") and args[0] == "m0":
+            base, imm = args[1], int(args[2]) if len(args) > 2 and args[2].isdigit() else 0
+            m0 = ("A" if base == S_ADST else "W", stage_of("A" if base == S_ADST else "W", imm)) if stages else ("any", 0)
             age = 0
-            return (frozenset(pend), dma, landed, rsb, m0, age)
+            return (pq, dma, landed, rsb, m0, age)
         elif op == "global_load_lds_dwordx4":
             if m0 is None or age < 1:
                 errors.add(("M0", i, t))
-            else:
+            elif stages:
                 if m0 in rsb:
                     errors.add(("WAR-lds", i, t))
                 dma = dma | {m0}
@@ -120,8 +126,10 @@ def lint(path):
                     errors.add(("RAW-reg", i, t))
             m0 = None
         elif op == "s_waitcnt":
-            if "lgkmcnt(0)" in t:
-                pend = frozenset()
+            m = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                pq = pq[len(pq) - n:] if n else ()
             if "vmcnt(0)" in t:
                 landed, dma = landed | dma, frozenset()
         elif op == "s_barrier":
@@ -131,17 +139,22 @@ def lint(path):
                 for r in regs_of(a):
                     if r in pend:
                         errors.add(("RAW-reg", i, t))
-        elif op.startswith("v_") and not op.startswith("v_accvgpr_write"):
-            for a in args[1:]:
-                for r in regs_of(a):
+        elif op.startswith("v_"):
+            srcs = args if op.startswith("v_permlane") else args[1:]      # permlane swaps read both operands
+            for a in srcs:
+                for r in regs_of(a.split()[0] if a else a):
                     if r in pend:
                         errors.add(("RAW-reg", i, t))
-        return (frozenset(pend), frozenset(dma), frozenset(landed), frozenset(rsb), m0, min(age + 1, 9))
+        return (pq, frozenset(dma), frozenset(landed), frozenset(rsb), m0, min(age + 1, 9))
 
     def join(a, b):
         if a is None:
             return b
-        return (a[0] | b[0], a[1] | b[1], a[2] | b[2], a[3] | b[3], a[4] if a[4] == b[4] else None, min(a[5], b[5]))
+        qa, qb = a[0], b[0]                       # align the in-flight reads from the most recent one backwards
+        n = max(len(qa), len(qb))
+        qa, qb = (frozenset(),) * (n - len(qa)) + qa, (frozenset(),) * (n - len(qb)) + qb
+        pq = tuple(x | y for x, y in zip(qa, qb))
+        return (pq, a[1] | b[1], a[2] | b[2], a[3] | b[3], a[4] if a[4] == b[4] else None, min(a[5], b[5]))
 
     while work:
         i = work.pop()
@@ -158,6 +171,13 @@ def lint(path):
 def test_generated_k_loop_has_no_static_hazard(path):
     errors, n = lint(path)
     assert n > 100
+    assert not errors, "%s: %d hazards, first: %s" % (os.path.basename(path), len(errors), errors[:5])
+
+
+@pytest.mark.parametrize("path", ATTN_BODIES, ids=[os.path.basename(p) for p in ATTN_BODIES])
+def test_generated_attention_loop_has_no_register_hazard(path):
+    errors, n = lint(path, stages=False)
+    assert n > 500
     assert not errors, "%s: %d hazards, first: %s" % (os.path.basename(path), len(errors), errors[:5])
 
 
