@@ -75,7 +75,42 @@ def _load() -> C.CDLL:
     return lib
 
 
+class _TracingLib:
+    """OSK_TRACE=1: every C-ABI call is recorded in TRACE_LOG as (entry point, arguments) before it is forwarded.  A pointer is
+    replaced by 'p<k>@<low 8 bits>', k = the order in which that exact address first appeared, so two runs of the same program
+    give the same log unless the SEQUENCE of launches, a scalar argument, the aliasing pattern of the buffers or an alignment
+    differs (tools/diff_traces.py compares two dumps).  A debugging aid: nothing in the product path sets it."""
+
+    def __init__(self, inner):
+        self._inner = inner
+        self._ids: dict = {}
+
+    def _norm(self, kind, v):
+        if kind is _vp:
+            if v is None:
+                return "NULL"
+            v = int(v)
+            k = self._ids.setdefault(v, len(self._ids))
+            return f"p{k}@{v & 0xFF:02x}"
+        return round(float(v), 9) if kind is _f32 else int(v)
+
+    def __getattr__(self, name):
+        fn = getattr(self._inner, name)
+        sig = SIGNATURES.get(name)
+        if sig is None:
+            return fn
+
+        def traced(*args):
+            TRACE_LOG.append((name,) + tuple(self._norm(k, a) for k, a in zip(sig, args)))
+            return fn(*args)
+
+        return traced
+
+
+TRACE_LOG: list = []
 lib = _load()
+if os.environ.get("OSK_TRACE"):
+    lib = _TracingLib(lib)
 
 
 OSK_EUNSUPPORTED = -2   # csrc/osk_common.h

@@ -57,3 +57,26 @@ def test_product_path_does_not_import_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports oracle"
+
+
+def test_osk_trace_records_calls(monkeypatch):
+    """OSK_TRACE=1: the binding records every C-ABI call (entry point, scalars, buffers by order of first appearance and their
+    alignment) before forwarding it -- the debugging aid behind tools/diff_traces.py.  No GPU needed: an argument check that
+    fails still goes through the tracer."""
+    import importlib
+
+    monkeypatch.setenv("OSK_TRACE", "1")
+    import open_sora_amd._C as C0
+    C1 = importlib.reload(C0)
+    try:
+        assert C1.lib.osk_abi_version() == 1            # not in SIGNATURES' argument-carrying set: passes through
+        n0 = len(C1.TRACE_LOG)
+        rc = C1.lib.osk_blend_bf16(None, None, 1, 1, 1, 0, 1, None)      # NULL pointers -> invalid argument, nothing launched
+        assert rc != 0
+        rec = C1.TRACE_LOG[n0:]
+        assert rec and rec[-1][0] == "osk_blend_bf16" and rec[-1][1] == "NULL" and rec[-1][3:8] == (1, 1, 1, 0, 1)
+        rc = C1.lib.osk_blend_bf16(0x1000, 0x2010, 1, 1, 1, -1, 1, None)  # extent < 0 -> invalid argument
+        assert rc != 0 and C1.TRACE_LOG[-1][1:3] == ("p0@00", "p1@10")
+    finally:
+        monkeypatch.delenv("OSK_TRACE")
+        importlib.reload(C1)
