@@ -233,7 +233,8 @@ int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, int W, int 
  * read of the tensor that osk_groupnorm_stats_ndhwc_bf16 costs.
  *   gn_sums f64 [B, gn_groups, 2], ZEROED BY THE CALLER; on return (stream order) it holds what
  *   osk_groupnorm_stats_ndhwc_bf16(out, ...) would (sums of the bf16-rounded outputs; f32 partials per 256-voxel tile,
- *   f64 atomics across tiles) -- feed it to osk_groupnorm_apply_ndhwc_bf16.
+ *   f64 atomics across tiles) -- feed it to osk_groupnorm_apply_ndhwc_bf16.  The waves of a tile add their partials with
+ *   LDS float atomics: the result is reproducible to f32 rounding of a tile's partial (~1e-7 relative), not bit for bit.
  * Only the large-tile kernels carry this epilogue: returns OSK_EUNSUPPORTED -- and launches NOTHING -- unless
  * Cin % 128 == 0, Cout >= 128, Cout % 32 == 0, Cout / gn_groups in {4, 8, 16}, >= 256 output voxels, out 16-byte aligned and
  * (B == 1 or To*Ho*Wo % 256 == 0); the caller then runs the plain conv + osk_groupnorm_stats_ndhwc_bf16. */
