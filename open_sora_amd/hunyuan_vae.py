@@ -232,8 +232,9 @@ class _ConvPlan:
 
 def _plan(mod, kind):
     """kernel-side image of a layer's parameters, cached on the module and keyed on the parameters' (storage pointer,
-    in-place version): a swapped or rewritten weight rebuilds it"""
-    key = tuple((q.data_ptr(), q._version) for q in mod.parameters())
+    in-place version; 0 for inference tensors, which track none): a swapped weight, or one rewritten in place through the
+    parameter itself, rebuilds it.  Writes through `p.data` are not visible to that key: drop `_osk_plan` after them."""
+    key = tuple((q.data_ptr(), 0 if q.is_inference() else q._version) for q in mod.parameters())
     c = getattr(mod, "_osk_plan", None)
     p = c[1] if c is not None and c[0] == key else None
     if p is None:

@@ -344,9 +344,19 @@ def _mod_layer(mod) -> tuple:
     return (_w(mod.lin.weight), None if mod.lin.bias is None else _w(mod.lin.bias))
 
 
+def _tensor_key(p: Tensor) -> tuple:
+    """(storage pointer, in-place version counter) of one parameter.  Inference tensors (parameters created or loaded
+    under torch.inference_mode(), as the reference's inference scripts do) do not track a version counter -- reading
+    `_version` raises on them -- and cannot be written in place outside inference mode either: their version is 0."""
+    return (p.data_ptr(), 0 if p.is_inference() else p._version)
+
+
 def _param_key(module):
-    """(storage pointer, in-place version) of the module's parameters: a cached plan built from other values is stale"""
-    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+    """_tensor_key of every parameter of the module: a cached plan built from other values is stale.  Detected: a storage
+    swap (load_state_dict, .to(), a new Parameter) and autograd-visible in-place writes (`p.mul_()`, `p.copy_()` under
+    no_grad, an optimizer step).  NOT detected: writes through `p.data` (`.data` is a detached alias with its own version
+    counter) and writes to inference tensors -- after those, call `model.invalidate_plan()`."""
+    return tuple(_tensor_key(p) for p in module.parameters())
 
 
 def plan_double(block) -> _DoublePlan:
@@ -710,9 +720,11 @@ class MMDiTModel(nn.Module):
         return r
 
     def _plan_key(self):
-        """(storage pointer, in-place version counter) of every parameter: the plan is rebuilt when a weight was
-        swapped or written in place (e.g. a LoRA merge, `p.data.copy_`, an optimizer step) since it was built"""
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """_param_key of the whole model: the plan is rebuilt when a weight's storage was swapped or the weight was written
+        in place through the parameter itself (`p.copy_()` / `p.add_()` under no_grad, an optimizer step) since it was
+        built.  Writes through `p.data` (a LoRA merge done as `p.data += ...`) are invisible to the version counter:
+        call `invalidate_plan()` after them (see _param_key)."""
+        return _param_key(self)
 
     def _build_plan(self, device):
         cfg = self.config

@@ -143,3 +143,49 @@ def test_pack_unpack_roundtrip_and_schedule(cpu_mmdit):
     alpha = (1 + 2 / 3840 * (1024 - 256)) * 4.0  # sampling.py:295-332
     t1 = 1 - 1 / 30
     assert abs(ts[1] - alpha * t1 / (1 + (alpha - 1) * t1)) < 1e-6
+
+
+def test_model_built_and_loaded_inside_inference_mode(cpu_mmdit):
+    """the reference's scripts/diffusion/inference.py builds and loads every model inside `@torch.inference_mode() main()`:
+    the parameters are then inference tensors, which track no version counter (`p._version` raises).  The plan keys must
+    not read it (the first forward crashed), and the result must equal the model built outside."""
+    name = "hd64_eager_fused"
+    cfg, B, T, h, w, L_txt = configs.GOLDEN[name]
+    inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF)
+    outside = _build(cpu_mmdit, cfg)
+    with torch.inference_mode():
+        inside = _build(cpu_mmdit, cfg)
+        assert all(p.is_inference() for p in inside.parameters())
+        a = inside(**inp)
+        a2 = inside(**inp)                      # second call: cached plan, same key
+        b = outside(**inp)
+        blk = inside.double_blocks[0]
+        o_img, o_txt = blk(torch.zeros(1, 8, cfg["hidden_size"], dtype=BF), torch.zeros(1, 4, cfg["hidden_size"], dtype=BF),
+                           torch.zeros(1, cfg["hidden_size"], dtype=BF),
+                           (torch.ones(1, 12, cfg["hidden_size"] // cfg["num_heads"]), torch.zeros(1, 12, cfg["hidden_size"] // cfg["num_heads"])))
+    assert torch.equal(a, b) and torch.equal(a, a2)
+    assert o_img.shape == (1, 8, cfg["hidden_size"]) and o_txt.shape == (1, 4, cfg["hidden_size"])
+
+
+def test_plan_key_sees_in_place_writes_but_not_data_writes(cpu_mmdit):
+    """what the staleness key detects (autograd-visible in-place writes, storage swaps) and what it documents it does not
+    (writes through `.data`: invalidate_plan() is the contract there)"""
+    cfg, B, T, h, w, L_txt = configs.GOLDEN["hd64_eager_fused"]
+    model = _build(cpu_mmdit, cfg)
+    inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF)
+    with torch.inference_mode():
+        base = model(**inp)
+    bias = model.final_layer.linear.bias        # the plan holds an f32 COPY of it (bf16 weights are aliased, not copied)
+    with torch.no_grad():
+        bias.add_(1.0)
+    with torch.inference_mode():
+        shifted = model(**inp)
+    assert not torch.equal(shifted, base)       # rebuilt
+    bias.data.sub_(1.0)                          # invisible to the key ...
+    with torch.inference_mode():
+        stale = model(**inp)
+    assert torch.equal(stale, shifted)
+    model.invalidate_plan()                      # ... so this is the documented contract
+    with torch.inference_mode():
+        fresh = model(**inp)
+    assert torch.allclose(fresh.float(), base.float(), atol=2e-2, rtol=2e-2) and not torch.equal(fresh, shifted)

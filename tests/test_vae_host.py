@@ -86,3 +86,19 @@ def test_vae_api_mirror(cpu_vae):
             m.encode(x[0])
         with pytest.raises(RuntimeError):
             m.encoder(x)  # parameter holders have no eager arithmetic
+
+
+def test_vae_built_and_loaded_inside_inference_mode(cpu_vae):
+    """scripts/vae/inference.py and scripts/diffusion/inference.py build the VAE inside torch.inference_mode(): its
+    parameters are inference tensors (no version counter); the per-layer plan key must not read `_version` on them."""
+    name = "c32_lpb1"
+    cfg, B, T, H, W = configs.VAE_GOLDEN[name]
+    x = torch.from_numpy(synth.vae_video(B, T, H, W)).to(BF)
+    outside = _model(cpu_vae, cfg)
+    with torch.inference_mode():
+        inside = _model(cpu_vae, cfg)
+        assert all(p.is_inference() for p in inside.parameters())
+        za = inside.encode(x, sample_posterior=False)
+        zb = outside.encode(x, sample_posterior=False)
+        da = inside.decode(za)
+    assert torch.equal(za, zb) and torch.isfinite(da.float()).all()

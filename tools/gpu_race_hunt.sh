@@ -1,0 +1,23 @@
+#!/bin/bash
+# One gpurun call: the sequence-parallel repeatability hunt (tools/sp_race_hunt.py) over contention / instrumentation / poison arms.
+#   ARMS="A B C" RUNS=40 bash tools/gpu_race_hunt.sh        -> gpurun_out/race/<arm>.json
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; O=gpurun_out/race; mkdir -p $O
+RUNS=${RUNS:-40}
+ARMS="${ARMS:-A B C D E F G H I J}"
+run() { name=$1; shift; echo "== $name: $*"; timeout ${ARM_TIMEOUT:-420} python tools/sp_race_hunt.py --runs $RUNS --out $O/$name.json "$@" > $O/$name.log 2>&1; echo "rc $?"; tail -c ${TAILC:-1500} $O/$name.log; echo; }
+for a in $ARMS; do case $a in
+  A) run A_plain ;;
+  B) run B_hammer --hammer matmul,copy ;;
+  C) run C_fp8_instr --fp8 --instrument ;;
+  D) run D_fp8w_instr --fp8-weights-only --instrument ;;
+  E) run E_instr_hammer --instrument --hammer matmul,copy ;;
+  F) run F_poison_nan --poison nan ;;
+  G) run G_poison_rand --poison rand --instrument ;;
+  H) run H_stream_hammer --stream-hammer --instrument ;;
+  I) run I_ulysses --mode ulysses --instrument --hammer small ;;
+  J) run J_w4 --world 4 --geom 1,4,8,8,64 --instrument ;;
+  K) run K_hd128 --name hd128_liger_split --geom 3,2,9,7,22 --instrument --hammer small ;;
+  L) run L_fp8_plain --fp8 ;;
+  *) echo "unknown arm $a" ;;
+esac; done
+echo "== done"
