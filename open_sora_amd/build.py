@@ -22,7 +22,13 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libosk_hip.so")
 ARCH = "gfx950"
-FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"]
+# -packed-fp32-ops: hipcc must not emit v_pk_{fma,mul,add}_f32 / v_pk_mov_b32 in the code it schedules.  Measured on MI355X
+# (round 3, tools/interfere_probe.py + tools/xproc_probe.py, profiles/r03_cross_kernel_interference.md): a wave running such
+# packed-FP32 sequences returns a wrong LOW half now and then while a workgroup of one of this library's MFMA kernels
+# (gemm256p, attn_asm72) is resident on the same CU -- from another stream or another process.  That made the batched adaLN
+# GEMV of one rank non-repeatable when two sequence-parallel ranks shared a GPU (GPUTEST_r02).  The same victim kernels built
+# without the feature never mismatch.  The hand-written loops (generated .inc bodies) contain no packed-FP32 instruction.
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def sources() -> list[str]:

@@ -18,6 +18,16 @@ for a in $ARMS; do case $a in
   J) run J_w4 --world 4 --geom 1,4,8,8,64 --instrument ;;
   K) run K_hd128 --name hd128_liger_split --geom 3,2,9,7,22 --instrument --hammer small ;;
   L) run L_fp8_plain --fp8 ;;
+  T0) run T0_plain ;;
+  T1) run T1_notailsplit --env OSK_ATTN_TAILSPLIT=0 ;;
+  T2) run T2_attn_compiler --env OSK_ATTN_VARIANT=0 ;;
+  T3) run T3_gemm_small --env OSK_GEMM_VARIANT=0 ;;
+  T4) run T4_qknorm_lanes --env OSK_QKNORM_VARIANT=0 ;;
+  T5) run T5_checkpoints --checkpoints ;;
+  T6) run T6_instrument --instrument ;;
+  T7) run T7_depth_1_0 --depth 1,0 --checkpoints ;;
+  T8) run T8_depth_0_1 --depth 0,1 --checkpoints ;;
+  P1) ARM_TIMEOUT=120 run P1_poison_nan_blocking --poison nan --runs 3 --env HIP_LAUNCH_BLOCKING=1,AMD_SERIALIZE_KERNEL=3 ;;
   *) echo "unknown arm $a" ;;
 esac; done
 echo "== done"

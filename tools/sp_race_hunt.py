@@ -233,8 +233,10 @@ def hammer_proc(kind):
 
 
 def worker(rank, args, port, q):
+    import faulthandler
     import torch.distributed as dist
 
+    faulthandler.enable()   # a GPU memory fault aborts the process: with HIP_LAUNCH_BLOCKING=1 the Python stack names the launch
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=args.world)
@@ -249,6 +251,23 @@ def worker(rank, args, port, q):
         hops.enabled = False
         if args.instrument:
             mmdit.set_ops_for_testing(hops)
+        if args.checkpoints:   # light instrumentation: the residual stream after every block (+ the gathered buffers, below)
+            rd, rs = mmdit.run_double_block, mmdit.run_single_block
+            counter = [0]
+
+            def run_double_block(plan, ws, *a, **k):
+                r = rd(plan, ws, *a, **k)
+                hops.mark(f"after double block (call {counter[0]})", [ws.x])
+                counter[0] += 1
+                return r
+
+            def run_single_block(plan, ws, *a, **k):
+                r = rs(plan, ws, *a, **k)
+                hops.mark(f"after single block (call {counter[0]})", [ws.x])
+                counter[0] += 1
+                return r
+
+            mmdit.run_double_block, mmdit.run_single_block = run_double_block, run_single_block
         stage_collectives_through_host(dist, hops.mark)
         gen_holder = {"on": False, "gen": torch.Generator(device="cuda")}
         if args.poison != "none":
@@ -287,7 +306,9 @@ def worker(rank, args, port, q):
                             ha @ ha
                             hdst.copy_(hsrc)
                 hops.reset()
-                hops.enabled = args.instrument
+                hops.enabled = args.instrument or args.checkpoints
+                if args.checkpoints:
+                    counter[0] = 0
                 out = model(**inp)
                 hops.enabled = False
                 gen_holder["on"] = False
@@ -300,16 +321,18 @@ def worker(rank, args, port, q):
                     continue
                 same = torch.equal(out, first) or (torch.isnan(out) == torch.isnan(first)).all() and torch.equal(torch.nan_to_num(out), torch.nan_to_num(first))
                 div = None
-                if args.instrument:
+                if args.instrument or args.checkpoints:
                     if names != first_names:
                         div = dict(kind="launch sequence differs", n=(len(names), len(first_names)))
                     else:
+                        # "pre" checksums of OUTPUT buffers hold whatever the previous forward left there: only "post" entries
+                        # can start a divergence (an input that differs was some earlier call's output)
                         for j, (x, y) in enumerate(zip(chain, first_chain)):
-                            if x != y:
+                            if x != y and names[j][2] == "post":
                                 label, argi, phase = names[j]
-                                # did every "pre" checksum of this call agree?
-                                pre_ok = all(chain[jj] == first_chain[jj] for jj in range(j) if names[jj][0] == label and names[jj][2] == "pre")
-                                div = dict(entry=j, call=label, arg=argi, phase=phase, inputs_agreed=pre_ok)
+                                pre_bad = [names[jj][1] for jj in range(j) if names[jj][0] == label and names[jj][2] == "pre"
+                                           and chain[jj] != first_chain[jj]]
+                                div = dict(entry=j, call=label, arg=argi, pre_args_that_differed=pre_bad)
                                 break
                 if not same or div is not None:
                     res["bad_runs"].append(run)
@@ -343,9 +366,15 @@ def main():
     ap.add_argument("--hammer", default="", help="comma list of contender processes: matmul, copy, small")
     ap.add_argument("--stream-hammer", action="store_true", help="contender work on a second stream of each rank process")
     ap.add_argument("--instrument", action="store_true")
+    ap.add_argument("--checkpoints", action="store_true", help="light instrumentation: checksum of the residual stream after every block")
+    ap.add_argument("--env", default="", help="comma list of K=V set in the environment of every process (library A/B switches)")
     ap.add_argument("--poison", default="none", choices=["none", "nan", "rand"])
     ap.add_argument("--out", default="")
     args = ap.parse_args()
+    for kv in args.env.split(","):
+        if kv:
+            k_, v_ = kv.split("=")
+            os.environ[k_] = v_
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
