@@ -52,6 +52,8 @@ def parse():
                          "never the default line -- the reference computes in bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1", action="store_true", help="skip the extra CFG-batch-1 timing")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the `vae` (BASELINE configs[2]) and `11b` (the shipped 11B geometry) sub-objects of the default line")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
     return ap.parse_args()
 
@@ -172,12 +174,18 @@ def vae_cpu_baseline(budget_s):
     return fl / dt, ncores, dt
 
 
-def bench_vae(args, dev):
-    """BASELINE configs[2]: 3D-VAE (CausalConv3d) encode + decode of a [1,3,T,256,256] video, 1x MI355X."""
+def vae_line(dev, T, S, steps, warmup, cpu_budget_s):
+    """BASELINE configs[2]: 3D-VAE (CausalConv3d) encode + decode of a [1,3,T,256,256] video, 1x MI355X.  Returns the JSON
+    object (`python bench.py --workload vae` prints it as its line; the default line carries it as `vae`)."""
     from open_sora_amd import _C, configs, hunyuan_vae
 
     cfg = dict(configs.VAE["hunyuan"])
-    T, S = args.vae_frames, args.vae_size
+
+    class _A:
+        pass
+
+    args = _A()
+    args.steps, args.warmup, args.no_cpu_baseline, args.cpu_budget_s = steps, warmup, cpu_budget_s is None, cpu_budget_s or 0.0
     torch.manual_seed(1234)
     model = hunyuan_vae.CausalVAE3D_HUNYUAN(device_map=dev, torch_dtype=torch.bfloat16, **cfg)
     g = torch.Generator(device=dev).manual_seed(42)
@@ -223,7 +231,7 @@ def bench_vae(args, dev):
         # conv256x_kernel<4> for Cout = 128), conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers
         "roofline": {"bound": "mfma", "kernel": "conv256x_kernel + conv3d_kernel (by layer shape)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "traffic_source": traffic_src,
+                     "traffic_kind": "recorded (PMC passes of this command, see traffic_source)", "traffic_source": traffic_src,
                      "launches": len(prof) // args.steps, "total_conv_ms_per_step": round(conv_ms, 3)},
     }
     if not args.no_cpu_baseline:
@@ -232,7 +240,9 @@ def bench_vae(args, dev):
         res["cpu_baseline"] = {"value": round(T / cpu_s, 5), "unit": "video frames/s", "cores": ncores, "kind": "port",
                                "sample": f"oracle CausalConv3d fp32 on {ncores} host threads: one 128->128 3x3x3 conv at 9x128x128 "
                                          f"({dt:.2f} s, {fps / 1e12:.3f} TFLOP/s), encode+decode extrapolated by FLOPs = {cpu_s:.1f} s"}
-    print(json.dumps(res), flush=True)
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
 def _self_spawn(n: int) -> int:
@@ -268,11 +278,53 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if args.workload == "vae":
         assert world == 1, "the VAE workload is single-GPU (BASELINE configs[2])"
-        return bench_vae(args, dev)
+        print(json.dumps(vae_line(dev, args.vae_frames, args.vae_size, args.steps, args.warmup,
+                                  None if args.no_cpu_baseline else args.cpu_budget_s)), flush=True)
+        return
 
-    from open_sora_amd import _C, configs, mmdit, sampling
+    out = dit_line(args, dev, dist, rank, world, args.model, args.steps, args.warmup, with_b1=not args.no_b1)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    from open_sora_amd import configs
 
     cfg = dict(configs.MMDIT[args.model])
+    T, hw = args.frames, args.latent_hw
+    L_img, L_txt = T * (hw // 2) * (hw // 2), 512
+    if world == 1 and not args.no_cpu_baseline:
+        td, tsg, cpu_step, ncores = cpu_baseline(cfg, L_img, L_txt, 3, args.cpu_budget_s)
+        out["cpu_baseline"] = {
+            "value": round(T / (SAMPLING_STEPS * cpu_step), 6), "unit": "latent frames/s", "cores": ncores,
+            "kind": "port",
+            "sample": f"EXTRAPOLATED: oracle fp32 on {ncores} host threads timed on 1 double block ({td:.2f} s) + 1 single block "
+                      f"({tsg:.2f} s) at B=1, L={L_img + L_txt}; step = x({cfg['depth']},{cfg['depth_single_blocks']}) x CFG batch 3 = {cpu_step:.1f} s "
+                      f"(a whole XL step is ~1 h of CPU; the un-extrapolated whole-forward line is cfg1)",
+            "cfg1": cfg1_line(dev, args.cpu_budget_s),
+        }
+    if world == 1 and not args.no_extra and args.model == "XL" and not args.fp8:
+        # the other two single-GPU workloads of SURVEY.md section 8(d), under the same clock as the headline: BASELINE configs[2]
+        # (the causal VAE) and the geometry the reference actually ships (11B: hidden 3072, 24 x 128, 19 + 38 blocks); each with
+        # its own roofline object.  Never part of `value`.
+        torch.cuda.empty_cache()
+        v = vae_line(dev, args.vae_frames, args.vae_size, 5, 2, None if args.no_cpu_baseline else min(args.cpu_budget_s, 20.0))
+        out["vae"] = {k: v[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "step_tflops", "step_mfma_frac",
+                                        "roofline", "cpu_baseline") if k in v}
+        b11 = dit_line(args, dev, None, 0, 1, "11B", 3, 1, with_b1=False)
+        out["11b"] = {k: b11[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "step_tflops", "step_mfma_frac",
+                                          "roofline", "timed")}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
+    """One denoise-step measurement of the product's sampler: `sampling.I2VDenoiser.denoise` (the reference's Euler loop,
+    opensora/utils/sampling.py:159-226) driving MMDiTModel.forward on the CFG triple, `warmup` untimed steps, then EXACTLY
+    `steps` steps between barriers.  Returns the JSON object of the line (rank 0; other ranks: None)."""
+    from open_sora_amd import _C, configs, mmdit, sampling
+
+    cfg = dict(configs.MMDIT[model_name])
     T, hw = args.frames, args.latent_hw
     L_img, L_txt = T * (hw // 2) * (hw // 2), 512
     L = L_img + L_txt
@@ -299,66 +351,74 @@ def main():
     g = torch.Generator(device=dev).manual_seed(42)
     z = torch.randn(1, 16, T, hw, hw, device=dev, dtype=torch.bfloat16, generator=g)
     ts = sampling.get_schedule(SAMPLING_STEPS, (hw // 2) * (hw // 2), T)
+    g2 = torch.Generator(device=dev).manual_seed(43)
 
-    def make_step(nb):
-        """one denoise step of the sampler at CFG batch nb (3 = the reference's triple, 1 = the pure step)"""
-        st = {"x": sampling.pack(z).contiguous()}                                # [1, L_img, 64]
-        st["x_next"] = torch.empty_like(st["x"])
-        g2 = torch.Generator(device=dev).manual_seed(43)
-        txt = (torch.randn(nb, L_txt, cfg["context_in_dim"], device=dev, generator=g2) * 0.2).to(torch.bfloat16)
-        y_vec = torch.randn(nb, cfg["vec_in_dim"], device=dev, generator=g2).to(torch.bfloat16)
-        img_ids, txt_ids = sampling.prepare_ids(nb, T, hw, hw, L_txt, dev, torch.bfloat16)
-        cond = torch.zeros(nb, L_img, 68, device=dev, dtype=torch.bfloat16)  # t2v: masks = 0, masked_ref = 0
-        img3 = torch.empty(nb, L_img, 64, device=dev, dtype=torch.bfloat16)
-
-        def step(i):
-            x, x_next = st["x"], st["x_next"]
-            t_curr, t_prev = ts[i % SAMPLING_STEPS], ts[i % SAMPLING_STEPS + 1]
-            t_vec = torch.full((nb,), t_curr, dtype=torch.bfloat16, device=dev)
-            img3.copy_(x.expand(nb, -1, -1))
-            pred = model(img=img3, img_ids=img_ids, txt=txt, txt_ids=txt_ids, timesteps=t_vec, y_vec=y_vec, cond=cond)
-            if nb == 3:
-                _C.cfg_euler(pred, x, x_next, 7.5, 3.0, float(t_prev - t_curr))
-            else:
-                _C.cfg_euler(pred.expand(3, -1, -1).contiguous(), x, x_next, 1.0, 1.0, float(t_prev - t_curr))
-            st["x"], st["x_next"] = x_next, x
-
-        return step, st
+    def sched(first, n):
+        """n steps of the 30-step schedule starting at step `first` (wrapping: a benchmark may time more than one sampling)"""
+        idx = [(first + i) % SAMPLING_STEPS for i in range(n)]
+        return [ts[i] for i in idx] + [ts[idx[-1] + 1]]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, n_warm, n_steps, profile):
-        for i in range(n_warm):
-            step(i)
-        _C.PROFILE_ATTENTION = [] if profile else None
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(n_steps):
-            step(i)
-        barrier()
-        dt = time.perf_counter() - t0
-        prof, _C.PROFILE_ATTENTION = _C.PROFILE_ATTENTION, None
-        return dt, prof
+    def run_denoise(x0, first, n):
+        """`n` Euler steps through the product's own sampler loop (t2v: masks = 0, no reference frames); returns the latents"""
+        return sampling.I2VDenoiser().denoise(
+            model, img=x0.repeat(3, 1, 1), timesteps=sched(first, n), guidance=7.5, guidance_img=3.0, masks=masks, masked_ref=masked_ref,
+            img_ids=img_ids, txt=txt, txt_ids=txt_ids, y_vec=y_vec)
 
-    nb = args.cfg_batch
+    timed_what = "sampling.I2VDenoiser.denoise (CFG triple)"
     with torch.inference_mode():
-        step, st = make_step(nb)
-        elapsed, prof = timed(step, args.warmup, args.steps, rank == 0)
-        x = st["x"]
+        if nb == 3:
+            txt = (torch.randn(3, L_txt, cfg["context_in_dim"], device=dev, generator=g2) * 0.2).to(torch.bfloat16)
+            y_vec = torch.randn(3, cfg["vec_in_dim"], device=dev, generator=g2).to(torch.bfloat16)
+            img_ids, txt_ids = sampling.prepare_ids(3, T, hw, hw, L_txt, dev, torch.bfloat16)
+            masks = torch.zeros(1, 1, T, hw, hw, device=dev, dtype=torch.bfloat16)
+            masked_ref = torch.zeros(1, 16, T, hw, hw, device=dev, dtype=torch.bfloat16)
+            x = sampling.pack(z).contiguous()
+            if warmup:
+                x = run_denoise(x, 0, warmup)
+            _C.PROFILE_ATTENTION = [] if rank == 0 else None
+            barrier()
+            t0 = time.perf_counter()
+            x = run_denoise(x, warmup, steps)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            prof, _C.PROFILE_ATTENTION = _C.PROFILE_ATTENTION, None
+        else:
+            timed_what = f"model forward + osk_cfg_euler_bf16 at CFG batch {nb} (a private loop: the sampler's loop is the triple)"
+            step, st = _plain_step(model, cfg, nb, z, ts, T, hw, L_img, L_txt, dev, g2)
+            for i in range(warmup):
+                step(i)
+            _C.PROFILE_ATTENTION = [] if rank == 0 else None
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(warmup + i)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            prof, _C.PROFILE_ATTENTION = _C.PROFILE_ATTENTION, None
+            x = st["x"]
         # SURVEY.md section 8(d) cfg 2 asks for B = 1 (the pure step) next to the reference's CFG triple: a second, separately
-        # timed run of the same loop at batch 1 (reported under "b1", never part of `value`)
+        # timed run at batch 1 (reported under "b1", never part of `value`)
         b1 = None
-        if nb != 1 and world == 1 and not args.no_b1:
-            step1, st1 = make_step(1)
-            n1 = max(3, min(args.steps, 10))
-            e1, _ = timed(step1, 1, n1, False)
+        if nb != 1 and world == 1 and with_b1:
+            step1, st1 = _plain_step(model, cfg, 1, z, ts, T, hw, L_img, L_txt, dev, g2)
+            n1 = max(3, min(steps, 10))
+            step1(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n1):
+                step1(1 + i)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t0
             assert torch.isfinite(st1["x"].float()).all()
             b1 = {"cfg_batch": 1, "steps": n1, "ms_per_step": round(e1 / n1 * 1e3, 3),
                   "latent_frames_per_sec": round(T / (SAMPLING_STEPS * e1 / n1), 4),
-                  "step_tflops": round(configs.flops_per_forward(cfg, 1, L_img, L_txt) / (e1 / n1) / 1e12, 1)}
+                  "step_tflops": round(configs.flops_per_forward(cfg, 1, L_img, L_txt) / (e1 / n1) / 1e12, 1),
+                  "timed": "model forward + osk_cfg_euler_bf16 at CFG batch 1 (a private loop: the sampler's loop is the triple)"}
             del step1, st1
 
     if dist is not None:
@@ -366,13 +426,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(x.float()).all(), "non-finite latents after the timed steps"
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step = elapsed / steps * 1e3
     frames_per_s = T / (SAMPLING_STEPS * ms_per_step * 1e-3)
-
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
     # ---- roofline of the dominant kernel (attention): HIP events recorded around every launch in the timed region
     roofline = None
@@ -386,8 +443,8 @@ def main():
         kname = _C.lib.osk_attention_kernel_name(hd, L // world).decode()
         if args.fp8 and hd in (72, 128):
             kname = f"attn_asm{hd}p8_kernel"   # fp8 mode: the fp8 P.V variant
-        # HBM bytes per launch: PMC passes (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE) of the same
-        # kernel at the same shape, collected by tools/gpu_attn_round.sh and committed under profiles/
+        # HBM bytes per launch: RECORDED, not measured in this run -- PMC passes (FETCH_SIZE doubled per the gfx950 correction,
+        # + WRITE_SIZE) of the same kernel at the same shape, collected by tools/gpu_attn_round.sh and committed under profiles/
         traffic, traffic_src = None, None
         rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "attn_traffic.json")
         if os.path.exists(rec_path):
@@ -401,21 +458,23 @@ def main():
             peak = round(2.0 / (1.0 / MFMA_BF16_PEAK_TFLOPS + 1.0 / (2 * MFMA_BF16_PEAK_TFLOPS)), 1)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic": traffic, "traffic_kind": "recorded (PMC passes of this kernel at this shape, see traffic_source)",
+                    "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": 4 * nb * Lq * H * hd * 2 if world == 1 else None,
                     "launches": len(durs), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": fl}
     step_flops = configs.flops_per_forward(cfg, nb, L_img, L_txt)
     out = {
         "metric": "latent_frames_per_sec (30-step rectified-flow sampling; denoise-step ms in ms_per_step)",
-        "value": round(frames_per_s, 4), "unit": "latent frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "value": round(frames_per_s, 4), "unit": "latent frames/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
         "dtype": "fp8-e4m3 block Linears (per-row scales) and attention P.V (per-head V scale); bf16 QK^T / norms / embedders" if args.fp8 else "bf16",
         "data": "synthetic",
-        "config": {"workload": f"MMDiT-{args.model} (hidden {D}, {H}x{hd}, {cfg['depth']}+{cfg['depth_single_blocks']} blocks) "
+        "config": {"workload": f"MMDiT-{model_name} (hidden {D}, {H}x{hd}, {cfg['depth']}+{cfg['depth_single_blocks']} blocks) "
                                f"denoise step, latent {T}x{hw}x{hw} (16x512x512 px), L={L} tokens, CFG batch {nb}, "
                                f"{SAMPLING_STEPS}-step Euler sampling",
                    "tokens": L, "cfg_batch": nb, "parallelism": "single GPU" if world == 1 else f"sp{world} (token axis; exchange around attention: {sp_mode})"},
+        "timed": timed_what,
         "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world, 1),
         "step_mfma_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4),
         "roofline": roofline,
@@ -424,19 +483,36 @@ def main():
         out["b1"] = b1
     if world > 1:
         out["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "exchange": sp_mode}
-    if world == 1 and not args.no_cpu_baseline:
-        td, tsg, cpu_step, ncores = cpu_baseline(cfg, L_img, L_txt, nb, args.cpu_budget_s)
-        out["cpu_baseline"] = {
-            "value": round(T / (SAMPLING_STEPS * cpu_step), 6), "unit": "latent frames/s", "cores": ncores,
-            "kind": "port",
-            "sample": f"EXTRAPOLATED: oracle fp32 on {ncores} host threads timed on 1 double block ({td:.2f} s) + 1 single block "
-                      f"({tsg:.2f} s) at B=1, L={L}; step = x({cfg['depth']},{cfg['depth_single_blocks']}) x CFG batch {nb} = {cpu_step:.1f} s "
-                      f"(a whole XL step is ~1 h of CPU; the un-extrapolated whole-forward line is cfg1)",
-            "cfg1": cfg1_line(dev, args.cpu_budget_s),
-        }
-    print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def _plain_step(model, cfg, nb, z, ts, T, hw, L_img, L_txt, dev, g2):
+    """forward + CFG/Euler update at an arbitrary CFG batch (the `b1` side measurement and `--cfg-batch N != 3`)"""
+    from open_sora_amd import _C, sampling
+
+    st = {"x": sampling.pack(z).contiguous()}                                # [1, L_img, 64]
+    st["x_next"] = torch.empty_like(st["x"])
+    txt = (torch.randn(nb, L_txt, cfg["context_in_dim"], device=dev, generator=g2) * 0.2).to(torch.bfloat16)
+    y_vec = torch.randn(nb, cfg["vec_in_dim"], device=dev, generator=g2).to(torch.bfloat16)
+    img_ids, txt_ids = sampling.prepare_ids(nb, T, hw, hw, L_txt, dev, torch.bfloat16)
+    cond = torch.zeros(nb, L_img, 68, device=dev, dtype=torch.bfloat16)  # t2v: masks = 0, masked_ref = 0
+    img3 = torch.empty(nb, L_img, 64, device=dev, dtype=torch.bfloat16)
+
+    def step(i):
+        x, x_next = st["x"], st["x_next"]
+        t_curr, t_prev = ts[i % SAMPLING_STEPS], ts[i % SAMPLING_STEPS + 1]
+        t_vec = torch.full((nb,), t_curr, dtype=torch.bfloat16, device=dev)
+        img3.copy_(x.expand(nb, -1, -1))
+        pred = model(img=img3, img_ids=img_ids, txt=txt, txt_ids=txt_ids, timesteps=t_vec, y_vec=y_vec, cond=cond)
+        if nb == 3:
+            _C.cfg_euler(pred, x, x_next, 7.5, 3.0, float(t_prev - t_curr))
+        else:
+            _C.cfg_euler(pred.expand(3, -1, -1).contiguous(), x, x_next, 1.0, 1.0, float(t_prev - t_curr))
+        st["x"], st["x_next"] = x_next, x
+
+    return step, st
 
 
 if __name__ == "__main__":
