@@ -22,7 +22,6 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
-template <int VAR>
 __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -134,15 +133,9 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
     "v"(fo[0]), "v"(fo[1]), "v"(fo[2]), "v"(fo[3]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(koffL[3]),      \
     "v"(maskval), "v"(onesaddr), "s"(kbase), "s"(vbase),                                                             \
     "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nvw)
-  if constexpr (VAR == 0) {
-    asm volatile(
+  asm volatile(
 #include "attention_asm128_n2_v0.inc"
-        OSK128_OPERANDS : OSK128N2_CLOBBERS);
-  } else {
-    asm volatile(
-#include "attention_asm128_n2_v1.inc"
-        OSK128_OPERANDS : OSK128N2_CLOBBERS);
-  }
+      OSK128_OPERANDS : OSK128N2_CLOBBERS);
 
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 128 (sum of P), store
 #pragma unroll
@@ -209,16 +202,9 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
   }
 }
 
-template <int VAR>
 int launch_one(const AttnParams& p, hipStream_t st) {
-  static bool attr_set = false;
-  auto kernel = attn_asm128_kernel<VAR>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, OSK128_SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  auto kernel = attn_asm128_kernel;
+  OSK_ENSURE_MAX_SMEM(kernel, OSK128_SMEM);
   const int units = ((p.Lq + 255) / 256) * p.B * p.H;
   const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
   dim3 grid(units + tail_units * (p.tail_split - 1)), block(64 * NW);
@@ -228,9 +214,6 @@ int launch_one(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
-// var 0 = production schedule, 1 = the experimental body of tools/gen_attn_asm.py --exp (default: hazard-padded debug)
-int launch_asm128(const AttnParams& p, int var, hipStream_t st) {
-  return var ? launch_one<1>(p, st) : launch_one<0>(p, st);
-}
+int launch_asm128(const AttnParams& p, hipStream_t st) { return launch_one(p, st); }
 
 }  // namespace osk_attn

@@ -31,7 +31,6 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
-template <int VAR>
 __global__ void __launch_bounds__(256, 1) attn_asm128p8_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -139,15 +138,9 @@ __global__ void __launch_bounds__(256, 1) attn_asm128p8_kernel(const AttnParams 
     "v"(fo[0]), "v"(fo[1]), "v"(fo[2]), "v"(fo[3]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(koffL[3]),      \
     "v"(vf0), "v"(vf1), "s"(kbase), "s"(vbase),                                                                      \
     "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nvw)
-  if constexpr (VAR == 0) {
-    asm volatile(
+  asm volatile(
 #include "attention_asm128p8_n2_v0.inc"
-        OSK128P8_OPERANDS : OSK128P8N2_CLOBBERS);
-  } else {
-    asm volatile(
-#include "attention_asm128p8_n2_v1.inc"
-        OSK128P8_OPERANDS : OSK128P8N2_CLOBBERS);
-  }
+      OSK128P8_OPERANDS : OSK128P8N2_CLOBBERS);
 
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 128 (sum of P), store
 #pragma unroll
@@ -214,16 +207,9 @@ __global__ void __launch_bounds__(256, 1) attn_asm128p8_kernel(const AttnParams 
   }
 }
 
-template <int VAR>
 int launch_one(const AttnParams& p, hipStream_t st) {
-  static bool attr_set = false;
-  auto kernel = attn_asm128p8_kernel<VAR>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, OSK128P8_SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  auto kernel = attn_asm128p8_kernel;
+  OSK_ENSURE_MAX_SMEM(kernel, OSK128P8_SMEM);
   const int units = ((p.Lq + 255) / 256) * p.B * p.H;
   const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
   dim3 grid(units + tail_units * (p.tail_split - 1)), block(64 * NW);
@@ -233,9 +219,6 @@ int launch_one(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
-// var 0 = production schedule, 1 = the experimental body of tools/gen_attn_asm.py --exp (default: hazard-padded debug)
-int launch_asm128p8(const AttnParams& p, int var, hipStream_t st) {
-  return var ? launch_one<1>(p, st) : launch_one<0>(p, st);
-}
+int launch_asm128p8(const AttnParams& p, hipStream_t st) { return launch_one(p, st); }
 
 }  // namespace osk_attn

@@ -1,6 +1,6 @@
 // Flash-attention forward for head_dim 72 (DiT-XL geometry), gfx950: hand-scheduled main loop.
 //
-// Structure = attention_w64.hip (4 waves x 64 query rows, one wave per SIMD -- or 8 waves x 32 rows, two per SIMD --
+// Structure: 4 waves x 64 query rows, one wave per SIMD (the generator can also emit 8 waves x 32 rows, two per SIMD),
 // LDS-DMA staged 64-key tiles, swapped-operand v_mfma_f32_32x32x16_bf16), but the whole K/V loop is ONE asm
 // statement emitted by tools/gen_attn_asm.py (attention_asm72_n{NU}_v{VAR}.inc): explicit register file (O^T and Q in AGPRs, two score tiles,
 // P and two 4-slot fragment rings in VGPRs), every MFMA shadow filled by hand with ~5 issue slots of LDS reads /
@@ -28,10 +28,10 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
-template <int NU, int VAR>
-__global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm72_kernel(const AttnParams p) {
-  constexpr int NW = 8 / NU;                                   // waves per workgroup
-  constexpr int NSLOT = NU == 2 ? OSK72N2_NSLOT : OSK72N1_NSLOT;  // LDS-DMA slots per wave and tile
+__global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) {
+  constexpr int NU = 2;                                        // 32-row query blocks per wave (the generator's 8 waves x 32
+  constexpr int NW = 8 / NU;                                   // rows layout tied this one in rounds 1-2 and is not shipped)
+  constexpr int NSLOT = OSK72N2_NSLOT;                         // LDS-DMA slots per wave and tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,14 +96,10 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),    \
       "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]), "v"(w[16]), "v"(w[17]), "v"(w[18]), \
       "v"(w[19])
-    if constexpr (NU == 2) {
-      if (u == 0) {
-        asm volatile(OSK72N2_QW0_0 ::OSK_QIN : OSK72N2_A_CLOBBERS);
-      } else {
-        asm volatile(OSK72N2_QW1_0 ::OSK_QIN : OSK72N2_A_CLOBBERS);
-      }
+    if (u == 0) {
+      asm volatile(OSK72N2_QW0_0 ::OSK_QIN : OSK72N2_A_CLOBBERS);
     } else {
-      asm volatile(OSK72N1_QW0_0 ::OSK_QIN : OSK72N1_A_CLOBBERS);
+      asm volatile(OSK72N2_QW1_0 ::OSK_QIN : OSK72N2_A_CLOBBERS);
     }
   }
 
@@ -166,23 +162,9 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
     "v"(fo[2]), "v"(fo[3]), "v"(kc[0]), "v"(kc[1]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(maskval),      \
     "v"(onesaddr), "s"(kbase), "s"(vbase),                                                                           \
     "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
-  if constexpr (NU == 2 && VAR == 0) {
-    asm volatile(
+  asm volatile(
 #include "attention_asm72_n2_v0.inc"
-        OSK72_OPERANDS : OSK72N2_CLOBBERS);
-  } else if constexpr (NU == 2) {
-    asm volatile(
-#include "attention_asm72_n2_v1.inc"
-        OSK72_OPERANDS : OSK72N2_CLOBBERS);
-  } else if constexpr (VAR == 0) {
-    asm volatile(
-#include "attention_asm72_n1_v0.inc"
-        OSK72_OPERANDS : OSK72N1_CLOBBERS);
-  } else {
-    asm volatile(
-#include "attention_asm72_n1_v1.inc"
-        OSK72_OPERANDS : OSK72N1_CLOBBERS);
-  }
+      OSK72_OPERANDS : OSK72N2_CLOBBERS);
 
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 72 (sum of P), store
 #pragma unroll
@@ -194,28 +176,18 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   "=v"(o[d][0]), "=v"(o[d][1]), "=v"(o[d][2]), "=v"(o[d][3]), "=v"(o[d][4]), "=v"(o[d][5]), "=v"(o[d][6]),          \
       "=v"(o[d][7]), "=v"(o[d][8]), "=v"(o[d][9]), "=v"(o[d][10]), "=v"(o[d][11]), "=v"(o[d][12]), "=v"(o[d][13]), \
       "=v"(o[d][14]), "=v"(o[d][15])
-      if constexpr (NU == 2) {
-        if (u == 0 && d == 0) {
-          asm volatile(OSK72N2_OR0 : OSK_OOUT);
-        } else if (u == 0 && d == 1) {
-          asm volatile(OSK72N2_OR1 : OSK_OOUT);
-        } else if (u == 0 && d == 2) {
-          asm volatile(OSK72N2_OR2 : OSK_OOUT);
-        } else if (u == 1 && d == 0) {
-          asm volatile(OSK72N2_OR3 : OSK_OOUT);
-        } else if (u == 1 && d == 1) {
-          asm volatile(OSK72N2_OR4 : OSK_OOUT);
-        } else {
-          asm volatile(OSK72N2_OR5 : OSK_OOUT);
-        }
+      if (u == 0 && d == 0) {
+        asm volatile(OSK72N2_OR0 : OSK_OOUT);
+      } else if (u == 0 && d == 1) {
+        asm volatile(OSK72N2_OR1 : OSK_OOUT);
+      } else if (u == 0 && d == 2) {
+        asm volatile(OSK72N2_OR2 : OSK_OOUT);
+      } else if (u == 1 && d == 0) {
+        asm volatile(OSK72N2_OR3 : OSK_OOUT);
+      } else if (u == 1 && d == 1) {
+        asm volatile(OSK72N2_OR4 : OSK_OOUT);
       } else {
-        if (d == 0) {
-          asm volatile(OSK72N1_OR0 : OSK_OOUT);
-        } else if (d == 1) {
-          asm volatile(OSK72N1_OR1 : OSK_OOUT);
-        } else {
-          asm volatile(OSK72N1_OR2 : OSK_OOUT);
-        }
+        asm volatile(OSK72N2_OR5 : OSK_OOUT);
       }
     }
     // row 72 of O^T = sum_k P: lanes hi == 0, register (8 & 3) + 4 (8 >> 3) = 4 of row tile 2
@@ -262,32 +234,18 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   }
 }
 
-template <int NU, int VAR>
 int launch_one(const AttnParams& p, hipStream_t st) {
-  static bool attr_set = false;
-  auto kernel = attn_asm72_kernel<NU, VAR>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, OSK72_SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  auto kernel = attn_asm72_kernel;
+  OSK_ENSURE_MAX_SMEM(kernel, OSK72_SMEM);
   const int units = ((p.Lq + 255) / 256) * p.B * p.H;
   const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
-  dim3 grid(units + tail_units * (p.tail_split - 1)), block(64 * (8 / NU));
+  dim3 grid(units + tail_units * (p.tail_split - 1)), block(256);
   hipLaunchKernelGGL(kernel, grid, block, OSK72_SMEM, st, p);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-bool asm72_supported(const AttnParams& p, int hd) { (void)p; return hd == 72; }
-
-// nu = query blocks per wave (2: 4 waves x 64 rows, 1: 8 waves x 32 rows); var 0 = production schedule, 1 = the
-// experimental body emitted by tools/gen_attn_asm.py --exp (default: the hazard-padded debug schedule)
-int launch_asm72(const AttnParams& p, int nu, int var, hipStream_t st) {
-  if (nu == 2) return var ? launch_one<2, 1>(p, st) : launch_one<2, 0>(p, st);
-  return var ? launch_one<1, 1>(p, st) : launch_one<1, 0>(p, st);
-}
+int launch_asm72(const AttnParams& p, hipStream_t st) { return launch_one(p, st); }
 
 }  // namespace osk_attn

@@ -17,7 +17,7 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
-template <int NU, int VAR>
+template <int NU>
 __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm72p8_kernel(const AttnParams p) {
   constexpr int NW = 8 / NU;                                   // waves per workgroup
   static_assert(NU == 2, "the fp8 P.V variant exists in the 4 waves x 64 rows layout only");
@@ -142,15 +142,9 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
     "v"(fo[2]), "v"(fo[3]), "v"(kc[0]), "v"(kc[1]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(vf0), "v"(vf1), \
     "s"(kbase), "s"(vbase),                                                                                          \
     "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
-  if constexpr (VAR == 0) {
-    asm volatile(
+  asm volatile(
 #include "attention_asm72p8_n2_v0.inc"
-        OSK72P8_OPERANDS : OSK72P8N2_CLOBBERS);
-  } else {
-    asm volatile(
-#include "attention_asm72p8_n2_v1.inc"
-        OSK72P8_OPERANDS : OSK72P8N2_CLOBBERS);
-  }
+      OSK72P8_OPERANDS : OSK72P8N2_CLOBBERS);
 
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 72 (sum of P), store
 #pragma unroll
@@ -222,28 +216,18 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   }
 }
 
-template <int NU, int VAR>
 int launch_one(const AttnParams& p, hipStream_t st) {
-  static bool attr_set = false;
-  auto kernel = attn_asm72p8_kernel<NU, VAR>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, OSK72P8_SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  auto kernel = attn_asm72p8_kernel<2>;
+  OSK_ENSURE_MAX_SMEM(kernel, OSK72P8_SMEM);
   const int units = ((p.Lq + 255) / 256) * p.B * p.H;
   const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
-  dim3 grid(units + tail_units * (p.tail_split - 1)), block(64 * (8 / NU));
+  dim3 grid(units + tail_units * (p.tail_split - 1)), block(64 * 4);
   hipLaunchKernelGGL(kernel, grid, block, OSK72P8_SMEM, st, p);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-// var 0 = production schedule, 1 = the experimental body of tools/gen_attn_asm.py --exp (default: hazard-padded debug)
-int launch_asm72p8(const AttnParams& p, int var, hipStream_t st) {
-  return var ? launch_one<2, 1>(p, st) : launch_one<2, 0>(p, st);
-}
+int launch_asm72p8(const AttnParams& p, hipStream_t st) { return launch_one(p, st); }
 
 }  // namespace osk_attn

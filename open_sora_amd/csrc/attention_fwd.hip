@@ -21,11 +21,9 @@
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 4 * B * H * Lq * Lk * hd (QK^T + PV, not halved).
 #include "attention_params.h"
 #include "../../include/osk.h"
-#include <stdlib.h>
 
 namespace {
 using osk_attn::AttnParams;
-#define OSK_ATTN_DEFAULT_NU 2
 
 template <int HD>
 struct Cfg {
@@ -46,226 +44,8 @@ struct Cfg {
   static constexpr int VIT = (NVC + 511) / 512;
 };
 
-template <int HD>
-__global__ void __launch_bounds__(512) attn_fwd_kernel_v1(const AttnParams p) {
-  using C = Cfg<HD>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int hi = lane >> 5, l31 = lane & 31;
-  int bh, qb;
-  osk_attn::block_to_work(p, (p.Lq + 255) / 256, bh, qb);
-  const int b = bh / p.H, h = bh - b * p.H;
-
-  // zero the whole LDS once: pad chunks / pad rows are never overwritten by the staging below
-  for (int i = tid; i < C::SMEM / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
-
-  // ---- Q fragments (B operand): Q[q][ks*16 + hi*8 .. +8]
-  const int qi = qb * 256 + wave * 32 + l31;
-  const int qc = qi < p.Lq ? qi : p.Lq - 1;
-  const unsigned short* qrow = p.q + b * p.qbs + (int64_t)qc * p.qrs + h * HD;
-  bf16x8_t qf[C::NKS];
-#pragma unroll
-  for (int ks = 0; ks < C::NKS; ++ks) {
-    const int e0 = ks * 16 + hi * 8;
-    uint4 u = make_uint4(0, 0, 0, 0);
-    if (e0 < HD) u = *reinterpret_cast<const uint4*>(qrow + e0);
-    qf[ks] = __builtin_bit_cast(bf16x8_t, u);
-  }
-
-  // ---- staging slots of this thread
-  int k_row[C::KIT], k_c[C::KIT], v_d[C::VIT], v_c[C::VIT];
-#pragma unroll
-  for (int it = 0; it < C::KIT; ++it) {
-    const int i = tid + it * 512;
-    k_row[it] = i / C::CPR;
-    k_c[it] = i - k_row[it] * C::CPR;
-  }
-#pragma unroll
-  for (int it = 0; it < C::VIT; ++it) {
-    const int i = tid + it * 512;
-    v_d[it] = i >> 3;
-    v_c[it] = i & 7;
-  }
-  const int bkv = b % p.Bkv;
-  const unsigned short* kbase_b = p.k + bkv * p.kbs + h * HD;
-  const unsigned short* vbase_bh = p.vt + (int64_t)(bkv * p.H + h) * HD * p.seg_lp;
-
-  // staging registers as named scalars (arrays written under a divergent guard were placed in scratch)
-  uint4 rk0 = make_uint4(0, 0, 0, 0), rk1 = rk0, rv0 = rk0, rv1 = rk0;
-  static_assert(C::KIT <= 2 && C::VIT <= 2, "staging assumes <= 1024 chunks per tile");
-  constexpr bool K1_FULL = C::NKC >= 1024, V1_FULL = C::NVC >= 1024;  // slot 1 unguarded?
-  const bool k1_on = K1_FULL || (tid + 512 < C::NKC);
-  const bool v1_on = V1_FULL || (tid + 512 < C::NVC);
-#define STAGE_ISSUE(T)                                                                               \
-  {                                                                                                  \
-    const int s_ = (T) / p.tps, tt_ = (T) - s_ * p.tps;                                              \
-    const int key0_ = tt_ * 64;                                                                      \
-    const int last_ = p.seg_len - 1;                                                                 \
-    const unsigned short* kb_ = kbase_b + s_ * p.kss;                                                \
-    const unsigned short* vb_ = vbase_bh + s_ * p.vtss + key0_;                                      \
-    {                                                                                                \
-      int key_ = key0_ + k_row[0];                                                                   \
-      key_ = key_ < last_ ? key_ : last_;                                                            \
-      rk0 = *reinterpret_cast<const uint4*>(kb_ + (int64_t)key_ * p.krs + k_c[0] * 8);               \
-      rv0 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)v_d[0] * p.seg_lp + v_c[0] * 8);         \
-    }                                                                                                \
-    if constexpr (C::KIT > 1) {                                                                      \
-      if (k1_on) {                                                                                   \
-        int key_ = key0_ + k_row[C::KIT - 1];                                                        \
-        key_ = key_ < last_ ? key_ : last_;                                                          \
-        rk1 = *reinterpret_cast<const uint4*>(kb_ + (int64_t)key_ * p.krs + k_c[C::KIT - 1] * 8);    \
-      }                                                                                              \
-    }                                                                                                \
-    if constexpr (C::VIT > 1) {                                                                      \
-      if (v1_on)                                                                                     \
-        rv1 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)v_d[C::VIT - 1] * p.seg_lp +            \
-                                              v_c[C::VIT - 1] * 8);                                  \
-    }                                                                                                \
-  }
-#define STAGE_COMMIT(BUFI)                                                                           \
-  {                                                                                                  \
-    unsigned char* kb_ = smem + (BUFI) * C::BUF;                                                     \
-    unsigned char* vb_ = kb_ + C::KTILE;                                                             \
-    *reinterpret_cast<uint4*>(kb_ + k_row[0] * C::KROW + k_c[0] * 16) = rk0;                         \
-    *reinterpret_cast<uint4*>(vb_ + v_d[0] * C::VROW + v_c[0] * 16) = rv0;                           \
-    if constexpr (C::KIT > 1) {                                                                      \
-      if (k1_on)                                                                                     \
-        *reinterpret_cast<uint4*>(kb_ + k_row[C::KIT - 1] * C::KROW + k_c[C::KIT - 1] * 16) = rk1;   \
-    }                                                                                                \
-    if constexpr (C::VIT > 1) {                                                                      \
-      if (v1_on)                                                                                     \
-        *reinterpret_cast<uint4*>(vb_ + v_d[C::VIT - 1] * C::VROW + v_c[C::VIT - 1] * 16) = rv1;     \
-    }                                                                                                \
-  }
-
-  f32x16_t o[C::NDT];
-#pragma unroll
-  for (int d = 0; d < C::NDT; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int nt = p.n_seg * p.tps;
-  __syncthreads();  // zero-fill done
-  STAGE_ISSUE(0);
-  STAGE_COMMIT(0);
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    const bool more = t + 1 < nt;
-    if (more) STAGE_ISSUE(t + 1);
-    const unsigned char* kb = smem + cur * C::BUF;
-    const unsigned char* vb = kb + C::KTILE;
-
-    // ---- S^T = K . Q^T : two 32-key sub-tiles
-    f32x16_t s[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < C::NKS; ++ks) {
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + (t2 * 32 + l31) * C::KROW + (ks * 2 + hi) * 16);
-        s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
-      }
-    }
-    // ---- mask the ragged tail of a segment
-    {
-      const int sidx = t / p.tps, tt = t - sidx * p.tps;
-      const int valid = p.seg_len - tt * 64;
-      if (valid < 64) {
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kl = t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (kl >= valid) s[t2][r] = -INFINITY;
-          }
-      }
-    }
-    // ---- online softmax (lane-local; one exchange with the other half-wave)
-    float mt = s[0][0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
-    const float msc = m_new * p.sc;
-    float rs = 0.f;
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[t2][r] * p.sc - msc);
-        s[t2][r] = e;
-        rs += e;
-      }
-    l_run = l_run * alpha + rs;
-    if (!__all(m_new == m_run)) {
-#pragma unroll
-      for (int d = 0; d < C::NDT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-    }
-    m_run = m_new;
-    // ---- P^T fragments (B operand): group g = 16 keys = regs [8*(g&1), +8) of sub-tile g>>1
-    bf16x8_t pb[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int t2 = g >> 1, r0 = (g & 1) * 8;
-      uint4 u;
-      u.x = pack_bf16x2(s[t2][r0 + 0], s[t2][r0 + 1]);
-      u.y = pack_bf16x2(s[t2][r0 + 2], s[t2][r0 + 3]);
-      u.z = pack_bf16x2(s[t2][r0 + 4], s[t2][r0 + 5]);
-      u.w = pack_bf16x2(s[t2][r0 + 6], s[t2][r0 + 7]);
-      pb[g] = __builtin_bit_cast(bf16x8_t, u);
-    }
-    // ---- O^T += V^T . P^T
-#pragma unroll
-    for (int d = 0; d < C::NDT; ++d) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + (d * 32 + l31) * C::VROW + (g * 2 + hi) * 16);
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[g], o[d], 0, 0, 0);
-      }
-    }
-    if (more) STAGE_COMMIT(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (qi < p.Lq) {
-    unsigned short* orow = p.out + b * p.obs + (int64_t)qi * p.ors + h * HD;
-#pragma unroll
-    for (int d = 0; d < C::NDT; ++d) {
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int d0 = d * 32 + qd * 8 + hi * 4;
-        if (d0 < HD) {
-          uint2 u;
-          u.x = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
-          u.y = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
-          *reinterpret_cast<uint2*>(orow + d0) = u;
-        }
-      }
-    }
-    if (p.lse && hi == 0)
-      p.lse[(int64_t)bh * p.Lq + qi] = (m_run * p.sc + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
-  }
-}
-
-
-#undef STAGE_ISSUE
-#undef STAGE_COMMIT
-
 // =====================================================================================================
-// v2: software-pipelined.  In iteration t a wave issues the QK^T MFMAs of tile t+1 BEFORE the softmax of
+// Software-pipelined (head_dim 64; head_dim 72 / 128 run the hand-scheduled kernels of attention_asm72.hip / attention_asm128.hip).  In iteration t a wave issues the QK^T MFMAs of tile t+1 BEFORE the softmax of
 // tile t, so the softmax VALU work (max / exp2 / pack) of one tile runs in the shadow of the next tile's
 // matrix work instead of both waves of a SIMD alternating "all-MFMA" and "all-VALU" phases in lockstep
 // behind the per-tile barrier (v1: MFMA pipe idle during every softmax).  K is therefore staged two tiles
@@ -638,68 +418,29 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnParams p) {
 #undef K_COMMIT
 #undef V_COMMIT
 
-int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-// kernel structure (A/B knob, read once): -1 (default) = best available: the hand-scheduled head_dim-72 / 128 kernels
-// (attention_asm72.hip, attention_asm128.hip) when they apply, else 0;  0 = 8 waves x 32 rows (this file), 1 / 2 = the same with
-// scheduling hints, 9 = v1, 3 / 4 = 4 waves x 64 rows compiler-scheduled (attention_w64.hip) without / with
-// sched_group_barrier pipelines, 5 / 6 = attention_asm72.hip, 4 waves x 64 rows: production / experimental body (hazard-padded debug schedule by
-// default), 7 / 8 = the same for its 8 waves x 32 rows layout
-int attn_variant() {
-  static const int v = env_int("OSK_ATTN_VARIANT", -1);
-  return v;
-}
-int attn_map() {
-  static const int v = env_int("OSK_ATTN_MAP", 1);
-  return v;
-}
-
 template <typename KernelT>
-int launch_kernel(KernelT kernel, int smem, const AttnParams& p, hipStream_t st, bool* attr_set) {
-  if (!*attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    *attr_set = true;
-  }
+int launch_kernel(KernelT kernel, int smem, const AttnParams& p, hipStream_t st) {
+  OSK_ENSURE_MAX_SMEM(kernel, smem);   // one instantiation of this template per kernel: attn_fwd_kernel<64, 0>
   const int nqb = (p.Lq + 255) / 256;
   dim3 grid(nqb * p.B * p.H), block(512);
   hipLaunchKernelGGL(kernel, grid, block, smem, st, p);
   return (int)hipGetLastError();
 }
 
+// ONE kernel per head_dim: 72 and 128 -> the hand-scheduled kernels (tail units split along the keys + merge when the caller
+// handed over a workspace); 64 -> the compiler-scheduled pipeline of this file.  (The A/B variants of rounds 1-2 -- 8 waves x
+// 32 rows, the compiler-scheduled 4 x 64 layout, scheduling hints -- lost their comparisons and are generator / git history.)
 template <int HD>
 int launch(const AttnParams& p, hipStream_t st) {
-  using C = Cfg<HD>;
-  static bool set0 = false, set1 = false, set2 = false, set9 = false;
-  switch (attn_variant()) {
-    case -1:
-    case 5:
-    case 6:
-    case 7:
-    case 8:
-      if (osk_attn::asm72_supported(p, HD)) {
-        const int v = attn_variant();
-        // 5 / 6: 4 waves x 64 rows production / experimental body; 7 / 8: 8 waves x 32 rows production / experimental
-        const int nu = (v == 7 || v == 8) ? 1 : 2, var = (v == 6 || v == 8) ? 1 : 0;
-        const int rc = osk_attn::launch_asm72(p, v == -1 ? OSK_ATTN_DEFAULT_NU : nu, var, st);
-        return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, HD, st);
-      }
-      if (HD == 128 && attn_variant() < 7) {   // head_dim 128 has the 4 waves x 64 rows layout only
-        const int rc = osk_attn::launch_asm128(p, attn_variant() == 6 ? 1 : 0, st);
-        return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, HD, st);
-      }
-      break;
-    case 3: return osk_attn::launch_w64(p, HD, 0, st);
-    case 4: return osk_attn::launch_w64(p, HD, 1, st);
-    case 9: return launch_kernel(attn_fwd_kernel_v1<HD>, C::SMEM, p, st, &set9);
-    case 1: return launch_kernel(attn_fwd_kernel<HD, 1>, C::SMEM, p, st, &set1);
-    case 2: return launch_kernel(attn_fwd_kernel<HD, 2>, C::SMEM, p, st, &set2);
-    default: break;
+  if constexpr (HD == 72) {
+    const int rc = osk_attn::launch_asm72(p, st);
+    return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, HD, st);
+  } else if constexpr (HD == 128) {
+    const int rc = osk_attn::launch_asm128(p, st);
+    return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, HD, st);
+  } else {
+    return launch_kernel(attn_fwd_kernel<HD, 0>, Cfg<HD>::SMEM, p, st);
   }
-  return launch_kernel(attn_fwd_kernel<HD, 0>, C::SMEM, p, st, &set0);
 }
 
 }  // namespace
@@ -741,16 +482,6 @@ __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
   }
 }
 
-int device_cus() {
-  static int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      v = 256;
-    return v > 0 ? v : 256;
-  }();
-  return n;
-}
-
 }  // namespace
 
 // A workgroup owns a CU for its whole key loop, so a launch takes ceil(units / CUs) rounds and the last round may run
@@ -761,11 +492,8 @@ int device_cus() {
 void split_tail(AttnParams& p, int units, int hd, void* workspace, int64_t workspace_bytes) {
   p.tail_split = 1;
   p.tail_first = 0x7fffffff;
-  const int v = attn_variant();
-  if (!workspace || !(v == -1 || (v >= 5 && v <= 8))) return;   // the hand-scheduled kernels only
-  static const int enable = env_int("OSK_ATTN_TAILSPLIT", 1);
-  if (!enable) return;
-  const int cus = device_cus();
+  if (!workspace) return;
+  const int cus = osk_device_cus();
   const int R = units % cus;
   if (R == 0) return;
   auto cost = [&](int s) { return (double)((R * s + cus - 1) / cus) / s; };
@@ -846,7 +574,7 @@ extern "C" int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, 
   p.q_prescaled = q_prescaled;
   if (kv_batches < 0 || kv_batches > B) return OSK_EINVAL;
   p.Bkv = kv_batches > 0 ? kv_batches : B;
-  p.map = attn_map();
+  p.map = 1;   // XCD-contiguous work order (each XCD walks one head's K / V^T stream)
   if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 0)) return OSK_EINVAL;
   if (hd == 72 || hd == 128) osk_attn::split_tail(p, ((Lq + 255) / 256) * B * H, hd, workspace, workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -859,13 +587,8 @@ extern "C" int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, 
 }
 
 extern "C" const char* osk_attention_kernel_name(int hd, int seg_len) {
-  const int v = attn_variant();
   (void)seg_len;
-  if ((v == -1 || (v >= 5 && v <= 8)) && hd == 72) return "attn_asm72_kernel";
-  if ((v == -1 || v == 5 || v == 6) && hd == 128) return "attn_asm128_kernel";
-  if (v == 3 || v == 4) return "attn_w64_kernel";
-  if (v == 9) return "attn_fwd_kernel_v1";
-  return "attn_fwd_kernel";
+  return hd == 72 ? "attn_asm72_kernel" : hd == 128 ? "attn_asm128_kernel" : "attn_fwd_kernel";
 }
 
 
@@ -1047,11 +770,10 @@ extern "C" int osk_attention_fwd_pv8_bf16(const void* q, int64_t q_batch_stride,
   p.q_prescaled = q_prescaled;
   if (kv_batches < 0 || kv_batches > B) return OSK_EINVAL;
   p.Bkv = kv_batches > 0 ? kv_batches : B;
-  p.map = attn_map();
+  p.map = 1;   // XCD-contiguous work order (each XCD walks one head's K / V^T stream)
   if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 0)) return OSK_EINVAL;
   osk_attn::split_tail(p, ((Lq + 255) / 256) * B * H, hd, workspace, workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
-  const int var = attn_variant() == 6 ? 1 : 0;
-  const int rc = hd == 128 ? osk_attn::launch_asm128p8(p, var, st) : osk_attn::launch_asm72p8(p, var, st);
+  const int rc = hd == 128 ? osk_attn::launch_asm128p8(p, st) : osk_attn::launch_asm72p8(p, st);
   return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, hd, st);
 }

@@ -213,13 +213,7 @@ extern "C" int osk_attention_hd512_fwd_bf16(const void* q, int64_t q_batch_strid
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)vt & 15) || ((uintptr_t)out & 7) || ((uintptr_t)bias_v & 15))
     return OSK_EINVAL;
   if (vt_row_stride < (int64_t)((S + KT - 1) / KT) * KT) return OSK_EINVAL;   // whole 32-key tiles are fetched
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_hd512_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  OSK_ENSURE_MAX_SMEM(attn_hd512_kernel, SMEM);
   P512 p;
   p.q = (const unsigned short*)q; p.qbs = q_batch_stride; p.qrs = q_row_stride;
   p.k = (const unsigned short*)k; p.kbs = k_batch_stride; p.krs = k_row_stride;

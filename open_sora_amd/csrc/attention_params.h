@@ -105,15 +105,12 @@ OSK_DEV KeyPart key_part(const AttnParams& p, bool tail, int part, bool ragged) 
 void split_tail(AttnParams& p, int units, int hd, void* workspace, int64_t workspace_bytes);
 int launch_merge(const AttnParams& p, int hd, hipStream_t st);
 
-// attention_w64.hip: 4 waves x 64 query rows, one wave per SIMD, LDS-DMA staged K / V^T
-int launch_w64(const AttnParams& p, int hd, int hints, hipStream_t st);
-// attention_asm72.hip: the same structure for head_dim 72 with a hand-scheduled (generated) main loop
-bool asm72_supported(const AttnParams& p, int hd);
-int launch_asm72(const AttnParams& p, int nu, int var, hipStream_t st);
-// attention_asm128.hip: head_dim 128, 4 waves x 64 rows, generated main loop
-int launch_asm128(const AttnParams& p, int var, hipStream_t st);
+// attention_asm72.hip: head_dim 72, 4 waves x 64 query rows, hand-scheduled (generated) main loop
+int launch_asm72(const AttnParams& p, hipStream_t st);
+// attention_asm128.hip: head_dim 128, the same layout and generator
+int launch_asm128(const AttnParams& p, hipStream_t st);
 // attention_asm128p8.hip / attention_asm72p8.hip: the same with the P.V product on the fp8 MFMA
-int launch_asm128p8(const AttnParams& p, int var, hipStream_t st);
-int launch_asm72p8(const AttnParams& p, int var, hipStream_t st);
+int launch_asm128p8(const AttnParams& p, hipStream_t st);
+int launch_asm72p8(const AttnParams& p, hipStream_t st);
 
 }  // namespace osk_attn

@@ -20,7 +20,6 @@
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 2 * Cin * Cout * k^3 * B*To*Ho*Wo  (SURVEY.md §8(d)).
 #include "conv_params.h"
 #include "../../include/osk.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -257,18 +256,16 @@ static int conv_entry(const void* x, int B, int T, int H, int W, int Cin, const 
   p.nk = (int)(Kp / BK);
   hipStream_t s = (hipStream_t)stream;
   {
-    // large-tile kernels with the hand-scheduled K loop (conv3d_256.hip); OSK_CONV_VARIANT=0 forces this file's kernel,
-    // 1 the per-tap segment version
-    static const int cv = [] { const char* e = getenv("OSK_CONV_VARIANT"); return e ? atoi(e) : -1; }();
+    // large-tile kernels with the hand-scheduled K loop (conv3d_256.hip) wherever the shape qualifies
     const int64_t x_bytes = (int64_t)B * T * H * W * Cin * 2;
-    const bool big = cv != 0 && osk_conv::conv256_supported(p, x_bytes, (int64_t)Cout * w_row_stride * 2);
+    const bool big = osk_conv::conv256_supported(p, x_bytes, (int64_t)Cout * w_row_stride * 2);
     if (gn_sums) {   // fused statistics live in the large-tile kernels' epilogue only; nothing is launched otherwise
       p.gn_sums = gn_sums;
       p.gn_G = gn_groups;
       // (the statistics ride in the 16-byte-store path of the epilogue: the output must be 16-byte aligned)
       if (!big || !osk_conv::conv256_gn_supported(p) || ((uintptr_t)out & 15)) return OSK_EUNSUPPORTED;
     }
-    if (big) return osk_conv::launch_conv256(p, cv, s);
+    if (big) return osk_conv::launch_conv256(p, s);
   }
   const int nblk = ((p.M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
   dim3 grid(nblk), block(256);

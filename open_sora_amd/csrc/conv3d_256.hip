@@ -1,20 +1,17 @@
 // CausalConv3d for gfx950, large tile + hand-scheduled K loop (Cin % 128 == 0, Cout >= 128, >= 256 output voxels).
 //
 // Same implicit GEMM as conv3d.hip (NDHWC activations, K = tap-major / channel-minor, replicate / causal padding as a
-// CLAMP and the decoder's nearest upsample as a SHIFT of the gathered coordinate, weights pre-laid as [Cout][27 Cin],
-// swapped-operand v_mfma_f32_32x32x16_bf16 so a lane owns one output voxel) on the tile and pipeline of gemm256.hip:
-// 256 voxels x 256 (or 128) output channels x 64, 8 waves, LDS-DMA double buffer, accumulators in AGPRs.
-// The K axis is walked one FILTER TAP at a time: within a tap the A rows are fixed gathered voxels and the K steps only
-// advance the channel block, i.e. exactly a GEMM K loop with per-lane row offsets.  Each tap is one call of the asm
-// segment emitted by tools/gen_gemm_asm.py (conv256_segment_n*.inc); the accumulators persist in the AGPRs between the
-// calls, the last K step of a segment already fetches the next tap's first step (its offsets are passed in), and the
-// per-tap voxel offsets (3 clamps per row slot) are ordinary compiler code between the calls.
+// CLAMP and the decoder's nearest upsample as a SHIFT of the gathered coordinate, weights pre-laid as [Cout][27 Cin]) on the
+// tile, LDS image and pipeline of gemm256x.hip: 256 voxels x 256 (NBJ = 8) or 128 (NBJ = 4) output channels x 64, 4 waves (one
+// per SIMD), v_mfma_f32_16x16x32_bf16, LDS-DMA double buffer, accumulators in AGPRs, persistent workgroups.  The K axis is all
+// 27 taps in ONE asm call (conv256x_body*.inc, tools/gen_gemm_asm.py::gen_conv_x4): inside a tap a K step only advances the
+// channel block (exactly a GEMM K step with per-lane row offsets); at a tap boundary every row slot takes a new voxel offset
+// from an LDS table [tap][256 rows] built per tile by build_tap_table().
+// (Rounds 1-2 also shipped 8-wave and 32x32x16 forms of this kernel and a per-tap-segment variant: they lost their A/B runs --
+// profiles/r02_* -- and are generator options / git history now.)
 //
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 2 * Cin * Cout * k^3 * B*To*Ho*Wo.
 #include "conv_params.h"
-#include "gemm256_regs_n256.inc"
-#include "gemm256_regs_n128.inc"
-#include "gemm256w_regs.inc"
 #include "gemm256x_regs.inc"
 #include <type_traits>
 
@@ -23,61 +20,6 @@ namespace {
 
 OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v); }
-
-#define OSKC_OUT16                                                                                               \
-  "=v"(v16[0]), "=v"(v16[1]), "=v"(v16[2]), "=v"(v16[3]), "=v"(v16[4]), "=v"(v16[5]), "=v"(v16[6]), "=v"(v16[7]),    \
-      "=v"(v16[8]), "=v"(v16[9]), "=v"(v16[10]), "=v"(v16[11]), "=v"(v16[12]), "=v"(v16[13]), "=v"(v16[14]),          \
-      "=v"(v16[15])
-
-// accumulator layouts: TM x TN MFMA tiles per wave, tile T = tn * TM + tm in AGPRs [16 T, 16 T + 16)
-struct Lay256 {   // 8 waves, 256 x 256 tile, wave tile 128 x 64
-  static constexpr int TM = OSKG256_TM, TN = OSKG256_TN;
-  template <int T>
-  OSK_DEV void read(float* v16) {
-    if constexpr (T == 0) asm volatile(OSKG256_AR0 : OSKC_OUT16);
-    else if constexpr (T == 1) asm volatile(OSKG256_AR1 : OSKC_OUT16);
-    else if constexpr (T == 2) asm volatile(OSKG256_AR2 : OSKC_OUT16);
-    else if constexpr (T == 3) asm volatile(OSKG256_AR3 : OSKC_OUT16);
-    else if constexpr (T == 4) asm volatile(OSKG256_AR4 : OSKC_OUT16);
-    else if constexpr (T == 5) asm volatile(OSKG256_AR5 : OSKC_OUT16);
-    else if constexpr (T == 6) asm volatile(OSKG256_AR6 : OSKC_OUT16);
-    else asm volatile(OSKG256_AR7 : OSKC_OUT16);
-  }
-};
-struct Lay128 {   // 8 waves, 256 x 128 tile, wave tile 64 x 64
-  static constexpr int TM = OSKG128_TM, TN = OSKG128_TN;
-  template <int T>
-  OSK_DEV void read(float* v16) {
-    if constexpr (T == 0) asm volatile(OSKG128_AR0 : OSKC_OUT16);
-    else if constexpr (T == 1) asm volatile(OSKG128_AR1 : OSKC_OUT16);
-    else if constexpr (T == 2) asm volatile(OSKG128_AR2 : OSKC_OUT16);
-    else asm volatile(OSKG128_AR3 : OSKC_OUT16);
-  }
-};
-struct LayW {     // 4 waves, 256 x 256 tile, wave tile 128 x 128
-  static constexpr int TM = OSKW_TM, TN = OSKW_TN;
-  template <int T>
-  OSK_DEV void read(float* v16) {
-    if constexpr (T == 0) asm volatile(OSKW_AR0 : OSKC_OUT16);
-    else if constexpr (T == 1) asm volatile(OSKW_AR1 : OSKC_OUT16);
-    else if constexpr (T == 2) asm volatile(OSKW_AR2 : OSKC_OUT16);
-    else if constexpr (T == 3) asm volatile(OSKW_AR3 : OSKC_OUT16);
-    else if constexpr (T == 4) asm volatile(OSKW_AR4 : OSKC_OUT16);
-    else if constexpr (T == 5) asm volatile(OSKW_AR5 : OSKC_OUT16);
-    else if constexpr (T == 6) asm volatile(OSKW_AR6 : OSKC_OUT16);
-    else if constexpr (T == 7) asm volatile(OSKW_AR7 : OSKC_OUT16);
-    else if constexpr (T == 8) asm volatile(OSKW_AR8 : OSKC_OUT16);
-    else if constexpr (T == 9) asm volatile(OSKW_AR9 : OSKC_OUT16);
-    else if constexpr (T == 10) asm volatile(OSKW_AR10 : OSKC_OUT16);
-    else if constexpr (T == 11) asm volatile(OSKW_AR11 : OSKC_OUT16);
-    else if constexpr (T == 12) asm volatile(OSKW_AR12 : OSKC_OUT16);
-    else if constexpr (T == 13) asm volatile(OSKW_AR13 : OSKC_OUT16);
-    else if constexpr (T == 14) asm volatile(OSKW_AR14 : OSKC_OUT16);
-    else asm volatile(OSKW_AR15 : OSKC_OUT16);
-  }
-};
-template <int BN>
-using LayOf = std::conditional_t<BN == 256, Lay256, Lay128>;
 
 // Tile row -> output voxel (linear index over [B, To, Ho, Wo]).
 //   linear (brick = 0): row r of M-tile bm is voxel 256 bm + r: a tile is a run of 256 voxels along W.
@@ -132,407 +74,7 @@ OSK_DEV void build_tap_table(const ConvParams& p, int bm, int tid, int tap_strid
   }
 }
 
-// bias + residual + bf16 store of one 32 x 32 accumulator tile T = tn * TM + tm (lane: voxel m, 4 channels per quad);
-// r0w = first tile row of this wave
-// fused GroupNorm statistics: a lane's partial (sum, sum of squares) of its voxel rows for the four 4-channel quads
-// (channels nstrip + 8 qd + 4 hi + j) of the 32-column strip being walked, accumulated over the strip's TM row tiles
-struct GnAcc {
-  float s[4], q[4];
-};
-
 typedef __bf16 gn_bf16x2_t __attribute__((ext_vector_type(2)));
-
-// two packed bf16 pairs = 4 rounded outputs: v_dot2c_f32_bf16 accumulates a pair's sum (against {1, 1}) or sum of squares
-// in one instruction (bf16 x bf16 products are exact in f32)
-OSK_DEV void gn_add(GnAcc& a, int qd, unsigned lo_hi0, unsigned lo_hi1) {
-  const gn_bf16x2_t p0 = __builtin_bit_cast(gn_bf16x2_t, lo_hi0), p1 = __builtin_bit_cast(gn_bf16x2_t, lo_hi1);
-  const gn_bf16x2_t one = __builtin_bit_cast(gn_bf16x2_t, 0x3f803f80u);
-  a.s[qd] = __builtin_amdgcn_fdot2_f32_bf16(p0, one, a.s[qd], false);
-  a.s[qd] = __builtin_amdgcn_fdot2_f32_bf16(p1, one, a.s[qd], false);
-  a.q[qd] = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, a.q[qd], false);
-  a.q[qd] = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, a.q[qd], false);
-}
-
-// sum over the 32 lanes of a half-wave, in every lane: four DPP adds inside a row of 16 (quad swaps, half mirror, mirror:
-// one VALU instruction each, no LDS crossbar) and one cross-row exchange
-OSK_DEV float half_wave_sum(float v) {
-#define OSKC_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
-  OSKC_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
-  OSKC_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
-  OSKC_DPP_ADD(0x141);   // row_half_mirror
-  OSKC_DPP_ADD(0x140);   // row_mirror
-#undef OSKC_DPP_ADD
-  return v + __shfl_xor(v, 16, 64);
-}
-
-// end of a strip: reduce over the 32 voxel lanes of each half-wave, then LDS float atomics into the tile's per-group slots
-// ls[2 * (group - first group of the tile) + {0, 1}]
-OSK_DEV void gn_flush(const ConvParams& p, GnAcc& a, int nstrip, int n0, int l31, int hi, float* ls) {
-  const int cpg = p.Cout / p.gn_G;
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const float s = half_wave_sum(a.s[qd]), q = half_wave_sum(a.q[qd]);
-    if (l31 == 0) {
-      const int n = nstrip + qd * 8 + hi * 4;
-      if (n < p.Cout) {
-        const int gl = n / cpg - n0 / cpg;
-        atomicAdd(ls + 2 * gl, s);
-        atomicAdd(ls + 2 * gl + 1, q);
-      }
-    }
-    a.s[qd] = 0.f;
-    a.q[qd] = 0.f;
-  }
-}
-
-// bias + residual + bf16 store of one 32 x 32 accumulator tile T = tn * TM + tm (lane: voxel m, 4 channels per quad);
-// r0w = first tile row of this wave; GN: accumulate the fused GroupNorm statistics (wave-uniform template switch)
-template <class Lay, int T, bool GN>
-OSK_DEV void epilogue_tile(const ConvParams& p, int bm, int r0w, int n0, int n0w, int l31, int hi, GnAcc& ga, float* ls) {
-  constexpr int TM = Lay::TM;
-  constexpr int tn = T / TM, tm = T % TM;
-  float acc[16];
-  Lay::template read<T>(acc);
-  const int m = tile_row_to_voxel(p, bm, r0w + tm * 32 + l31);
-  const bool valid = m < p.M;
-  const int64_t roff = (int64_t)(valid ? m : 0) * p.Cout;
-  const bool vec_ok = (p.Cout & 3) == 0;
-  // whole 32-channel strip inside Cout and the row 16-byte aligned (Cout % 8 == 0): pair the half-waves and store 16 B
-  // (v_permlane32_swap per dword: the lower half-wave takes the whole 8-channel block qd, the upper one block qd + 1)
-  const int nstrip = n0w + tn * 32;
-  if (vec_ok && (p.Cout & 7) == 0 && nstrip + 32 <= p.Cout && (((uintptr_t)p.out) & 15) == 0) {
-    uint2 packed[4];
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int n = nstrip + qd * 8 + hi * 4;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[qd * 4 + j];
-      if (p.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
-      if (p.res) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
-        v[0] += bf16_lo(rv.x); v[1] += bf16_hi(rv.x); v[2] += bf16_lo(rv.y); v[3] += bf16_hi(rv.y);
-      }
-      packed[qd].x = pack_bf16x2(v[0], v[1]);
-      packed[qd].y = pack_bf16x2(v[2], v[3]);
-      if constexpr (GN) {
-        if (valid) gn_add(ga, qd, packed[qd].x, packed[qd].y);
-      }
-    }
-#pragma unroll
-    for (int qd = 0; qd < 4; qd += 2) {
-      auto sx = __builtin_amdgcn_permlane32_swap(packed[qd].x, packed[qd + 1].x, false, false);
-      auto sy = __builtin_amdgcn_permlane32_swap(packed[qd].y, packed[qd + 1].y, false, false);
-      if (valid) *reinterpret_cast<uint4*>(p.out + roff + nstrip + (qd + hi) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-    }
-  } else {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int n = n0w + tn * 32 + qd * 8 + hi * 4;
-      if (n >= p.Cout || !valid) continue;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[qd * 4 + j];
-      if (vec_ok && n + 3 < p.Cout) {
-        if (p.bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
-        if (p.res) {
-          const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
-          v[0] += bf16_lo(rv.x); v[1] += bf16_hi(rv.x); v[2] += bf16_lo(rv.y); v[3] += bf16_hi(rv.y);
-        }
-        uint2 o;
-        o.x = pack_bf16x2(v[0], v[1]);
-        o.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(p.out + roff + n) = o;
-        if constexpr (GN) gn_add(ga, qd, o.x, o.y);
-      } else {
-        for (int j = 0; j < 4 && n + j < p.Cout; ++j) {
-          float t = v[j] + (p.bias ? p.bias[n + j] : 0.f);
-          if (p.res) t += bf16_bits_to_f32(p.res[roff + n + j]);
-          p.out[roff + n + j] = f32_to_bf16_bits(t);
-        }
-      }
-    }
-  }
-  if constexpr (GN && tm == TM - 1) gn_flush(p, ga, nstrip, n0, l31, hi, ls);
-}
-
-template <class Lay, bool GN, int... Ts>
-OSK_DEV void epilogue_tiles(const ConvParams& p, int bm, int r0w, int n0, int n0w, int l31, int hi, float* ls,
-                            std::integer_sequence<int, Ts...>) {
-  GnAcc ga;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) ga.s[i] = ga.q[i] = 0.f;
-  (epilogue_tile<Lay, Ts, GN>(p, bm, r0w, n0, n0w, l31, hi, ga, ls), ...);
-}
-
-// The whole workgroup calls this after its K loop (LDS is quiescent: every stage read and every LDS-DMA write was waited
-// for before the loop's last barrier).  BN = channels per workgroup tile, n0 = its first channel.
-// With p.gn_sums: the tile's per-group (sum, sum of squares) are collected in LDS floats (<= 256 voxels x 16 channels per
-// slot), then ONE f64 atomic per (group, statistic) and tile goes to sums[b][g] -- the tile lies inside one batch item
-// (conv256_gn_supported).
-template <class Lay, int BN>
-OSK_DEV void epilogue_all(const ConvParams& p, int bm, int r0w, int n0, int n0w, int l31, int hi, unsigned char* smem) {
-  constexpr auto seq = std::make_integer_sequence<int, Lay::TM * Lay::TN>{};
-  if (!p.gn_sums) {
-    epilogue_tiles<Lay, false>(p, bm, r0w, n0, n0w, l31, hi, nullptr, seq);
-    return;
-  }
-  float* ls = reinterpret_cast<float*>(smem);
-  const int tid = threadIdx.x;
-  const int cpg = p.Cout / p.gn_G;
-  int nch = p.Cout - n0;
-  nch = nch < BN ? nch : BN;
-  const int nslots = 2 * (nch / cpg);              // <= 2 * 256 / 4 = 128
-  if (tid < nslots) ls[tid] = 0.f;
-  __syncthreads();
-  epilogue_tiles<Lay, true>(p, bm, r0w, n0, n0w, l31, hi, ls, seq);
-  __syncthreads();
-  if (tid < nslots) {
-    const int m = tile_row_to_voxel(p, bm, 0);
-    const int b = m / (p.To * p.Ho * p.Wo);
-    atomicAdd(p.gn_sums + ((int64_t)b * p.gn_G + n0 / cpg) * 2 + tid, (double)ls[tid]);
-  }
-}
-
-template <int BN>
-__global__ void __launch_bounds__(512, 2) conv256_kernel(const ConvParams p) {
-  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
-  constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
-  constexpr int WN = BN / (TN * 32);
-  constexpr int W_BASE = BN == 256 ? OSKG256_W_BASE : OSKG128_W_BASE;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  const int nbm = (p.M + 255) / 256, nbn = (p.Cout + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, nbm * nbn);
-  const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int m0 = bm * 256, n0 = bn * BN;
-
-  // ---- LDS-DMA row slots of this lane: instruction j = wave + 8 i covers tile rows [8 j, 8 j + 8)
-  const int srow8 = lane >> 3, spos = lane & 7;
-  unsigned woff[4], chunk16[4];
-  int cb[4], cto[4], cho[4], cwo[4];   // batch, output coordinates of the slot's voxel
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave + 8 * i) * 8 + srow8;
-    const int c = spos ^ ((r >> 1) & 7);
-    chunk16[i] = (unsigned)(c * 16);
-    int n = n0 + (r < BN ? r : 0);
-    n = n < p.Cout ? n : p.Cout - 1;
-    woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
-    int m = m0 + r;
-    m = m < p.M ? m : p.M - 1;
-    cwo[i] = m % p.Wo;
-    int q = m / p.Wo;
-    cho[i] = q % p.Ho;
-    q /= p.Ho;
-    cto[i] = q % p.To;
-    cb[i] = q / p.To;
-  }
-  const int HW = p.H * p.W;
-  const unsigned cin_bytes = (unsigned)p.Cin * 2;
-  // byte offset of the slot's gathered voxel for filter tap (dt, dh, dw): clamp = replicate / causal padding,
-  // shift = nearest upsample (frame 0 is spatial-only)   [conv3d.hip / unet_causal_3d_blocks.py:82-96,136-150]
-  auto tap_offset = [&](int i, int dt, int dh, int dw) -> unsigned {
-    int tu = cto[i] * p.st + dt - (p.ks - 1);
-    tu = tu < 0 ? 0 : (tu > p.Tu - 1 ? p.Tu - 1 : tu);
-    const int ts = p.up_t ? (tu == 0 ? 0 : 1 + ((tu - 1) >> 1)) : tu;
-    int hu = cho[i] * p.sh + dh - (p.ks >> 1);
-    hu = hu < 0 ? 0 : (hu > p.Hu - 1 ? p.Hu - 1 : hu);
-    const int hs = p.up_hw ? (hu >> 1) : hu;
-    int wu = cwo[i] * p.sw + dw - (p.ks >> 1);
-    wu = wu < 0 ? 0 : (wu > p.Wu - 1 ? p.Wu - 1 : wu);
-    const int ws = p.up_hw ? (wu >> 1) : wu;
-    const unsigned pos = (unsigned)((cb[i] * p.T + ts) * HW + hs * p.W + ws);
-    return pos * cin_bytes + chunk16[i];
-  };
-
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const int sw = (l31 >> 1) & 7;
-  unsigned faA[4], faW[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const unsigned sz = (unsigned)((((ks << 1) | hi) ^ sw) << 4);
-    faA[ks] = lds_base + (wm * TM * 32 + l31) * 128 + sz;
-    faW[ks] = lds_base + W_BASE + (wn * TN * 32 + l31) * 128 + sz;
-  }
-  const uint64_t xbase = rfl64((uint64_t)(uintptr_t)p.x);
-  const unsigned nk = rfl((unsigned)(p.Cin / 64));   // K steps per tap (even: Cin % 128 == 0)
-  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + W_BASE + wave * 1024);
-
-  unsigned aoffc[4], aoffn[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) aoffc[i] = tap_offset(i, 0, 0, 0);
-  for (int tap = 0; tap < p.ntaps; ++tap) {
-    const int tn_ = tap + 1 < p.ntaps ? tap + 1 : tap;   // last segment: "next" = itself (harmless re-fetch)
-    int dt = 0, dh = 0, dw = 0;
-    if (p.ks == 3) {
-      dt = tn_ / 9;
-      const int r9 = tn_ - dt * 9;
-      dh = r9 / 3;
-      dw = r9 - dh * 3;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) aoffn[i] = tap_offset(i, dt, dh, dw);
-    const uint64_t wbase = rfl64((uint64_t)(uintptr_t)(p.w + (int64_t)tap * p.Cin));
-    const unsigned flags = rfl((tap == 0 ? 1u : 0u) | (tap + 1 == p.ntaps ? 2u : 0u));
-#define OSKC_OPERANDS                                                                                              \
-  ::"v"(faA[0]), "v"(faA[1]), "v"(faA[2]), "v"(faA[3]), "v"(faW[0]), "v"(faW[1]), "v"(faW[2]), "v"(faW[3]),         \
-      "v"(aoffc[0]), "v"(aoffc[1]), "v"(aoffc[2]), "v"(aoffc[3]), "v"(aoffn[0]), "v"(aoffn[1]), "v"(aoffn[2]),      \
-      "v"(aoffn[3]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "s"(xbase), "s"(wbase), "s"(nk),       \
-      "s"(adst), "s"(wdst), "s"(flags)
-    if constexpr (BN == 256) {
-      asm volatile(
-#include "conv256_segment_n256.inc"
-          OSKC_OPERANDS : OSKG256_SEG_CLOBBERS);
-    } else {
-      asm volatile(
-#include "conv256_segment_n128.inc"
-          OSKC_OPERANDS : OSKG128_SEG_CLOBBERS);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) aoffc[i] = aoffn[i];
-  }
-
-  epilogue_all<LayOf<BN>, BN>(p, bm, wm * TM * 32, n0, n0 + wn * TN * 32, l31, hi, smem);   // (linear tiles: the launcher clears p.brick)
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// One asm call for the whole K axis (conv256_body_n*.inc): the per-tap voxel offsets of the tile's 256 rows come from
-// an LDS table [tap][row] built here, so the full gemm256 pipeline (LDS-DMA one step ahead, last k-sub-step issued
-// across the barrier) runs uninterrupted over all 27 taps.
-template <int BN>
-__global__ void __launch_bounds__(512, 2) conv256t_kernel(const ConvParams p) {
-  constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
-  constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
-  constexpr int WN = BN / (TN * 32);
-  constexpr int W_BASE = BN == 256 ? OSKG256_W_BASE : OSKG128_W_BASE;
-  constexpr int TABLE = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;   // the table sits behind the two stages
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  const int nbm = (p.M + 255) / 256, nbn = (p.Cout + BN - 1) / BN;
-  const int ntiles = nbm * nbn;
-  for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {   // persistent (see conv256w_kernel)
-  const int tile = xcd_remap(it, ntiles);
-  const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int n0 = bn * BN;
-
-  build_tap_table(p, bm, tid, 2, reinterpret_cast<unsigned*>(smem + TABLE));
-  __syncthreads();
-
-  // ---- LDS-DMA row slots of this lane: instruction j = wave + 8 i covers tile rows [8 j, 8 j + 8)
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const int srow8 = lane >> 3, spos = lane & 7;
-  unsigned woff[4], chk[4], arow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave + 8 * i) * 8 + srow8;
-    const int c = spos ^ ((r >> 1) & 7);
-    chk[i] = (unsigned)(c * 16);
-    arow[i] = lds_base + TABLE + r * 4;
-    int n = n0 + (r < BN ? r : 0);
-    n = n < p.Cout ? n : p.Cout - 1;
-    woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
-  }
-  const int sw = (l31 >> 1) & 7;
-  unsigned faA[4], faW[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const unsigned sz = (unsigned)((((ks << 1) | hi) ^ sw) << 4);
-    faA[ks] = lds_base + (wm * TM * 32 + l31) * 128 + sz;
-    faW[ks] = lds_base + W_BASE + (wn * TN * 32 + l31) * 128 + sz;
-  }
-  const uint64_t xbase = rfl64((uint64_t)(uintptr_t)p.x), wbase = rfl64((uint64_t)(uintptr_t)p.w);
-  const unsigned nkt = rfl((unsigned)(p.Cin / 64)), nk = rfl((unsigned)(p.ntaps * (p.Cin / 64)));
-  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + W_BASE + wave * 1024);
-#define OSKCT_OPERANDS                                                                                             \
-  ::"v"(faA[0]), "v"(faA[1]), "v"(faA[2]), "v"(faA[3]), "v"(faW[0]), "v"(faW[1]), "v"(faW[2]), "v"(faW[3]),         \
-      "v"(arow[0]), "v"(arow[1]), "v"(arow[2]), "v"(arow[3]), "v"(chk[0]), "v"(chk[1]), "v"(chk[2]), "v"(chk[3]),   \
-      "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "s"(xbase), "s"(wbase), "s"(nk), "s"(nkt), "s"(adst), \
-      "s"(wdst)
-  if constexpr (BN == 256) {
-    asm volatile(
-#include "conv256_body_n256.inc"
-        OSKCT_OPERANDS : OSKG256_CONV_CLOBBERS);
-  } else {
-    asm volatile(
-#include "conv256_body_n128.inc"
-        OSKCT_OPERANDS : OSKG128_CONV_CLOBBERS);
-  }
-  epilogue_all<LayOf<BN>, BN>(p, bm, wm * TM * 32, n0, n0 + wn * TN * 32, l31, hi, smem);
-  }   // tile loop
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// 4-wave form of conv256t_kernel<256> (Cout >= 256): one wave per SIMD with the whole register file, wave tile 128 x 128
-// (gemm256w.hip's layout: a third less LDS read traffic per flop), K loop conv256w_body.inc = the table-driven loop above
-// with the LDS-DMA instructions one per two MFMA shadows (what bounded the GEMM: profiles/r02_gemm_experiments.md).
-__global__ void __launch_bounds__(256, 1) conv256w_kernel(const ConvParams p) {
-  constexpr int TM = OSKW_TM, TN = OSKW_TN, BN = 256;
-  constexpr int TABLE = OSKW_SMEM;   // the table sits behind the two stages
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  // persistent: one workgroup per CU (155 KB of LDS) walks the tile list with stride gridDim.x -- a one-tile workgroup's
-  // successor cannot be dispatched before it retires, so every tile paid a dispatch gap on top of its serial prologue
-  const int nbm = (p.M + 255) / 256, nbn = (p.Cout + BN - 1) / BN;
-  const int ntiles = nbm * nbn;
-  for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
-  const int tile = xcd_remap(it, ntiles);
-  const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int n0 = bn * BN;
-
-  build_tap_table(p, bm, tid, 1, reinterpret_cast<unsigned*>(smem + TABLE));
-  __syncthreads();
-
-  // ---- LDS-DMA row slots of this lane: instruction j = wave + 4 i (i = 0..7) covers tile rows [8 j, 8 j + 8); the swizzle
-  // key (r >> 1) & 7 of row r = 8 (wave + 4 i) + lane / 8 does not depend on i
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const int srow8 = lane >> 3, spos = lane & 7;
-  const int r0 = wave * 8 + srow8;
-  const int c = spos ^ ((r0 >> 1) & 7);
-  const unsigned chk = (unsigned)(c * 16);
-  const unsigned arow0 = lds_base + TABLE + r0 * 4;
-  unsigned woff[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    int n = n0 + r0 + 32 * i;
-    n = n < p.Cout ? n : p.Cout - 1;
-    woff[i] = (unsigned)(((int64_t)n * p.wrs + c * 8) * 2);
-  }
-  const unsigned sz0 = (unsigned)((hi ^ ((l31 >> 1) & 7)) << 4);
-  const unsigned faA0 = lds_base + (wm * TM * 32 + l31) * 128 + sz0;
-  const unsigned faW0 = lds_base + OSKW_W_BASE + (wn * TN * 32 + l31) * 128 + sz0;
-  const uint64_t xbase = rfl64((uint64_t)(uintptr_t)p.x), wbase = rfl64((uint64_t)(uintptr_t)p.w);
-  const unsigned nkt = rfl((unsigned)(p.Cin / 64)), nk = rfl((unsigned)(p.ntaps * (p.Cin / 64)));
-  const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + OSKW_W_BASE + wave * 1024);
-  asm volatile(
-#include "conv256w_body.inc"
-      ::"v"(faA0), "v"(faW0), "v"(arow0), "v"(chk), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]),
-      "v"(woff[5]), "v"(woff[6]), "v"(woff[7]), "s"(xbase), "s"(wbase), "s"(nk), "s"(nkt), "s"(adst), "s"(wdst)
-      : OSKW_CONV_CLOBBERS);
-  epilogue_all<LayW, BN>(p, bm, wm * TM * 32, n0, n0 + wn * TN * 32, l31, hi, smem);
-  }   // tile loop (the next tile's table build ends in a barrier: nobody refills stage 0 while the statistics slots are read)
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // conv256w_kernel on v_mfma_f32_16x16x32_bf16 (gemm256x.hip's compute side: at the board's power cap the 16x16x32 stream is the
@@ -788,58 +330,20 @@ __global__ void __launch_bounds__(256, 1) conv256x_kernel(const ConvParams p) {
   }   // tile loop
 }
 
-// grid of the persistent kernels: one workgroup per CU (a multiple of 8, so that the XCD remap of the tile list keeps a
-// workgroup inside one XCD's range); OSK_CONV_PERSIST=0: one workgroup per tile (A/B runs)
+// one workgroup per CU (a multiple of 8, so that the XCD remap of the tile list keeps a workgroup inside one XCD's range)
 int persistent_grid(int ntiles) {
-  static const bool on = [] { const char* e = getenv("OSK_CONV_PERSIST"); return !e || atoi(e) != 0; }();
-  static const int n_cu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    n -= n % 8;
-    return n < 8 ? 8 : n;
-  }();
-  return on && ntiles > n_cu ? n_cu : ntiles;
+  int n_cu = osk_device_cus();
+  n_cu -= n_cu % 8;
+  if (n_cu < 8) n_cu = 8;
+  return ntiles > n_cu ? n_cu : ntiles;
 }
 
 template <int NBJ>
 int launch_x(const ConvParams& p, hipStream_t st) {
-  static bool attr_set = false;
   constexpr int BN = 32 * NBJ, SMEM = (NBJ == 8 ? OSKX_SMEM : OSKX128_SMEM) + 27 * 1024;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv256x_kernel<NBJ>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  OSK_ENSURE_MAX_SMEM(conv256x_kernel<NBJ>, SMEM);
   const int nblk = ((p.M + 255) / 256) * ((p.Cout + BN - 1) / BN);
   hipLaunchKernelGGL(conv256x_kernel<NBJ>, dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
-  return (int)hipGetLastError();
-}
-
-int launch_w(const ConvParams& p, hipStream_t st) {
-  static bool attr_set = false;
-  constexpr int SMEM = OSKW_SMEM + 27 * 1024;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv256w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int nblk = ((p.M + 255) / 256) * ((p.Cout + 255) / 256);
-  hipLaunchKernelGGL(conv256w_kernel, dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
-  return (int)hipGetLastError();
-}
-
-template <int BN, bool TABLE_VERSION>
-int launch_one(const ConvParams& p, hipStream_t st) {
-  static bool attr_set = false;
-  constexpr int SMEM = (BN == 256 ? OSKG256_SMEM : OSKG128_SMEM) + (TABLE_VERSION ? 27 * 1024 : 0);
-  auto kernel = TABLE_VERSION ? conv256t_kernel<BN> : conv256_kernel<BN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int nblk = ((p.M + 255) / 256) * ((p.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL(kernel, dim3(TABLE_VERSION ? persistent_grid(nblk) : nblk), dim3(512), SMEM, st, p);
   return (int)hipGetLastError();
 }
 
@@ -860,28 +364,12 @@ bool conv256_gn_supported(const ConvParams& p) {
   return p.B == 1 || per_b % 256 == 0;
 }
 
-// variant 1: one asm segment per filter tap (conv256_kernel); otherwise the single-call table version
-int launch_conv256(const ConvParams& p0, int variant, hipStream_t st) {
+// linear 256-voxel tiles (the 16 x 16-brick tile order measured in round 2 -- same time, 12 % more fabric-side reads,
+// profiles/r02_pmc_gemm_conv.txt -- stays a ConvParams field the kernel honours, never set)
+int launch_conv256(const ConvParams& p0, hipStream_t st) {
   ConvParams p = p0;
   p.brick = 0;
-  if (variant == 1) return p.Cout >= 256 ? launch_one<256, false>(p, st) : launch_one<128, false>(p, st);
-  // OSK_CONV_BRICK=1: 16 x 16 spatial bricks in frame-fastest order instead of linear 256-voxel runs.  Measured (round 2,
-  // profiles/r02_pmc_gemm_conv.txt): parity-green, same time (69.4 vs 69.0 ms per VAE encode+decode) and 12 % MORE fabric-side
-  // reads (49.3 vs 43.8 GB) -- the short 16-voxel row segments cost more than the time-tap reuse saves -- so it stays off.
-  static const bool brick = [] { const char* e = getenv("OSK_CONV_BRICK"); return e && atoi(e) != 0; }();
-  p.brick = brick && (p.Ho % 16 == 0) && (p.Wo % 16 == 0) ? 1 : 0;
-  // OSK_CONV_W4=0: the 8-wave kernel for Cout >= 256 too (A/B runs)
-  static const bool w4 = [] { const char* e = getenv("OSK_CONV_W4"); return !e || atoi(e) != 0; }();
-  // the 4-wave kernel on v_mfma_f32_16x16x32_bf16 (conv256x_kernel: VAE encode + decode 64.5 -> 62.2 ms); OSK_CONV_X=0 = the
-  // 32x32x16 form (conv256w_kernel) for A/B runs
-  static const bool x16 = [] { const char* e = getenv("OSK_CONV_X"); return !e || atoi(e) != 0; }();
-  if (p.Cout >= 256 && w4 && x16) return launch_x<8>(p, st);
-  // Cout < 256: the 4-wave 256 x 128 tile of the same kernel (VAE encode + decode 62.8 -> 61.6 ms); OSK_CONV_X128=0 = the 8-wave
-  // conv256t_kernel<128> for A/B runs
-  static const bool x128 = [] { const char* e = getenv("OSK_CONV_X128"); return !e || atoi(e) != 0; }();
-  if (p.Cout < 256 && x128) return launch_x<4>(p, st);
-  if (p.Cout >= 256) return w4 ? launch_w(p, st) : launch_one<256, true>(p, st);
-  return launch_one<128, true>(p, st);
+  return p.Cout >= 256 ? launch_x<8>(p, st) : launch_x<4>(p, st);
 }
 
 }  // namespace osk_conv

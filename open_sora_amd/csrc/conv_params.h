@@ -18,7 +18,7 @@ struct ConvParams {
   int lg_cpt, ntaps, nk;
   int M;
   int64_t wrs;
-  int brick = 0;      // conv256t: 1 = a tile is a 16 x 16 spatial brick of one frame, tiles ordered frame-fastest (conv3d_256.hip)
+  int brick = 0;      // 1 = a tile is a 16 x 16 spatial brick of one frame, tiles ordered frame-fastest (conv3d_256.hip)
   // fused GroupNorm statistics of the OUTPUT (conv3d_256.hip only): sums[b][g] += (sum y, sum y^2) over the bf16-rounded
   // outputs of group g (gn_G groups of Cout / gn_G adjacent channels); null = off
   double* gn_sums = nullptr;
@@ -26,9 +26,9 @@ struct ConvParams {
 };
 
 
-// conv3d_256.hip: 256 voxels x {256,128} channels x 64 tile, 8 waves, one hand-scheduled asm K segment per filter tap
+// conv3d_256.hip: 256 voxels x {256,128} channels x 64 tile, 4 waves, all 27 taps in one hand-scheduled asm K loop
 bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes);
 bool conv256_gn_supported(const ConvParams& p);   // the fused-statistics epilogue takes this output geometry
-int launch_conv256(const ConvParams& p, int variant, hipStream_t st);
+int launch_conv256(const ConvParams& p, hipStream_t st);
 
 }  // namespace osk_conv

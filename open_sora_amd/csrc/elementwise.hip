@@ -2,7 +2,6 @@
 // V transpose, skinny GEMV task list (adaLN modulation / embedders), timestep embedding, RoPE tables,
 // CFG + Euler update.  All loads/stores are 16 B per lane (8 bf16) where the layout allows (guide G13).
 #include "osk_common.h"
-#include <stdlib.h>
 #include "../../include/osk.h"
 
 // =============================================================================================
@@ -374,9 +373,8 @@ extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, co
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)B * L * H;
   {
-    // row-per-thread kernel (coalesced spans through LDS); OSK_QKNORM_VARIANT=0 forces the lane-group kernel below
-    static const int qv = [] { const char* e = getenv("OSK_QKNORM_VARIANT"); return e ? atoi(e) : -1; }();
-    if (qv != 0 && H <= 256 && (hd == 64 || hd == 72) && (rope_mode == 0 || rope_mode == 1)) {  // hd 128: the lane-group
+    // row-per-thread kernel (coalesced spans through LDS)
+    if (H <= 256 && (hd == 64 || hd == 72) && (rope_mode == 0 || rope_mode == 1)) {  // hd 128: the lane-group
       // kernel below already uses every lane (16 x 16 B per row) and a whole row per thread would need 256 VGPRs
       const int tpb = 256 / H;
       const int64_t ntok = (int64_t)B * L;

@@ -1,4 +1,6 @@
-// Large-tile bf16 GEMM for gfx950 with a hand-scheduled K loop:  C = epi(A[M,K] @ W[N,K]^T + bias)
+// Large-tile GEMM frame of round 1 (one output tile per workgroup), now instantiated for FP8 operands only -- the bf16
+// Linears run on gemm256x.hip (256-wide tiles) / gemm256p.hip (128-wide) / gemm_bf16.hip (small shapes):
+//     C = epi(A[M,K] @ W[N,K]^T + bias)
 //
 // Tile 256 (M) x BN (N, 256 or 128) x 64 (K), 512 threads = 8 waves (two per SIMD).  The K loop is ONE asm
 // statement emitted by tools/gen_gemm_asm.py (gemm256_body_n*.inc): two LDS stages filled by LDS-DMA one K step
@@ -229,15 +231,8 @@ __global__ void __launch_bounds__(512, 2) gemm256_kernel(const GemmParams p) {
   ::"v"(faA[0]), "v"(faA[1]), "v"(faA[2]), "v"(faA[3]), "v"(faW[0]), "v"(faW[1]), "v"(faW[2]), "v"(faW[3]),         \
       "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), \
       "s"(abase), "s"(wbase), "s"(nk), "s"(adst), "s"(wdst)
-  if constexpr (BN == 256 && !FP8) {
-    asm volatile(
-#include "gemm256_body_n256.inc"
-        OSKG_OPERANDS : OSKG256_CLOBBERS);
-  } else if constexpr (!FP8) {
-    asm volatile(
-#include "gemm256_body_n128.inc"
-        OSKG_OPERANDS : OSKG128_CLOBBERS);
-  } else if constexpr (BN == 256) {
+  static_assert(FP8, "the bf16 instantiations of this one-tile-per-workgroup kernel were replaced by gemm256x.hip / gemm256p.hip");
+  if constexpr (BN == 256) {
     asm volatile(
 #include "gemm256_fp8_body_n256.inc"
         OSKG_OPERANDS : OSKQ256_CLOBBERS);
@@ -256,16 +251,11 @@ __global__ void __launch_bounds__(512, 2) gemm256_kernel(const GemmParams p) {
   else epilogue_all<BN, OUT_F32, FP8, false>(p, m0w, n0w, l31, hi);
 }
 
-template <int BN, bool OUT_F32, bool FP8 = false>
+template <int BN, bool OUT_F32, bool FP8>
 int launch_one(const GemmParams& p, hipStream_t st) {
-  static bool attr_set = false;
   constexpr int SMEM = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;
   auto kernel = gemm256_kernel<BN, OUT_F32, FP8>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  OSK_ENSURE_MAX_SMEM(kernel, SMEM);
   const int nblk = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
   hipLaunchKernelGGL(kernel, dim3(nblk), dim3(512), SMEM, st, p);
   return (int)hipGetLastError();
@@ -277,11 +267,6 @@ int launch_one(const GemmParams& p, hipStream_t st) {
 bool gemm256_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems) {
   return p.K % 64 == 0 && p.M >= 256 && p.N >= 128 && a_span_elems * 2 < (int64_t)0xFFFFFFFF &&
          w_span_elems * 2 < (int64_t)0xFFFFFFFF;
-}
-
-int launch_gemm256(const GemmParams& p, int bn, int out_f32, hipStream_t st) {
-  if (bn == 256) return out_f32 ? launch_one<256, true>(p, st) : launch_one<256, false>(p, st);
-  return out_f32 ? launch_one<128, true>(p, st) : launch_one<128, false>(p, st);
 }
 
 // fp8 operands (1 byte per element: spans in bytes), K % 128 == 0, per-row scales p.sa / p.sw

@@ -19,7 +19,6 @@
 #include "gemm_epilogue.h"
 #include "gemm256_regs_n256.inc"
 #include "gemm256_regs_n128.inc"
-#include "gemm256p_regs_n256.inc"
 #include "gemm256p_regs_n128.inc"
 
 namespace osk_gemm {
@@ -139,27 +138,10 @@ __global__ void __launch_bounds__(512, 2) gemm256p_kernel(const GemmParams p) {
       "v"(woff[2]), "v"(woff[3]), "v"(aoffn[0]), "v"(aoffn[1]), "v"(aoffn[2]), "v"(aoffn[3]), "v"(woffn[0]),         \
       "v"(woffn[1]), "v"(woffn[2]), "v"(woffn[3]), "v"(boff), "s"(abase), "s"(wbase), "s"(bbase), "s"(nk), "s"(adst), \
       "s"(wdst), "s"(flags)
-    if constexpr (BN == 256 && SCHED == 2) {
-      asm volatile(
-#include "gemm256p_body_n256_s2.inc"
-          OSKP_OPERANDS : OSKP256_CLOBBERS);
-    } else if constexpr (BN == 256 && SCHED == 1) {
-      asm volatile(
-#include "gemm256p_body_n256_s1.inc"
-          OSKP_OPERANDS : OSKP256_CLOBBERS);
-    } else if constexpr (BN == 256) {
-      asm volatile(
-#include "gemm256p_body_n256_s0.inc"
-          OSKP_OPERANDS : OSKP256_CLOBBERS);
-    } else if constexpr (SCHED == 1) {
-      asm volatile(
-#include "gemm256p_body_n128_s1.inc"
-          OSKP_OPERANDS : OSKP128_CLOBBERS);
-    } else {
-      asm volatile(
+    static_assert(BN == 128 && SCHED == 0, "shipped: the 128-wide tile, schedule 0 (256-wide tiles run on gemm256x.hip)");
+    asm volatile(
 #include "gemm256p_body_n128_s0.inc"
-          OSKP_OPERANDS : OSKP128_CLOBBERS);
-    }
+        OSKP_OPERANDS : OSKP128_CLOBBERS);
 
     const int b_first = m0w / p.crpb, b_last = (m0w + TM * 32 - 1) / p.crpb;
     const bool interior = m0w + TM * 32 <= p.M && n0w + TN * 32 <= p.N && b_first == b_last;  // wave-uniform
@@ -170,40 +152,23 @@ __global__ void __launch_bounds__(512, 2) gemm256p_kernel(const GemmParams p) {
 
 template <int BN, bool OUT_F32, int SCHED>
 int launch_one(const GemmParams& p, hipStream_t st) {
-  static bool attr_set = false;
-  static int n_cu = 0;
   constexpr int SMEM = BN == 256 ? OSKG256_SMEM : OSKG128_SMEM;
   auto kernel = gemm256p_kernel<BN, OUT_F32, SCHED>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    int dev = 0;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
-    if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
-    n_cu -= n_cu % 8;    // the tile walk keeps a workgroup inside one XCD's range only for a grid that is a multiple of 8
-    if (n_cu < 8) n_cu = 8;
-    attr_set = true;
-  }
+  OSK_ENSURE_MAX_SMEM(kernel, SMEM);
+  int n_cu = osk_device_cus();
+  n_cu -= n_cu % 8;    // the tile walk keeps a workgroup inside one XCD's range only for a grid that is a multiple of 8
+  if (n_cu < 8) n_cu = 8;
   const int ntiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-  const int grid = ntiles < n_cu ? ntiles : n_cu;   // one workgroup per CU (LDS: 128 KiB of 160)
+  const int grid = ntiles < n_cu ? ntiles : n_cu;   // one workgroup per CU (LDS: 96 KiB of 160)
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), SMEM, st, p);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-int launch_gemm256p(const GemmParams& p, int bn, int out_f32, hipStream_t st) {
-  // OSK_GEMM_SCHED: 0 / 1 / 2 (A/B runs); default: schedule 2 (schedule 1 with the LDS-DMA instructions one per two MFMA
-  // shadows: +2..4 % measured, profiles/r02_gemm_experiments.md) for the 256-wide tile, 0 for the 128-wide one (its 4-MFMA
-  // sub-steps leave no head shadows for paired reads)
-  static const int forced = [] { const char* e = getenv("OSK_GEMM_SCHED"); return e ? atoi(e) : -1; }();
-  const int sched = forced >= 0 ? forced : (bn == 256 ? 2 : 0);
-  if (bn == 256) {
-    if (sched == 2) return out_f32 ? launch_one<256, true, 2>(p, st) : launch_one<256, false, 2>(p, st);
-    if (sched == 1) return out_f32 ? launch_one<256, true, 1>(p, st) : launch_one<256, false, 1>(p, st);
-    return out_f32 ? launch_one<256, true, 0>(p, st) : launch_one<256, false, 0>(p, st);
-  }
-  if (sched >= 1) return out_f32 ? launch_one<128, true, 1>(p, st) : launch_one<128, false, 1>(p, st);
+// 256 x 128 tiles, 8 waves, persistent workgroups (the generator's other K-step schedules and the 256-wide instantiation of
+// this frame lost their A/B runs in round 2 -- profiles/r02_gemm_experiments.md -- and are generator options only)
+int launch_gemm256p(const GemmParams& p, int out_f32, hipStream_t st) {
   return out_f32 ? launch_one<128, true, 0>(p, st) : launch_one<128, false, 0>(p, st);
 }
 

@@ -148,19 +148,11 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmParams p) {
 
 template <bool OUT_F32>
 int launch_one(const GemmParams& p, hipStream_t st) {
-  static bool attr_set = false;
-  static int n_cu = 0;
   auto kernel = gemm256x_kernel<OUT_F32>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OSKX_SMEM);
-    if (e != hipSuccess) return (int)e;
-    int dev = 0;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
-    if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
-    n_cu -= n_cu % 8;    // the tile walk keeps a workgroup inside one XCD's range only for a grid that is a multiple of 8
-    if (n_cu < 8) n_cu = 8;
-    attr_set = true;
-  }
+  OSK_ENSURE_MAX_SMEM(kernel, OSKX_SMEM);
+  int n_cu = osk_device_cus();
+  n_cu -= n_cu % 8;    // the tile walk keeps a workgroup inside one XCD's range only for a grid that is a multiple of 8
+  if (n_cu < 8) n_cu = 8;
   const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   const int grid = ntiles < n_cu ? ntiles : n_cu;   // one workgroup per CU (LDS: 128 KiB of 160)
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), OSKX_SMEM, st, p);

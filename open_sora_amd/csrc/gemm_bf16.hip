@@ -10,12 +10,10 @@
 // buffered, one barrier per K tile.  The 128-B LDS rows are XOR-swizzled on the SOURCE side
 // (chunk' = chunk ^ ((row >> 1) & 7)) and un-swizzled on the ds_read_b128 side: conflict-free for the
 // 32-row x 16-B fragment reads of the 32x32x16 MFMA (see DESIGN.md "LDS layouts").
-// A register-staged variant (same LDS image) is kept for A/B testing (OSK_GEMM_VARIANT=1).
 //
 // Roofline: MFMA bf16 (2.5 PFLOP/s dense).  Algorithmic FLOPs = 2*M*N*K.
 #include "gemm_params.h"
 #include "../../include/osk.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -30,7 +28,7 @@ OSK_DEV void glds16(const unsigned short* g, unsigned char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <bool GLDS, bool OUT_F32>
+template <bool OUT_F32>
 __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -78,46 +76,17 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(const GemmParams p) {
   const int a_row_off = (wm * 64 + l31) * 128;
   const int w_row_off = (wn * 64 + l31) * 128;
 
-  uint4 ra0 = make_uint4(0, 0, 0, 0), ra1 = ra0, ra2 = ra0, ra3 = ra0, rw0 = ra0, rw1 = ra0, rw2 = ra0,
-        rw3 = ra0;  // register staging (variant !GLDS); named scalars, arrays went to scratch
   // (macros rather than lambdas: by-reference captured arrays were placed in scratch by hipcc)
 #define STAGE_ISSUE(BUFI, KT)                                                                  \
   {                                                                                            \
     const int k0_ = (KT) * BK;                                                                 \
     unsigned char* ta_ = smem + (BUFI) * 2 * TILE_BYTES;                                       \
     unsigned char* tw_ = ta_ + TILE_BYTES;                                                     \
-    if constexpr (GLDS) {                                                                      \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16(ga[i] + k0_, ta_ + lds_off[i]);     \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16(gw[i] + k0_, tw_ + lds_off[i]);     \
-    } else {                                                                                   \
-      ra0 = *reinterpret_cast<const uint4*>(ga[0] + k0_);                                      \
-      ra1 = *reinterpret_cast<const uint4*>(ga[1] + k0_);                                      \
-      ra2 = *reinterpret_cast<const uint4*>(ga[2] + k0_);                                      \
-      ra3 = *reinterpret_cast<const uint4*>(ga[3] + k0_);                                      \
-      rw0 = *reinterpret_cast<const uint4*>(gw[0] + k0_);                                      \
-      rw1 = *reinterpret_cast<const uint4*>(gw[1] + k0_);                                      \
-      rw2 = *reinterpret_cast<const uint4*>(gw[2] + k0_);                                      \
-      rw3 = *reinterpret_cast<const uint4*>(gw[3] + k0_);                                      \
-    }                                                                                          \
-  }
-#define STAGE_COMMIT(BUFI)                                                                     \
-  {                                                                                            \
-    if constexpr (!GLDS) {                                                                     \
-      unsigned char* ta_ = smem + (BUFI) * 2 * TILE_BYTES;                                     \
-      unsigned char* tw_ = ta_ + TILE_BYTES;                                                   \
-      *reinterpret_cast<uint4*>(ta_ + lds_off[0] + lane * 16) = ra0;                           \
-      *reinterpret_cast<uint4*>(ta_ + lds_off[1] + lane * 16) = ra1;                           \
-      *reinterpret_cast<uint4*>(ta_ + lds_off[2] + lane * 16) = ra2;                           \
-      *reinterpret_cast<uint4*>(ta_ + lds_off[3] + lane * 16) = ra3;                           \
-      *reinterpret_cast<uint4*>(tw_ + lds_off[0] + lane * 16) = rw0;                           \
-      *reinterpret_cast<uint4*>(tw_ + lds_off[1] + lane * 16) = rw1;                           \
-      *reinterpret_cast<uint4*>(tw_ + lds_off[2] + lane * 16) = rw2;                           \
-      *reinterpret_cast<uint4*>(tw_ + lds_off[3] + lane * 16) = rw3;                           \
-    }                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16(ga[i] + k0_, ta_ + lds_off[i]);       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16(gw[i] + k0_, tw_ + lds_off[i]);       \
   }
 
   STAGE_ISSUE(0, 0);
-  STAGE_COMMIT(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -142,7 +111,6 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(const GemmParams p) {
         for (int tm = 0; tm < 2; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
     }
-    if (more) STAGE_COMMIT(cur ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
@@ -203,18 +171,6 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(const GemmParams p) {
   }
 }
 
-// A/B knob (read once): -1 (default) = the large-tile hand-scheduled kernel (gemm256.hip) whenever it applies,
-// else this file's kernel; 0 = always this file (LDS-DMA staging), 1 = this file, register staging;
-// 2 / 3 = gemm256.hip with BN forced to 256 / 128
-int gemm_variant() {
-  static int v = -2;
-  if (v == -2) {
-    const char* e = getenv("OSK_GEMM_VARIANT");
-    v = e ? atoi(e) : -1;
-  }
-  return v;
-}
-
 }  // namespace
 
 extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride,
@@ -237,52 +193,32 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
   p.C = C; p.cbs = c_batch_stride; p.crs = c_row_stride; p.crpb = c_rows_per_batch;
   p.res = (const unsigned short*)res; p.gate = gate; p.gbs = gate_batch_stride;
   p.M = M; p.N = N; p.K = K; p.gelu_from = gelu_from;
-  {
-    // row bands per tile group of gemm256 (L2 blocking of the tile order; measured at the XL shapes: 8 for wide N,
-    // 4 when there are only a few weight tiles); OSK_GEMM_GROUP overrides
-    static const int grp = [] { const char* e = getenv("OSK_GEMM_GROUP"); return e ? atoi(e) : 0; }();
-    p.group = grp > 0 ? grp : ((N + 255) / 256 <= 6 ? 4 : 8);
-  }
+  // row bands per tile group (L2 blocking of the large tiles' order; measured at the XL shapes: 8 for wide N, 4 when there
+  // are only a few weight tiles)
+  p.group = (N + 255) / 256 <= 6 ? 4 : 8;
   hipStream_t st = (hipStream_t)stream;
-  const int gv = gemm_variant();
-  if (gv == -1 || gv >= 2) {
+  {
     const int nb = (M + a_rows_per_batch - 1) / a_rows_per_batch;
     const int64_t a_span = (int64_t)(nb - 1) * a_batch_stride + (int64_t)(a_rows_per_batch - 1) * a_row_stride + K;
     const int64_t w_span = (int64_t)(N - 1) * w_row_stride + K;
     if (osk_gemm::gemm256_supported(p, a_span, w_span)) {
       // tile choice by estimated time = rounds of the grid over the chip x time of one tile.  Per-tile throughput
       // measured at the XL shapes (MI355X, random data): 256x256 ~1.0, 256x128 ~0.78, 128x128 (this file) ~0.72 of the
-      // large tile's rate; one 512-thread workgroup per CU for gemm256, two 256-thread ones for this file's kernel.
+      // large tile's rate; one workgroup per CU for the large tiles, two 256-thread ones for this file's kernel.
       auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
       const int64_t m256 = (M + 255) / 256, m128 = (M + 127) / 128;
       const double c256 = rounds(m256 * ((N + 255) / 256), 256) * 4.0 / 1.00;
       const double c128 = rounds(m256 * ((N + 127) / 128), 256) * 2.0 / 0.78;
       const double cold = rounds(m128 * ((N + 127) / 128), 512) * 1.0 / (0.5 * 0.72);  // 2 co-resident tiles share a CU
-      int bn = (N >= 256 && c256 <= c128) ? 256 : 128;
-      bool use_old = cold < (bn == 256 ? c256 : c128);
-      if (gv == 2) { bn = 256; use_old = false; }
-      if (gv == 3) { bn = 128; use_old = false; }
-      // persistent-workgroup form (gemm256p.hip) unless OSK_GEMM_PERSIST=0 (round-1 kernel, kept for A/B runs)
-      static const bool persist = [] { const char* e = getenv("OSK_GEMM_PERSIST"); return !e || atoi(e) != 0; }();
-      // 256-wide tiles: the 4-wave layout (gemm256w.hip: 128 x 128 wave tiles) unless OSK_GEMM_W4=0
-      static const bool w4 = [] { const char* e = getenv("OSK_GEMM_W4"); return !e || atoi(e) != 0; }();
-      // ... on v_mfma_f32_16x16x32_bf16 (gemm256x.hip: +7-13 % at the XL shapes over the 32x32x16 form, gemm256w.hip, which
-      // OSK_GEMM_X=0 selects for A/B runs)
-      static const bool x16 = [] { const char* e = getenv("OSK_GEMM_X"); return !e || atoi(e) != 0; }();
-      if (!use_old && persist && w4 && bn == 256 && x16) return osk_gemm::launch_gemm256x(p, out_f32, st);
-      if (!use_old && persist && w4 && bn == 256) return osk_gemm::launch_gemm256w(p, out_f32, st);
-      if (!use_old) return persist ? osk_gemm::launch_gemm256p(p, bn, out_f32, st) : osk_gemm::launch_gemm256(p, bn, out_f32, st);
+      const bool wide = N >= 256 && c256 <= c128;
+      if (!(cold < (wide ? c256 : c128)))
+        return wide ? osk_gemm::launch_gemm256x(p, out_f32, st)    // 256 x 256 tiles, 4 waves, v_mfma_f32_16x16x32_bf16
+                    : osk_gemm::launch_gemm256p(p, out_f32, st);   // 256 x 128 tiles, 8 waves, v_mfma_f32_32x32x16_bf16
     }
   }
   const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   dim3 grid(nblk), block(256);
-  const bool glds = gv != 1;
-  if (glds) {
-    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, SMEM_BYTES, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, SMEM_BYTES, st, p);
-  } else {
-    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, SMEM_BYTES, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, SMEM_BYTES, st, p);
-  }
+  if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<true>), grid, block, SMEM_BYTES, st, p);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false>), grid, block, SMEM_BYTES, st, p);
   return (int)hipGetLastError();
 }

@@ -24,15 +24,13 @@ struct GemmParams {
   const float* sw = nullptr;
 };
 
-// gemm256.hip: 256 x {256,128} x 64 tiles, 8 waves, hand-scheduled (generated) K loop
+// large tiles need M >= 256, N >= 128, K % 64 == 0 and both operand tensors within the kernels' 32-bit per-lane offsets
 bool gemm256_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
-int launch_gemm256(const GemmParams& p, int bn, int out_f32, hipStream_t st);
-// gemm256p.hip: the same tiles walked by one persistent workgroup per CU (cross-tile prefetch, bias-initialised accumulators)
-int launch_gemm256p(const GemmParams& p, int bn, int out_f32, hipStream_t st);
-// gemm256w.hip: the persistent walk with 4 waves per workgroup (one per SIMD, 128 x 128 wave tiles, 256 accumulator AGPRs)
-int launch_gemm256w(const GemmParams& p, int out_f32, hipStream_t st);
-int launch_gemm256x(const GemmParams& p, int out_f32, hipStream_t st);   // gemm256x.hip: the same on v_mfma_f32_16x16x32_bf16
-// the same kernel on OCP e4m3 operands (A, W point at bytes; strides in elements = bytes)
+// gemm256p.hip: 256 x 128 tiles walked by one persistent 8-wave workgroup per CU (cross-tile prefetch, bias-initialised accumulators)
+int launch_gemm256p(const GemmParams& p, int out_f32, hipStream_t st);
+// gemm256x.hip: 256 x 256 tiles, 4 waves (one per SIMD, 128 x 128 wave tiles, 256 accumulator AGPRs) on v_mfma_f32_16x16x32_bf16
+int launch_gemm256x(const GemmParams& p, int out_f32, hipStream_t st);
+// gemm256.hip: the one-tile-per-workgroup frame on OCP e4m3 operands (A, W point at bytes; strides in elements = bytes)
 bool gemm256_fp8_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
 int launch_gemm256_fp8(const GemmParams& p, int bn, int out_f32, hipStream_t st);
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define OSK_OK 0
 #define OSK_EINVAL (-1)       // bad shape / alignment / unsupported configuration
@@ -76,4 +77,36 @@ OSK_DEV int xcd_remap(int bid, int nblk) {
   const int xcd = bid & 7, idx = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// ---- per-DEVICE one-time launch state (host side).  hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current
+// device only, and the CU count differs between devices: a process that drives several GPUs, or two host threads making their
+// first call at the same time, must not share one `static bool`.  One bit / one slot per device ordinal, atomics;
+// setting the attribute twice is harmless, so a lost race costs one redundant call.
+#define OSK_ENSURE_MAX_SMEM(KERNEL, BYTES)                                                                         \
+  do {                                                                                                             \
+    static std::atomic<uint64_t> osk_done_{0};                                                                     \
+    int osk_dev_ = 0;                                                                                              \
+    hipError_t osk_e_ = hipGetDevice(&osk_dev_);                                                                   \
+    if (osk_e_ != hipSuccess) return (int)osk_e_;                                                                  \
+    const uint64_t osk_bit_ = 1ull << (osk_dev_ & 63);                                                             \
+    if (!(osk_done_.load(std::memory_order_acquire) & osk_bit_)) {                                                 \
+      osk_e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (BYTES)); \
+      if (osk_e_ != hipSuccess) return (int)osk_e_;                                                                \
+      osk_done_.fetch_or(osk_bit_, std::memory_order_release);                                                     \
+    }                                                                                                              \
+  } while (0)
+
+// compute units of the CURRENT device (cached per ordinal; 256 if the query fails)
+static inline int osk_device_cus() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::atomic<int>& slot = cus[dev & 63];
+  int n = slot.load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    slot.store(n, std::memory_order_relaxed);
+  }
+  return n;
 }

@@ -688,45 +688,53 @@ def generate(L, safe=False, ablate=frozenset()):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--table", type=int, default=0, help="print the production schedule of layout NU (1 or 2)")
+    ap.add_argument("--table", type=int, default=0, help="print the schedule of layout NU (1 or 2) shadow by shadow")
     ap.add_argument("--hd", type=int, default=72, help="head dim of the schedule --table prints")
     ap.add_argument("--pv8", action="store_true", help="--table: the fp8 P.V variant")
-    ap.add_argument("--exp", default="safe", help="experimental variant 1: safe | ablations joined by + (noexp nobar "
-                    "nodma nolds novalu nomfma norare nocvt nomax pv80): timing only, wrong results")
+    ap.add_argument("--exp", default="", help="emit an EXPERIMENTAL body in place of the production one (never into the shipped tree: "
+                    "point --out at a scratch copy of csrc, see tools/make_ablated_libs.sh): safe = hazard-padded debug schedule | "
+                    "dmagapN[cC] = LDS-DMA items every N shadows | timing ablations joined by + (noexp nobar nodma nolds novalu "
+                    "nomfma norare nocvt nomax pv80: WRONG RESULTS)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
     args = ap.parse_args()
-    layouts = [(72, 2, False), (72, 1, False), (128, 2, False), (72, 2, True), (128, 2, True)]
+    # shipped: the 4 waves x 64 rows layout (NU = 2) of both head dims, bf16 and fp8 P.V.  The 8 waves x 32 rows layout
+    # (NU = 1, head_dim 72) tied it in rounds 1-2 and stays a generator option (--table 1) without a shipped body.
+    layouts = [(72, 2, False), (128, 2, False), (72, 2, True), (128, 2, True)]
     tagof = lambda hd, pv8: "%d%s" % (hd, "p8" if pv8 else "")
+    global DMAGAP, DMACOST
+    safe = args.exp == "safe"
+    gap = args.exp.startswith("dmagap")
+    ablate = frozenset() if (safe or gap or not args.exp) else frozenset(args.exp.split("+"))
+    if args.exp and os.path.realpath(args.out) == os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc")):
+        raise SystemExit("--exp bodies are experiments: give --out a scratch directory, not the shipped csrc")
+    if args.table:
+        L = Layout(args.table, args.hd, args.pv8)
+        st = generate(L, False, frozenset())
+        row = []
+        for kind, text in st.table:
+            if kind in ("M", "F"):
+                print("".join(row)); row = [kind + " "]
+            elif kind == "L":
+                print("".join(row)); row = []; print(text + ":")
+            else:
+                row.append({"x": "v"}.get(kind, kind))
+        print("".join(row))
+        return
     for hd, nu, pv8 in layouts:
         L = Layout(nu, hd, pv8)
-        exp_safe = args.exp == "safe"
-        exp_gap = args.exp.startswith("dmagap")    # "dmagap2" / "dmagap2c30": a SCHEDULE variant (correct results), not an ablation
-        exp_ab = frozenset() if (exp_safe or exp_gap) else frozenset(args.exp.split("+"))
-        for vi, (safe, ablate) in enumerate([(False, frozenset()), (exp_safe, exp_ab)]):
-            global DMAGAP, DMACOST
-            DMAGAP, DMACOST = 1, 12
-            if vi == 1 and exp_gap:
-                spec = args.exp[len("dmagap"):].split("c")
-                DMAGAP, DMACOST = int(spec[0]), int(spec[1]) if len(spec) > 1 else 12
-            st = generate(L, safe, ablate)
-            DMAGAP, DMACOST = 1, 12
-            if args.table == nu and args.hd == hd and vi == 0 and args.pv8 == pv8:
-                gap = []
-                for kind, text in st.table:
-                    if kind in ("M", "F"):
-                        print("".join(gap)); gap = [kind + " "]
-                    elif kind == "L":
-                        print("".join(gap)); gap = []; print(text + ":")
-                    else:
-                        gap.append({"x": "v"}.get(kind, kind))
-                print("".join(gap))
-            with open(os.path.join(args.out, "attention_asm%s_n%d_v%d.inc" % (tagof(hd, pv8), nu, vi)), "w") as f:
-                f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d%s, layout NU=%d, variant %d: %s\n" %
-                        (hd, ", fp8 P.V" if pv8 else "", nu, vi,
-                         "production" if vi == 0 else ("hazard-padded (debug)" if safe else
-                                                       ("schedule experiment " + args.exp if exp_gap else "timing ablation " + "+".join(sorted(ablate))))))
-                for ln in st.lines:
-                    f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%dv%d" % (tagof(hd, pv8), nu, vi)))
+        DMAGAP, DMACOST = 1, 12
+        if gap:
+            spec = args.exp[len("dmagap"):].split("c")
+            DMAGAP, DMACOST = int(spec[0]), int(spec[1]) if len(spec) > 1 else 12
+        st = generate(L, safe, ablate)
+        DMAGAP, DMACOST = 1, 12
+        what = "production" if not args.exp else ("hazard-padded (debug)" if safe else ("schedule experiment " + args.exp if gap else
+                                                                                         "timing ablation " + "+".join(sorted(ablate))))
+        with open(os.path.join(args.out, "attention_asm%s_n%d_v0.inc" % (tagof(hd, pv8), nu)), "w") as f:
+            f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d%s, layout NU=%d: %s\n" %
+                    (hd, ", fp8 P.V" if pv8 else "", nu, what))
+            for ln in st.lines:
+                f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%dv0" % (tagof(hd, pv8), nu)))
     # register / operand contract for the wrapper
     with open(os.path.join(args.out, "attention_asm_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.\n")

@@ -1758,14 +1758,27 @@ def gen_conv_x4(c, spread=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
-    ap.add_argument("--ablations", action="store_true", help="also emit the timing-only ablation bodies of the 4-wave GEMM")
+    ap.add_argument("--experiments", action="store_true",
+                    help="also emit the bodies that lost their A/B runs in rounds 1-2 and are no longer shipped (one-tile-per-workgroup "
+                         "bf16 GEMM, 256-wide / schedule-1 persistent 8-wave GEMM, 4-wave 32x32x16 GEMM and conv, 8-wave and per-tap "
+                         "conv) -- into a scratch --out, never the shipped csrc")
+    ap.add_argument("--ablations", action="store_true", help="with --experiments: the timing-only ablation bodies of the 4-wave GEMM")
     args = ap.parse_args()
+    shipped_dir = os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
+    if args.experiments and os.path.realpath(args.out) == shipped_dir:
+        raise SystemExit("--experiments bodies are not shipped: give --out a scratch directory")
+
+    def write_body(name, header, lines, shipped=True):
+        if not shipped and not args.experiments:
+            return
+        with open(os.path.join(args.out, name), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  %s\n" % header)
+            for ln in lines():
+                f.write('"%s\\n"\n' % ln)
+
     for bn in (256, 128):
         c = Cfg(bn)
-        with open(os.path.join(args.out, "gemm256_body_n%d.inc" % bn), "w") as f:
-            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile K loop.\n" % bn)
-            for ln in gen(c):
-                f.write('"%s\\n"\n' % ln)
+        write_body("gemm256_body_n%d.inc" % bn, "256 x %d x 64 tile K loop." % bn, lambda: gen(c), shipped=False)
         with open(os.path.join(args.out, "gemm256_regs_n%d.inc" % bn), "w") as f:
             f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
             P = "OSKG%d_" % bn
@@ -1775,72 +1788,53 @@ def main():
             f.write("#define %sCLOBBERS %s\n" % (P, ", ".join(clob)))
             for t in range(c.TM * c.TN):
                 f.write("#define %sAR%d %s\n" % (P, t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
-            sclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 4)] + ['"a%d"' % i for i in range(c.NACC)] + \
-                    ['"s%d"' % i for i in range(S_FIRST, SEG_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
-            f.write("#define %sSEG_CLOBBERS %s\n" % (P, ", ".join(sclob)))
-            cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 12)] + ['"a%d"' % i for i in range(c.NACC)] + \
-                    ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
-            f.write("#define %sCONV_CLOBBERS %s\n" % (P, ", ".join(cclob)))
+            if args.experiments:
+                sclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 4)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                        ['"s%d"' % i for i in range(S_FIRST, SEG_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+                f.write("#define %sSEG_CLOBBERS %s\n" % (P, ", ".join(sclob)))
+                cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 12)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                        ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+                f.write("#define %sCONV_CLOBBERS %s\n" % (P, ", ".join(cclob)))
         for sched in (0, 1, 2) if bn == 256 else (0, 1):
-            with open(os.path.join(args.out, "gemm256p_body_n%d_s%d.inc" % (bn, sched)), "w") as f:
-                f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile K loop, persistent workgroup, schedule %d.\n" % (bn, sched))
-                for ln in gen_pers(c, sched):
-                    f.write('"%s\\n"\n' % ln)
-        with open(os.path.join(args.out, "gemm256p_regs_n%d.inc" % bn), "w") as f:
-            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
-            pclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 6)] + ['"a%d"' % i for i in range(c.NACC)] + \
-                    ['"s%d"' % i for i in range(S_FIRST, PERS_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
-            f.write("#define OSKP%d_CLOBBERS %s\n" % (bn, ", ".join(pclob)))
-        with open(os.path.join(args.out, "conv256_body_n%d.inc" % bn), "w") as f:
-            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile, whole K axis (all filter taps).\n" % bn)
-            for ln in gen_conv(c):
-                f.write('"%s\\n"\n' % ln)
-        with open(os.path.join(args.out, "conv256_segment_n%d.inc" % bn), "w") as f:
-            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x %d x 64 tile, one K segment (filter tap).\n" % bn)
-            for ln in gen_segment(c):
-                f.write('"%s\\n"\n' % ln)
+            write_body("gemm256p_body_n%d_s%d.inc" % (bn, sched), "256 x %d x 64 tile K loop, persistent workgroup, schedule %d." % (bn, sched),
+                       lambda: gen_pers(c, sched), shipped=(bn == 128 and sched == 0))
+        if bn == 128 or args.experiments:
+            with open(os.path.join(args.out, "gemm256p_regs_n%d.inc" % bn), "w") as f:
+                f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
+                pclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 6)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                        ['"s%d"' % i for i in range(S_FIRST, PERS_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+                f.write("#define OSKP%d_CLOBBERS %s\n" % (bn, ", ".join(pclob)))
+        write_body("conv256_body_n%d.inc" % bn, "256 x %d x 64 tile, whole K axis (all filter taps)." % bn, lambda: gen_conv(c), shipped=False)
+        write_body("conv256_segment_n%d.inc" % bn, "256 x %d x 64 tile, one K segment (filter tap)." % bn, lambda: gen_segment(c), shipped=False)
     c = Cfg4()
-    if args.ablations:   # timing-only experiments for tools/: never committed, never shipped
-        for abl in (1, 2, 3, 4, 8, 12, 15, 16, 24, 31, 32, 56, 96):     # on the default (spread 2) schedule
-            with open(os.path.join(args.out, "gemm256w_body_abl%d.inc" % abl), "w") as f:
-                f.write("// GENERATED by tools/gen_gemm_asm.py --ablations -- timing experiment, WRONG RESULTS.\n")
-                for ln in gen_w4(c, 0, abl, 0, 2):
-                    f.write('"%s\\n"\n' % ln)
-    # the 4-wave 32x32x16 kernel ships ONE body (LDS-DMA one piece per 2 shadows); the other schedules measured in round 2
-    # are generator options kept for experiments: gen_w4(c, pf=1) L2 prefetch, dmak=1 buffer_load ... lds, spread=1 / 3, rd_per=1
-    with open(os.path.join(args.out, "gemm256w_body_spread2.inc"), "w") as f:
-        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, one LDS-DMA piece per 2 MFMA shadows.\n")
-        for ln in gen_w4(c, 0, 0, 0, 2):
-            f.write('"%s\\n"\n' % ln)
-    with open(os.path.join(args.out, "conv256w_body.inc"), "w") as f:
-        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128), whole K axis (all filter taps), one LDS-DMA piece per 2 MFMA shadows.\n")
-        for ln in gen_conv_w4(c, 2):
-            f.write('"%s\\n"\n' % ln)
-    with open(os.path.join(args.out, "gemm256w_regs.inc"), "w") as f:
-        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
-        f.write("#define OSKW_SMEM %d\n#define OSKW_W_BASE %d\n#define OSKW_TM %d\n#define OSKW_TN %d\n" % (c.SMEM, c.W_BASE, c.TM, c.TN))
-        clob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 8)] + ['"a%d"' % i for i in range(c.NACC)] + \
-               ['"s%d"' % i for i in range(S_FIRST, W4_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
-        f.write("#define OSKW_CLOBBERS %s\n" % ", ".join(clob))
-        cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 6 + 1 + 2 * c.NA)] + ['"a%d"' % i for i in range(c.NACC)] + \
-                ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
-        f.write("#define OSKW_CONV_CLOBBERS %s\n" % ", ".join(cclob))
-        for t in range(c.TM * c.TN):
-            f.write("#define OSKW_AR%d %s\n" % (t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
+    if args.ablations and args.experiments:   # timing-only experiments: never committed, never shipped
+        for abl in (1, 2, 3, 4, 8, 12, 15, 16, 24, 31, 32, 56, 96):     # on the spread-2 schedule
+            write_body("gemm256w_body_abl%d.inc" % abl, "timing experiment, WRONG RESULTS.", lambda: gen_w4(c, 0, abl, 0, 2), shipped=False)
+    # the 4-wave 32x32x16 forms (LDS-DMA one piece per 2 shadows; other schedules: gen_w4(c, pf=1) L2 prefetch, dmak=1
+    # buffer_load ... lds, spread=1 / 3, rd_per=1) were replaced by the 16x16x32 forms below
+    write_body("gemm256w_body_spread2.inc", "256 x 256 x 64 tile, 4 waves x (128 x 128), persistent workgroup, one LDS-DMA piece per 2 MFMA shadows.",
+               lambda: gen_w4(c, 0, 0, 0, 2), shipped=False)
+    write_body("conv256w_body.inc", "256 x 256 x 64 tile, 4 waves x (128 x 128), whole K axis (all filter taps), one LDS-DMA piece per 2 MFMA shadows.",
+               lambda: gen_conv_w4(c, 2), shipped=False)
+    if args.experiments:
+        with open(os.path.join(args.out, "gemm256w_regs.inc"), "w") as f:
+            f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
+            f.write("#define OSKW_SMEM %d\n#define OSKW_W_BASE %d\n#define OSKW_TM %d\n#define OSKW_TN %d\n" % (c.SMEM, c.W_BASE, c.TM, c.TN))
+            clob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 8)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                   ['"s%d"' % i for i in range(S_FIRST, W4_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+            f.write("#define OSKW_CLOBBERS %s\n" % ", ".join(clob))
+            cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 6 + 1 + 2 * c.NA)] + ['"a%d"' % i for i in range(c.NACC)] + \
+                    ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+            f.write("#define OSKW_CONV_CLOBBERS %s\n" % ", ".join(cclob))
+            for t in range(c.TM * c.TN):
+                f.write("#define OSKW_AR%d %s\n" % (t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
     cx = Cfg4x()
-    with open(os.path.join(args.out, "gemm256x_body.inc"), "w") as f:
-        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, persistent workgroup.\n")
-        for ln in gen_x4(cx):
-            f.write('"%s\\n"\n' % ln)
-    with open(os.path.join(args.out, "conv256x_body.inc"), "w") as f:
-        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, whole K axis (all filter taps).\n")
-        for ln in gen_conv_x4(cx):
-            f.write('"%s\\n"\n' % ln)
+    write_body("gemm256x_body.inc", "256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, persistent workgroup.", lambda: gen_x4(cx))
+    write_body("conv256x_body.inc", "256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, whole K axis (all filter taps).",
+               lambda: gen_conv_x4(cx))
     cx128 = Cfg4x(4)
-    with open(os.path.join(args.out, "conv256x_body_n128.inc"), "w") as f:
-        f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.  256 x 128 x 64 tile, 4 waves x (128 x 64) on v_mfma_f32_16x16x32_bf16, whole K axis (all filter taps).\n")
-        for ln in gen_conv_x4(cx128):
-            f.write('"%s\\n"\n' % ln)
+    write_body("conv256x_body_n128.inc", "256 x 128 x 64 tile, 4 waves x (128 x 64) on v_mfma_f32_16x16x32_bf16, whole K axis (all filter taps).",
+               lambda: gen_conv_x4(cx128))
     with open(os.path.join(args.out, "gemm256x_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit.\n")
         cclob = ['"v%d"' % i for i in range(cx128.V0, cx128.V0 + cx128.VN + 2 + 1 + 2 * cx128.NA)] + ['"a%d"' % i for i in range(cx128.NACC)] + \
