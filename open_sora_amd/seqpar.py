@@ -9,11 +9,15 @@ prediction at the end (:678-679).
 MI355X design: the exchange is ONE all-gather of K and of V^T per block instead of P-1 ring
 hops — xGMI is a full point-to-point mesh, every rank can pull from all 7 peers at once, and the local flash
 kernel then runs once over the whole key axis (segment-addressed: key j lives in gathered segment j / (L/P)), so
-there is no per-hop LSE merge and no P small launches.  The collectives are issued asynchronously
-(ProcessGroupNCCL runs them on its own stream, ordered after the producing kernels) right after the K/V
-projection + K-norm, and the Q projection (+ the MLP-up projection in single blocks) runs on the compute stream
-meanwhile; the attention launch waits on the collectives' events (stream-level, the host never blocks).
+there is no per-hop LSE merge and no P small launches.  Every exchange runs on a SECOND HIP stream owned by the transport
+(`DistTransport`: an event recorded on the compute stream behind the producing kernels, the collective issued on the
+communication stream behind that event, a completion event the attention launch waits on -- stream-level, the host never
+blocks), so the Q projection (+ the MLP-up projection in single blocks) runs on the compute stream beside the exchange.
 No reduce-scatter is needed for inference (it is the backward of the all-gather).
+The transport is an object (`all_gather / all_to_all / all_reduce_max`, each returning a handle with `wait()`): production =
+`DistTransport` over `torch.distributed` (`nccl` = RCCL over xGMI); tests/local_transport.py runs P ranks as threads of ONE
+process on ONE GPU with device-copy "collectives" on per-rank communication streams (tests/test_gpu_overlap.py), which
+exercises the same event protocol and the overlap itself where no multi-GPU node is available.
 
 Head-parallel exchange ("ulysses", the reference's other mode, distributed.py:473-495): when the head count divides
 by P the block can instead all-to-all q, k, v from "my tokens, all heads" to "all tokens, my H/P heads", run the flash
@@ -41,14 +45,75 @@ from . import mmdit
 BF16 = torch.bfloat16
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+class _EventWork:
+    """completion of an exchange issued on the communication stream: wait() makes the CURRENT stream wait for it"""
+
+    def __init__(self, event, device):
+        self.event, self.device = event, device
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_event(self.event)
+        return True
+
+
+class DistTransport:
+    """Collectives of one process group (`nccl` = RCCL in production, `gloo` in the CPU tests).  For device tensors every call
+    is issued on this transport's communication stream behind an event of the calling (compute) stream and returns a handle
+    whose wait() orders the caller's stream behind the exchange: compute queued between the call and the wait() overlaps it.
+    The buffers handed in are persistent (SeqPar._bufs), so no allocator stream bookkeeping is needed."""
+
+    def __init__(self, group=None, overlap: bool = True):
+        self.group = group if group is not None else dist.group.WORLD
+        self.P = dist.get_world_size(self.group)
+        self.rank = dist.get_rank(self.group)
+        self.overlap = overlap
+        self._comm = {}
+
+    def comm_stream(self, device):
+        st = self._comm.get(str(device))
+        if st is None:
+            st = self._comm[str(device)] = torch.cuda.Stream(device)
+        return st
+
+    def _run(self, t: Tensor, fn):
+        if not (t.is_cuda and self.overlap):
+            fn()
+            return _Done()
+        cur, comm = torch.cuda.current_stream(t.device), self.comm_stream(t.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                    # everything queued so far (the kernels that produced the send buffer)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            fn()                             # a synchronous collective orders `comm` behind the backend's own stream
+            done = torch.cuda.Event()
+            done.record(comm)
+        return _EventWork(done, t.device)
+
+    def all_gather(self, out: Tensor, inp: Tensor):
+        """out (flat, P chunks) <- every rank's inp (flat, one chunk; may alias out's own chunk)"""
+        return self._run(out, lambda: dist.all_gather_into_tensor(out, inp, group=self.group))
+
+    def all_to_all(self, out: Tensor, inp: Tensor):
+        """chunk s of out <- chunk `rank` of rank s's inp"""
+        return self._run(out, lambda: dist.all_to_all_single(out, inp, group=self.group))
+
+    def all_reduce_max(self, t: Tensor):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)   # a few floats, on the compute stream, before the exchange
+        return _Done()
+
+
 class SeqPar:
     """Per-model sequence-parallel state: process group + the gathered K / V^T buffers (allocated once per
     geometry, reused by all 28/57 blocks: 2 * B * L * D * 2 bytes)."""
 
-    def __init__(self, group=None, mode: str | None = None):
-        self.group = group if group is not None else dist.group.WORLD
-        self.P = dist.get_world_size(self.group)
-        self.rank = dist.get_rank(self.group)
+    def __init__(self, group=None, mode: str | None = None, transport=None):
+        self.tp = transport if transport is not None else DistTransport(group)
+        self.P, self.rank = self.tp.P, self.tp.rank
         self._bufs = {}
         self.mode = mode or os.environ.get("OSK_SP_MODE", "auto")   # "allgather" | "ulysses" | "auto"
         if self.mode not in ("allgather", "ulysses", "auto"):
@@ -111,18 +176,18 @@ class SeqPar:
         B, Lloc, _ = k.shape
         if pv8:
             sv = mmdit.v_scale_fp8(v, H, hd)
-            dist.all_reduce(sv, op=dist.ReduceOp.MAX, group=self.group)
+            self.tp.all_reduce_max(sv)
             k_all, vt8_all = self._buffers8(B, Lloc, H, hd, k.device)
             k_all[self.rank].copy_(k)
             mmdit.ops().v_transpose_fp8(v, sv, vt8_all[self.rank], H, hd)
-            wk = dist.all_gather_into_tensor(k_all.view(-1), k_all[self.rank].view(-1), group=self.group, async_op=True)
-            wv = dist.all_gather_into_tensor(vt8_all.view(-1), vt8_all[self.rank].view(-1), group=self.group, async_op=True)
+            wk = self.tp.all_gather(k_all.view(-1), k_all[self.rank].view(-1))
+            wv = self.tp.all_gather(vt8_all.view(-1), vt8_all[self.rank].view(-1))
             return "pv8", k_all, vt8_all, sv, wk, wv
         k_all, vt_all = self._buffers(B, Lloc, H, hd, k.device)
         k_all[self.rank].copy_(k)
         mmdit.ops().v_transpose(v, vt_all[self.rank], H, hd)
-        wk = dist.all_gather_into_tensor(k_all.view(-1), k_all[self.rank].view(-1), group=self.group, async_op=True)
-        wv = dist.all_gather_into_tensor(vt_all.view(-1), vt_all[self.rank].view(-1), group=self.group, async_op=True)
+        wk = self.tp.all_gather(k_all.view(-1), k_all[self.rank].view(-1))
+        wv = self.tp.all_gather(vt_all.view(-1), vt_all[self.rank].view(-1))
         return k_all, vt_all, wk, wv
 
     def attention(self, ws, pending, q: Tensor, out: Tensor, H: int, hd: int):
@@ -170,9 +235,9 @@ class SeqPar:
         B, Lloc, _ = k.shape
         bufs = self._heads_buffers(B, Lloc, H, hd, k.device)
         self._to_head_chunks(bufs["ks"], k)
-        wk = dist.all_to_all_single(bufs["kr"].view(-1), bufs["ks"].view(-1), group=self.group, async_op=True)
+        wk = self.tp.all_to_all(bufs["kr"].view(-1), bufs["ks"].view(-1))
         self._to_head_chunks(bufs["vs"], v)
-        wv = dist.all_to_all_single(bufs["vr"].view(-1), bufs["vs"].view(-1), group=self.group, async_op=True)
+        wv = self.tp.all_to_all(bufs["vr"].view(-1), bufs["vs"].view(-1))
         return "heads", bufs, wk, wv, pv8
 
     def _heads_attention(self, pending, q: Tensor, out: Tensor, H: int, hd: int):
@@ -180,7 +245,7 @@ class SeqPar:
         B, Lloc, D = q.shape
         P, Hg = self.P, H // self.P
         self._to_head_chunks(bufs["qs"], q)
-        dist.all_to_all_single(bufs["qr"].view(-1), bufs["qs"].view(-1), group=self.group)
+        self.tp.all_to_all(bufs["qr"].view(-1), bufs["qs"].view(-1)).wait()
         wk.wait()
         wv.wait()
         # received chunk s = source rank s's tokens = key segment s; [P, B] is also the query "batch" axis
@@ -202,7 +267,7 @@ class SeqPar:
                               vt_seg_stride=vt.stride(0), q_prescaled=True, kv_batches=B,
                               workspace=ops.attention_workspace(q.device))
         # chunk s of the output belongs to rank s's tokens: straight back, then head groups side by side
-        dist.all_to_all_single(bufs["orr"].view(-1), bufs["os"].view(-1), group=self.group)
+        self.tp.all_to_all(bufs["orr"].view(-1), bufs["os"].view(-1)).wait()
         out.view(B, Lloc, P, D // P).permute(2, 0, 1, 3).copy_(bufs["orr"])
 
     # ------------------------------------------------------------------ output
@@ -212,15 +277,15 @@ class SeqPar:
         B, Lloc = ws.B, ws.L
         full = torch.empty(self.P, B, Lloc, C_out, dtype=BF16, device=ws.x.device)
         project(full[self.rank])
-        dist.all_gather_into_tensor(full.view(-1), full[self.rank].view(-1), group=self.group)
+        self.tp.all_gather(full.view(-1), full[self.rank].view(-1)).wait()
         return full.permute(1, 0, 2, 3).reshape(B, self.P * Lloc, C_out)[:, L_txt:].contiguous()
 
 
-def enable(model, group=None, mode: str | None = None) -> SeqPar:
+def enable(model, group=None, mode: str | None = None, transport=None) -> SeqPar:
     """Shard `model`'s denoise step over `group` (default: WORLD).  The counterpart of installing
     MMDiTPolicy / Distributed*Processor through booster.boost (distributed.py:686-760): weights stay replicated,
     MMDiTModel.forward keeps its signature and returns the full prediction on every rank."""
-    sp = SeqPar(group, mode)
+    sp = SeqPar(group, mode, transport)
     model._sp = sp if sp.P > 1 else None
     return sp
 

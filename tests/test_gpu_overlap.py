@@ -69,3 +69,72 @@ def test_library_has_no_packed_fp32_instructions(hip_lib):
     assert dis.count("s_endpgm") > 50, "disassembly looks empty"
     hits = [ln for ln in dis.splitlines() if "v_pk_fma_f32" in ln or "v_pk_mul_f32" in ln or "v_pk_add_f32" in ln or "v_pk_mov_b32" in ln]
     assert not hits, hits[:5]
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the sequence-parallel step with P ranks as threads of this process on the one GPU (tests/local_transport.py): every rank has
+# its own compute stream and its own communication stream, the K / V^T exchange really overlaps the Q / MLP-up GEMMs
+SP_CASES = [
+    (2, "hd72_eager_split", (2, 4, 8, 8, 64)),     # L = 320, 160 per rank: whole + ragged 64-key tiles per segment
+    (4, "hd72_eager_split", (1, 4, 8, 8, 64)),     # 4 ranks: 8 heads / 4, 80 tokens per rank
+    (2, "hd128_liger_split", (3, 2, 9, 7, 22)),    # L = 148, CFG-triple batch, liger RoPE
+]
+
+
+@gpu
+@pytest.mark.parametrize("mode", ["allgather", "ulysses"])
+@pytest.mark.parametrize("case", SP_CASES, ids=lambda c: f"w{c[0]}-{c[1]}")
+def test_seqpar_ranks_as_threads_overlapped_exchange_equals_serial_order(hip_lib, case, mode):
+    """north_star: the exchange around attention runs on a second HIP stream, overlapped with compute.  No multi-GPU node is
+    available to this suite, so the overlap is exercised here: device-copy collectives on per-rank communication streams
+    (same event protocol as DistTransport), P x 2 streams live on one GPU.  Overlapped == serial order bit for bit, every
+    rank returns the same prediction, three forwards repeat, and the result matches the single-GPU forward and the oracle."""
+    import copy
+
+    from open_sora_amd import mmdit, seqpar
+    from oracle import configs, mmdit_oracle as O
+    from tests.local_transport import LocalTransport, run_ranks
+    from tests.util import rel_l2, torch_inputs, torch_params
+
+    P, name, geom = case
+    cfg = configs.GOLDEN[name][0]
+    if mode == "ulysses" and cfg["num_heads"] % P:
+        pytest.skip("head exchange needs num_heads % P == 0")
+    B, T, h, w, L_txt = geom
+    dev = "cuda:0"
+    model = mmdit.Flux(device_map=dev, torch_dtype=torch.bfloat16, **cfg)
+    model.load_state_dict(torch_params(cfg, dtype=torch.bfloat16, device=dev), strict=True)
+    inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=torch.bfloat16, device=dev)
+    with torch.inference_mode():
+        single = model(**inp).float().cpu()          # also builds the (shared, read-only) plan before the threads start
+    torch.cuda.synchronize()
+
+    def run(overlap):
+        def rank_fn(rank, world):
+            m = copy.copy(model)                       # shares parameters and plan; own sequence-parallel state and workspaces
+            m.forward = m.forward_ckpt
+            object.__setattr__(m, "_osk_ws_cache", {})
+            tp = LocalTransport(world, rank, dev, overlap=overlap)
+            sp = seqpar.enable(m, mode=mode, transport=tp)
+            assert m._sp is sp and sp.P == P and sp.rank == rank
+            with torch.inference_mode():
+                outs = [m(**inp).float() for _ in range(3)]
+            torch.cuda.current_stream().synchronize()
+            return [o.cpu() for o in outs], tp.calls
+
+        return run_ranks(P, rank_fn, dev)
+
+    serial, over = run(False), run(True)
+    n_blocks = cfg["depth"] + cfg["depth_single_blocks"]
+    for res in (serial, over):
+        for outs, calls in res:
+            assert calls >= 3 * (2 * n_blocks + 1)     # K and V (or q, k, v, o) per block + the output gather, per forward
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), "sequence-parallel forward is not repeatable"
+            assert torch.equal(outs[0], res[0][0][0]), "ranks disagree on the gathered prediction"
+    assert torch.equal(over[0][0][0], serial[0][0][0]), "overlapped exchange differs from the serial order"
+    with torch.inference_mode():
+        truth = O.forward(torch_params(cfg), cfg, **torch_inputs(cfg, B, T, h, w, L_txt))
+        ref_bf16 = O.forward(torch_params(cfg, dtype=torch.bfloat16), cfg, **torch_inputs(cfg, B, T, h, w, L_txt, dtype=torch.bfloat16))
+    e_ref, e_sp = rel_l2(ref_bf16.float(), truth), rel_l2(over[0][0][0], truth)
+    assert e_sp <= max(1.5 * e_ref, 2.0 ** -8), (e_sp, e_ref)
+    assert rel_l2(over[0][0][0], single) <= 2.0 ** -7
