@@ -260,11 +260,12 @@ class _Clip:
 
 
 @pytest.mark.parametrize("cond_type,causal", [("t2v", False), ("t2v", True), ("i2v_head", True)])
-def test_api_fn_on_gpu_vs_oracle_pipeline(hip_lib, cond_type, causal):
-    """prepare_api / api_fn (sampling.py:562-726) with the PRODUCT modules on the GPU -- HIP denoiser, the package's own
-    AutoencoderKLCausal3D (t2v with is_causal_vae=False is the default path ADVICE r1 found broken) -- against the
-    same pipeline restated on the oracle: noise -> 3 denoise steps -> unpack -> (i2v: reference frame) -> VAE decode."""
-    from open_sora_amd import api, hunyuan_vae, mmdit
+def test_sampling_pipeline_on_gpu_vs_oracle_pipeline(hip_lib, cond_type, causal):
+    """what the reference's api_fn (sampling.py:562-726) does between the prompt and the video, with the PRODUCT modules on
+    the GPU -- noise -> 3 steps of sampling.I2VDenoiser.denoise on the HIP denoiser -> unpack -> (i2v: reference frame) -> the
+    package's own AutoencoderKLCausal3D.decode -- against the same pipeline restated on the oracle.  (The API glue itself is
+    the reference's own function: tests/test_reference_api_dropin.py runs it on these modules.)"""
+    from open_sora_amd import hunyuan_vae, mmdit, sampling
 
     cfg, sd = _sampler_case()
     sdb = {k: v.bfloat16() for k, v in sd.items()}
@@ -275,26 +276,32 @@ def test_api_fn_on_gpu_vs_oracle_pipeline(hip_lib, cond_type, causal):
     vsdb = {k: v.bfloat16() for k, v in vsd.items()}
     ae = hunyuan_vae.CausalVAE3D_HUNYUAN(device_map=DEV, torch_dtype=BF, **vcfg)
     ae.load_state_dict({k: v.to(DEV, BF) for k, v in vsd.items()}, strict=True)
-    # collect_references_batch calls model_ae.encode(x) -> a SAMPLE of the posterior from the global RNG (as in the
-    # reference); the comparison needs a deterministic latent, so the reference frame is encoded to the posterior mode
-    enc = ae.encode
-    ae.encode = lambda x, *a, **k: enc(x, sample_posterior=False)
     height, width, frames, steps, seed = 64, 96, 9, 3, 5
-    opt = api.sanitize_sampling_option(api.SamplingOption(
-        height=height, width=width, num_frames=frames, num_steps=steps, guidance=7.5, guidance_img=3.0, text_osci=True,
-        image_osci=True, scale_temporal_osci=True, seed=seed, is_causal_vae=causal, temporal_reduction=4, method="i2v"))
     ref_img = torch.from_numpy(synth.vae_video(1, 1, height, width, seed=31))[0]          # [3, 1, H, W] "pixels"
-
-    def reader(path, image_size, transform_name="resize_crop"):
-        return ref_img.clone()
-
-    extra = dict(ref=["some/path.png"]) if cond_type != "t2v" else {}
-    with torch.inference_mode():
-        ours = api.prepare_api(model, ae, _T5(), _Clip(), {}, reader=reader)(opt, cond_type=cond_type, text=["a cat"],
-                                                                             channel=64, **dict(extra))
-    # ---- the same pipeline on the oracle (fp32 truth, bf16 comparator); the noise comes from the device generator
     T_lat = (frames - 1) // 4 + 1 if causal else frames // 4
-    z0 = api.get_noise(1, height, width, T_lat, torch.device(DEV), BF, seed, patch_size=2, channel=16).cpu()
+    with torch.inference_mode():
+        z = sampling.get_noise(1, height, width, T_lat, torch.device(DEV), BF, seed, patch_size=2, channel=16)
+        Hl, Wl = z.shape[-2:]
+        txt = _T5()(["a cat", "", ""]).to(DEV, BF)
+        y_vec = _Clip()(["a cat", "", ""]).to(DEV, BF)
+        img_ids, txt_ids = sampling.prepare_ids(3, T_lat, Hl, Wl, txt.shape[1], DEV, BF)
+        masks = torch.zeros(1, 1, T_lat, Hl, Wl, device=DEV, dtype=BF)
+        masked_ref = torch.zeros(1, 16, T_lat, Hl, Wl, device=DEV, dtype=BF)
+        lat = None
+        if cond_type == "i2v_head":          # inference.py:248-274, 283-351: the first latent frame is the encoded reference
+            lat = ae.encode(ref_img[None].to(DEV, BF), sample_posterior=False)            # posterior mode: deterministic
+            masks[:, :, 0] = 1
+            masked_ref[:, :, 0] = lat[:, :, 0]
+        x = sampling.I2VDenoiser().denoise(
+            model, img=sampling.pack(z).repeat(3, 1, 1), timesteps=sampling.get_schedule(steps, (Hl // 2) * (Wl // 2), T_lat),
+            guidance=7.5, guidance_img=3.0, masks=masks, masked_ref=masked_ref, text_osci=True, image_osci=True,
+            scale_temporal_osci="i2v" in cond_type, img_ids=img_ids, txt=txt, txt_ids=txt_ids, y_vec=y_vec)
+        x = sampling.unpack(x, height, width, T_lat)
+        if cond_type == "i2v_head":
+            x[0, :, :1] = lat[0, :, :1]
+        ours = ae.decode(x)[:, :, :frames]
+    # ---- the same pipeline on the oracle (fp32 truth, bf16 comparator); the noise comes from the device generator
+    z0 = z.cpu()
     hp, wp = z0.shape[-2] // 2, z0.shape[-1] // 2
     txt3 = _T5()(["a cat", "", ""]).cpu()
     y3 = _Clip()(["a cat", "", ""]).cpu()
@@ -322,4 +329,4 @@ def test_api_fn_on_gpu_vs_oracle_pipeline(hip_lib, cond_type, causal):
         truth = pipeline(torch.float32, sd, vsd)
         ref = finite_retry(lambda: pipeline(BF, sdb, vsdb))
     assert ours.shape == truth.shape, (ours.shape, truth.shape)
-    assert_parity(ours, truth, ref, f"api_fn [{cond_type}, is_causal_vae={causal}] on the GPU vs the oracle pipeline")
+    assert_parity(ours, truth, ref, f"sampling pipeline [{cond_type}, is_causal_vae={causal}] on the GPU vs the oracle pipeline")
