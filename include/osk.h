@@ -169,6 +169,23 @@ int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_r
                            float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
                            float scale, int q_prescaled, int kv_batches, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same call with a caller-supplied BOUND on the scores: |scale * log2(e) * q . k| <= score_bound for every (query, key) of
+ * the launch (log2 units; with q_prescaled the bound is on q . k as stored).  The denoiser knows one for free: q and k come out
+ * of an RMS norm (layers.py:102-135), so |q| <= sqrt(hd) max|w_q| and |k| <= sqrt(hd) max|w_k| (RoPE is a rotation).  With a bound
+ * in (0, 56], n_seg == 1 and seg_len % 64 == 0 the head_dim-72 / 128 kernels run their FAST body: the online-softmax reference
+ * is the constant bound instead of a tracked maximum (P = exp2(s - bound) can neither overflow nor vanish), which removes the
+ * per-tile max chains, the rescale path and the segment / ragged-tile bookkeeping from the issue-bound loop.  The result is the
+ * same softmax (a different, equally valid reference point: same error bound against the exact result).  score_bound == 0, or
+ * any call shape outside the above: exactly osk_attention_fwd_ws_bf16.  A bound that is violated is the caller's bug: scores
+ * above it by more than ~100 overflow. */
+int osk_attention_fwd_bounded_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+                           const void* k, int64_t k_seg_stride, int64_t k_batch_stride, int64_t k_row_stride,
+                           const void* vt, int64_t vt_seg_stride,
+                           void* out, int64_t o_batch_stride, int64_t o_row_stride,
+                           float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                           float scale, int q_prescaled, int kv_batches, float score_bound,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- fp8 P.V variant of the attention (opt-in fp8 mode, BASELINE configs[4]; head_dim 72 / 128): QK^T, the softmax and
  * the output as osk_attention_fwd_ws_bf16, but P (<= 2^8 by construction) and V^T are OCP e4m3 and a 64-key tile's P.V
  * is one v_mfma_f32_32x32x64_f8f6f4 per O^T row tile.

@@ -38,6 +38,8 @@ SIGNATURES = {
                                _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp],
     "osk_attention_fwd_ws_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
                                   _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _i64, _vp],
+    "osk_attention_fwd_bounded_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
+                                       _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _f32, _vp, _i64, _vp],
     "osk_attention_workspace_bytes": [],
     "osk_v_scale_fp8": [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "osk_v_transpose_fp8": [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -312,10 +314,12 @@ def attention_workspace(device) -> torch.Tensor:
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, H: int, hd: int,
                   scale: float, *, lse=None, n_seg: int = 1, seg_len: int | None = None,
                   k_seg_stride: int = 0, vt_seg_stride: int = 0, q_prescaled: bool = False, kv_batches: int = 0,
-                  workspace: torch.Tensor | None = None):
+                  workspace: torch.Tensor | None = None, score_bound: float = 0.0):
     """q bf16 [B, Lq, H*hd] view; k bf16 [B, seg_len, H*hd] view of segment 0 (further segments k_seg_stride
     elements apart); vt from v_transpose (per segment); out bf16 [B, Lq, H*hd] view.  workspace (uint8, from
-    attention_workspace()): lets the library split the workgroups of the grid's last partial round along the keys."""
+    attention_workspace()): lets the library split the workgroups of the grid's last partial round along the keys.
+    score_bound > 0: |q . k| (as the kernel sees the scores, log2 units) never exceeds it -- enables the fast body
+    (include/osk.h, osk_attention_fwd_bounded_bf16)."""
     B, Lq, _ = q.shape
     if seg_len is None:
         seg_len = k.shape[1]
@@ -323,12 +327,12 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _check(lib.osk_attention_fwd_ws_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
-                                         k.stride(0), k.stride(1), vt.data_ptr(), vt_seg_stride, out.data_ptr(),
-                                         out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg, seg_len, hd,
-                                         scale, int(q_prescaled), kv_batches, _p(workspace),
-                                         0 if workspace is None else workspace.numel(), _stream()),
-           "osk_attention_fwd_ws_bf16")
+    _check(lib.osk_attention_fwd_bounded_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
+                                              k.stride(0), k.stride(1), vt.data_ptr(), vt_seg_stride, out.data_ptr(),
+                                              out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg, seg_len, hd,
+                                              scale, int(q_prescaled), kv_batches, float(score_bound), _p(workspace),
+                                              0 if workspace is None else workspace.numel(), _stream()),
+           "osk_attention_fwd_bounded_bf16")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))

@@ -22,6 +22,7 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
+template <bool FAST>   // FAST: score bound + one segment of whole tiles (attention_params.h::attn_fast_path)
 __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -78,6 +79,11 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
       }
       w[ks * 4 + 0] = s.x; w[ks * 4 + 1] = s.y; w[ks * 4 + 2] = s.z; w[ks * 4 + 3] = s.w;
     }
+    // FAST: the reference "max" is the caller's bound B: the padding k-step 8 (dim 128 = word 0 low half of lanes 0..31) carries
+    // -B against the constant 1.0 K fragment -> the MFMA returns s - B from tile 0 on (see attention_asm72.hip)
+    if constexpr (FAST) {
+      if (!hi) w[32] = (__float_as_uint(-p.bound) >> 16) & 0xFFFFu;
+    }
 #define OSK_QIN_A                                                                                            \
   "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),    \
       "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]), "v"(w[16]), "v"(w[17]), "v"(w[18]), \
@@ -133,9 +139,16 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
     "v"(fo[0]), "v"(fo[1]), "v"(fo[2]), "v"(fo[3]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(koffL[3]),      \
     "v"(maskval), "v"(onesaddr), "s"(kbase), "s"(vbase),                                                             \
     "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nvw)
-  asm volatile(
+  if constexpr (FAST) {
+    asm volatile(
+#include "attention_asm128_n2_f0.inc"
+        OSK128_OPERANDS : OSK128N2_CLOBBERS);
+    m_ref[0] = m_ref[1] = p.bound;
+  } else {
+    asm volatile(
 #include "attention_asm128_n2_v0.inc"
-      OSK128_OPERANDS : OSK128N2_CLOBBERS);
+        OSK128_OPERANDS : OSK128N2_CLOBBERS);
+  }
 
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 128 (sum of P), store
 #pragma unroll
@@ -202,8 +215,9 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
   }
 }
 
+template <bool FAST>
 int launch_one(const AttnParams& p, hipStream_t st) {
-  auto kernel = attn_asm128_kernel;
+  auto kernel = attn_asm128_kernel<FAST>;
   OSK_ENSURE_MAX_SMEM(kernel, OSK128_SMEM);
   const int units = ((p.Lq + 255) / 256) * p.B * p.H;
   const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
@@ -214,6 +228,6 @@ int launch_one(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
-int launch_asm128(const AttnParams& p, hipStream_t st) { return launch_one(p, st); }
+int launch_asm128(const AttnParams& p, hipStream_t st) { return attn_fast_path(p) ? launch_one<true>(p, st) : launch_one<false>(p, st); }
 
 }  // namespace osk_attn

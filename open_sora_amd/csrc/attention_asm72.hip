@@ -28,6 +28,7 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
+template <bool FAST>   // FAST: score bound + one segment of whole tiles (attention_params.h::attn_fast_path)
 __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) {
   constexpr int NU = 2;                                        // 32-row query blocks per wave (the generator's 8 waves x 32
   constexpr int NW = 8 / NU;                                   // rows layout tied this one in rounds 1-2 and is not shipped)
@@ -91,6 +92,11 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
         s = pack8(f);
       }
       w[ks * 4 + 0] = s.x; w[ks * 4 + 1] = s.y; w[ks * 4 + 2] = s.z; w[ks * 4 + 3] = s.w;
+    }
+    // FAST: the reference "max" is the caller's bound B, constant for the whole launch: Q's padding dim 72 (k-step 4, lanes
+    // 32..63, word 0 low half) = -B against the 1.0 in K's padding dim -> the MFMA returns s - B directly, from tile 0 on
+    if constexpr (FAST) {
+      if (hi) w[16] = (__float_as_uint(-p.bound) >> 16) & 0xFFFFu;
     }
 #define OSK_QIN                                                                                              \
   "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),    \
@@ -162,9 +168,16 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
     "v"(fo[2]), "v"(fo[3]), "v"(kc[0]), "v"(kc[1]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(maskval),      \
     "v"(onesaddr), "s"(kbase), "s"(vbase),                                                                           \
     "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
-  asm volatile(
+  if constexpr (FAST) {
+    asm volatile(
+#include "attention_asm72_n2_f0.inc"
+        OSK72_OPERANDS : OSK72N2_CLOBBERS);
+    m_ref[0] = m_ref[1] = p.bound;
+  } else {
+    asm volatile(
 #include "attention_asm72_n2_v0.inc"
-      OSK72_OPERANDS : OSK72N2_CLOBBERS);
+        OSK72_OPERANDS : OSK72N2_CLOBBERS);
+  }
 
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 72 (sum of P), store
 #pragma unroll
@@ -234,8 +247,9 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   }
 }
 
+template <bool FAST>
 int launch_one(const AttnParams& p, hipStream_t st) {
-  auto kernel = attn_asm72_kernel;
+  auto kernel = attn_asm72_kernel<FAST>;
   OSK_ENSURE_MAX_SMEM(kernel, OSK72_SMEM);
   const int units = ((p.Lq + 255) / 256) * p.B * p.H;
   const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
@@ -246,6 +260,6 @@ int launch_one(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
-int launch_asm72(const AttnParams& p, hipStream_t st) { return launch_one(p, st); }
+int launch_asm72(const AttnParams& p, hipStream_t st) { return attn_fast_path(p) ? launch_one<true>(p, st) : launch_one<false>(p, st); }
 
 }  // namespace osk_attn

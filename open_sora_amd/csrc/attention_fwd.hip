@@ -550,13 +550,13 @@ extern "C" int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int
                                    scale, q_prescaled, kv_batches, nullptr, 0, stream);
 }
 
-extern "C" int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+extern "C" int osk_attention_fwd_bounded_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
                                          const void* k, int64_t k_seg_stride, int64_t k_batch_stride,
                                          int64_t k_row_stride, const void* vt, int64_t vt_seg_stride,
                                          void* out, int64_t o_batch_stride, int64_t o_row_stride,
                                          float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
-                                         float scale, int q_prescaled, int kv_batches, void* workspace,
-                                         int64_t workspace_bytes, void* stream) {
+                                         float scale, int q_prescaled, int kv_batches, float score_bound,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
   if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Lq <= 0 || n_seg <= 0 || seg_len <= 0) return OSK_EINVAL;
   if ((q_batch_stride & 7) || (q_row_stride & 7) || (k_seg_stride & 7) || (k_batch_stride & 7) ||
       (k_row_stride & 7) || (vt_seg_stride & 7) || (o_batch_stride & 3) || (o_row_stride & 3))
@@ -572,6 +572,12 @@ extern "C" int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, 
   p.tps = p.seg_lp / 64;
   p.sc = q_prescaled ? 1.0f : scale * 1.4426950408889634f;  // log2 units; 1: q already carries it
   p.q_prescaled = q_prescaled;
+  if (!(score_bound >= 0.f)) return OSK_EINVAL;   // (also rejects NaN)
+  {
+    // the kernels keep the bound in a bf16 field of Q's padding dim: round it UP to the next bf16 value (it stays a bound)
+    const unsigned bits = __builtin_bit_cast(unsigned, score_bound);
+    p.bound = __builtin_bit_cast(float, (bits + 0xFFFFu) & 0xFFFF0000u);
+  }
   if (kv_batches < 0 || kv_batches > B) return OSK_EINVAL;
   p.Bkv = kv_batches > 0 ? kv_batches : B;
   p.map = 1;   // XCD-contiguous work order (each XCD walks one head's K / V^T stream)
@@ -584,6 +590,18 @@ extern "C" int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, 
     case 128: return launch<128>(p, st);
     default: return OSK_EUNSUPPORTED;
   }
+}
+
+extern "C" int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+                                         const void* k, int64_t k_seg_stride, int64_t k_batch_stride,
+                                         int64_t k_row_stride, const void* vt, int64_t vt_seg_stride,
+                                         void* out, int64_t o_batch_stride, int64_t o_row_stride,
+                                         float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                                         float scale, int q_prescaled, int kv_batches, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+  return osk_attention_fwd_bounded_bf16(q, q_batch_stride, q_row_stride, k, k_seg_stride, k_batch_stride, k_row_stride, vt,
+                                        vt_seg_stride, out, o_batch_stride, o_row_stride, lse, B, H, Lq, n_seg, seg_len, hd,
+                                        scale, q_prescaled, kv_batches, 0.0f, workspace, workspace_bytes, stream);
 }
 
 extern "C" const char* osk_attention_kernel_name(int hd, int seg_len) {

@@ -16,6 +16,10 @@ struct AttnParams {
   float* lse;
   int B, H, Lq, n_seg, seg_len, seg_lp, tps;
   float sc;   // softmax scale * log2(e); 1.0 when q_prescaled
+  // caller-supplied bound on the scores as the kernel sees them (|q . k| * sc <= bound, log2 units), rounded UP to a bf16 value;
+  // 0 = unknown.  With a bound <= OSK_ATTN_MAX_BOUND, one key segment and whole 64-key tiles the hand-scheduled kernels run their
+  // FAST body: reference max = bound (a constant in Q's padding dim), no max tracking, branch-free loader advance
+  float bound = 0.f;
   int q_prescaled;
   int Bkv;    // key / value batches: query batch b reads key batch b % Bkv
   int map;    // block -> (head, query block) order: 0 = heads fastest, 1 = XCD-contiguous, query blocks fastest
@@ -30,6 +34,12 @@ struct AttnParams {
   const unsigned char* vt8 = nullptr;
   const float* v_scale = nullptr;
 };
+
+#define OSK_ATTN_MAX_BOUND 56.0f   // P = exp2(s - bound) >= 2^-112 for every admissible score: no underflow to zero
+
+static inline bool attn_fast_path(const AttnParams& p) {   // host side
+  return p.bound > 0.f && p.bound <= OSK_ATTN_MAX_BOUND && p.n_seg == 1 && (p.seg_len & 63) == 0;
+}
 
 // (batch*head, query block) of a workgroup.  map 1 hands every XCD (block b runs on XCD b % 8) a contiguous
 // range of the (head-major) work list, so the workgroups resident on one XCD walk the SAME head's K / V^T

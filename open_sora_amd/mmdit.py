@@ -311,6 +311,7 @@ class _DoublePlan:
     mod_layers: list = field(default_factory=list)  # [(w bf16, b bf16)] img then txt
     pv8: bool = False   # fp8 mode: attention with the P.V product on the fp8 MFMA
     key: tuple = ()     # _param_key of the block the plan was built from
+    score_bound: float = 0.0   # bound on |q . k| as the attention kernel sees it (log2 units): _score_bound()
 
 
 @dataclass
@@ -324,6 +325,18 @@ class _SinglePlan:
     mod_layers: list = field(default_factory=list)
     pv8: bool = False
     key: tuple = ()
+    score_bound: float = 0.0
+
+
+def _score_bound(hd: int, q_scales, k_scales) -> float:
+    """Upper bound on |q . k| for the q, k the attention kernel receives from osk_qknorm_rope_bf16 (log2 units: q carries
+    q_mult(hd) = hd^-1/2 log2 e).  QKNorm (layers.py:102-135) = RMS norm times a learned scale vector: sum_i (x_i rrms)^2 <= hd,
+    so |q| <= sqrt(hd) max|w_q| and |k| <= sqrt(hd) max|w_k|; RoPE is a rotation; the three bf16 roundings on each side add
+    < 2.5 % (covered by the 1.05).  Cauchy-Schwarz gives the bound the fast attention body uses as its softmax reference
+    (include/osk.h, osk_attention_fwd_bounded_bf16)."""
+    wq = max(float(t.detach().float().abs().max()) for t in q_scales)
+    wk = max(float(t.detach().float().abs().max()) for t in k_scales)
+    return 1.05 * q_mult(hd) * hd * wq * wk
 
 
 def _attn_weights(sa, wrap=lambda w: w) -> _AttnW:
@@ -373,6 +386,8 @@ def plan_double(block) -> _DoublePlan:
             mod_layers=[_mod_layer(block.img_mod), _mod_layer(block.txt_mod)],
             pv8=bool(getattr(block, "_osk_fp8", False)),
         )
+        hd = block.head_dim if hasattr(block, "head_dim") else block.hidden_size // block.num_heads
+        p.score_bound = _score_bound(hd, (p.img.q_scale, p.txt.q_scale), (p.img.k_scale, p.txt.k_scale))
         p.key = _param_key(block)
         object.__setattr__(block, "_osk_plan", p)
     return p
@@ -391,6 +406,8 @@ def plan_single(block) -> _SinglePlan:
         p = _SinglePlan(wr(w1), b1, wr(_w(block.linear2.weight)), _b32(block.linear2.bias),
                         _w(block.norm.query_norm.scale), _w(block.norm.key_norm.scale),
                         mod_layers=[_mod_layer(block.modulation)], pv8=bool(getattr(block, "_osk_fp8", False)))
+        hd = block.head_dim if hasattr(block, "head_dim") else block.hidden_size // block.num_heads
+        p.score_bound = _score_bound(hd, (p.q_scale,), (p.k_scale,))
         p.key = _param_key(block)
         object.__setattr__(block, "_osk_plan", p)
     return p
@@ -500,7 +517,8 @@ def v_scale_fp8(v: Tensor, H: int, hd: int) -> Tensor:
     return _OPS.v_scale_fp8(v, H, hd)
 
 
-def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False):
+def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False,
+                     score_bound: float = 0.0):
     """attention() of math.py:22-36 on the joint [txt;img] sequence; the output overwrites the (dead) v slot.
     pv8 (fp8 mode, head_dim 72 / 128): V^T as e4m3 with one scale per (batch, head), P.V on the fp8 MFMA."""
     wsp = _OPS.attention_workspace(q.device)
@@ -514,7 +532,7 @@ def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd
         _OPS.attention_fwd_pv8(q, k, vt8, sv, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=wsp)
         return
     _OPS.v_transpose(v, ws.vt, H, hd)
-    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=wsp)
+    _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=wsp, score_bound=score_bound)
 
 
 def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: int, col_txt: int, rope: _RopeTable,
@@ -544,7 +562,7 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
         for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):
             _linear(act, aw.qkv_w, aw.qkv_b, y_s)
         _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
-        _joint_attention(ws, q, k, v, H, hd, plan.pv8)
+        _joint_attention(ws, q, k, v, H, hd, plan.pv8, plan.score_bound)
     else:
         for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):  # K, V first: their all-gather overlaps the Q projection
             _linear(act, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
@@ -581,7 +599,7 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
     if sp is None:
         _linear(act, plan.w1, plan.b1, y, gelu_from=3 * D)
         _OPS.qknorm_rope(q, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
-        _joint_attention(ws, q, k, v, H, hd, plan.pv8)
+        _joint_attention(ws, q, k, v, H, hd, plan.pv8, plan.score_bound)
     else:
         b1 = plan.b1
         _linear(act, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])

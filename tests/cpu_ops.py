@@ -231,7 +231,7 @@ def attention_workspace(device):
 
 
 def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=None, k_seg_stride=0, vt_seg_stride=0,
-                  q_prescaled=False, kv_batches=0, workspace=None):
+                  q_prescaled=False, kv_batches=0, workspace=None, score_bound=0.0):
     Bq, Lq, D = q.shape
     B = kv_batches if kv_batches else Bq     # key / value batches; query batch b reads key batch b % B
     _abi_check("osk_attention_fwd_bf16", q.stride(0) % 8 == 0, q.stride(1) % 8 == 0, k.stride(0) % 8 == 0,
@@ -260,6 +260,9 @@ def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=Non
         idx = torch.arange(Bq) % B
         K, V = K[idx], V[idx]
     s_ = (Q @ K.transpose(-1, -2)) * (0.6931471805599453 if q_prescaled else scale)  # prescaled q: log2 units
+    if score_bound:   # the caller's promise (include/osk.h, osk_attention_fwd_bounded_bf16): checked here on every call
+        worst = float(s_.abs().max()) / 0.6931471805599453
+        assert worst <= score_bound, f"score bound {score_bound} violated: |score| reaches {worst} (log2 units)"
     o = torch.softmax(s_, -1) @ V
     res = o.permute(0, 2, 1, 3).reshape(Bq, Lq, D).to(out.dtype)
     out.copy_(res)

@@ -326,6 +326,58 @@ def test_attention_rescale_branch(hip_lib, hd):
     _attn_case(hip_lib, 1, 2, hd, 128, 900, spike=True, lse_tol=5e-2)
 
 
+# ----------------------------------------------------------------------------- attention with a caller-supplied score bound
+def _bounded_case(hip_lib, B, H, hd, Lq, Lk, bound_slack=1.0, ws=False, seed=11, scale_q=1.0):
+    """osk_attention_fwd_bounded_bf16 (FAST body when Lk % 64 == 0): against f64 and against the tracked-max kernel"""
+    D = H * hd
+    q = (rnd("q", (B, Lq, D), seed=seed).float() * (scale_q * hd ** -0.5 * 1.4426950408889634)).to(BF)   # as the model path: prescaled
+    kv = rnd("kv", (B, Lk, 2 * D), seed=seed + 1)
+    k, v = kv[:, :, :D], kv[:, :, D:]
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.empty(B, H, hd, Lp, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+
+    def heads(t, L):
+        return t.float().cpu().view(B, L, H, hd).permute(0, 2, 1, 3)
+
+    qh, kh, vh = heads(q, Lq), heads(k, Lk), heads(v, Lk)
+    s2 = qh.double() @ kh.double().transpose(-1, -2)                       # log2 units
+    # a Cauchy-Schwarz bound like the model's (|q| |k| per head), optionally looser
+    bound = float((qh.norm(dim=-1).amax() * kh.norm(dim=-1).amax())) * bound_slack
+    assert float(s2.abs().max()) <= bound
+    w = hip_lib.attention_workspace(torch.device(DEV)) if ws else None
+    out_b = torch.empty(B, Lq, D, dtype=BF, device=DEV)
+    lse_b = torch.empty(B, H, Lq, dtype=torch.float32, device=DEV)
+    hip_lib.attention_fwd(q, k, vt, out_b, H, hd, hd ** -0.5, lse=lse_b, q_prescaled=True, workspace=w, score_bound=bound)
+    out_t = torch.empty_like(out_b)
+    hip_lib.attention_fwd(q, k, vt, out_t, H, hd, hd ** -0.5, q_prescaled=True, workspace=w)
+    s = s2 * 0.6931471805599453
+    ref = (torch.softmax(s, -1) @ vh.double()).permute(0, 2, 1, 3).reshape(B, Lq, D)
+    got = out_b.float().cpu().double()
+    assert torch.isfinite(got).all()
+    err, rel = (got - ref).abs().max().item(), ((got - ref).norm() / ref.norm()).item()
+    assert err <= 2.5e-2 and rel <= 6e-3, (err, rel, bound)
+    assert (lse_b.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() <= 4e-3
+    # same softmax from a different reference point: the two kernels agree to the bf16 rounding of P
+    assert ((got - out_t.float().cpu().double()).norm() / ref.norm()).item() <= 6e-3
+    return bound
+
+
+@pytest.mark.parametrize("hd", [72, 128])
+@pytest.mark.parametrize("Lq,Lk", [(256, 64), (300, 128), (64, 192), (257, 1024), (33, 4096)])
+def test_attention_bounded_fast_body_vs_f64(hip_lib, hd, Lq, Lk):
+    _bounded_case(hip_lib, 2, 2, hd, Lq, Lk)
+
+
+@pytest.mark.parametrize("hd", [72, 128])
+def test_attention_bounded_loose_bound_tail_split_and_fallbacks(hip_lib, hd):
+    b = _bounded_case(hip_lib, 1, 3, hd, 512, 2048, bound_slack=3.0, ws=True)      # loose bound (P ~ 2^-2B), tail split + merge
+    assert b <= 56.0
+    _bounded_case(hip_lib, 2, 2, hd, 200, 1000)                                   # ragged last tile: the general body runs
+    _bounded_case(hip_lib, 1, 2, hd, 128, 512, bound_slack=40.0)                  # bound > 56: the general body runs
+    _bounded_case(hip_lib, 1, 2, hd, 128, 512, scale_q=2.5)                       # larger logits, tight bound
+
+
 # the hand-scheduled kernels (attention_asm72.hip, attention_asm128.hip) at whole 64-key tiles: 1, 2, 3 and many key
 # tiles (prologue-only, one body, both bodies of the 2x unrolled loop), ragged query blocks, several heads/batches
 @pytest.mark.parametrize("hd", [72, 128])

@@ -20,6 +20,14 @@ negated, in Q's padding dim 72 and K's padding dim 72 reads 1.0 from a constant 
 S' = q.k - M and P = exp2(S') needs ONE v_exp per score; row sums come out of the P.V MFMA (ones row of V^T,
 accumulator row 72).  M only moves when some score exceeds it by more than 2^THR (rare path: rescale O, shift the
 pending scores, rewrite the padding dim).
+FAST bodies (`generate(..., fast=True)`, attention_asm*_n2_f0.inc): the loop the single-GPU denoise step runs.  The gap of a
+32-cycle MFMA hides at most ~5 other instructions of the one wave on the SIMD (MI355X_MICROARCH.md); the general body carries
+~230 per 44 MFMAs, i.e. it is ISSUE-bound.  Two launch-uniform facts remove a third of them:
+  * a caller-supplied BOUND on the scores (|q.k| <= B, log2 units; the model path knows it from the QK-norm scale vectors): the
+    reference max is the constant B -- Q's padding dim holds -B from the start, P = exp2(s - B) <= 1 can never overflow -- so
+    the per-lane max chains (34 VALU per tile), the compare, the branch and the whole rare path disappear;
+  * one key segment of whole 64-key tiles: no ragged-tile lane masks, no ones-row rewrite, no segment jumps -- both loaders
+    advance with six branch-free SALU instructions (clamped at the last tile) instead of ~36 with branches.
 Body t (starts right after barrier t-1): the last 2 fragment pairs' P.V MFMAs of tile t-1 | QK^T of tile t+1 |
 P.V of tile t (first 10 of 12 fragment pairs); beside them: K / V^T fragment reads (4-deep rings), LDS-DMA of
 K(t+2), V(t+1), exp2 + pack of tile t, max of tile t+1.
@@ -323,15 +331,21 @@ def rowmax_from_chains(st, L):
         st.emit("v_max_f32 %s, %s, %s" % (vr(L.MT[u]), vr(ta), vr(tb)))
 
 
+FAST = False   # set by generate(): the body being emitted is the bounded / single-segment / whole-tile variant
+
+
 def k_dma(st, L, slot, i, part=3):
     """K loader slot i of this wave -> ring slot `slot` (instruction j = wave + NW i).  part 1 = M0 write only,
     2 = the DMA only (one other instruction must sit between them), 3 = both with an s_nop.  On the ragged last tile
     of a key segment (lane mask S_KRG) the rows past the segment re-fetch its last key (offsets koffL)."""
     if part & 1:
         st.emit("s_add_u32 m0, s%d, %d" % (S_KDST, L.G.KOFF[slot] + 1024 * L.NW * i), "s")
-        st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(L.TX[3]), L.OP["koff%d" % i], L.OP["koffL%d" % i], S_KRG, S_KRG + 1), "v")
+        if not FAST:
+            st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(L.TX[3]), L.OP["koff%d" % i], L.OP["koffL%d" % i], S_KRG, S_KRG + 1), "v")
+        elif part == 3:
+            st.emit("s_nop 0", "n")
     if part & 2:
-        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (vr(L.TX[3]), S_KB, S_KB + 1), "g")
+        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (L.OP["koff%d" % i] if FAST else vr(L.TX[3]), S_KB, S_KB + 1), "g")
 
 
 def v_dma(st, L, slot, i, part=3):
@@ -362,6 +376,18 @@ def dma_last(st, L, which, slot, uid):
 
 def advance(st, which, uid, vstep=128):
     """point the loader at its next tile; past the last tile it stays (harmless re-fetch of the last tile)"""
+    if FAST:   # one segment of whole tiles: branch-free, six SALU instructions
+        sl, sb = (S_KL, S_KB) if which == "k" else (S_VL, S_VB)
+        st.emit("s_add_u32 s%d, s%d, 1" % (S_TMP, sl), "s")
+        st.emit("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NT), "s")
+        st.emit("s_cselect_b32 s%d, s%d, s%d" % (sl, S_TMP, sl), "s")
+        if which == "k":
+            st.emit("s_cselect_b32 s%d, s%d, 0" % (S_TMP, S_KSTEP), "s")
+        else:
+            st.emit("s_cselect_b32 s%d, %d, 0" % (S_TMP, vstep), "s")
+        st.emit("s_add_u32 s%d, s%d, s%d" % (sb, sb, S_TMP), "s")
+        st.emit("s_addc_u32 s%d, s%d, 0" % (sb + 1, sb + 1), "s")
+        return
     lab = ".L@@_%sa%s" % (which, uid)
     sl, sb, stt, sj = (S_KL, S_KB, S_KTT, S_KJ) if which == "k" else (S_VL, S_VB, S_VTT, S_VJ)
     st.emit("s_add_u32 s%d, s%d, 1" % (S_TMP, sl), "s")
@@ -384,6 +410,8 @@ def advance(st, which, uid, vstep=128):
 
 def ragged_masks(st):
     """refresh both loaders' ragged-tile lane masks; skipped entirely when the launch has no ragged tile"""
+    if FAST:
+        return
     lab = ".L@@_rg%d" % len(st.lines)
     st.emit("s_cmp_lg_u32 s%d, 0" % S_NRG, "s")
     st.emit("s_cbranch_scc1 %s" % lab, "s")
@@ -504,7 +532,8 @@ def body(st, L, k, safe):
         if pn < len(pieces):
             piece(pieces[pn], 2)
     # -- decision: did some score of tile t exceed the reference by more than 2^THR (VCC from the previous body)?
-    st.emit("s_cbranch_vccnz .L@@_rare%d" % k)
+    if not FAST:   # (fast: the reference is a bound, nothing to decide)
+        st.emit("s_cbranch_vccnz .L@@_rare%d" % k)
     st.label(".L@@_entry%d" % k)
 
     # -- remaining LDS-DMA work, one item per shadow right after the entry point: (emitter, cycles)
@@ -515,10 +544,10 @@ def body(st, L, k, safe):
     for i in range(done["v"], nslot(L, "v") - 1):
         later.append((lambda i=i: v_dma(st, L, cur ^ 1, i), DMACOST))
     later.append((lambda: dma_last(st, L, "v", cur ^ 1, uid), DMACOST))
-    if not L.PV8:   # pv8: the ones / key-validity row arrives with the V^T tile itself
+    if not L.PV8 and not FAST:   # pv8: the ones / key-validity row arrives with the V^T tile itself; fast: whole tiles only
         later.append((lambda: ones_row(st, L, cur ^ 1), 8))   # before the V^T loader moves on: S_VRG is tile t+1's
-    later.append((lambda: advance(st, "k", uid), 28))
-    later.append((lambda: (advance(st, "v", uid, L.G.VSTEP), ragged_masks(st)), 32))
+    later.append((lambda: advance(st, "k", uid), 12 if FAST else 28))
+    later.append((lambda: (advance(st, "v", uid, L.G.VSTEP), ragged_masks(st)), 12 if FAST else 32))
 
     # -- fillers paced in CYCLES (v_exp 8, other VALU 4): three classes, each spread uniformly over its window
     cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
@@ -532,6 +561,8 @@ def body(st, L, k, safe):
     n_first_b = len(clsC)
     clsC.extend([o for grp in zip(*cb) for o in grp])
     clsC.extend(lanemax_final(L))
+    if FAST:   # no reference max to maintain
+        clsC, n_first_b = [], 0
     W = L.WINDOWS
     classes = [[clsA, W[0], W[1], 0, 0.0], [clsB, W[2], W[3], 0, 0.0], [clsC, W[4], W[5], 0, 0.0]]
     totals = [sum(cost(o[0]) for o in c[0]) for c in classes]
@@ -600,7 +631,19 @@ def body(st, L, k, safe):
     return pieces
 
 
-def generate(L, safe=False, ablate=frozenset()):
+def generate(L, safe=False, ablate=frozenset(), fast=False):
+    """fast: the bounded / single-segment / whole-tile variant (see the header); not for the fp8 P.V kernels, whose e4m3 P
+    needs the reference max within 2^8 of the true one"""
+    global FAST
+    assert not (fast and L.PV8)
+    FAST = fast
+    try:
+        return _generate(L, safe, ablate)
+    finally:
+        FAST = False
+
+
+def _generate(L, safe, ablate):
     st = Stream(ablate)
     e = st.emit
     # ---- copy the mutable scalars into asm-owned SGPRs
@@ -629,8 +672,9 @@ def generate(L, safe=False, ablate=frozenset()):
     e("s_lshr_b32 s%d, s%d, 8" % (S_FLG, S_NVW))
     e("s_and_b32 s%d, s%d, 1" % (S_NRG, S_FLG))
     e("s_and_b32 s%d, s%d, 0xff" % (S_NVW, S_NVW))
-    ragged_mask(st, "k")
-    ragged_mask(st, "v")
+    if not FAST:
+        ragged_mask(st, "k")
+        ragged_mask(st, "v")
     for u in range(2):
         e("v_mov_b32 %s, 0" % vr(L.MM[u]))
     for r in range(L.A_O0, L.A_Q0):
@@ -651,11 +695,12 @@ def generate(L, safe=False, ablate=frozenset()):
     e("s_barrier")                      # every wave has read K0: slot 0 may be refilled
     e("s_nop 15")
     e("s_nop 15")
-    for t2 in range(2):
-        for u in range(L.NU):
-            for op in max_chain(L, L.SA0, u, t2, chain_tmp(L, u, t2)):
-                e(op[1])
-    fixup(st, L, L.SA0, init=True)
+    if not FAST:   # (fast: Q's padding dim already carries the bound, the scores above are final)
+        for t2 in range(2):
+            for u in range(L.NU):
+                for op in max_chain(L, L.SA0, u, t2, chain_tmp(L, u, t2)):
+                    e(op[1])
+        fixup(st, L, L.SA0, init=True)
     # what body 0 does before its entry point: the first LDS-DMA pieces of K(2) -> slot 0 and V(1) -> slot 1 (the
     # same ones body() puts into the trailing shadows), the first K fragment reads of tile 1
     pieces = body(Stream(), L, 0, False)
@@ -671,7 +716,7 @@ def generate(L, safe=False, ablate=frozenset()):
         body(st, L, k, safe)
     st.in_body = False
     # ---- rare paths
-    for k in range(2):
+    for k in range(0 if FAST else 2):
         st.label(".L@@_rare%d" % k)
         fixup(st, L, L.SA0 if k == 0 else L.SB0, init=False)
         e("s_branch .L@@_entry%d" % k)
@@ -735,6 +780,16 @@ def main():
                     (hd, ", fp8 P.V" if pv8 else "", nu, what))
             for ln in st.lines:
                 f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%dv0" % (tagof(hd, pv8), nu)))
+        if not pv8:   # the bounded / single-segment / whole-tile body of the same layout
+            if gap:
+                DMAGAP, DMACOST = int(spec[0]), int(spec[1]) if len(spec) > 1 else 12
+            stf = generate(L, safe, ablate, fast=True)
+            DMAGAP, DMACOST = 1, 12
+            with open(os.path.join(args.out, "attention_asm%s_n%d_f0.inc" % (tagof(hd, pv8), nu)), "w") as f:
+                f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d, layout NU=%d, FAST body (score bound, one "
+                        "segment of whole tiles): %s\n" % (hd, nu, what))
+                for ln in stf.lines:
+                    f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%df0" % (tagof(hd, pv8), nu)))
     # register / operand contract for the wrapper
     with open(os.path.join(args.out, "attention_asm_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.\n")
