@@ -73,6 +73,13 @@ def bench_attn(B, H, L, hd, tag):
     emit(kernel="attention_fwd+tailsplit", tag=tag, B=B, H=H, L=L, hd=hd, ms=round(ms, 4),
          tflops=round(4.0 * B * H * L * L * hd / ms / 1e9, 1),
          parts=_C.lib.osk_attention_tail_split_factor(B, H, L, 1, L, hd, ws.numel()))
+    # with a score bound (what the model path passes: FAST body when the key count is a multiple of 64)
+    D_ = H * hd
+    qn = q.float().view(B, L, H, hd).norm(dim=-1).amax().item() * hd ** -0.5 * 1.4426950408889634
+    kn = k.float().view(B, L, H, hd).norm(dim=-1).amax().item()
+    ms = timeit(lambda: _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5, workspace=ws, score_bound=qn * kn), iters=5, warm=2)
+    emit(kernel="attention_fwd+tailsplit+bound", tag=tag, B=B, H=H, L=L, hd=hd, ms=round(ms, 4),
+         tflops=round(4.0 * B * H * L * L * hd / ms / 1e9, 1), bound=round(qn * kn, 2))
     ms = timeit(lambda: _C.v_transpose(v, vt, H, hd))
     emit(kernel="v_transpose", tag=tag, ms=round(ms, 4), gbps=round(4.0 * B * L * D / ms / 1e6, 1))
     if hd in (72, 128):
