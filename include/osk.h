@@ -123,9 +123,12 @@ int osk_qknorm_rope_bf16(void* q, void* k, int64_t batch_stride, int64_t row_str
 /* ---- V -> key-major transposed copy for the attention kernel's PV operand.
  * (internal layout, no reference counterpart: flash-attn does this transpose in shared memory.)
  * v row (b,l) head h at v + b*batch_stride + l*row_stride + h*hd.
- * vt [B, H, hd, Lp], Lp = round_up(L, 64), zero-filled for keys >= L; inside every group of 16 keys the
- * two middle quads are swapped (k0-3, k8-11, k4-7, k12-15): the order the 32x32x16 MFMA accumulator
- * hands P back to the next MFMA, so no cross-lane shuffle is needed. */
+ * vt [B, H, hd, Lp], Lp = round_up(L, 64), zero-filled for keys >= L.  The key order inside a 64-key tile is the one in
+ * which the attention kernel of that head_dim holds P for its second product (an internal contract between the two calls):
+ *   hd 64 / 128 (P.V on 32x32x16 MFMAs): inside every group of 16 keys the two middle quads are swapped (k0-3, k8-11, k4-7,
+ *     k12-15) -- the order the score accumulators hand P back, no cross-lane shuffle;
+ *   hd 72 (P.V on 16x16x32 MFMAs, 80 instead of 96 padded rows): 16-byte chunk c of a tile row = 32-key half c / 4, MFMA
+ *     lane row c % 4, holding keys {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31} of that half for rows 0..3. */
 int osk_v_transpose_bf16(const void* v, int64_t batch_stride, int64_t row_stride,
                          void* vt, int B, int L, int H, int hd, void* stream);
 

@@ -1,7 +1,9 @@
 // Flash-attention forward for head_dim 72 (DiT-XL geometry), gfx950: hand-scheduled main loop.
 //
 // Structure: 4 waves x 64 query rows, one wave per SIMD (the generator can also emit 8 waves x 32 rows, two per SIMD),
-// LDS-DMA staged 64-key tiles, swapped-operand v_mfma_f32_32x32x16_bf16), but the whole K/V loop is ONE asm
+// LDS-DMA staged 64-key tiles, swapped operands: S^T = K . Q^T on v_mfma_f32_32x32x16_bf16 (80 padded dims), O^T += V^T . P^T
+// on v_mfma_f32_16x16x32_bf16 (80 padded rows = 5 blocks of 16 instead of 3 x 32; P crosses from the 32-query score layout
+// to the 16-query operand layout by one v_permlane16_swap per packed register pair), and the whole K/V loop is ONE asm
 // statement emitted by tools/gen_attn_asm.py (attention_asm72_n{NU}_v{VAR}.inc): explicit register file (O^T and Q in AGPRs, two score tiles,
 // P and two 4-slot fragment rings in VGPRs), every MFMA shadow filled by hand with ~5 issue slots of LDS reads /
 // exp2 / pack / max work, counted lgkmcnt waits, one barrier per tile.  See the generator's header for the
@@ -60,11 +62,15 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   const bool ragged = kp.ragged;
   unsigned maskval = 0;
   if (lane < 32) {
-    // dword `lane` of LDS row 72: 16-byte position lane / 4 holds logical chunk (lane / 4) ^ ((72 >> 1) & 7) of the
-    // swizzled 128-byte row image; columns of the V^T tile: key = 16 (c / 16) + perm(c % 16)
-    const int c0 = (((lane >> 2) ^ ((HD >> 1) & 7)) << 3) + (lane & 3) * 2, c1 = c0 + 1;
-    auto key_of = [](int c) { const int j = c & 15; return (c & ~15) + ((j & 3) | ((j & 4) << 1) | ((j & 8) >> 1)); };
-    maskval = (key_of(c0) < last_valid ? 0x3F80u : 0u) | (key_of(c1) < last_valid ? 0x3F800000u : 0u);
+    // dword `lane` of LDS row 72: 16-byte position lane / 4 holds logical chunk c = (lane / 4) ^ ((72 >> 1) & 7) of the swizzled
+    // 128-byte row image; chunk c of the V^T tile = 32-key half c / 4, lane row c % 4, whose 8 keys (baked by
+    // osk_v_transpose_bf16 for this head_dim) are PV16_KEYS[c % 4] (tools/gen_attn_asm.py)
+    const int c = (lane >> 2) ^ ((HD >> 1) & 7), e0 = (lane & 3) * 2;
+    auto key_of = [](int c_, int e_) {
+      const int r_ = c_ & 3;   // lane row: keys {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31}
+      return 32 * (c_ >> 2) + ((r_ & 1) << 4) + ((r_ >> 1) << 2) + ((e_ >> 2) << 3) + (e_ & 3);
+    };
+    maskval = (key_of(c, e0) < last_valid ? 0x3F80u : 0u) | (key_of(c, e0 + 1) < last_valid ? 0x3F800000u : 0u);
   }
   if (ragged && kp.tps == 1 && tid < 32)                 // tile 0 itself is ragged: no loop body precedes it
     reinterpret_cast<unsigned*>(smem + OSK72_VOFF0 + HD * 128)[tid] = maskval;
@@ -147,6 +153,12 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   for (int t2 = 0; t2 < 2; ++t2)   // ring slot 1 = + KTILE (immediate), for the column image and the constant chunk alike
     kc[t2] = hi ? lds_base + OSK72_CONST_OFF : lds_base + 8192 + t2 * 512 + l31 * 16;
   const unsigned onesaddr = lds_base + OSK72_VOFF0 + HD * 128 + lane * 4;   // lanes 32..63: the zero row behind it
+  // V^T fragments of the 16x16x32 P.V product: lane (row r4 = lane / 16, dim l15 = lane % 16 of a 16-row block) reads chunk
+  // 4 t2 + r4 of its row (+ block and ring-slot immediates in the asm); same swizzled 128-byte-row image as K
+  const int l15 = lane & 15, r4 = lane >> 4;
+  unsigned vo[2];
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) vo[t2] = lds_base + l15 * 128 + (((4 * t2 + r4) ^ ((l15 >> 1) & 7)) << 4);
 
   const int bkv = b % p.Bkv;   // key / value batch of this query batch
   const uint64_t kbase = rfl64((uint64_t)(uintptr_t)(p.k + bkv * p.kbs + h * HD + kp.k_off));
@@ -154,20 +166,21 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
   const unsigned kstep = rfl((unsigned)(128 * p.krs));
   const uint64_t kjump = rfl64((uint64_t)((p.kss - (int64_t)p.tps * 64 * p.krs) * 2));
   const uint64_t vjump = rfl64((uint64_t)((p.vtss - (int64_t)p.tps * 64) * 2));
-  const unsigned tps = rfl((unsigned)kp.tps), nt = rfl((unsigned)kp.nt);
+  const unsigned tpsnt = rfl((unsigned)kp.tps | ((unsigned)kp.nt << 16));   // (two operand slots went to vo[])
   const unsigned kdst = rfl(lds_base + wave * 1024), vdst = rfl(lds_base + OSK72_VOFF0 + (NW - 1 - wave) * 1024);
   // valid loader slots of this wave: the last one only where its instruction index is < 9
   const unsigned nkw = rfl(wave + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1));
   const unsigned nvw = rfl(((NW - 1 - wave) + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1)) |
                            (ragged ? 0u : 1u << 8) | ((ragged && wave == 0) ? 1u << 9 : 0u));
+  const unsigned nkvw = rfl(nvw | (nkw << 16));
 
   float m_ref[2];
 #define OSK72_OPERANDS                                                                                              \
   : "=&v"(m_ref[0]), "=&v"(m_ref[1])                                                                                 \
   : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(fo[0]), "v"(fo[1]),     \
     "v"(fo[2]), "v"(fo[3]), "v"(kc[0]), "v"(kc[1]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(maskval),      \
-    "v"(onesaddr), "s"(kbase), "s"(vbase),                                                                           \
-    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
+    "v"(onesaddr), "v"(vo[0]), "v"(vo[1]), "s"(kbase), "s"(vbase),                                                   \
+    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tpsnt), "s"(kdst), "s"(vdst), "s"(nkvw)
   if constexpr (FAST) {
     asm volatile(
 #include "attention_asm72_n2_f0.inc"
@@ -179,70 +192,60 @@ __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) 
         OSK72_OPERANDS : OSK72N2_CLOBBERS);
   }
 
-  // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 72 (sum of P), store
+  // ---- epilogue: O^T out of the AGPRs -- per 16-query block (u, half): lane = query l15, dims 16 db + 4 r4 + i in register
+  //      4 db + i -- normalise by accumulator row 72 (sum of P: block 4, lane row 2, register 0), store
+  static_assert(OSK72_NDB == 5, "epilogue written for 5 row blocks of 16");
+#define OSK_OOUT20                                                                                                   \
+  "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]), "=v"(o[4]), "=v"(o[5]), "=v"(o[6]), "=v"(o[7]), "=v"(o[8]), "=v"(o[9]), \
+      "=v"(o[10]), "=v"(o[11]), "=v"(o[12]), "=v"(o[13]), "=v"(o[14]), "=v"(o[15]), "=v"(o[16]), "=v"(o[17]), "=v"(o[18]),  \
+      "=v"(o[19])
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    float o[NDT][16];
 #pragma unroll
-    for (int d = 0; d < NDT; ++d) {
-#define OSK_OOUT                                                                                             \
-  "=v"(o[d][0]), "=v"(o[d][1]), "=v"(o[d][2]), "=v"(o[d][3]), "=v"(o[d][4]), "=v"(o[d][5]), "=v"(o[d][6]),          \
-      "=v"(o[d][7]), "=v"(o[d][8]), "=v"(o[d][9]), "=v"(o[d][10]), "=v"(o[d][11]), "=v"(o[d][12]), "=v"(o[d][13]), \
-      "=v"(o[d][14]), "=v"(o[d][15])
-      if (u == 0 && d == 0) {
-        asm volatile(OSK72N2_OR0 : OSK_OOUT);
-      } else if (u == 0 && d == 1) {
-        asm volatile(OSK72N2_OR1 : OSK_OOUT);
-      } else if (u == 0 && d == 2) {
-        asm volatile(OSK72N2_OR2 : OSK_OOUT);
-      } else if (u == 1 && d == 0) {
-        asm volatile(OSK72N2_OR3 : OSK_OOUT);
-      } else if (u == 1 && d == 1) {
-        asm volatile(OSK72N2_OR4 : OSK_OOUT);
+    for (int half = 0; half < 2; ++half) {
+      float o[20];
+      if (u == 0 && half == 0) {
+        asm volatile(OSK72N2_OR0 : OSK_OOUT20);
+      } else if (u == 0) {
+        asm volatile(OSK72N2_OR1 : OSK_OOUT20);
+      } else if (half == 0) {
+        asm volatile(OSK72N2_OR2 : OSK_OOUT20);
       } else {
-        asm volatile(OSK72N2_OR5 : OSK_OOUT);
+        asm volatile(OSK72N2_OR3 : OSK_OOUT20);
       }
-    }
-    // row 72 of O^T = sum_k P: lanes hi == 0, register (8 & 3) + 4 (8 >> 3) = 4 of row tile 2
-    const unsigned lu = __float_as_uint(o[2][4]);
-    auto sw2 = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
-    const float l_tot = __uint_as_float(sw2[0]);
-    const float inv = 1.0f / l_tot;
-    if (tail) {
-      // part of a split tail unit: normalised partial O (f32) + log2-domain LSE -> workspace (attn_merge_kernel)
-      if (qi[u] < p.Lq) {
-        const int64_t slot = ((int64_t)tail_unit * p.tail_split + part) * 256 + (wave * (32 * NU) + u * 32 + l31);
+      const float l_tot = __shfl(o[16], 32 + l15, 64);
+      const float inv = 1.0f / l_tot;
+      // the reference max lives in the SCORE layout (lane = query lane % 32 of block u): fetch this lane's query's
+      const float mq = __shfl(m_ref[u], half * 16 + l15, 64);
+      const int wrow = wave * (32 * NU) + u * 32 + half * 16 + l15;   // row inside the workgroup's 256
+      const int qrow = qb * 256 + wrow;
+      if (qrow >= p.Lq) continue;
+      if (tail) {
+        // part of a split tail unit: normalised partial O (f32) + log2-domain LSE -> workspace (attn_merge_kernel)
+        const int64_t slot = ((int64_t)tail_unit * p.tail_split + part) * 256 + wrow;
         float* wo = p.ws_o + slot * HD;
 #pragma unroll
-        for (int d = 0; d < NDT; ++d) {
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const int d0 = d * 32 + qd * 8 + hi * 4;
-          if (d0 < HD) {
-              *reinterpret_cast<float4*>(wo + d0) = make_float4(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv,
-                                                                 o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
-            }
-          }
+        for (int db = 0; db < 5; ++db) {
+          const int d0 = db * 16 + r4 * 4;
+          if (d0 < HD)
+            *reinterpret_cast<float4*>(wo + d0) = make_float4(o[db * 4 + 0] * inv, o[db * 4 + 1] * inv, o[db * 4 + 2] * inv, o[db * 4 + 3] * inv);
         }
-        if (hi == 0) p.ws_lse[slot] = m_ref[u] + __builtin_amdgcn_logf(l_tot);
-      }
-    } else if (qi[u] < p.Lq) {
-      unsigned short* orow = p.out + b * p.obs + (int64_t)qi[u] * p.ors + h * HD;
+        if (r4 == 0) p.ws_lse[slot] = mq + __builtin_amdgcn_logf(l_tot);
+      } else {
+        unsigned short* orow = p.out + b * p.obs + (int64_t)qrow * p.ors + h * HD;
 #pragma unroll
-      for (int d = 0; d < NDT; ++d) {
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int d0 = d * 32 + qd * 8 + hi * 4;
+        for (int db = 0; db < 5; ++db) {
+          const int d0 = db * 16 + r4 * 4;
           if (d0 < HD) {
             uint2 w2;
-            w2.x = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
-            w2.y = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+            w2.x = pack_bf16x2(o[db * 4 + 0] * inv, o[db * 4 + 1] * inv);
+            w2.y = pack_bf16x2(o[db * 4 + 2] * inv, o[db * 4 + 3] * inv);
             *reinterpret_cast<uint2*>(orow + d0) = w2;
           }
         }
+        if (p.lse && r4 == 0)
+          p.lse[(int64_t)bh * p.Lq + qrow] = (mq + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
       }
-      if (p.lse && hi == 0)
-        p.lse[(int64_t)bh * p.Lq + qi[u]] = (m_ref[u] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     }
   }
 }

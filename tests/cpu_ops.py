@@ -15,6 +15,18 @@ from oracle import mmdit_oracle as O
 BF = torch.bfloat16
 PROFILE_ATTENTION = None
 _PERM = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+_PV16_KEYS = torch.tensor([[0, 1, 2, 3, 8, 9, 10, 11], [16, 17, 18, 19, 24, 25, 26, 27], [4, 5, 6, 7, 12, 13, 14, 15], [20, 21, 22, 23, 28, 29, 30, 31]])
+
+
+def pos2key(hd: int, Lp: int) -> torch.Tensor:
+    """key stored at position p of a V^T row (include/osk.h, osk_v_transpose_bf16): the order the attention kernel of that head_dim
+    holds its P operand in.  head_dim 72 (16x16x32 P.V): 16-byte chunk c of a 64-key tile = the 8 keys of lane row c % 4 in the
+    32-key half c / 4; head_dim 64 / 128 (32x32x16): a 4-key swap inside every 16 keys."""
+    p = torch.arange(Lp)
+    if hd == 72:
+        c, e = (p % 64) // 8, p % 8
+        return (p // 64) * 64 + 32 * (c // 4) + _PV16_KEYS[c % 4, e]
+    return (p // 16 * 16) + _PERM[p % 16]
 
 
 def _abi_check(what: str, *conds) -> None:
@@ -156,8 +168,7 @@ def v_transpose(v, vt, H, hd):
     Lp = vt.shape[-1]
     pad = torch.zeros(B, Lp, H, hd, dtype=v.dtype)
     pad[:, :L] = v.reshape(B, L, H, hd)
-    pos2key = (torch.arange(Lp) // 16 * 16) + _PERM[torch.arange(Lp) % 16]
-    vt.copy_(pad[:, pos2key].permute(0, 2, 3, 1))
+    vt.copy_(pad[:, pos2key(hd, Lp)].permute(0, 2, 3, 1))
 
 
 def vt8_rows(hd):
@@ -243,7 +254,7 @@ def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=Non
     # rebuild the key-major K and V from the segment layout
     ks, vs = [], []
     key2pos = torch.empty(seg_lp, dtype=torch.long)
-    key2pos[(torch.arange(seg_lp) // 16 * 16) + _PERM[torch.arange(seg_lp) % 16]] = torch.arange(seg_lp)
+    key2pos[pos2key(hd, seg_lp)] = torch.arange(seg_lp)
     for s in range(n_seg):
         if n_seg == 1:
             k_s, vt_s = k, vt

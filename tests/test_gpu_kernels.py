@@ -268,11 +268,11 @@ def test_v_transpose_exact(hip_lib, hd):
     Lp = (L + 63) // 64 * 64
     vt = torch.full((B, H, hd, Lp), 7.0, dtype=BF, device=DEV)
     hip_lib.v_transpose(v, vt, H, hd)
-    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
-    pos2key = (torch.arange(Lp) // 16 * 16) + perm[torch.arange(Lp) % 16]
+    from tests.cpu_ops import pos2key   # the documented key order per head_dim (16x16x32 P.V for 72, 32x32x16 otherwise)
+
     vpad = torch.zeros(B, Lp, H, hd, dtype=BF)
     vpad[:, :L] = v.cpu().view(B, L, H, hd)
-    ref = vpad[:, pos2key].permute(0, 2, 3, 1)
+    ref = vpad[:, pos2key(hd, Lp)].permute(0, 2, 3, 1)
     assert torch.equal(vt.cpu(), ref)
 
 

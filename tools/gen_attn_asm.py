@@ -45,9 +45,17 @@ class Geometry:
     hd 128: 8 real k-steps + 1 pure padding step whose K fragment is a CONSTANT register quad {1.0, 0...} (no LDS
             read) and whose Q fragment carries M; 4 real O^T row tiles + a 5th that only holds the ones row 128."""
 
-    def __init__(self, hd, pv8=False):
+    def __init__(self, hd, pv8=False, pv16=False):
         self.HD = hd
         self.PV8 = pv8   # P.V on the fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4): P and V^T as OCP e4m3, see the header
+        # P.V on v_mfma_f32_16x16x32_bf16 (head_dim 72): O^T in 16-row blocks, so the padding of the 72 dims + ones row shrinks
+        # from 96 rows (3 x 32) to 80 (5 x 16): 40 x 16 cycles instead of 24 x 32 per 64-key tile and 64 query rows.  The scores
+        # still come out of 32 x 32 x 16 MFMAs (QK^T at 80 padded dims; 16x16x32 would pad it to 96): a lane's 16 P values of a
+        # 32-key half (one query, keys 8 j + 4 (lane / 32) + i) become two 16x16x32 B operands (queries 0..15 / 16..31 of the
+        # block, 8 keys per lane) by ONE v_permlane16_swap per packed register pair; V^T's key order inside a 32-key half is
+        # baked to match by osk_v_transpose_bf16 (chunk 4 t2 + r of a 64-key row = the keys of lane row r: PV16_KEYS).
+        self.PV16 = pv16
+        assert not (pv8 and pv16) and (not pv16 or hd == 72)
         if hd == 72:
             self.NKS, self.NDT, self.KIMG, self.HAS_COL = 5, 3, 1, True
             self.M_KS, self.M_HI = 4, 1          # M sits in k-step 4, lanes 32..63 (dims 72..79), word 0
@@ -71,6 +79,12 @@ class Geometry:
             self.VROW = 64
             self.VTILE = max(self.RP, self.NDT * 32 if self.HAS_COL else self.RP) * 64
             self.VSTEP = 64                      # bytes per 64-key tile along a V^T row
+        elif pv16:
+            self.NDB = 5                         # O^T row blocks of 16: dims 0..71, ones row 72, zero rows 73..79
+            self.NPV = 2 * self.NDB              # P.V fragment "pairs" (32-key half, row block): 2 NU MFMAs each
+            self.VROW = 128
+            self.VSTEP = 128
+            self.VTILE = self.NDB * 16 * 128
         else:
             self.NPV = 4 * self.NDT              # P.V fragment pairs (key group, row tile)
             self.VROW = 128
@@ -90,6 +104,9 @@ class Geometry:
         self.CONST_OFF = 2 * self.KTILE + 2 * self.VTILE
         self.SMEM = self.CONST_OFF + (self.KTILE + 16 if self.HAS_COL else 0)
 
+# key order of V^T inside a 32-key half for the 16x16x32 P.V product: the 16-byte chunk r (= lane row r of the A / B operands) holds
+PV16_KEYS = [[0, 1, 2, 3, 8, 9, 10, 11], [16, 17, 18, 19, 24, 25, 26, 27], [4, 5, 6, 7, 12, 13, 14, 15], [20, 21, 22, 23, 28, 29, 30, 31]]
+
 # ---- asm-owned SGPRs
 S_FIRST, S_LAST = 36, 67
 S_HI2 = 66                                 # lanes 32..63 (hd 128, where S_HIM selects lanes 0..31)
@@ -105,9 +122,11 @@ def operand_names(geo, nslot_k, nslot_v):
             ["fo0", "fo1", "fo2", "fo3"] + (["kc0", "kc1"] if geo.HAS_COL else []) + \
             ["koffL%d" % i for i in range(nslot_k)] + \
             (["vf0", "vf1"] if geo.PV8 else ["maskval", "onesaddr"]) + \
-            ["kbase", "vbase", "kstep", "kjump", "vjump", "tps", "nt", "kdst", "vdst"]
+            (["vo0", "vo1"] if geo.PV16 else []) + \
+            ["kbase", "vbase", "kstep", "kjump", "vjump"] + (["tpsnt"] if geo.PV16 else ["tps", "nt"]) + ["kdst", "vdst"]
     # the K loader's conditional last slot only exists when 4 | NKD does not hold; otherwise no slot count is needed
-    names += (["nkw"] if geo.NKD % 4 or geo.NKD % 8 else []) + ["nvw"]
+    # (PV16: the two V^T fragment addresses took two operand slots, so tps | nt << 16 and nvw | nkw << 16 travel packed)
+    names += ["nkvw"] if geo.PV16 else ((["nkw"] if geo.NKD % 4 or geo.NKD % 8 else []) + ["nvw"])
     assert len(names) <= 30, len(names)
     return names
 
@@ -120,13 +139,18 @@ def ar(base, n=1):
     return "a%d" % base if n == 1 else "a[%d:%d]" % (base, base + n - 1)
 
 
+FAST_WINDOWS_OVERRIDE = {}   # (hd, nu) -> [a0, a1, b0, b1, c0, c1]; set by --fast-windows (experiments) or below (production)
+
+
 class Layout:
     """register file and schedule geometry for NU query blocks per wave"""
 
-    def __init__(self, nu, hd=72, pv8=False):
+    def __init__(self, nu, hd=72, pv8=False, pv16=False):
         self.NU = nu
-        self.G = G = Geometry(hd, pv8)
+        self.G = G = Geometry(hd, pv8, pv16)
         self.PV8 = pv8
+        self.PV16 = pv16
+        self.MPP = 2 * nu if pv16 else nu      # MFMAs per P.V pair (pv16: query blocks of 16: two per 32-row block u)
         NKS, NDT = G.NKS, G.NDT
         self.NW = 8 // nu                      # waves per workgroup
         self.NSLOT = (G.NKD + self.NW - 1) // self.NW   # K LDS-DMA slots per wave and tile
@@ -151,11 +175,11 @@ class Layout:
         self.TX = [self.TMP0 + 12 + i for i in range(4)]
         self.V_END = self.TMP0 + 16
         self.A_O0 = 0
-        self.A_Q0 = 16 * NDT * nu
+        self.A_Q0 = (4 * G.NDB * 2 * nu) if pv16 else 16 * NDT * nu
         self.A_END = self.A_Q0 + 4 * NKS * nu
-        self.NTRAIL = self.NTP * nu            # MFMAs of the trailing P.V pairs
+        self.NTRAIL = self.NTP * self.MPP      # MFMAs of the trailing P.V pairs
         self.NQK = G.NPK * nu
-        self.NPVB = (G.NPV - self.NTP) * nu    # P.V MFMAs inside the body
+        self.NPVB = (G.NPV - self.NTP) * self.MPP    # P.V MFMAs inside the body
         self.I_QK0 = self.NTRAIL               # global shadow index of the first QK^T MFMA
         self.I_PV0 = self.I_QK0 + self.NQK
         last = self.I_PV0 + self.NPVB - 1
@@ -167,6 +191,13 @@ class Layout:
             # (64-cycle) P.V MFMAs
             self.WINDOWS = [self.I_QK0, self.I_PV0 - 3, self.I_QK0 + self.NQK // 2, self.I_PV0 - 2, self.I_PV0 + 1, last]
             self.C_T2_RELEASE = self.I_PV0 + 2
+        elif pv16:
+            # shadows: 8 trailing P.V (16 cycles) | 20 QK^T (32 cycles) from I_QK0 = 8 | 32 P.V from I_PV0 = 28; class A = exp2 +
+            # pack + lane-row swaps of keys 0..31 (before the first P.V MFMA, shadow 28), B = keys 32..63 (before pair 5,
+            # shadow 48), C = max of tile t+1 (after its QK^T MFMAs)
+            assert nu == 2
+            self.WINDOWS = [1, 26, 20, 46, 29, last]
+            self.C_T2_RELEASE = 31
         elif hd == 72:
             self.WINDOWS = [4, 25, 24, 40, 26, 43] if nu == 2 else [2, 13, 12, 19, 14, 21]
             self.C_T2_RELEASE = 28 if nu == 2 else 15   # chains over keys 32..63: their last QK^T MFMAs come last
@@ -174,6 +205,9 @@ class Layout:
             self.WINDOWS = [self.I_QK0, self.I_PV0 + 1, self.I_PV0, self.I_PV0 + 3 * NDT * nu - 2, self.I_PV0 + 2, last]
             self.C_T2_RELEASE = self.I_PV0 + 2 * nu
         self.S_ONESMASK = S_HIM if G.M_HI else S_HI2   # lanes 32..63
+        # FAST bodies carry no class C: exp2 + pack paced evenly over the whole iteration (deadlines: group g before the P.V
+        # pairs of group g, which start at shadow I_PV0 + g NDT NU)
+        self.FAST_WINDOWS = FAST_WINDOWS_OVERRIDE.get((hd, nu)) or self.WINDOWS
 
     def S(self, setbase, u, t2, r=0):
         return setbase + (u * 2 + t2) * 16 + r
@@ -184,6 +218,11 @@ class Layout:
 
     def AO(self, u, d):
         return self.A_O0 + (u * self.G.NDT + d) * 16
+
+    def AO16(self, u, qb, db):
+        """pv16: the 4 accumulator registers of O^T rows 16 db .. + 15 x queries 16 qb .. + 15 of block u (lane: query l % 16,
+        rows 4 (l / 16) + i)"""
+        return self.A_O0 + ((u * 2 + qb) * self.G.NDB + db) * 4
 
     def AQ(self, u, ks):
         return self.A_Q0 + (u * self.G.NKS + ks) * 4
@@ -247,6 +286,10 @@ def v_read(st, L, slot, r, tag):
         st.ds_read(base, L.OP["vf0"], L.G.VOFF[slot] + r * 2048, ("vx", tag[1]))
         st.ds_read(base + 4, L.OP["vf1"], L.G.VOFF[slot] + r * 2048, tag)
         return
+    if L.PV16:   # pair r = (32-key half t2, row block db): lane (row l / 16, dim l % 16) reads chunk 4 t2 + l / 16 of its row
+        t2, db = r // L.G.NDB, r % L.G.NDB
+        st.ds_read(L.VR0 + (r % 4) * 4, L.OP["vo%d" % t2], L.G.VOFF[slot] + db * 2048, tag)
+        return
     g, d = r // L.G.NDT, r % L.G.NDT
     st.ds_read(L.VR0 + (r % 4) * 4, L.OP["fo%d" % g], L.G.VOFF[slot] + d * 4096, tag)
 
@@ -260,6 +303,13 @@ def qk_mfma(st, L, sn, a):
 
 
 def pv_mfma(st, L, b):
+    if L.PV16:   # O^T[16 dims x 16 queries] += V^T[16 x 32 keys] . P^T[32 keys x 16 queries]
+        r, sub = b // L.MPP, b % L.MPP
+        u, qb = sub // 2, sub % 2
+        t2, db = r // L.G.NDB, r % L.G.NDB
+        dst = ar(L.AO16(u, qb, db), 4)
+        st.emit("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (dst, vr(L.VR0 + (r % 4) * 4, 4), vr(L.PB(u, 2 * t2 + qb), 4), dst), "X")
+        return
     r, u = b // L.NU, b % L.NU
     if L.PV8:   # one K = 64 fp8 MFMA per O^T row tile: all 64 keys of the tile at once
         dst = ar(L.AO(u, r), 16)
@@ -291,6 +341,18 @@ def exp_group(L, sc, u, g):
     for w in range(4):
         ops.append(("v", "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(L.PB(u, g, w)), vr(L.S(sc, u, t2, r0 + 2 * w)),
                                                            vr(L.S(sc, u, t2, r0 + 2 * w + 1)))))
+    return ops
+
+
+def swap_group(L, u, t2):
+    """pv16: the 8 packed P registers of one 32-key half (lane = one query of the 32-row block, 16 keys) -> two 16x16x32 B operands
+    (queries 0..15 in PB(u, 2 t2), queries 16..31 in PB(u, 2 t2 + 1); lane row r holds the keys PV16_KEYS[r]): v_permlane16_swap
+    exchanges the odd lane rows of the first register with the even rows of the second.  s_nop: VALU write -> permlane read,
+    permlane write -> MFMA operand read."""
+    ops = [("n", "s_nop 1")]
+    for i in range(4):
+        ops.append(("v", "v_permlane16_swap_b32 %s, %s" % (vr(L.PB(u, 2 * t2, i)), vr(L.PB(u, 2 * t2 + 1, i)))))
+    ops.append(("n", "s_nop 1"))
     return ops
 
 
@@ -486,7 +548,26 @@ def fixup(st, L, sx, init):
             for r in range(16):
                 x = vr(L.S(sx, u, t2, r))
                 st.emit("v_add_f32 %s, %s, %s" % (x, x, vr(de)))
-        if not init:
+        if not init and L.PV16:
+            # O^T of block u lives in 16-query blocks (lane = query l % 16 of block qb, every lane row): bring alpha of query
+            # 16 qb + (l % 16) into all four lane rows -- swap(X, Y) with X = Y = alpha leaves X = alpha of queries 0..15, Y = 16..31
+            ax, ay = L.TX[0], L.TX[1]   # (d, n: dead by now)
+            st.emit("v_mov_b32 %s, %s" % (vr(ax), vr(al)))
+            st.emit("v_mov_b32 %s, %s" % (vr(ay), vr(al)))
+            st.emit("s_nop 1", "n")
+            st.emit("v_permlane16_swap_b32 %s, %s" % (vr(ax), vr(ay)))
+            st.emit("s_nop 1", "n")
+            for qb in range(2):
+                for db in range(L.G.NDB):
+                    for r in range(4):
+                        st.emit("v_accvgpr_read_b32 %s, %s" % (vr(T + r), ar(L.AO16(u, qb, db) + r)))
+                    st.emit("s_nop 0", "n")
+                    for r in range(4):
+                        st.emit("v_mul_f32 %s, %s, %s" % (vr(T + r), vr(T + r), vr(ax if qb == 0 else ay)))
+                    st.emit("s_nop 0", "n")
+                    for r in range(4):
+                        st.emit("v_accvgpr_write_b32 %s, %s" % (ar(L.AO16(u, qb, db) + r), vr(T + r)))
+        elif not init:
             for dd in range(L.G.NDT):
                 for r0 in range(0, 16, 4):
                     for r in range(r0, r0 + 4):
@@ -503,6 +584,28 @@ def fixup(st, L, sx, init):
 # ------------------------------------------------------------------------------------------ body
 DMAGAP = 1     # LDS-DMA items: one per DMAGAP MFMA shadows (set by --exp dmagapN for the experimental variant)
 DMACOST = 12   # issue cycles a shadow's filler budget is charged for an LDS-DMA item
+
+
+def _check_p_ready(st, L, k):
+    """every P.V MFMA of this body's own tile must come AFTER the v_cvt_pk instructions that write its P operand registers
+    (the filler windows are hand-set: this is what keeps an edited window honest).  The trailing MFMAs at the top of the body
+    consume the PREVIOUS tile's last fragments and are exempt."""
+    import re as _re
+    start = max(i for i, (kind, text) in enumerate(st.table) if kind == "L" and text.endswith("_entry%d" % k))
+    written, swapped = set(), set()
+    for kind, text in st.table[start:]:
+        if text.startswith("v_cvt_pk"):
+            written.add(int(_re.match(r"v_cvt_pk_\w+ v(\d+),", text).group(1)))
+        elif text.startswith("v_permlane16_swap"):
+            a_, b_ = (int(x) for x in _re.match(r"v_permlane16_swap_b32 v(\d+), v(\d+)", text).groups())
+            assert {a_, b_} <= written, "lane-row swap before its registers are packed: " + text
+            swapped |= {a_, b_}
+        elif text.startswith("v_mfma") and kind in ("M", "F") and ", a[" in text.split(",", 1)[0] + ",":   # accumulating into O^T (AGPRs)
+            m = _re.match(r"v_mfma_\w+ a\[\d+:\d+\], v\[\d+:\d+\], v\[(\d+):(\d+)\]", text)
+            if m:
+                need = set(range(int(m.group(1)), int(m.group(2)) + 1))
+                assert need <= written, "P.V MFMA reads P registers %s before their v_cvt_pk: %s" % (sorted(need - written), text)
+                assert not L.PV16 or need <= swapped, "P.V MFMA reads P registers before their lane-row swap: " + text
 
 
 def body(st, L, k, safe):
@@ -528,7 +631,7 @@ def body(st, L, k, safe):
         pn = n // DMAGAP if n % DMAGAP == 0 else len(pieces)
         if pn < len(pieces):
             piece(pieces[pn], 1)
-        pv_mfma(st, L, (L.G.NPV - L.NTP) * NU + n)
+        pv_mfma(st, L, (L.G.NPV - L.NTP) * L.MPP + n)
         if pn < len(pieces):
             piece(pieces[pn], 2)
     # -- decision: did some score of tile t exceed the reference by more than 2^THR (VCC from the previous body)?
@@ -554,7 +657,13 @@ def body(st, L, k, safe):
     clsA, clsB, clsC = [], [], []
     for g in range(4):
         for u in range(NU):
-            (clsA if g < 3 else clsB).extend(exp_group(L, sc, u, g))
+            if L.PV16:   # a 32-key half (two key groups) feeds the first P.V pairs: class A = keys 0..31, B = keys 32..63
+                (clsA if g < 2 else clsB).extend(exp_group(L, sc, u, g))
+            else:
+                (clsA if g < 3 else clsB).extend(exp_group(L, sc, u, g))
+        if L.PV16 and g % 2 == 1:
+            for u in range(NU):
+                (clsA if g < 2 else clsB).extend(swap_group(L, u, g // 2))
     ca = [max_chain(L, sn, u, 0, chain_tmp(L, u, 0)) for u in range(NU)]
     cb = [max_chain(L, sn, u, 1, chain_tmp(L, u, 1)) for u in range(NU)]
     clsC.extend([o for grp in zip(*ca) for o in grp])
@@ -563,13 +672,14 @@ def body(st, L, k, safe):
     clsC.extend(lanemax_final(L))
     if FAST:   # no reference max to maintain
         clsC, n_first_b = [], 0
-    W = L.WINDOWS
+    W = L.FAST_WINDOWS if FAST else L.WINDOWS
     classes = [[clsA, W[0], W[1], 0, 0.0], [clsB, W[2], W[3], 0, 0.0], [clsC, W[4], W[5], 0, 0.0]]
     totals = [sum(cost(o[0]) for o in c[0]) for c in classes]
     mf = [("qk", a) for a in range(L.NQK)] + [("pv", b) for b in range(L.NPVB)]
     for n, (kind, idx) in enumerate(mf):
         i = L.I_QK0 + n
-        pair, u = idx // NU, idx % NU
+        per = L.MPP if kind == "pv" else NU
+        pair, u = idx // per, idx % per
         if kind == "pv" and L.PV8:
             if u == 0:
                 st.need(("v", pair))
@@ -583,7 +693,7 @@ def body(st, L, k, safe):
             st.emit("s_nop 7", "n")
         used = 0.0
         # ring reads: after the last MFMA of pair x its ring slot is free -> read pair x + 4
-        if u == NU - 1:
+        if u == per - 1:
             if kind == "qk":
                 NR = L.G.NPK_READ
                 if pair + 4 < NR:
@@ -610,7 +720,7 @@ def body(st, L, k, safe):
                     break
                 if totals[ci] * frac - c[4] <= 0 and i < last:
                     break
-                if used >= (60 if kind == "pv" and L.PV8 else 30) and i < last:
+                if used >= (60 if kind == "pv" and L.PV8 else (13 if kind == "pv" and L.PV16 else 30)) and i < last:
                     break
                 st.emit(text, kind_)
                 used += cost(kind_)
@@ -619,6 +729,7 @@ def body(st, L, k, safe):
     for c in classes:
         assert c[3] == len(c[0]), "unscheduled filler work"
     assert not later
+    _check_p_ready(st, L, k)
     # -- end of body: DMA landed + every fragment read retired, then the tile barrier
     st.emit("s_waitcnt vmcnt(0) lgkmcnt(0)", "w")
     st.pending = []
@@ -655,6 +766,11 @@ def _generate(L, safe, ablate):
     for sreg, name in ((S_TPS, "tps"), (S_NT, "nt"), (S_KDST, "kdst"), (S_VDST, "vdst"), (S_NKW, "nkw"), (S_NVW, "nvw")):
         if name in L.OP:
             e("s_mov_b32 s%d, %s" % (sreg, L.OP[name]))
+    if L.PV16:   # tps | nt << 16 and nvw | nkw << 16 arrive packed (operand slots)
+        e("s_and_b32 s%d, %s, 0xffff" % (S_TPS, L.OP["tpsnt"]))
+        e("s_lshr_b32 s%d, %s, 16" % (S_NT, L.OP["tpsnt"]))
+        e("s_lshr_b32 s%d, %s, 16" % (S_NKW, L.OP["nkvw"]))
+        e("s_and_b32 s%d, %s, 0xffff" % (S_NVW, L.OP["nkvw"]))
     for sreg in (S_T, S_KTT, S_VTT, S_KL, S_VL):
         e("s_mov_b32 s%d, 0" % sreg)
     if L.G.M_HI:       # S_HIM = the half-wave whose lanes hold Q's M-carrying padding dim
@@ -723,7 +839,7 @@ def _generate(L, safe, ablate):
     # ---- exit: the trailing P.V MFMAs of the last tile
     st.label(".L@@_exit")
     for n in range(L.NTRAIL):
-        pv_mfma(st, L, (L.G.NPV - L.NTP) * L.NU + n)
+        pv_mfma(st, L, (L.G.NPV - L.NTP) * L.MPP + n)
     e("s_nop 15")
     e("s_nop 15")
     e("v_mov_b32 %s, %s" % (L.OP["m0out"], vr(L.MM[0])))
@@ -741,23 +857,33 @@ def main():
                     "dmagapN[cC] = LDS-DMA items every N shadows | timing ablations joined by + (noexp nobar nodma nolds novalu "
                     "nomfma norare nocvt nomax pv80: WRONG RESULTS)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
+    ap.add_argument("--no-pv16", action="store_true", help="experiment: head_dim 72 with the P.V product on 32x32x16 MFMAs (96 padded rows) as in "
+                    "rounds 1-2; changes the V^T key order the kernel expects, so only for timing runs with matching wrappers")
+    ap.add_argument("--fast-windows", default="", help="experiment: hd:a0,a1,b0,b1 filler windows of the FAST body (layout NU = 2), e.g. 72:1,33,30,42")
+    ap.add_argument("--fast-exp", default="", help="experiment: like --exp, applied to the FAST bodies only")
     args = ap.parse_args()
+    if args.fast_windows:
+        for spec_ in args.fast_windows.split(";"):
+            hd_, w_ = spec_.split(":")
+            w_ = [int(x) for x in w_.split(",")]
+            FAST_WINDOWS_OVERRIDE[(int(hd_), 2)] = w_ + [w_[3], w_[3]]
     # shipped: the 4 waves x 64 rows layout (NU = 2) of both head dims, bf16 and fp8 P.V.  The 8 waves x 32 rows layout
     # (NU = 1, head_dim 72) tied it in rounds 1-2 and stays a generator option (--table 1) without a shipped body.
     layouts = [(72, 2, False), (128, 2, False), (72, 2, True), (128, 2, True)]
+    mk = lambda nu, hd, pv8: Layout(nu, hd, pv8, pv16=(hd == 72 and not pv8 and not args.no_pv16))
     tagof = lambda hd, pv8: "%d%s" % (hd, "p8" if pv8 else "")
     global DMAGAP, DMACOST
     safe = args.exp == "safe"
     gap = args.exp.startswith("dmagap")
     ablate = frozenset() if (safe or gap or not args.exp) else frozenset(args.exp.split("+"))
-    if args.exp and os.path.realpath(args.out) == os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc")):
+    if (args.exp or args.fast_windows or args.fast_exp or args.no_pv16) and os.path.realpath(args.out) == os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc")):
         raise SystemExit("--exp bodies are experiments: give --out a scratch directory, not the shipped csrc")
     if args.table:
-        L = Layout(args.table, args.hd, args.pv8)
+        L = mk(args.table, args.hd, args.pv8) if args.table == 2 else Layout(args.table, args.hd, args.pv8)
         st = generate(L, False, frozenset())
         row = []
         for kind, text in st.table:
-            if kind in ("M", "F"):
+            if kind in ("M", "F", "X"):
                 print("".join(row)); row = [kind + " "]
             elif kind == "L":
                 print("".join(row)); row = []; print(text + ":")
@@ -766,7 +892,7 @@ def main():
         print("".join(row))
         return
     for hd, nu, pv8 in layouts:
-        L = Layout(nu, hd, pv8)
+        L = mk(nu, hd, pv8)
         DMAGAP, DMACOST = 1, 12
         if gap:
             spec = args.exp[len("dmagap"):].split("c")
@@ -781,7 +907,9 @@ def main():
             for ln in st.lines:
                 f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%dv0" % (tagof(hd, pv8), nu)))
         if not pv8:   # the bounded / single-segment / whole-tile body of the same layout
-            if gap:
+            fexp = args.fast_exp or args.exp
+            if fexp.startswith("dmagap"):
+                spec = fexp[len("dmagap"):].split("c")
                 DMAGAP, DMACOST = int(spec[0]), int(spec[1]) if len(spec) > 1 else 12
             stf = generate(L, safe, ablate, fast=True)
             DMAGAP, DMACOST = 1, 12
@@ -794,7 +922,7 @@ def main():
     with open(os.path.join(args.out, "attention_asm_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.\n")
         for hd, pv8 in sorted({(h, p8) for h, _, p8 in layouts}):
-            G = Geometry(hd, pv8)
+            G = mk(2, hd, pv8).G
             P = "OSK%s_" % tagof(hd, pv8).upper()
             f.write("#define %sSMEM %d\n#define %sCONST_OFF %d\n" % (P, G.SMEM, P, G.CONST_OFF))
             f.write("#define %sKTILE %d\n#define %sVTILE %d\n#define %sVOFF0 %d\n#define %sKOFF0 %d\n" % (P, G.KTILE, P, G.VTILE, P, G.VOFF[0], P, G.KOFF[0]))
@@ -802,9 +930,11 @@ def main():
             if pv8:
                 f.write("#define %sRP %d\n#define %sNVD %d\n" % (P, G.RP, P, G.NVD))
         for hd, nu, pv8 in layouts:
-            L = Layout(nu, hd, pv8)
+            L = mk(nu, hd, pv8)
             G = L.G
             P = "OSK%sN%d_" % (tagof(hd, pv8).upper(), nu)
+            if L.PV16:
+                f.write("#define %sPV16 1\n#define OSK%s_NDB %d\n" % (P, tagof(hd, pv8).upper(), G.NDB))
             clob = ['"v%d"' % i for i in range(L.V_FIRST, L.V_END)] + ['"a%d"' % i for i in range(0, L.A_END)] + \
                    ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
             f.write("#define %sCLOBBERS %s\n" % (P, ", ".join(clob)))
@@ -817,6 +947,12 @@ def main():
                 for part, w0 in enumerate(range(0, words, 20)):
                     n = min(20, words - w0)
                     f.write("#define %sQW%d_%d %s\n" % (P, u, part, " ".join('"v_accvgpr_write_b32 a%d, %%%d\\n"' % (L.AQ(u, 0) + w0 + i, i) for i in range(n))))
+            if L.PV16:   # O^T of (u, 16-query block qb): 4 NDB registers (row block db, register i) -> operands %0..%19
+                for u in range(nu):
+                    for qb in range(2):
+                        f.write("#define %sOR%d %s\n" % (P, u * 2 + qb, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (db * 4 + i, L.AO16(u, qb, db) + i)
+                                                                                  for db in range(G.NDB) for i in range(4))))
+                continue
             for u in range(nu):   # O^T row tile (u, d) -> operands %0..%15
                 for d in range(G.NDT):
                     f.write("#define %sOR%d %s\n" % (P, u * G.NDT + d, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, L.AO(u, d) + i) for i in range(16))))

@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 
+from tools import _altlib
+
+_altlib.install()   # OSK_ALT_LIB: an experiment library instead of the shipped one
 from open_sora_amd import _C
 
 DEV = "cuda"
