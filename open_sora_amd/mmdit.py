@@ -81,6 +81,20 @@ class MMDiTConfig:
         return hasattr(self, attribute_name)
 
 
+class _OskState:
+    """mix-in: the kernel-side caches hung on a module (`_osk_plan`: derived weight images and raw device pointers,
+    `_osk_ws_cache`: activation workspaces) are rebuilt on demand and must not travel with copy.deepcopy / pickle / torch.save
+    (they would duplicate or serialise large device buffers: ADVICE r2)."""
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        for k in [k for k in d if k.startswith("_osk_")]:
+            del d[k]
+        if "_plan" in d:
+            d["_plan"] = None
+        return d
+
+
 class _Holder(nn.Module):
     """A module that owns parameters but whose arithmetic lives in the HIP engine."""
 
@@ -144,7 +158,7 @@ class _NoParamNorm(_Holder):
         self.eps = eps
 
 
-class DoubleStreamBlock(nn.Module):
+class DoubleStreamBlock(_OskState, nn.Module):
     def __init__(self, hidden_size: int, num_heads: int, mlp_ratio: float, qkv_bias: bool = False,
                  fused_qkv: bool = True):
         super().__init__()
@@ -174,7 +188,7 @@ class DoubleStreamBlock(nn.Module):
         return self.processor(self, img, txt, vec, pe)
 
 
-class SingleStreamBlock(nn.Module):
+class SingleStreamBlock(_OskState, nn.Module):
     def __init__(self, hidden_size: int, num_heads: int, mlp_ratio: float = 4.0, qk_scale: float | None = None,
                  fused_qkv: bool = True):
         super().__init__()
@@ -625,6 +639,15 @@ def _run_modulation(vec32: Tensor, layers, D: int) -> Tensor:
     return mod, cols
 
 
+class _ProcessorPool:
+    """owner of the activation workspaces of STAND-ALONE processor calls: one per (geometry, device, stream) shared by every
+    block driven that way (57 blocks called one by one used to hold 57 workspaces: ADVICE r2).  Calls on one stream are ordered,
+    so blocks sharing a stream can share buffers; another stream gets its own (the key carries the stream)."""
+
+
+_PROC_POOL = _ProcessorPool()
+
+
 class HipDoubleStreamBlockProcessor:
     """Drop-in for DoubleStreamBlockProcessor (layers.py:195-253): `(block, img, txt, vec, pe) -> (img, txt)`."""
 
@@ -635,7 +658,7 @@ class HipDoubleStreamBlockProcessor:
         B, Li, _ = img.shape
         Lt = txt.shape[1]
         R = plan.img_mlp[0].shape[0]
-        ws = _workspace(attn, B, Lt, Li, D, R, H, hd, img.device)
+        ws = _workspace(_PROC_POOL, B, Lt, Li, D, R, H, hd, img.device)
         cos, sin, mode = _pe_to_cos_sin(pe, hd)
         mod, cols = _run_modulation(vec.float().contiguous(), plan.mod_layers, D)
         ws.x[:, Lt:].copy_(img)
@@ -653,7 +676,7 @@ class HipSingleStreamBlockProcessor:
         plan = plan_single(attn)
         B, L, _ = x.shape
         R = plan.w1.shape[0] - 3 * D
-        ws = _workspace(attn, B, 0, L, D, R, H, hd, x.device)
+        ws = _workspace(_PROC_POOL, B, 0, L, D, R, H, hd, x.device)
         cos, sin, mode = _pe_to_cos_sin(pe, hd)
         mod, cols = _run_modulation(vec.float().contiguous(), plan.mod_layers, D)
         ws.x.copy_(x)
@@ -664,7 +687,7 @@ class HipSingleStreamBlockProcessor:
 # =============================================================================================
 # the model
 # =============================================================================================
-class MMDiTModel(nn.Module):
+class MMDiTModel(_OskState, nn.Module):
     """Reference MMDiTModel (model.py:69-233) with the arithmetic in gfx950 kernels."""
 
     config_class = MMDiTConfig

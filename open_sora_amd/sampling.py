@@ -130,6 +130,24 @@ class I2VDenoiser:
         img3 = torch.empty(n3, *x.shape[1:], device=dev, dtype=dt)
         t_vec = torch.empty(n3, dtype=dt, device=dev)
         graph, pred = None, None
+        if hip_graph:
+            # capture needs a non-default stream, and the model's workspaces are keyed on the stream: run the WHOLE loop (the
+            # eager step 0 as well) on one side stream, so capture re-uses step 0's workspaces instead of allocating a second
+            # set from the graph's private pool that would stay pinned for the model's lifetime
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                out = self._loop(model, kwargs, x, x_next, img3, t_vec, cond3, guidance_vec, timesteps, guidance, guidance_img,
+                                 text_osci, image_osci, scale_temporal_osci, patch_size, b, c, t, h_, w_, dev, True, side)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            return out.to(dt)
+        return self._loop(model, kwargs, x, x_next, img3, t_vec, cond3, guidance_vec, timesteps, guidance, guidance_img, text_osci,
+                          image_osci, scale_temporal_osci, patch_size, b, c, t, h_, w_, dev, False, None).to(dt)
+
+    @staticmethod
+    def _loop(model, kwargs, x, x_next, img3, t_vec, cond3, guidance_vec, timesteps, guidance, guidance_img, text_osci, image_osci,
+              scale_temporal_osci, patch_size, b, c, t, h_, w_, dev, hip_graph, side):
+        graph, pred = None, None
         for i, (t_curr, t_prev) in enumerate(zip(timesteps[:-1], timesteps[1:])):
             t_vec.fill_(t_curr)
             img3.view(3, *x.shape).copy_(x.unsqueeze(0).expand(3, *x.shape))
@@ -140,7 +158,7 @@ class I2VDenoiser:
                 if hip_graph and i == 0 and len(timesteps) > 2:
                     # step 0 ran eagerly (it built the plans and workspaces); capture the same call for the rest
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
+                    with torch.cuda.graph(graph, stream=side):
                         pred_g = model(img=img3, **kwargs, cond=cond3, timesteps=t_vec, guidance=guidance_vec)
             text_gs = get_oscillation_gs(guidance, i) if text_osci else guidance
             image_gs = get_oscillation_gs(guidance_img, i) if image_osci else guidance_img
@@ -155,7 +173,7 @@ class I2VDenoiser:
             x, x_next = x_next, x
             if graph is not None:
                 pred = pred_g                     # from now on the forward's output is the captured tensor
-        return x.to(dt)
+        return x
 
     def prepare_guidance(self, text: list, optional_models: dict, device, dtype, **kwargs):
         ret = {"guidance_img": kwargs.pop("guidance_img")}

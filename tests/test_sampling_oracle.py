@@ -13,7 +13,7 @@ BF = torch.bfloat16
 
 @pytest.fixture(scope="module")
 def ref():
-    from tests.test_api import _ref_namespace
+    from tests.test_reference_api_dropin import _ref_namespace
 
     return _ref_namespace()
 
