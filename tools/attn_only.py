@@ -17,9 +17,13 @@ if pv8:
     sv = (v.float().abs().view(B, L, H, hd).amax(dim=(1, 3)) / 448.0).contiguous()
     vt8 = torch.empty(B, H, _C.vt8_rows(hd), (L + 63) // 64 * 64, dtype=torch.uint8, device="cuda")
     _C.v_transpose_fp8(v, sv, vt8, H, hd)
+# the model path hands the kernel a score bound (QK-norm scales): here the Cauchy-Schwarz bound of the data -> the FAST body runs
+qn = q.float().view(B, L, H, hd).norm(dim=-1).amax().item() * hd ** -0.5 * 1.4426950408889634
+kn = k.float().view(B, L, H, hd).norm(dim=-1).amax().item()
+bound = 0.0 if "nobound" in sys.argv else qn * kn
 for _ in range(3):
     if pv8:
         _C.attention_fwd_pv8(q, k, vt8, sv, out, H, hd, hd ** -0.5, workspace=_C.attention_workspace(out.device))
     else:
-        _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5, workspace=_C.attention_workspace(out.device))   # as the model calls it: tail split + merge
+        _C.attention_fwd(q, k, vt, out, H, hd, hd ** -0.5, workspace=_C.attention_workspace(out.device), score_bound=bound)   # as the model calls it
 torch.cuda.synchronize()

@@ -45,8 +45,13 @@ class Geometry:
     hd 128: 8 real k-steps + 1 pure padding step whose K fragment is a CONSTANT register quad {1.0, 0...} (no LDS
             read) and whose Q fragment carries M; 4 real O^T row tiles + a 5th that only holds the ones row 128."""
 
-    def __init__(self, hd, pv8=False, pv16=False):
+    def __init__(self, hd, pv8=False, pv16=False, nom=False):
         self.HD = hd
+        # nom (head_dim 128 FAST body): no padding k-step at all.  That step exists only to carry the reference max through the
+        # MFMA; with a score bound B <= 56 no reference is needed for range control -- P = exp2(s), |s| <= B, stays inside
+        # [2^-56, 2^56] and every sum inside f32 -- so QK^T is 8 k-steps instead of 9 (72 instead of 76 MFMAs per tile)
+        self.NOM = nom
+        assert not nom or (hd == 128 and not pv8)
         self.PV8 = pv8   # P.V on the fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4): P and V^T as OCP e4m3, see the header
         # P.V on v_mfma_f32_16x16x32_bf16 (head_dim 72): O^T in 16-row blocks, so the padding of the 72 dims + ones row shrinks
         # from 96 rows (3 x 32) to 80 (5 x 16): 40 x 16 cycles instead of 24 x 32 per 64-key tile and 64 query rows.  The scores
@@ -66,7 +71,7 @@ class Geometry:
             self.NKD = self.NVD = 16
         else:
             raise ValueError(hd)
-        self.NPK = 2 * self.NKS                  # QK^T fragment pairs (k-step, 32-key half)
+        self.NPK = 2 * (self.NKS - (1 if nom else 0))   # QK^T fragment pairs (k-step, 32-key half)
         self.NPK_READ = 2 * (self.NKS - (0 if self.HAS_COL else 1))   # ... that are read from LDS
         self.KTILE = self.KIMG * 8192 + (1024 if self.HAS_COL else 0)
         if pv8:
@@ -145,9 +150,9 @@ FAST_WINDOWS_OVERRIDE = {}   # (hd, nu) -> [a0, a1, b0, b1, c0, c1]; set by --fa
 class Layout:
     """register file and schedule geometry for NU query blocks per wave"""
 
-    def __init__(self, nu, hd=72, pv8=False, pv16=False):
+    def __init__(self, nu, hd=72, pv8=False, pv16=False, nom=False):
         self.NU = nu
-        self.G = G = Geometry(hd, pv8, pv16)
+        self.G = G = Geometry(hd, pv8, pv16, nom)
         self.PV8 = pv8
         self.PV16 = pv16
         self.MPP = 2 * nu if pv16 else nu      # MFMAs per P.V pair (pv16: query blocks of 16: two per 32-row block u)
@@ -743,6 +748,7 @@ def body(st, L, k, safe):
 
 
 def generate(L, safe=False, ablate=frozenset(), fast=False):
+    assert not L.G.NOM or fast, "the padding k-step may only be dropped in the bounded (FAST) body"
     """fast: the bounded / single-segment / whole-tile variant (see the header); not for the fp8 P.V kernels, whose e4m3 P
     needs the reference max within 2^8 of the true one"""
     global FAST
@@ -911,7 +917,8 @@ def main():
             if fexp.startswith("dmagap"):
                 spec = fexp[len("dmagap"):].split("c")
                 DMAGAP, DMACOST = int(spec[0]), int(spec[1]) if len(spec) > 1 else 12
-            stf = generate(L, safe, ablate, fast=True)
+            Lf = Layout(nu, hd, pv8, pv16=L.PV16, nom=(hd == 128))   # hd 128: the padding k-step is dropped too
+            stf = generate(Lf, safe, ablate, fast=True)
             DMAGAP, DMACOST = 1, 12
             with open(os.path.join(args.out, "attention_asm%s_n%d_f0.inc" % (tagof(hd, pv8), nu)), "w") as f:
                 f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d, layout NU=%d, FAST body (score bound, one "
