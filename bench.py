@@ -444,7 +444,7 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
         if args.fp8 and hd in (72, 128):
             kname = f"attn_asm{hd}p8_kernel"   # fp8 mode: the fp8 P.V variant
         # HBM bytes per launch: RECORDED, not measured in this run -- PMC passes (FETCH_SIZE doubled per the gfx950 correction,
-        # + WRITE_SIZE) of the same kernel at the same shape, collected by tools/gpu_attn_round.sh and committed under profiles/
+        # + WRITE_SIZE) of the same kernel at the same shape, collected by tools/gpu_final_r3.sh (its PMC passes over tools/attn_only.py) and committed under profiles/
         traffic, traffic_src = None, None
         rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "attn_traffic.json")
         if os.path.exists(rec_path):

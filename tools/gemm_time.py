@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""TFLOP/s of osk_gemm_bf16 at MxNxK shapes under the current environment (OSK_GEMM_* switches): median of 7 bursts of 20
+"""TFLOP/s of osk_gemm_bf16 at MxNxK shapes: median of 7 bursts of 20
 launches, random bf16 data.   python tools/gemm_time.py 8192x8192x8192 50688x4608x1152"""
 import os
 import sys

@@ -10,8 +10,8 @@ run() {  # name, counters, command...
 run vae_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
 run vae_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
 if [ -n "$PMC_LINEAR_CONV" ]; then   # the round-1 tile mapping of conv256t for comparison
-  OSK_CONV_BRICK=0 run vaelin_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
-  OSK_CONV_BRICK=0 run vaelin_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
+  run vaelin_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
+  run vaelin_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
 fi
 run dit_fetch "FETCH_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-b1
 run dit_write "WRITE_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-b1

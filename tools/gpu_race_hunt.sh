@@ -1,5 +1,6 @@
 #!/bin/bash
 # One gpurun call: the sequence-parallel repeatability hunt (tools/sp_race_hunt.py) over contention / instrumentation / poison arms.
+# (arms T1-T4 of the original hunt switched kernels through OSK_* environment variables; the library no longer reads any)
 #   ARMS="A B C" RUNS=40 bash tools/gpu_race_hunt.sh        -> gpurun_out/race/<arm>.json
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; O=gpurun_out/race; mkdir -p $O
 RUNS=${RUNS:-40}
@@ -19,10 +20,6 @@ for a in $ARMS; do case $a in
   K) run K_hd128 --name hd128_liger_split --geom 3,2,9,7,22 --instrument --hammer small ;;
   L) run L_fp8_plain --fp8 ;;
   T0) run T0_plain ;;
-  T1) run T1_notailsplit --env OSK_ATTN_TAILSPLIT=0 ;;
-  T2) run T2_attn_compiler --env OSK_ATTN_VARIANT=0 ;;
-  T3) run T3_gemm_small --env OSK_GEMM_VARIANT=0 ;;
-  T4) run T4_qknorm_lanes --env OSK_QKNORM_VARIANT=0 ;;
   T5) run T5_checkpoints --checkpoints ;;
   T6) run T6_instrument --instrument ;;
   T7) run T7_depth_1_0 --depth 1,0 --checkpoints ;;

@@ -41,7 +41,7 @@ def bench_gemm(M, N, K, tag):
     bias = torch.randn(N, device=DEV)
     out = torch.empty(1, M, N, dtype=BF, device=DEV)
     ms = timeit(lambda: _C.gemm(a, w, bias, out), iters=40, warm=10)
-    emit(kernel="gemm_bf16", variant=os.environ.get("OSK_GEMM_VARIANT", "0"), tag=tag, M=M, N=N, K=K, ms=round(ms, 4),
+    emit(kernel="gemm_bf16", tag=tag, M=M, N=N, K=K, ms=round(ms, 4),
          tflops=round(2.0 * M * N * K / ms / 1e9, 1))
 
 
