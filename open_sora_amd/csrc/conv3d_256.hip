@@ -13,6 +13,7 @@
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 2 * Cin * Cout * k^3 * B*To*Ho*Wo.
 #include "conv_params.h"
 #include "gemm256x_regs.inc"
+#include "convsw_regs.inc"
 #include <type_traits>
 
 namespace osk_conv {
@@ -330,6 +331,95 @@ __global__ void __launch_bounds__(256, 1) conv256x_kernel(const ConvParams p) {
   }   // tile loop
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sliding-window form (3 x 3 x 3, stride 1, no fused upsample, Ho % 16 == 0 and Wo % 16 == 0, Cin % 64 == 0): a tile is the
+// 16 x 16 spatial brick of one output frame; the 3-frame x 18 x 18 halo brick of one 32-channel block sits in LDS and the 27
+// taps differ only in the immediate offset of their fragment reads -- the activations of a tile cross the fabric once per
+// channel block instead of 27 times.  K loop, LDS plan and the lane formulas below: tools/gen_conv_sw_asm.py (its header is the
+// design note; tests/test_conv_sw_model.py executes the generated stream symbolically and lane by lane in numpy with THESE
+// formulas).  Accumulator layout and epilogue are conv256x_kernel's.
+template <int NBJ>
+__global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
+  constexpr int WT = OSKX_NB * 16, WTN = NBJ * 16, BN = 32 * NBJ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int nwb = p.Wo >> 4, nhb = p.Ho >> 4;
+  const int nbm = p.B * p.To * nhb * nwb, nbn = (p.Cout + BN - 1) / BN;
+  const int ntiles = nbm * nbn;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  // ---- fragment side (tile-independent): activation row l15 of a 16-voxel block = brick column l15; 16-byte chunk q4 of the
+  // voxel at position q4 ^ key(halo column), key(ww) = (ww >> 1) & 3, halo column = l15 + dw
+  unsigned xa[3];
+#pragma unroll
+  for (int dw = 0; dw < 3; ++dw) xa[dw] = lds_base + (unsigned)((144 * wm + l15) * 64 + ((q4 ^ (((l15 + dw) >> 1) & 3)) << 4));
+  const unsigned yb = lds_base + (unsigned)((wn * WTN + l15) * 64 + ((q4 ^ ((l15 >> 1) & 3)) << 4));
+  const unsigned dst = rfl(lds_base + wave * 1024), dst5 = rfl(lds_base + 20 * 1024);
+  const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = rfl((unsigned)p.Cin / 64);
+  const int sub = lane >> 2, pos = lane & 3;                     // an LDS-DMA piece = 16 rows of 64 bytes: lane -> (row, position)
+
+  for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
+  const int tile = xcd_remap(it, ntiles);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int n0 = bn * BN;
+  const int t = bm % p.To, sb = bm / p.To;                         // tile_row_to_voxel()'s brick order: frame fastest
+  const int wb = sb % nwb, qq = sb / nwb;
+  const int hb = qq % nhb, b = qq / nhb;
+  __syncthreads();                                                 // every wave has left the previous tile's K loop and epilogue
+
+  // ---- weight pieces: piece k of this wave = rows 16 (4 k + wave) .. + 15 of the BN-row stage
+  unsigned woff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int nl = 16 * (4 * (k & (NBJ / 2 - 1)) + wave) + sub;
+    int n = n0 + nl;
+    n = n < p.Cout ? n : p.Cout - 1;
+    woff[k] = (unsigned)(((int64_t)n * p.wrs + (pos ^ ((nl >> 1) & 3)) * 8) * 2);
+  }
+  // ---- halo pieces: piece k of this wave = halo voxels 16 q .. + 15 of a frame slot, q = min(4 k + wave, 20); voxel v = 18 hh + ww
+  // reads input (hb 16 - 1 + hh, wb 16 - 1 + ww) clamped into the frame (replicate padding)
+  unsigned hoff[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int q = 4 * k + wave;
+    q = q < 20 ? q : 20;
+    int v = 16 * q + sub;
+    v = v < 323 ? v : 323;
+    const int hh = v / 18, ww = v - hh * 18;
+    int hs = hb * 16 - 1 + hh, ws = wb * 16 - 1 + ww;
+    hs = hs < 0 ? 0 : (hs > p.H - 1 ? p.H - 1 : hs);
+    ws = ws < 0 ? 0 : (ws > p.W - 1 ? p.W - 1 : ws);
+    hoff[k] = (unsigned)((((int64_t)hs * p.W + ws) * p.Cin + (pos ^ ((ww >> 1) & 3)) * 8) * 2);
+  }
+  // ---- frame slot dt holds input frame clamp(t + dt - 2) (causal padding = replicate the first frame)
+  uint64_t xb[3];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt) {
+    int fs = t + dt - 2;
+    fs = fs < 0 ? 0 : fs;
+    xb[dt] = rfl64((uint64_t)(uintptr_t)(p.x + ((int64_t)b * p.T + fs) * p.H * p.W * p.Cin));
+  }
+  const uint64_t wbase = rfl64((uint64_t)(uintptr_t)p.w);
+#define OSKSW_OPERANDS                                                                                                       \
+  ::"v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(yb), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(hoff[0]),       \
+      "v"(hoff[1]), "v"(hoff[2]), "v"(hoff[3]), "v"(hoff[4]), "v"(hoff[5]), "s"(wbase), "s"(xb[0]), "s"(xb[1]), "s"(xb[2]),  \
+      "s"(cin2), "s"(nbody), "s"(dst), "s"(dst), "s"(dst5)
+  if constexpr (NBJ == 8) {
+    asm volatile(
+#include "convsw_body_n256.inc"
+        OSKSW_OPERANDS : OSKSW256_CLOBBERS);
+  } else {
+    asm volatile(
+#include "convsw_body_n128.inc"
+        OSKSW_OPERANDS : OSKSW128_CLOBBERS);
+  }
+  epilogue_all_x<NBJ>(p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
+  }   // tile loop
+}
+
 // one workgroup per CU (a multiple of 8, so that the XCD remap of the tile list keeps a workgroup inside one XCD's range)
 int persistent_grid(int ntiles) {
   int n_cu = osk_device_cus();
@@ -345,6 +435,24 @@ int launch_x(const ConvParams& p, hipStream_t st) {
   const int nblk = ((p.M + 255) / 256) * ((p.Cout + BN - 1) / BN);
   hipLaunchKernelGGL(conv256x_kernel<NBJ>, dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
   return (int)hipGetLastError();
+}
+
+template <int NBJ>
+int launch_sw(const ConvParams& p0, hipStream_t st) {
+  constexpr int BN = 32 * NBJ, SMEM = NBJ == 8 ? OSKSW256_SMEM : OSKSW128_SMEM;
+  ConvParams p = p0;
+  p.brick = 1;
+  OSK_ENSURE_MAX_SMEM(convsw_kernel<NBJ>, SMEM);
+  const int nblk = (p.M / 256) * ((p.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL(convsw_kernel<NBJ>, dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
+  return (int)hipGetLastError();
+}
+
+// sliding-window form: 3 x 3 x 3, stride 1, the conv sees the tensor as stored (no virtual upsample), whole 16 x 16 bricks, whole
+// pairs of 32-channel blocks; per-lane byte offsets inside one frame / the weight tensor are 32-bit (conv256_supported)
+bool convsw_supported(const ConvParams& p) {
+  return p.ks == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.up_t && !p.up_hw && (p.Ho & 15) == 0 && (p.Wo & 15) == 0 &&
+         p.Cin % 64 == 0 && p.Cout >= 128;
 }
 
 }  // namespace
@@ -368,6 +476,9 @@ bool conv256_gn_supported(const ConvParams& p) {
 // profiles/r02_pmc_gemm_conv.txt -- stays a ConvParams field the kernel honours, never set)
 int launch_conv256(const ConvParams& p0, hipStream_t st) {
   ConvParams p = p0;
+#ifndef OSK_CONV_NO_SW   // (A/B builds of tools/: -DOSK_CONV_NO_SW keeps every layer on the implicit-GEMM kernel)
+  if (convsw_supported(p)) return p.Cout >= 256 ? launch_sw<8>(p, st) : launch_sw<4>(p, st);
+#endif
   p.brick = 0;
   return p.Cout >= 256 ? launch_x<8>(p, st) : launch_x<4>(p, st);
 }

@@ -1,0 +1,68 @@
+"""CPU checks of the sliding-window CausalConv3d K loop (tools/gen_conv_sw_asm.py -> csrc/convsw_body_n*.inc): the generated
+instruction stream is executed symbolically (hazards, pointer arithmetic, completeness of the accumulation) and numerically,
+lane by lane, against a float64 convolution (tests/conv_sw_emulator.py).  No GPU: this is what guards edits of the generator
+and of the wrapper's lane formulas on a machine without one; tests/test_gpu_vae.py compares the kernel itself with the oracle."""
+import numpy as np
+import pytest
+
+from tests import conv_sw_emulator as E
+from tests.test_lds_fragment_maps import conflicts
+
+
+@pytest.mark.parametrize("cin", [64, 128, 256])
+@pytest.mark.parametrize("nbj", [8, 4])
+def test_schedule_is_hazard_free_and_complete(nbj, cin):
+    for wave in (0, 3):
+        r = E.check_schedule(nbj, cin, wave)
+        assert r["barriers"] == 1 + 54 * (cin // 64)
+
+
+@pytest.mark.parametrize("nbj", [8, 4])
+def test_pieces_of_the_four_waves_cover_a_stage_and_a_frame_slot(nbj):
+    assert E.piece_coverage(nbj) == (True, True)
+
+
+def test_lds_budget():
+    assert E.G.Cfg(8).SMEM <= 160 * 1024 and E.G.HALO == 3 * 21 * 1024
+    assert max(E.G.a_offset(tap, i)[0] for tap in range(27) for i in range(8)) + 16 * 64 + 64 <= 65536   # 16-bit ds_read immediates
+
+
+def test_fragment_reads_are_bank_conflict_free():
+    """halo: 64-byte voxels, chunk c of halo column ww at position c ^ ((ww >> 1) & 3); lane l reads brick column l % 16 shifted by
+    the tap's dw, chunk l / 16 -- every tap, every row block, both voxel halves; weights: 64-byte rows, key (row >> 1) & 3"""
+    for tap in range(27):
+        for i in range(8):
+            off, dw = E.G.a_offset(tap, i)
+            for wm in range(2):
+                assert conflicts(lambda l: (144 * wm + (l & 15)) * 64 + (((l >> 4) ^ ((((l & 15) + dw) >> 1) & 3)) << 4) + off) == 0
+    for base in range(0, 256, 16):
+        assert conflicts(lambda l: (base + (l & 15)) * 64 + (((l >> 4) ^ (((l & 15) >> 1) & 3)) << 4)) == 0
+    assert conflicts(lambda l: (l & 15) * 64 + ((l >> 4) << 4)) > 0          # the check has teeth: no swizzle -> conflicts
+
+
+def _case(seed, T, H, W, cin, cout):
+    rng = np.random.default_rng(seed)
+    wrs = (27 * cin + 63) // 64 * 64
+    x = rng.standard_normal((T, H, W, cin)).astype(np.float32)
+    w = np.zeros((cout, wrs), np.float32)
+    w[:, : 27 * cin] = rng.standard_normal((cout, 27 * cin)).astype(np.float32) * (27 * cin) ** -0.5
+    xb = (x.view(np.uint32) >> 16).astype(np.uint16)             # truncate to bf16: exact inputs for both sides
+    wb = (w.view(np.uint32) >> 16).astype(np.uint16)
+    x = (xb.astype(np.uint32) << 16).view(np.float32)
+    w = (wb.astype(np.uint32) << 16).view(np.float32)
+    return x, w, xb, wb, (T, H, W, cin, cout, wrs)
+
+
+@pytest.mark.parametrize("nbj,cin,cout,tile", [
+    (4, 64, 128, (0, 0, 0, 0)),          # first frame (causal clamp), top-left corner (replicate clamp), one body iteration
+    (4, 128, 128, (2, 1, 1, 0)),         # interior brick, two body iterations (the loop's back edge, channel-block wrap)
+    (8, 64, 320, (1, 2, 1, 256)),        # bottom edge, 256-wide tile whose last rows lie beyond Cout (clamped weight rows)
+    (8, 128, 256, (2, 1, 2, 0)),         # right edge, two iterations, 256-wide
+])
+def test_generated_stream_computes_the_convolution(nbj, cin, cout, tile):
+    x, w, xb, wb, geom = _case(3, 3, 48, 48, cin, cout)
+    got = E.emulate_tile(nbj, xb, wb, geom, tile)
+    ncols = min(32 * nbj, cout - tile[3])
+    ref = E.reference_tile(x, w, geom, tile, ncols)
+    err = np.abs(got[:, :ncols] - ref).max()
+    assert err <= 2e-4 * max(1.0, np.abs(ref).max()), err

@@ -66,6 +66,11 @@ CONV_CASES = [
     (512, 512, 3, (2, 2, 2), (False, False), 1, 5, 24, 24, True),    # spatio-temporal stride, 8 K steps per tap
     (256, 256, 3, (1, 1, 1), (True, True), 1, 2, 7, 9, False),       # upsample T,H,W folded into the gather
     (128, 384, 3, (1, 1, 1), (False, True), 1, 2, 8, 8, False),      # H,W upsample only, ragged N for the 256-wide tile
+    # stride 1, no upsample, whole 16 x 16 bricks, Cin % 128 == 0: the sliding-window kernel (convsw_kernel, halo brick in LDS)
+    (128, 128, 3, (1, 1, 1), (False, False), 1, 3, 32, 48, True),    # 128-wide tile, 2 body iterations, corner / edge / interior bricks
+    (256, 256, 3, (1, 1, 1), (False, False), 2, 2, 16, 32, False),   # 256-wide tile, two batch items, 4 body iterations
+    (128, 384, 3, (1, 1, 1), (False, False), 1, 4, 16, 16, True),    # one brick per frame (every side clamps), ragged N (256 + 128)
+    (512, 128, 3, (1, 1, 1), (False, False), 1, 1, 16, 16, False),   # single frame: all three frame slots hold frame 0; 8 iterations
 ]
 
 
@@ -102,6 +107,8 @@ GN_FUSED_CASES = [
     (128, 256, 3, (1, 1, 1), (False, False), 2, 3, 10, 11, False, 32, False),  # a 256-voxel tile would straddle the batch items
     (64, 128, 3, (1, 1, 1), (False, False), 1, 3, 12, 12, False, 32, False),   # Cin % 128 != 0: small-tile kernel, no fused epilogue
     (128, 160, 3, (1, 1, 1), (False, False), 1, 3, 12, 12, False, 32, False),  # 5 channels per group
+    (128, 128, 3, (1, 1, 1), (False, False), 1, 3, 32, 16, True, 32, True),    # sliding-window kernel, 128-wide, 4 per group
+    (256, 512, 3, (1, 1, 1), (False, False), 2, 2, 16, 16, False, 32, True),   # sliding-window kernel, 256-wide, two batch items
 ]
 
 

@@ -1,0 +1,330 @@
+#!/usr/bin/env python
+"""Generator of the hand-scheduled gfx950 K loop of the SLIDING-WINDOW CausalConv3d (open_sora_amd/csrc/conv3d_256.hip,
+convsw_kernel): 3 x 3 x 3, stride 1, no fused upsample, a workgroup tile = the 16 x 16 spatial brick of ONE output frame x
+256 (NBJ = 8) or 128 (NBJ = 4) output channels.
+
+Why: conv256x_kernel (tools/gen_gemm_asm.py::gen_conv_x4) is an implicit GEMM whose every filter tap re-fetches its 256 x 64
+activation tile through L2 -- 27 fetches of (almost) the same voxels, fabric-side 103 GB per VAE encode + decode against ~2 GB
+of activations, 57 % of the wave cycles waiting (profiles/r02_pmc_conv.txt).  Here the activations of a tile cross the fabric
+ONCE per 32-channel block: the 3-frame x 18 x 18 halo brick of the block sits in LDS (64 bytes per voxel) and the 27 taps
+differ only in the IMMEDIATE offset of their fragment reads.
+
+K axis = channel block (32 channels, outer) x tap (inner, frame-major: tap = 9 dt + 3 dh + dw).  One step = one tap = one
+v_mfma_f32_16x16x32_bf16 k-step over the wave tile (128 voxels x 16 NBJ channels: 8 x NBJ MFMAs, accumulators in AGPRs, the
+same accumulator layout as conv256x_kernel, so the epilogue is shared).
+
+LDS (all filled by LDS-DMA, global_load_lds_dwordx4, 1 KiB per wave instruction):
+  halo   3 frame slots x 21 KiB: voxel v = 18 hh + ww of slot dt at (336 dt + v) * 64, 16-byte chunk c of a voxel at position
+         c ^ ((ww >> 1) & 3) (conflict-free for the 16-row x 32-k lane map at every tap shift, tests/test_conv_sw_model.py);
+         ROLLING refill: slot dt is last read by tap 9 dt + 8, so the NEXT channel block's frame dt streams in during taps
+         9 dt + 9 .. + 2 of this block -- one halo buffer, 17 taps of slack.
+  W ring 6 stages x (32 NBJ rows x 64 bytes): stage s % 6 holds the weights of step s, fetched 5 steps ahead (the stage is free
+         as soon as the barrier of step s has passed: its last reader was step s - 1).
+The body is TWO channel blocks = 54 steps, fully unrolled (immediate offsets, stage numbers, fragment-set parity and the vmcnt
+of every step are static); Cin / 32 is even for every supported layer.
+
+One step of a wave:   s_waitcnt vmcnt(N) ; s_barrier          -- the weights of step s + 1 have landed for every wave
+  MFMA groups j = 0 .. NBJ - 1 of 8 (one weight fragment against the 8 activation fragments); in their shadows:
+    the 8 activation fragment reads of step s + 1 (other fragment set), weight fragment j of step s + 1 into the register quad
+    group j has just released (one set of weight fragments, rolling), the LDS-DMA pieces of step s + 5's weights and -- on 9 of
+    27 steps -- two halo pieces, the scalar address advances.
+The generator keeps its own model of what every instruction does (`Op.meta`); tests/test_conv_sw_model.py executes that model
+symbolically (every accumulator tile receives every (channel block, tap) product exactly once, no fragment is used before its
+wait, no LDS region is refilled before a barrier behind its last read or read before its fill is published).
+"""
+import argparse
+import os
+
+NB = 8                      # 16-voxel row blocks per wave tile
+SLOT = 336 * 64             # one halo frame slot: 18 x 18 voxels padded to 21 LDS-DMA pieces
+HALO = 3 * SLOT
+NS = 6                      # W ring stages
+LEAD = NS - 1
+TAPS = 27
+BODY = 2 * TAPS             # steps per loop body (two channel blocks)
+HALO_STEPS = {0: (2, 0), 1: (2, 1), 2: (2, 2), 9: (0, 0), 10: (0, 1), 11: (0, 2), 18: (1, 0), 19: (1, 1), 20: (1, 2)}   # tap -> (slot, third)
+
+V_OPERANDS = ["xa0", "xa1", "xa2", "yb", "woff0", "woff1", "woff2", "woff3", "hoff0", "hoff1", "hoff2", "hoff3", "hoff4", "hoff5"]
+S_OPERANDS = ["wbase", "xb0", "xb1", "xb2", "cin2", "nbody", "wdst", "hdst", "hdst5"]
+OPERANDS = V_OPERANDS + S_OPERANDS
+OPN = {n: "%%%d" % i for i, n in enumerate(OPERANDS)}
+
+# asm-owned scalars
+S_WB, S_X0, S_X1, S_X2 = 40, 42, 44, 46          # 64-bit running pointers: weights of the next step to fetch, halo frame bases
+S_CIN2, S_NBODY, S_IT = 48, 49, 50
+S_WDST, S_HDST, S_HDST5 = 51, 52, 53
+S_WRAP, S_WRAPL = 54, 56                         # 64-bit: 64 - 26 cin2 (next block, tap 0) / -26 cin2 (same block, tap 0)
+S_TMP, S_T2, S_T3 = 58, 59, 60
+S_FIRST, S_LAST = 40, 61
+S_X = [S_X0, S_X1, S_X2]
+
+
+def vr(b, n=1):
+    return "v%d" % b if n == 1 else "v[%d:%d]" % (b, b + n - 1)
+
+
+def ar(b, n=1):
+    return "a%d" % b if n == 1 else "a[%d:%d]" % (b, b + n - 1)
+
+
+class Cfg:
+    def __init__(self, nbj):
+        self.NBJ = nbj
+        self.BN = 32 * nbj                        # output channels per workgroup tile
+        self.W_STAGE = self.BN * 64
+        self.W_BASE = HALO
+        self.SMEM = HALO + NS * self.W_STAGE
+        self.NWP = nbj // 2                       # weight LDS-DMA pieces per wave and step
+        self.NM = NB * nbj                        # MFMAs per step
+        self.NACC = 4 * self.NM
+        self.V0 = 96
+        self.VA = [self.V0, self.V0 + 32]         # two activation fragment sets
+        self.VB = self.V0 + 64                    # one rolling weight fragment set
+        self.VY = self.VB + 4 * nbj               # weight fragment address of each ring stage (ds_read immediates are 16 bits)
+        self.VN = 64 + 4 * nbj + NS
+        self.tag = "sw%d" % self.BN
+
+
+class Op:
+    __slots__ = ("text", "kind", "meta")
+
+    def __init__(self, text, kind, meta=None):
+        self.text, self.kind, self.meta = text, kind, meta
+
+
+def a_offset(tap, i):
+    dt, r9 = divmod(tap, 9)
+    dh, dw = divmod(r9, 3)
+    return (336 * dt + (i + dh) * 18 + dw) * 64, dw
+
+
+def generate(c):
+    """-> list of Op.  kinds: M mfma, R ds_read, D lds-dma, m0, S salu, W waitcnt, B barrier, L label, J branch, X other"""
+    ops = []
+    pend = []          # LDS reads in flight, in order (tags)
+    vm = []            # LDS-DMA pieces in flight, in order (tags)
+
+    def emit(text, kind="X", meta=None):
+        ops.append(Op(text, kind, meta))
+
+    def ds_read(dst, addr, imm, tag, meta):
+        assert 0 <= imm < 65536, imm
+        emit("ds_read_b128 %s, %s offset:%d" % (vr(dst, 4), addr, imm), "R", dict(meta, dst=dst, tag=tag))
+        pend.append(tag)
+
+    def need(tag):
+        if tag in pend:
+            idx = len(pend) - 1 - pend[::-1].index(tag)
+            emit("s_waitcnt lgkmcnt(%d)" % (len(pend) - 1 - idx), "W", dict(lgkm=len(pend) - 1 - idx))
+            del pend[: idx + 1]
+
+    def a_read(step, i):       # activation fragment i of step `step` (body-relative, may be BODY = next body's step 0)
+        tap = step % TAPS
+        off, dw = a_offset(tap, i)
+        ds_read(c.VA[step % 2] + 4 * i, OPN["xa%d" % dw], off, ("A", step, i), dict(region=("H", tap // 9), step=step, frag=("A", i), off=off, dw=dw))
+
+    def b_read(step, j):
+        ds_read(c.VB + 4 * j, vr(c.VY + step % NS), j * 1024, ("B", step, j),
+                dict(region=("W", step % NS), step=step, frag=("B", j)))
+
+    def mfma(step, j, i):
+        acc = ar((j * NB + i) * 4, 4)
+        emit("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc, vr(c.VB + 4 * j, 4), vr(c.VA[step % 2] + 4 * i, 4), acc), "M",
+             dict(step=step, j=j, i=i, a=c.VA[step % 2] + 4 * i, b=c.VB + 4 * j))
+
+    def w_pieces(fstep):       # LDS-DMA of the weights of step `fstep` (body-relative; the running pointer S_WB addresses them)
+        out = []
+        for k in range(c.NWP):
+            out.append((Op("s_add_u32 m0, s%d, %d" % (S_WDST, c.W_BASE + (fstep % NS) * c.W_STAGE + k * 4096), "m0"),
+                        Op("global_load_lds_dwordx4 %s, s[%d:%d]" % (OPN["woff%d" % k], S_WB, S_WB + 1), "D",
+                           dict(region=("W", fstep % NS), fstep=fstep, tag=("W", fstep)))))
+        return out
+
+    def h_pieces(slot, third, tag):
+        out = []
+        for k in (2 * third, 2 * third + 1):
+            base, imm = (S_HDST, slot * SLOT + k * 4096) if k < 5 else (S_HDST5, slot * SLOT)
+            out.append((Op("s_add_u32 m0, s%d, %d" % (base, imm), "m0"),
+                        Op("global_load_lds_dwordx4 %s, s[%d:%d]" % (OPN["hoff%d" % k], S_X[slot], S_X[slot] + 1), "D",
+                           dict(region=("H", slot), tag=tag, piece=k))))
+        return out
+
+    def add64(reg, lo, hi=None):
+        """reg(64) += (lo, hi) ; hi None = immediate / zero-extended 32-bit register"""
+        out = [Op("s_add_u32 s%d, s%d, %s" % (reg, reg, lo), "S")]
+        out.append(Op("s_addc_u32 s%d, s%d, %s" % (reg + 1, reg + 1, "0" if hi is None else hi), "S"))
+        return out
+
+    def cond_next():           # scc = (another body iteration follows)
+        return [Op("s_add_u32 s%d, s%d, 1" % (S_TMP, S_IT), "S"), Op("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NBODY), "S")]
+
+    def w_advance(fstep):      # after the pieces of step fstep: point at step fstep + 1
+        tap = fstep % TAPS
+        if tap != TAPS - 1:
+            return add64(S_WB, "s%d" % S_CIN2)
+        if fstep // TAPS == 0:                           # first block of the body -> second block: always exists
+            return add64(S_WB, "s%d" % S_WRAP, "s%d" % (S_WRAP + 1))
+        return cond_next() + [Op("s_cselect_b32 s%d, s%d, s%d" % (S_T2, S_WRAP, S_WRAPL), "S"),
+                              Op("s_cselect_b32 s%d, s%d, s%d" % (S_T3, S_WRAP + 1, S_WRAPL + 1), "S")] + \
+            add64(S_WB, "s%d" % S_T2, "s%d" % S_T3)
+
+    def h_advance(step):       # after the LAST halo piece of a refill group (third == 2): move that slot's base to its next block
+        tap = step % TAPS
+        slot, third = HALO_STEPS[tap]
+        assert third == 2
+        cond = (step in (11, 20, 29))                    # the block fetched next is the first of the NEXT body: only if one follows
+        if not cond:
+            return add64(S_X[slot], "64")
+        return cond_next() + [Op("s_cselect_b32 s%d, 64, 0" % S_T2, "S")] + add64(S_X[slot], "s%d" % S_T2)
+
+    def dma_issue(piece):
+        m0w, d = piece
+        ops.append(m0w)
+        emit("s_nop 0")
+        ops.append(d)
+        vm.append(d.meta["tag"])
+
+    def vm_need(tag):
+        """wait until every piece tagged `tag` has landed (pieces retire in order)"""
+        if tag in vm:
+            idx = len(vm) - 1 - vm[::-1].index(tag)
+            n = len(vm) - 1 - idx
+            assert n < 64
+            emit("s_waitcnt vmcnt(%d)" % n, "W", dict(vm=n))
+            del vm[: idx + 1]
+
+    lab = lambda n: emit(".L%s_%s_%%=:" % (c.tag, n), "L", dict(name=n))
+    ref = lambda n: ".L%s_%s_%%=" % (c.tag, n)
+
+    # ------------------------------------------------------------------------------------------------ prologue
+    emit("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, OPN["wbase"]), "S")
+    for d in range(3):
+        emit("s_mov_b64 s[%d:%d], %s" % (S_X[d], S_X[d] + 1, OPN["xb%d" % d]), "S")
+    emit("s_mov_b32 s%d, %s" % (S_CIN2, OPN["cin2"]), "S")
+    emit("s_mov_b32 s%d, %s" % (S_NBODY, OPN["nbody"]), "S")
+    emit("s_mov_b32 s%d, %s" % (S_WDST, OPN["wdst"]), "S")
+    emit("s_mov_b32 s%d, %s" % (S_HDST, OPN["hdst"]), "S")
+    emit("s_mov_b32 s%d, %s" % (S_HDST5, OPN["hdst5"]), "S")
+    emit("s_mov_b32 s%d, 0" % S_IT, "S")
+    emit("s_mul_i32 s%d, s%d, 26" % (S_TMP, S_CIN2), "S")                  # 26 cin2 < 2^31
+    emit("s_sub_u32 s%d, 0, s%d" % (S_WRAPL, S_TMP), "S")                  # -26 cin2, sign-extended to 64 bits
+    emit("s_mov_b32 s%d, -1" % (S_WRAPL + 1), "S")
+    emit("s_sub_u32 s%d, 64, s%d" % (S_WRAP, S_TMP), "S")                  # 64 - 26 cin2 < 0 for cin2 >= 64
+    emit("s_mov_b32 s%d, -1" % (S_WRAP + 1), "S")
+    for k in range(NS):
+        emit("v_add_u32_e32 %s, %d, %s" % (vr(c.VY + k), c.W_BASE + k * c.W_STAGE, OPN["yb"]), "X")
+    for r in range(c.NACC):
+        emit("v_accvgpr_write_b32 %s, 0" % ar(r))
+    for slot in (0, 1):                                                    # halo frames 0, 1 of channel block 0
+        for third in range(3):
+            for p in h_pieces(slot, third, ("H", slot, "pro")):
+                dma_issue(p)
+        for o in add64(S_X[slot], "64"):
+            ops.append(o)
+    for p in w_pieces(0):
+        dma_issue(p)
+    for o in w_advance(0):
+        ops.append(o)
+    emit("s_waitcnt vmcnt(0)", "W", dict(vm=0))
+    del vm[:]
+    emit("s_barrier", "B")
+    for f in range(1, LEAD):                                               # the pieces a steady-state step top finds in flight
+        for p in w_pieces(f):
+            dma_issue(p)
+        for o in w_advance(f):
+            ops.append(o)
+    for i in range(NB):
+        a_read(0, i)
+    for j in range(c.NBJ - 1):
+        b_read(0, j)
+
+    # ------------------------------------------------------------------------------------------------ body
+    lab("body")
+    emit("s_waitcnt lgkmcnt(0)", "W", dict(lgkm=0))                        # canonical state at the loop top (once per 54 steps)
+    del pend[:]
+    vm_top = list(vm)
+    for s in range(BODY):
+        vm_need(("W", s + 1))
+        emit("s_barrier", "B", dict(step=s))
+        # fillers by MFMA index
+        fill = [[] for _ in range(c.NM)]
+        for i in range(NB):
+            fill[i].append(("a", s + 1, i))
+        fill[1].append(("b", s, c.NBJ - 1))
+        for j in range(c.NBJ - 1):
+            fill[8 * j + 9].append(("b", s + 1, j))
+        pieces = [("w", p) for p in w_pieces(s + LEAD)]
+        tap = s % TAPS
+        if tap in HALO_STEPS:
+            slot, third = HALO_STEPS[tap]
+            pieces += [("h", p) for p in h_pieces(slot, third, ("H", slot, s))]
+        gap = c.NM // max(len(pieces), 4)
+        for n, (kind, p) in enumerate(pieces):
+            fill[3 + n * gap].append(("m0", p[0]))
+            fill[4 + n * gap].append(("dma", p[1]))
+            if kind == "w" and n == c.NWP - 1:
+                fill[4 + n * gap].append(("salu", w_advance(s + LEAD)))
+            if kind == "h" and n == len(pieces) - 1 and HALO_STEPS[tap][1] == 2:
+                fill[4 + n * gap].append(("salu", h_advance(s)))
+        m = 0
+        for j in range(c.NBJ):
+            for i in range(NB):
+                need(("A", s, i))
+                need(("B", s, j))
+                mfma(s, j, i)
+                for f in fill[m]:
+                    if f[0] == "a":
+                        a_read(f[1], f[2])
+                    elif f[0] == "b":
+                        b_read(f[1], f[2])
+                    elif f[0] == "m0":
+                        ops.append(f[1])
+                    elif f[0] == "dma":
+                        ops.append(f[1])
+                        vm.append(f[1].meta["tag"])
+                    else:
+                        ops.extend(f[1])
+                m += 1
+    # loop control: the reads issued for "step 54" are the next body's step 0 (same registers, same offsets)
+    emit("s_add_u32 s%d, s%d, 1" % (S_IT, S_IT), "S")
+    emit("s_cmp_lt_u32 s%d, s%d" % (S_IT, S_NBODY), "S")
+    emit("s_cbranch_scc1 %s" % ref("body"), "J", dict(target="body"))
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)", "W", dict(vm=0, lgkm=0))
+    emit("s_nop 15")
+    emit("s_nop 15")
+    # the in-flight piece tags at the back edge must be the prologue's (same vmcnt immediates on both entries)
+    norm = lambda tags: [(t[0], t[1] % BODY) for t in tags]
+    assert norm(vm) == norm(vm_top), (vm, vm_top)
+    return ops
+
+
+def body_lines(c):
+    return [o.text if o.kind == "L" else "  " + o.text for o in generate(c)]
+
+
+def clobbers(c):
+    return ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN)] + ['"a%d"' % i for i in range(c.NACC)] + \
+           ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
+    args = ap.parse_args()
+    for nbj in (8, 4):
+        c = Cfg(nbj)
+        with open(os.path.join(args.out, "convsw_body_n%d.inc" % c.BN), "w") as f:
+            f.write("// GENERATED by tools/gen_conv_sw_asm.py -- do not edit.  Sliding-window CausalConv3d K loop: 16 x 16 voxel brick x %d "
+                    "channels, two 32-channel blocks x 27 taps per body.\n" % c.BN)
+            for ln in body_lines(c):
+                f.write('"%s\\n"\n' % ln)
+    with open(os.path.join(args.out, "convsw_regs.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_conv_sw_asm.py -- do not edit.\n")
+        f.write("#define OSKSW_SLOT %d\n#define OSKSW_HALO %d\n#define OSKSW_NS %d\n" % (SLOT, HALO, NS))
+        for nbj in (8, 4):
+            c = Cfg(nbj)
+            f.write("#define OSKSW%d_SMEM %d\n#define OSKSW%d_CLOBBERS %s\n" % (c.BN, c.SMEM, c.BN, ", ".join(clobbers(c))))
+
+
+if __name__ == "__main__":
+    main()
