@@ -338,7 +338,11 @@ __global__ void __launch_bounds__(256, 1) conv256x_kernel(const ConvParams p) {
 // channel block instead of 27 times.  K loop, LDS plan and the lane formulas below: tools/gen_conv_sw_asm.py (its header is the
 // design note; tests/test_conv_sw_model.py executes the generated stream symbolically and lane by lane in numpy with THESE
 // formulas).  Accumulator layout and epilogue are conv256x_kernel's.
-template <int NBJ>
+// UP: the decoder's nearest 2x upsample in H and W (and, with p.up_t, in T) folded in: a 16 x 16 OUTPUT brick reads a 10 x 10
+// SOURCE patch per frame slot (output row o reads source row o >> 1), pairs of lanes share a source voxel.
+OSK_DEV int swu_key(int ww) { return ww >= 6 ? 2 : 0; }   // swizzle key of source halo column ww (tests/conv_sw_emulator.py::up_key)
+
+template <int NBJ, bool UP>
 __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   constexpr int WT = OSKX_NB * 16, WTN = NBJ * 16, BN = 32 * NBJ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -355,9 +359,17 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   // voxel at position q4 ^ key(halo column), key(ww) = (ww >> 1) & 3, halo column = l15 + dw
   unsigned xa[3];
 #pragma unroll
-  for (int dw = 0; dw < 3; ++dw) xa[dw] = lds_base + (unsigned)((144 * wm + l15) * 64 + ((q4 ^ (((l15 + dw) >> 1) & 3)) << 4));
+  for (int dw = 0; dw < 3; ++dw) {
+    if constexpr (UP) {
+      const int ww = ((l15 + dw - 1) >> 1) + 1;                    // source halo column of brick column l15 under tap shift dw
+      xa[dw] = lds_base + (unsigned)((40 * wm + ww) * 64 + ((q4 ^ swu_key(ww)) << 4));
+    } else {
+      xa[dw] = lds_base + (unsigned)((144 * wm + l15) * 64 + ((q4 ^ (((l15 + dw) >> 1) & 3)) << 4));
+    }
+  }
   const unsigned yb = lds_base + (unsigned)((wn * WTN + l15) * 64 + ((q4 ^ ((l15 >> 1) & 3)) << 4));
-  const unsigned dst = rfl(lds_base + wave * 1024), dst5 = rfl(lds_base + 20 * 1024);
+  // the last halo piece of a slot: block 20 of 21 (every wave) / block min(4 + wave, 6) of 7
+  const unsigned dst = rfl(lds_base + wave * 1024), dst5 = rfl(lds_base + (UP ? (4 + wave < 6 ? 4 + wave : 6) : 20) * 1024);
   const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = rfl((unsigned)p.Cin / 64);
   const int sub = lane >> 2, pos = lane & 3;                     // an LDS-DMA piece = 16 rows of 64 bytes: lane -> (row, position)
 
@@ -381,25 +393,38 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   }
   // ---- halo pieces: piece k of this wave = halo voxels 16 q .. + 15 of a frame slot, q = min(4 k + wave, 20); voxel v = 18 hh + ww
   // reads input (hb 16 - 1 + hh, wb 16 - 1 + ww) clamped into the frame (replicate padding)
+  // (UP: two pieces per wave, q = min(4 k + wave, 6), of the 10 x 10 source patch from (hb 8 - 1, wb 8 - 1))
   unsigned hoff[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    int q = 4 * k + wave;
-    q = q < 20 ? q : 20;
-    int v = 16 * q + sub;
-    v = v < 323 ? v : 323;
-    const int hh = v / 18, ww = v - hh * 18;
-    int hs = hb * 16 - 1 + hh, ws = wb * 16 - 1 + ww;
+    int hs, ws, key;
+    if constexpr (UP) {
+      int q = 4 * (k & 1) + wave;
+      q = q < 6 ? q : 6;
+      int v = 16 * q + sub;
+      v = v < 99 ? v : 99;
+      const int hh = v / 10, ww = v - hh * 10;
+      hs = hb * 8 - 1 + hh; ws = wb * 8 - 1 + ww; key = swu_key(ww);
+    } else {
+      int q = 4 * k + wave;
+      q = q < 20 ? q : 20;
+      int v = 16 * q + sub;
+      v = v < 323 ? v : 323;
+      const int hh = v / 18, ww = v - hh * 18;
+      hs = hb * 16 - 1 + hh; ws = wb * 16 - 1 + ww; key = (ww >> 1) & 3;
+    }
     hs = hs < 0 ? 0 : (hs > p.H - 1 ? p.H - 1 : hs);
     ws = ws < 0 ? 0 : (ws > p.W - 1 ? p.W - 1 : ws);
-    hoff[k] = (unsigned)((((int64_t)hs * p.W + ws) * p.Cin + (pos ^ ((ww >> 1) & 3)) * 8) * 2);
+    hoff[k] = (unsigned)((((int64_t)hs * p.W + ws) * p.Cin + (pos ^ key) * 8) * 2);
   }
-  // ---- frame slot dt holds input frame clamp(t + dt - 2) (causal padding = replicate the first frame)
+  // ---- frame slot dt holds the source frame of conv-input frame max(t + dt - 2, 0) (causal padding = replicate the first frame;
+  // under the time upsample conv-input frame tu > 0 is source frame 1 + (tu - 1) / 2, frame 0 stays single)
   uint64_t xb[3];
 #pragma unroll
   for (int dt = 0; dt < 3; ++dt) {
-    int fs = t + dt - 2;
-    fs = fs < 0 ? 0 : fs;
+    int tu = t + dt - 2;
+    tu = tu < 0 ? 0 : tu;
+    const int fs = p.up_t ? (tu == 0 ? 0 : 1 + ((tu - 1) >> 1)) : tu;
     xb[dt] = rfl64((uint64_t)(uintptr_t)(p.x + ((int64_t)b * p.T + fs) * p.H * p.W * p.Cin));
   }
   const uint64_t wbase = rfl64((uint64_t)(uintptr_t)p.w);
@@ -407,13 +432,21 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   ::"v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(yb), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(hoff[0]),       \
       "v"(hoff[1]), "v"(hoff[2]), "v"(hoff[3]), "v"(hoff[4]), "v"(hoff[5]), "s"(wbase), "s"(xb[0]), "s"(xb[1]), "s"(xb[2]),  \
       "s"(cin2), "s"(nbody), "s"(dst), "s"(dst), "s"(dst5)
-  if constexpr (NBJ == 8) {
+  if constexpr (NBJ == 8 && !UP) {
     asm volatile(
 #include "convsw_body_n256.inc"
         OSKSW_OPERANDS : OSKSW256_CLOBBERS);
-  } else {
+  } else if constexpr (NBJ == 4 && !UP) {
     asm volatile(
 #include "convsw_body_n128.inc"
+        OSKSW_OPERANDS : OSKSW128_CLOBBERS);
+  } else if constexpr (NBJ == 8) {
+    asm volatile(
+#include "convswu_body_n256.inc"
+        OSKSW_OPERANDS : OSKSW256_CLOBBERS);
+  } else {
+    asm volatile(
+#include "convswu_body_n128.inc"
         OSKSW_OPERANDS : OSKSW128_CLOBBERS);
   }
   epilogue_all_x<NBJ>(p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
@@ -437,21 +470,23 @@ int launch_x(const ConvParams& p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-template <int NBJ>
+template <int NBJ, bool UP>
 int launch_sw(const ConvParams& p0, hipStream_t st) {
-  constexpr int BN = 32 * NBJ, SMEM = NBJ == 8 ? OSKSW256_SMEM : OSKSW128_SMEM;
+  constexpr int BN = 32 * NBJ;
+  constexpr int SMEM = UP ? (NBJ == 8 ? OSKSWU256_SMEM : OSKSWU128_SMEM) : (NBJ == 8 ? OSKSW256_SMEM : OSKSW128_SMEM);
   ConvParams p = p0;
   p.brick = 1;
-  OSK_ENSURE_MAX_SMEM(convsw_kernel<NBJ>, SMEM);
+  OSK_ENSURE_MAX_SMEM((convsw_kernel<NBJ, UP>), SMEM);
   const int nblk = (p.M / 256) * ((p.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL(convsw_kernel<NBJ>, dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
+  hipLaunchKernelGGL((convsw_kernel<NBJ, UP>), dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
   return (int)hipGetLastError();
 }
 
-// sliding-window form: 3 x 3 x 3, stride 1, the conv sees the tensor as stored (no virtual upsample), whole 16 x 16 bricks, whole
-// pairs of 32-channel blocks; per-lane byte offsets inside one frame / the weight tensor are 32-bit (conv256_supported)
+// sliding-window form: 3 x 3 x 3, stride 1, whole 16 x 16 output bricks, whole pairs of 32-channel blocks; the tensor as stored or
+// under the decoder's upsample (H and W together, T optionally); per-lane byte offsets inside one frame / the weight tensor
+// are 32-bit (conv256_supported)
 bool convsw_supported(const ConvParams& p) {
-  return p.ks == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.up_t && !p.up_hw && (p.Ho & 15) == 0 && (p.Wo & 15) == 0 &&
+  return p.ks == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && (p.up_hw || !p.up_t) && (p.Ho & 15) == 0 && (p.Wo & 15) == 0 &&
          p.Cin % 64 == 0 && p.Cout >= 128;
 }
 
@@ -477,7 +512,10 @@ bool conv256_gn_supported(const ConvParams& p) {
 int launch_conv256(const ConvParams& p0, hipStream_t st) {
   ConvParams p = p0;
 #ifndef OSK_CONV_NO_SW   // (A/B builds of tools/: -DOSK_CONV_NO_SW keeps every layer on the implicit-GEMM kernel)
-  if (convsw_supported(p)) return p.Cout >= 256 ? launch_sw<8>(p, st) : launch_sw<4>(p, st);
+  if (convsw_supported(p)) {
+    if (p.up_hw) return p.Cout >= 256 ? launch_sw<8, true>(p, st) : launch_sw<4, true>(p, st);
+    return p.Cout >= 256 ? launch_sw<8, false>(p, st) : launch_sw<4, false>(p, st);
+  }
 #endif
   p.brick = 0;
   return p.Cout >= 256 ? launch_x<8>(p, st) : launch_x<4>(p, st);

@@ -106,17 +106,17 @@ def run_stream(ops, on_op, scal):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-def check_schedule(nbj, cin, wave=0):
-    c = G.Cfg(nbj)
+def check_schedule(nbj, cin, wave=0, up=False):
+    c = G.Cfg(nbj, up)
     ops = G.generate(c)
     ncb = cin // 32
     scal = Scalars(dict(wbase=WBASE, xb0=XBASE[0], xb1=XBASE[1], xb2=XBASE[2], cin2=2 * cin, nbody=cin // 64,
-                        wdst=wave * 1024, hdst=wave * 1024, hdst5=20 * 1024))
+                        wdst=wave * 1024, hdst=wave * 1024, hdst5=min(4 + wave, 6) * 1024 if up else 20 * 1024))
     st = dict(epoch=0, m0_fresh=False)
     reads, lg = [], []                 # every ds_read record; indices still in flight (in order)
     dmas, vmq = [], []
     content = {("H", d): None for d in range(3)}
-    content.update({("W", k): None for k in range(G.NS)})
+    content.update({("W", k): None for k in range(c.NS)})
     dirty = {r: False for r in content}     # a multi-step refill (halo slot) is in progress
     hpieces = {d: set() for d in range(3)}
     reg_sym, reg_read = {}, {}
@@ -137,7 +137,7 @@ def check_schedule(nbj, cin, wave=0):
             region = o.meta["region"]
             # M0: written by the instruction pair right before (run_stream executed it), decode the destination
             base = 0 if region[0] == "H" else c.W_BASE
-            size = G.SLOT if region[0] == "H" else c.W_STAGE
+            size = c.SLOT if region[0] == "H" else c.W_STAGE
             rel = scal.m0 - base - region[1] * size
             assert 0 <= rel < size and rel % 1024 == 0, ("M0 outside its region", o.text, scal.m0, region)
             for r in reads:                                     # WAR: every earlier read of the region retired before the last barrier
@@ -173,7 +173,7 @@ def check_schedule(nbj, cin, wave=0):
                 syms = {d["sym"] for d in pend_fill}
                 assert len(syms) == 1, ("mixed contents", region, syms)
                 if region[0] == "H":
-                    assert hpieces[region[1]] == set(range(6)), ("halo slot read while its refill is incomplete", region, hpieces[region[1]])
+                    assert hpieces[region[1]] == set(range(2 * c.NT)), ("halo slot read while its refill is incomplete", region, hpieces[region[1]])
                     hpieces[region[1]] = set()
                     dirty[region] = False
                 content[region] = syms.pop()
@@ -186,11 +186,17 @@ def check_schedule(nbj, cin, wave=0):
                 i = o.meta["frag"][1]
                 assert dst in (c.VA[0] + 4 * i, c.VA[1] + 4 * i)
                 voff = o.meta["off"] // 64
-                dt, rem = divmod(voff, 336)
-                row, dw = divmod(rem, 18)
-                dh = row - i
-                assert dt == region[1] and 0 <= dh < 3 and 0 <= dw < 3 and dw == o.meta["dw"], o.text
-                reg_sym[dst] = None if sym is None else ("A", sym[0], 9 * dt + 3 * dh + dw, i)
+                dt, rem = divmod(voff, c.SLOTV)
+                assert dt == region[1], o.text
+                if up:      # two taps may read the same halo row (the upsample repeats it): the tap is the generator's claim,
+                    tap = o.meta["step"] % 27                       # checked against the offset it must produce
+                    assert c.a_offset(tap, i) == (o.meta["off"], o.meta["dw"]) and tap // 9 == dt, o.text
+                else:
+                    row, dw = divmod(rem, c.PITCH)
+                    dh = row - i
+                    assert 0 <= dh < 3 and 0 <= dw < 3 and dw == o.meta["dw"], o.text
+                    tap = 9 * dt + 3 * dh + dw
+                reg_sym[dst] = None if sym is None else ("A", sym[0], tap, i)
             else:
                 j = o.meta["frag"][1]
                 assert dst == c.VB + 4 * j
@@ -217,42 +223,65 @@ def check_schedule(nbj, cin, wave=0):
     return dict(instructions=len(ops), reads=len(reads), pieces=len(dmas), barriers=st["epoch"])
 
 
-def piece_coverage(nbj):
+def piece_coverage(nbj, up=False):
     """the pieces the four waves issue for one refill cover every 1-KiB block of the stage / frame slot"""
-    c = G.Cfg(nbj)
+    c = G.Cfg(nbj, up)
     w = sorted({4 * k + wv for k in range(c.NWP) for wv in range(4)})
-    h = sorted({min(4 * k + wv, 20) for k in range(6) for wv in range(4)})
-    return w == list(range(c.W_STAGE // 1024)), h == list(range(21))
+    h = sorted({min(4 * k + wv, c.NPIECE - 1) for k in range(2 * c.NT) for wv in range(4)})
+    return w == list(range(c.W_STAGE // 1024)), h == list(range(c.NPIECE))
+
+
+def up_key(ww):
+    """swizzle key of source halo column ww (0..9) in the upsampled form: pairs of lanes share a voxel, so the 16-row fragment
+    read touches 5-6 voxels per chunk value; 2 for ww >= 6 separates the ones four columns apart"""
+    return np.where(np.asarray(ww) >= 6, 2, 0)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-def wrapper_operands(nbj, wave, geom, tile):
-    """per-lane / per-wave asm operands of convsw_kernel<NBJ> for one tile -- the C++ formulas, re-stated"""
+def wrapper_operands(nbj, wave, geom, tile, up=(False, False)):
+    """per-lane / per-wave asm operands of convsw_kernel<NBJ, UP> for one tile -- the C++ formulas, re-stated.
+    geom = SOURCE dims (T, H, W, Cin, Cout, wrs); up = (up_t, up_hw); tile = (output frame, brick row, brick column, n0)"""
     T, H, W, Cin, Cout, wrs = geom
     t, hb, wb, n0 = tile
+    up_t, up_hw = up
     lane = np.arange(64)
     q4, l15 = lane >> 4, lane & 15
     wm, wn = wave >> 1, wave & 1
     sub, pos = lane >> 2, lane & 3
     op = {}
     for dw in range(3):
-        op["xa%d" % dw] = (144 * wm + l15) * 64 + ((q4 ^ (((l15 + dw) >> 1) & 3)) << 4)
+        if up_hw:
+            ww = ((l15 + dw - 1) >> 1) + 1
+            op["xa%d" % dw] = (40 * wm + ww) * 64 + ((q4 ^ up_key(ww)) << 4)
+        else:
+            op["xa%d" % dw] = (144 * wm + l15) * 64 + ((q4 ^ (((l15 + dw) >> 1) & 3)) << 4)
     op["yb"] = (wn * nbj * 16 + l15) * 64 + ((q4 ^ ((l15 >> 1) & 3)) << 4)
     for k in range(4):
         nl = 16 * (4 * (k & (nbj // 2 - 1)) + wave) + sub
         n = np.minimum(n0 + nl, Cout - 1)
         op["woff%d" % k] = (n * wrs + (pos ^ ((nl >> 1) & 3)) * 8) * 2
     for k in range(6):
-        q = min(4 * k + wave, 20)
-        v = np.minimum(16 * q + sub, 323)
-        hh, ww = v // 18, v % 18
-        hs = np.clip(hb * 16 - 1 + hh, 0, H - 1)
-        ws = np.clip(wb * 16 - 1 + ww, 0, W - 1)
-        op["hoff%d" % k] = ((hs * W + ws) * Cin + (pos ^ ((ww >> 1) & 3)) * 8) * 2
+        if up_hw:
+            q = min(4 * (k & 1) + wave, 6)
+            v = np.minimum(16 * q + sub, 99)
+            hh, ww = v // 10, v % 10
+            hs = np.clip(hb * 8 - 1 + hh, 0, H - 1)
+            ws = np.clip(wb * 8 - 1 + ww, 0, W - 1)
+            key = up_key(ww)
+        else:
+            q = min(4 * k + wave, 20)
+            v = np.minimum(16 * q + sub, 323)
+            hh, ww = v // 18, v % 18
+            hs = np.clip(hb * 16 - 1 + hh, 0, H - 1)
+            ws = np.clip(wb * 16 - 1 + ww, 0, W - 1)
+            key = (ww >> 1) & 3
+        op["hoff%d" % k] = ((hs * W + ws) * Cin + (pos ^ key) * 8) * 2
     for dt in range(3):
-        fs = max(t + dt - 2, 0)
+        tu = max(t + dt - 2, 0)
+        fs = (0 if tu == 0 else 1 + ((tu - 1) >> 1)) if up_t else tu
         op["xb%d" % dt] = XBASE[0] + fs * H * W * Cin * 2          # one tensor: frame fs of batch item 0
-    op.update(wbase=WBASE, cin2=2 * Cin, nbody=Cin // 64, wdst=wave * 1024, hdst=wave * 1024, hdst5=20 * 1024)
+    op.update(wbase=WBASE, cin2=2 * Cin, nbody=Cin // 64, wdst=wave * 1024, hdst=wave * 1024,
+              hdst5=(min(4 + wave, 6) if up_hw else 20) * 1024)
     return op
 
 
@@ -263,15 +292,15 @@ def _bf16_pairs(u32):
     return np.stack([lo, hi], axis=-1).reshape(*u32.shape[:-1], -1)
 
 
-def emulate_tile(nbj, x_bits, w_bits, geom, tile):
+def emulate_tile(nbj, x_bits, w_bits, geom, tile, up=(False, False)):
     """x_bits [T, H, W, Cin] uint16, w_bits [Cout, wrs] uint16 -> out [256 tile rows, 32 nbj channels] float32 (no bias)"""
-    c = G.Cfg(nbj)
+    c = G.Cfg(nbj, up[1])
     ops = G.generate(c)
     xb, wbts = x_bits.reshape(-1).view(np.uint8), w_bits.reshape(-1).view(np.uint8)
     lds = np.zeros(c.SMEM, np.uint8)
     waves = []
     for wv in range(4):
-        opv = wrapper_operands(nbj, wv, geom, tile)
+        opv = wrapper_operands(nbj, wv, geom, tile, up)
         waves.append(dict(op=opv, scal=Scalars({k: int(v) for k, v in opv.items() if np.ndim(v) == 0}),
                           v=np.zeros((256, 64), np.uint32), a=np.zeros((256, 64), np.float32)))
     lane = np.arange(64)
@@ -357,11 +386,14 @@ def emulate_tile(nbj, x_bits, w_bits, geom, tile):
     return out
 
 
-def reference_tile(x, w, geom, tile, ncols):
+def reference_tile(x, w, geom, tile, ncols, up=(False, False)):
     """float64 conv of the tile's 256 voxels (row r = brick (r >> 4, r & 15)) x ncols channels from n0: replicate spatial padding,
-    causal (first-frame replicate) time padding, weights [Cout, tap-major / channel-minor]"""
+    causal (first-frame replicate) time padding, weights [Cout, tap-major / channel-minor]; with up: the conv sees the nearest-
+    upsampled tensor (frame 0 kept single in time: unet_causal_3d_blocks.py's UpsampleCausal3D), x is the SOURCE"""
     T, H, W, Cin, Cout, wrs = geom
     t, hb, wb, n0 = tile
+    up_t, up_hw = up
+    Hu, Wu = (2 * H, 2 * W) if up_hw else (H, W)
     out = np.zeros((256, ncols))
     wmat = w[n0: n0 + ncols, : 27 * Cin].astype(np.float64)
     for r in range(256):
@@ -370,9 +402,11 @@ def reference_tile(x, w, geom, tile, ncols):
         for dt in range(3):
             for dh in range(3):
                 for dw in range(3):
-                    ts = max(t + dt - 2, 0)
-                    hs = min(max(h + dh - 1, 0), H - 1)
-                    ws = min(max(ww + dw - 1, 0), W - 1)
+                    tu = max(t + dt - 2, 0)
+                    ts = (0 if tu == 0 else 1 + ((tu - 1) >> 1)) if up_t else tu
+                    hu = min(max(h + dh - 1, 0), Hu - 1)
+                    wu = min(max(ww + dw - 1, 0), Wu - 1)
+                    hs, ws = (hu >> 1, wu >> 1) if up_hw else (hu, wu)
                     cols.append(x[ts, hs, ws])
         out[r] = wmat @ np.concatenate(cols).astype(np.float64)
     return out

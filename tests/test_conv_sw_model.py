@@ -9,32 +9,40 @@ from tests import conv_sw_emulator as E
 from tests.test_lds_fragment_maps import conflicts
 
 
+@pytest.mark.parametrize("up", [False, True])
 @pytest.mark.parametrize("cin", [64, 128, 256])
 @pytest.mark.parametrize("nbj", [8, 4])
-def test_schedule_is_hazard_free_and_complete(nbj, cin):
+def test_schedule_is_hazard_free_and_complete(nbj, cin, up):
     for wave in (0, 3):
-        r = E.check_schedule(nbj, cin, wave)
-        assert r["barriers"] == 1 + 54 * (cin // 64)
+        r = E.check_schedule(nbj, cin, wave, up)
+        assert r["barriers"] == 1 + (54 // E.G.Cfg(nbj).BAR) * (cin // 64)
 
 
+@pytest.mark.parametrize("up", [False, True])
 @pytest.mark.parametrize("nbj", [8, 4])
-def test_pieces_of_the_four_waves_cover_a_stage_and_a_frame_slot(nbj):
-    assert E.piece_coverage(nbj) == (True, True)
+def test_pieces_of_the_four_waves_cover_a_stage_and_a_frame_slot(nbj, up):
+    assert E.piece_coverage(nbj, up) == (True, True)
 
 
 def test_lds_budget():
-    assert E.G.Cfg(8).SMEM <= 160 * 1024 and E.G.HALO == 3 * 21 * 1024
-    assert max(E.G.a_offset(tap, i)[0] for tap in range(27) for i in range(8)) + 16 * 64 + 64 <= 65536   # 16-bit ds_read immediates
+    c = E.G.Cfg(8)
+    assert c.SMEM <= 160 * 1024 and c.HALO == 3 * 21 * 1024 and E.G.Cfg(8, True).HALO == 3 * 7 * 1024
+    assert max(c.a_offset(tap, i)[0] for tap in range(27) for i in range(8)) + 16 * 64 + 64 <= 65536   # 16-bit ds_read immediates
 
 
 def test_fragment_reads_are_bank_conflict_free():
     """halo: 64-byte voxels, chunk c of halo column ww at position c ^ ((ww >> 1) & 3); lane l reads brick column l % 16 shifted by
     the tap's dw, chunk l / 16 -- every tap, every row block, both voxel halves; weights: 64-byte rows, key (row >> 1) & 3"""
+    c, cu = E.G.Cfg(8), E.G.Cfg(8, True)
     for tap in range(27):
         for i in range(8):
-            off, dw = E.G.a_offset(tap, i)
+            off, dw = c.a_offset(tap, i)
+            offu, _ = cu.a_offset(tap, i)
             for wm in range(2):
                 assert conflicts(lambda l: (144 * wm + (l & 15)) * 64 + (((l >> 4) ^ ((((l & 15) + dw) >> 1) & 3)) << 4) + off) == 0
+                # upsampled form: lane pairs share a source voxel (same address: a broadcast, no conflict)
+                ww = lambda l: (((l & 15) + dw - 1) >> 1) + 1
+                assert conflicts(lambda l: (40 * wm + ww(l)) * 64 + (((l >> 4) ^ int(E.up_key(ww(l)))) << 4) + offu) == 0
     for base in range(0, 256, 16):
         assert conflicts(lambda l: (base + (l & 15)) * 64 + (((l >> 4) ^ (((l & 15) >> 1) & 3)) << 4)) == 0
     assert conflicts(lambda l: (l & 15) * 64 + ((l >> 4) << 4)) > 0          # the check has teeth: no swizzle -> conflicts
@@ -53,16 +61,20 @@ def _case(seed, T, H, W, cin, cout):
     return x, w, xb, wb, (T, H, W, cin, cout, wrs)
 
 
-@pytest.mark.parametrize("nbj,cin,cout,tile", [
-    (4, 64, 128, (0, 0, 0, 0)),          # first frame (causal clamp), top-left corner (replicate clamp), one body iteration
-    (4, 128, 128, (2, 1, 1, 0)),         # interior brick, two body iterations (the loop's back edge, channel-block wrap)
-    (8, 64, 320, (1, 2, 1, 256)),        # bottom edge, 256-wide tile whose last rows lie beyond Cout (clamped weight rows)
-    (8, 128, 256, (2, 1, 2, 0)),         # right edge, two iterations, 256-wide
+@pytest.mark.parametrize("nbj,cin,cout,tile,up", [
+    (4, 64, 128, (0, 0, 0, 0), (False, False)),     # first frame (causal clamp), top-left corner (replicate clamp), one body iteration
+    (4, 128, 128, (2, 1, 1, 0), (False, False)),    # interior brick, two body iterations (the loop's back edge, channel-block wrap)
+    (8, 64, 320, (1, 2, 1, 256), (False, False)),   # bottom edge, 256-wide tile whose last rows lie beyond Cout (clamped weight rows)
+    (8, 128, 256, (2, 1, 2, 0), (False, False)),    # right edge, two iterations, 256-wide
+    (8, 64, 256, (0, 0, 0, 0), (True, True)),       # upsample T, H, W: output frame 0 (all taps read source frame 0), corner
+    (8, 128, 256, (3, 2, 3, 0), (True, True)),      # output frame 3 = source frames 1, 1, 2; interior brick of the 96 x 96 output
+    (4, 64, 128, (4, 5, 5, 0), (True, True)),       # last brick row / column (replicate clamp at the far sides), output frame 4
+    (8, 64, 256, (1, 3, 0, 0), (False, True)),      # H, W upsample only: frames map one to one
 ])
-def test_generated_stream_computes_the_convolution(nbj, cin, cout, tile):
+def test_generated_stream_computes_the_convolution(nbj, cin, cout, tile, up):
     x, w, xb, wb, geom = _case(3, 3, 48, 48, cin, cout)
-    got = E.emulate_tile(nbj, xb, wb, geom, tile)
+    got = E.emulate_tile(nbj, xb, wb, geom, tile, up)
     ncols = min(32 * nbj, cout - tile[3])
-    ref = E.reference_tile(x, w, geom, tile, ncols)
+    ref = E.reference_tile(x, w, geom, tile, ncols, up)
     err = np.abs(got[:, :ncols] - ref).max()
     assert err <= 2e-4 * max(1.0, np.abs(ref).max()), err

@@ -71,6 +71,10 @@ CONV_CASES = [
     (256, 256, 3, (1, 1, 1), (False, False), 2, 2, 16, 32, False),   # 256-wide tile, two batch items, 4 body iterations
     (128, 384, 3, (1, 1, 1), (False, False), 1, 4, 16, 16, True),    # one brick per frame (every side clamps), ragged N (256 + 128)
     (512, 128, 3, (1, 1, 1), (False, False), 1, 1, 16, 16, False),   # single frame: all three frame slots hold frame 0; 8 iterations
+    # the same kernel with the decoder's upsample folded into the halo (10 x 10 source patch per frame slot)
+    (256, 256, 3, (1, 1, 1), (True, True), 1, 2, 8, 16, False),      # T, H, W upsample: 3 output frames of 16 x 32
+    (128, 128, 3, (1, 1, 1), (False, True), 2, 2, 16, 8, True),      # H, W only, 128-wide tile, residual, two batch items
+    (512, 384, 3, (1, 1, 1), (True, True), 1, 3, 8, 8, True),        # 5 output frames, ragged N (256 + 128), 8 iterations
 ]
 
 
@@ -109,6 +113,7 @@ GN_FUSED_CASES = [
     (128, 160, 3, (1, 1, 1), (False, False), 1, 3, 12, 12, False, 32, False),  # 5 channels per group
     (128, 128, 3, (1, 1, 1), (False, False), 1, 3, 32, 16, True, 32, True),    # sliding-window kernel, 128-wide, 4 per group
     (256, 512, 3, (1, 1, 1), (False, False), 2, 2, 16, 16, False, 32, True),   # sliding-window kernel, 256-wide, two batch items
+    (128, 256, 3, (1, 1, 1), (True, True), 1, 2, 8, 8, False, 32, True),       # sliding-window kernel, upsample folded in
 ]
 
 

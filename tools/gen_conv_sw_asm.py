@@ -36,13 +36,11 @@ import argparse
 import os
 
 NB = 8                      # 16-voxel row blocks per wave tile
-SLOT = 336 * 64             # one halo frame slot: 18 x 18 voxels padded to 21 LDS-DMA pieces
-HALO = 3 * SLOT
-NS = 6                      # W ring stages
-LEAD = NS - 1
 TAPS = 27
 BODY = 2 * TAPS             # steps per loop body (two channel blocks)
-HALO_STEPS = {0: (2, 0), 1: (2, 1), 2: (2, 2), 9: (0, 0), 10: (0, 1), 11: (0, 2), 18: (1, 0), 19: (1, 1), 20: (1, 2)}   # tap -> (slot, third)
+# body step at which the refill of a halo frame slot starts (three steps, two pieces per wave each): right behind the first
+# barrier after the slot's last reader (tap 9 slot + 8 of either block) has retired its fragment reads
+REFILL_START = {1: {0: 2, 9: 0, 18: 1, 27: 2, 36: 0, 45: 1}, 2: {0: 2, 10: 0, 18: 1, 28: 2, 36: 0, 46: 1}}
 
 V_OPERANDS = ["xa0", "xa1", "xa2", "yb", "woff0", "woff1", "woff2", "woff3", "hoff0", "hoff1", "hoff2", "hoff3", "hoff4", "hoff5"]
 S_OPERANDS = ["wbase", "xb0", "xb1", "xb2", "cin2", "nbody", "wdst", "hdst", "hdst5"]
@@ -68,12 +66,26 @@ def ar(b, n=1):
 
 
 class Cfg:
-    def __init__(self, nbj):
+    def __init__(self, nbj, up=False):
         self.NBJ = nbj
+        self.UP = up                              # the decoder's nearest 2x (H, W) upsample folded into the halo (see a_offset)
         self.BN = 32 * nbj                        # output channels per workgroup tile
+        # one halo frame slot: 18 x 18 voxels padded to 21 LDS-DMA pieces; upsampled: the 10 x 10 SOURCE voxels, 7 pieces
+        self.PITCH, self.SLOTV, self.NPIECE = (10, 112, 7) if up else (18, 336, 21)
+        self.SLOT = self.SLOTV * 64
+        self.HALO = 3 * self.SLOT
+        self.NT = 1 if up else 3                  # steps per slot refill (two pieces per wave and step)
+        self.BAR = 1 if nbj == 8 else 2           # steps per barrier (64 MFMAs per wave between barriers in both forms)
+        self.NS = 6 if nbj == 8 else 9            # W ring stages (one step each); BODY % NS == 0: stage numbers are static
+        self.LEAD = self.NS - self.BAR            # step s fetches the weights of step s + LEAD into the stage of step s + LEAD - NS,
+        assert BODY % self.NS == 0                # whose last reader retired before the latest barrier (<= s - s % BAR)
+        self.HALO_STEPS = {}                      # body step -> (slot, third, the pointer advance behind it is conditional)
+        for start, slot in REFILL_START[self.BAR].items():
+            for third in range(self.NT):
+                self.HALO_STEPS[start + third] = (slot, third, (slot == 2) == (start >= TAPS))
         self.W_STAGE = self.BN * 64
-        self.W_BASE = HALO
-        self.SMEM = HALO + NS * self.W_STAGE
+        self.W_BASE = self.HALO
+        self.SMEM = self.HALO + self.NS * self.W_STAGE
         self.NWP = nbj // 2                       # weight LDS-DMA pieces per wave and step
         self.NM = NB * nbj                        # MFMAs per step
         self.NACC = 4 * self.NM
@@ -81,8 +93,19 @@ class Cfg:
         self.VA = [self.V0, self.V0 + 32]         # two activation fragment sets
         self.VB = self.V0 + 64                    # one rolling weight fragment set
         self.VY = self.VB + 4 * nbj               # weight fragment address of each ring stage (ds_read immediates are 16 bits)
-        self.VN = 64 + 4 * nbj + NS
-        self.tag = "sw%d" % self.BN
+        self.VN = 64 + 4 * nbj + self.NS
+        self.tag = "sw%s%d" % ("u" if up else "", self.BN)
+
+    def a_offset(self, tap, i):
+        """immediate of activation fragment i (brick rows 8 wm + i) of tap (dt, dh, dw), and the address operand it adds to.
+        Plain: halo voxel (dt, i + dh, l15 + dw); the column shift dw is part of the immediate AND selects the operand (the swizzle
+        key depends on the halo column).  Upsampled: output row i + dh - 1 of the brick reads SOURCE row (i + dh - 1) >> 1, i.e.
+        halo row ((i + dh - 1) >> 1) + 1; the column map (l15 + dw - 1) >> 1 is per lane and lives in the operand."""
+        dt, r9 = divmod(tap, 9)
+        dh, dw = divmod(r9, 3)
+        if self.UP:
+            return (self.SLOTV * dt + (((i + dh - 1) >> 1) + 1) * self.PITCH) * 64, dw
+        return (self.SLOTV * dt + (i + dh) * self.PITCH + dw) * 64, dw
 
 
 class Op:
@@ -92,15 +115,10 @@ class Op:
         self.text, self.kind, self.meta = text, kind, meta
 
 
-def a_offset(tap, i):
-    dt, r9 = divmod(tap, 9)
-    dh, dw = divmod(r9, 3)
-    return (336 * dt + (i + dh) * 18 + dw) * 64, dw
-
-
 def generate(c):
     """-> list of Op.  kinds: M mfma, R ds_read, D lds-dma, m0, S salu, W waitcnt, B barrier, L label, J branch, X other"""
     ops = []
+    NS, LEAD, HALO_STEPS = c.NS, c.LEAD, c.HALO_STEPS
     pend = []          # LDS reads in flight, in order (tags)
     vm = []            # LDS-DMA pieces in flight, in order (tags)
 
@@ -120,7 +138,7 @@ def generate(c):
 
     def a_read(step, i):       # activation fragment i of step `step` (body-relative, may be BODY = next body's step 0)
         tap = step % TAPS
-        off, dw = a_offset(tap, i)
+        off, dw = c.a_offset(tap, i)
         ds_read(c.VA[step % 2] + 4 * i, OPN["xa%d" % dw], off, ("A", step, i), dict(region=("H", tap // 9), step=step, frag=("A", i), off=off, dw=dw))
 
     def b_read(step, j):
@@ -142,8 +160,8 @@ def generate(c):
 
     def h_pieces(slot, third, tag):
         out = []
-        for k in (2 * third, 2 * third + 1):
-            base, imm = (S_HDST, slot * SLOT + k * 4096) if k < 5 else (S_HDST5, slot * SLOT)
+        for k in (2 * third, 2 * third + 1):      # piece k of wave w = 1-KiB block min(4 k + w, NPIECE - 1) of the slot
+            base, imm = (S_HDST, slot * c.SLOT + k * 4096) if 4 * k + 3 < c.NPIECE else (S_HDST5, slot * c.SLOT)
             out.append((Op("s_add_u32 m0, s%d, %d" % (base, imm), "m0"),
                         Op("global_load_lds_dwordx4 %s, s[%d:%d]" % (OPN["hoff%d" % k], S_X[slot], S_X[slot] + 1), "D",
                            dict(region=("H", slot), tag=tag, piece=k))))
@@ -169,10 +187,8 @@ def generate(c):
             add64(S_WB, "s%d" % S_T2, "s%d" % S_T3)
 
     def h_advance(step):       # after the LAST halo piece of a refill group (third == 2): move that slot's base to its next block
-        tap = step % TAPS
-        slot, third = HALO_STEPS[tap]
-        assert third == 2
-        cond = (step in (11, 20, 29))                    # the block fetched next is the first of the NEXT body: only if one follows
+        slot, third, cond = HALO_STEPS[step]             # cond: the block fetched next is the first of the NEXT body: only if one follows
+        assert third == c.NT - 1
         if not cond:
             return add64(S_X[slot], "64")
         return cond_next() + [Op("s_cselect_b32 s%d, 64, 0" % S_T2, "S")] + add64(S_X[slot], "s%d" % S_T2)
@@ -216,19 +232,19 @@ def generate(c):
     for r in range(c.NACC):
         emit("v_accvgpr_write_b32 %s, 0" % ar(r))
     for slot in (0, 1):                                                    # halo frames 0, 1 of channel block 0
-        for third in range(3):
+        for third in range(c.NT):
             for p in h_pieces(slot, third, ("H", slot, "pro")):
                 dma_issue(p)
         for o in add64(S_X[slot], "64"):
             ops.append(o)
-    for p in w_pieces(0):
+    for p in w_pieces(0):                                                  # the prologue's own fragment reads need step 0's weights
         dma_issue(p)
     for o in w_advance(0):
         ops.append(o)
     emit("s_waitcnt vmcnt(0)", "W", dict(vm=0))
     del vm[:]
     emit("s_barrier", "B")
-    for f in range(1, LEAD):                                               # the pieces a steady-state step top finds in flight
+    for f in range(1, LEAD):                                               # the pieces a steady-state body top finds in flight
         for p in w_pieces(f):
             dma_issue(p)
         for o in w_advance(f):
@@ -244,8 +260,9 @@ def generate(c):
     del pend[:]
     vm_top = list(vm)
     for s in range(BODY):
-        vm_need(("W", s + 1))
-        emit("s_barrier", "B", dict(step=s))
+        if s % c.BAR == 0:
+            vm_need(("W", s + c.BAR))      # every step whose fragment reads are issued before the next barrier
+            emit("s_barrier", "B", dict(step=s))
         # fillers by MFMA index
         fill = [[] for _ in range(c.NM)]
         for i in range(NB):
@@ -254,9 +271,8 @@ def generate(c):
         for j in range(c.NBJ - 1):
             fill[8 * j + 9].append(("b", s + 1, j))
         pieces = [("w", p) for p in w_pieces(s + LEAD)]
-        tap = s % TAPS
-        if tap in HALO_STEPS:
-            slot, third = HALO_STEPS[tap]
+        if s in HALO_STEPS:
+            slot, third = HALO_STEPS[s][:2]
             pieces += [("h", p) for p in h_pieces(slot, third, ("H", slot, s))]
         gap = c.NM // max(len(pieces), 4)
         for n, (kind, p) in enumerate(pieces):
@@ -264,7 +280,7 @@ def generate(c):
             fill[4 + n * gap].append(("dma", p[1]))
             if kind == "w" and n == c.NWP - 1:
                 fill[4 + n * gap].append(("salu", w_advance(s + LEAD)))
-            if kind == "h" and n == len(pieces) - 1 and HALO_STEPS[tap][1] == 2:
+            if kind == "h" and n == len(pieces) - 1 and HALO_STEPS[s][1] == c.NT - 1:
                 fill[4 + n * gap].append(("salu", h_advance(s)))
         m = 0
         for j in range(c.NBJ):
@@ -292,9 +308,13 @@ def generate(c):
     emit("s_waitcnt vmcnt(0) lgkmcnt(0)", "W", dict(vm=0, lgkm=0))
     emit("s_nop 15")
     emit("s_nop 15")
-    # the in-flight piece tags at the back edge must be the prologue's (same vmcnt immediates on both entries)
-    norm = lambda tags: [(t[0], t[1] % BODY) for t in tags]
-    assert norm(vm) == norm(vm_top), (vm, vm_top)
+    # both entries of the body (prologue, back edge) must find the same pieces in flight BEHIND the ones its first wait retires
+    # (older pieces -- the last halo refill of the previous body -- are retired by that wait on either path): same vmcnt immediates
+    def behind_first_wait(tags):
+        norm = [(t[0], t[1] % BODY) if t[0] == "W" else t for t in tags]
+        last = len(norm) - 1 - norm[::-1].index(("W", c.BAR))
+        return norm[last + 1:]
+    assert behind_first_wait(vm) == behind_first_wait(vm_top), (vm, vm_top)
     return ops
 
 
@@ -311,19 +331,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
     args = ap.parse_args()
-    for nbj in (8, 4):
-        c = Cfg(nbj)
-        with open(os.path.join(args.out, "convsw_body_n%d.inc" % c.BN), "w") as f:
-            f.write("// GENERATED by tools/gen_conv_sw_asm.py -- do not edit.  Sliding-window CausalConv3d K loop: 16 x 16 voxel brick x %d "
-                    "channels, two 32-channel blocks x 27 taps per body.\n" % c.BN)
-            for ln in body_lines(c):
-                f.write('"%s\\n"\n' % ln)
+    for up in (False, True):
+        for nbj in (8, 4):
+            c = Cfg(nbj, up)
+            with open(os.path.join(args.out, "convsw%s_body_n%d.inc" % ("u" if up else "", c.BN)), "w") as f:
+                f.write("// GENERATED by tools/gen_conv_sw_asm.py -- do not edit.  Sliding-window CausalConv3d K loop%s: 16 x 16 voxel brick x "
+                        "%d channels, two 32-channel blocks x 27 taps per body.\n" % (" (nearest 2x upsample folded in)" if up else "", c.BN))
+                for ln in body_lines(c):
+                    f.write('"%s\\n"\n' % ln)
     with open(os.path.join(args.out, "convsw_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_conv_sw_asm.py -- do not edit.\n")
-        f.write("#define OSKSW_SLOT %d\n#define OSKSW_HALO %d\n#define OSKSW_NS %d\n" % (SLOT, HALO, NS))
-        for nbj in (8, 4):
+        for up in (False, True):
+            for nbj in (8, 4):
+                c = Cfg(nbj, up)
+                P = "OSKSW%s%d" % ("U" if up else "", c.BN)
+                f.write("#define %s_SMEM %d\n#define %s_SLOT %d\n" % (P, c.SMEM, P, c.SLOT))
+        for nbj in (8, 4):                       # the register footprint does not depend on the halo geometry
             c = Cfg(nbj)
-            f.write("#define OSKSW%d_SMEM %d\n#define OSKSW%d_CLOBBERS %s\n" % (c.BN, c.SMEM, c.BN, ", ".join(clobbers(c))))
+            f.write("#define OSKSW%d_CLOBBERS %s\n" % (c.BN, ", ".join(clobbers(c))))
 
 
 if __name__ == "__main__":
