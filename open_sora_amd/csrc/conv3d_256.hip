@@ -32,6 +32,16 @@ OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) 
 //     algorithmic bytes); the in-plane halo of a 16 x 16 brick is 27 % instead of 200 % of a one-row tile's.
 OSK_DEV int tile_row_to_voxel(const ConvParams& p, int bm, int r) {
   if (!p.brick) return bm * 256 + r;
+  if (p.brick == 2) {   // 512-row tiles (convsw2_kernel): the 16 x 16 brick of the frame PAIR (2 tp, 2 tp + 1), pair index fastest;
+    const int ntp = (p.To + 1) >> 1;                 // rows 256.. are the second frame (beyond To for the last pair of an odd To:
+    const int tp = bm % ntp, sb = bm / ntp;          // "row >= M", which every caller masks)
+    const int t = 2 * tp + (r >> 8);
+    if (t >= p.To) return p.M;
+    const int nwb = p.Wo >> 4, nhb = p.Ho >> 4;
+    const int wb = sb % nwb, q = sb / nwb;
+    const int hb = q % nhb, b = q / nhb;
+    return ((b * p.To + t) * p.Ho + hb * 16 + ((r >> 4) & 15)) * p.Wo + wb * 16 + (r & 15);
+  }
   const int t = bm % p.To, sb = bm / p.To;
   const int nwb = p.Wo >> 4, nhb = p.Ho >> 4;
   const int wb = sb % nwb, q = sb / nwb;
@@ -370,7 +380,11 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   const unsigned yb = lds_base + (unsigned)((wn * WTN + l15) * 64 + ((q4 ^ ((l15 >> 1) & 3)) << 4));
   // the last halo piece of a slot: block 20 of 21 (every wave) / block min(4 + wave, 6) of 7
   const unsigned dst = rfl(lds_base + wave * 1024), dst5 = rfl(lds_base + (UP ? (4 + wave < 6 ? 4 + wave : 6) : 20) * 1024);
+#ifdef OSK_CONV_EXP_ONEBODY   // timing experiments only (tools/make_conv_exp_libs.sh): WRONG RESULTS
+  const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = 1;
+#else
   const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = rfl((unsigned)p.Cin / 64);
+#endif
   const int sub = lane >> 2, pos = lane & 3;                     // an LDS-DMA piece = 16 rows of 64 bytes: lane -> (row, position)
 
   for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
@@ -419,7 +433,7 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   }
   // ---- frame slot dt holds the source frame of conv-input frame max(t + dt - 2, 0) (causal padding = replicate the first frame;
   // under the time upsample conv-input frame tu > 0 is source frame 1 + (tu - 1) / 2, frame 0 stays single)
-  uint64_t xb[3];
+  uint64_t xb[4];
 #pragma unroll
   for (int dt = 0; dt < 3; ++dt) {
     int tu = t + dt - 2;
@@ -427,11 +441,12 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
     const int fs = p.up_t ? (tu == 0 ? 0 : 1 + ((tu - 1) >> 1)) : tu;
     xb[dt] = rfl64((uint64_t)(uintptr_t)(p.x + ((int64_t)b * p.T + fs) * p.H * p.W * p.Cin));
   }
+  xb[3] = xb[2];                                                   // (the two-frame form's fourth slot: unused here)
   const uint64_t wbase = rfl64((uint64_t)(uintptr_t)p.w);
 #define OSKSW_OPERANDS                                                                                                       \
   ::"v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(yb), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(hoff[0]),       \
       "v"(hoff[1]), "v"(hoff[2]), "v"(hoff[3]), "v"(hoff[4]), "v"(hoff[5]), "s"(wbase), "s"(xb[0]), "s"(xb[1]), "s"(xb[2]),  \
-      "s"(cin2), "s"(nbody), "s"(dst), "s"(dst), "s"(dst5)
+      "s"(xb[3]), "s"(cin2), "s"(nbody), "s"(dst), "s"(dst), "s"(dst5)
   if constexpr (NBJ == 8 && !UP) {
     asm volatile(
 #include "convsw_body_n256.inc"
@@ -449,7 +464,81 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
 #include "convswu_body_n128.inc"
         OSKSW_OPERANDS : OSKSW128_CLOBBERS);
   }
+#ifndef OSK_CONV_EXP_NOEPI
   epilogue_all_x<NBJ>(p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
+#endif
+  }   // tile loop
+}
+
+// Two-frame form for Cout == 128 (plain geometry): the tile is the 16 x 16 brick of TWO consecutive output frames x all 128
+// channels = 512 voxels; wave = (frame f = wave >> 1, brick half = wave & 1) with a 128 x 128 wave tile (the 256-wide form's 64
+// accumulator tiles), four frame slots in LDS (frame f's taps read slots f .. f + 2).  Per 512 voxels ONE prologue / epilogue
+// ramp and one pass of the weights instead of two, 16 fragment reads per 64 MFMAs instead of 12 per 32: the 128-channel layers at
+// full resolution (a third of the VAE's conv FLOPs) lost 37 % of their time to per-tile fixed costs in the one-frame form.
+__global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
+  constexpr int NBJ = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = wave >> 1, half = wave & 1;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int nwb = p.Wo >> 4, nhb = p.Ho >> 4, ntp = (p.To + 1) >> 1;
+  const int ntiles = p.B * ntp * nhb * nwb;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned xa[3];
+#pragma unroll
+  for (int dw = 0; dw < 3; ++dw)
+    xa[dw] = lds_base + (unsigned)(fr * OSKSWF128_SLOT + (144 * half + l15) * 64 + ((q4 ^ (((l15 + dw) >> 1) & 3)) << 4));
+  const unsigned yb = lds_base + (unsigned)(l15 * 64 + ((q4 ^ ((l15 >> 1) & 3)) << 4));
+  const unsigned dst = rfl(lds_base + wave * 1024), dst5 = rfl(lds_base + 20 * 1024);
+#ifdef OSK_CONV_EXP_ONEBODY
+  const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = 1;
+#else
+  const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = rfl((unsigned)p.Cin / 64);
+#endif
+  const int sub = lane >> 2, pos = lane & 3;
+
+  for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
+  const int bm = xcd_remap(it, ntiles);
+  const int tp = bm % ntp, sb = bm / ntp;                          // tile_row_to_voxel()'s brick = 2 order
+  const int wb = sb % nwb, qq = sb / nwb;
+  const int hb = qq % nhb, b = qq / nhb;
+  __syncthreads();
+  unsigned woff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                                    // 8 pieces cover the 128 weight rows: two per wave
+    const int nl = 16 * (4 * (k & 1) + wave) + sub;
+    const int n = nl < p.Cout ? nl : p.Cout - 1;
+    woff[k] = (unsigned)(((int64_t)n * p.wrs + (pos ^ ((nl >> 1) & 3)) * 8) * 2);
+  }
+  unsigned hoff[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int q = 4 * k + wave;
+    q = q < 20 ? q : 20;
+    int v = 16 * q + sub;
+    v = v < 323 ? v : 323;
+    const int hh = v / 18, ww = v - hh * 18;
+    int hs = hb * 16 - 1 + hh, ws = wb * 16 - 1 + ww;
+    hs = hs < 0 ? 0 : (hs > p.H - 1 ? p.H - 1 : hs);
+    ws = ws < 0 ? 0 : (ws > p.W - 1 ? p.W - 1 : ws);
+    hoff[k] = (unsigned)((((int64_t)hs * p.W + ws) * p.Cin + (pos ^ ((ww >> 1) & 3)) * 8) * 2);
+  }
+  uint64_t xb[4];                                                  // slot d = input frame clamp(2 tp + d - 2) (the last one exists
+#pragma unroll                                                     // only if the pair's second frame does: clamped to T - 1 otherwise)
+  for (int d = 0; d < 4; ++d) {
+    int fs = 2 * tp + d - 2;
+    fs = fs < 0 ? 0 : (fs > p.T - 1 ? p.T - 1 : fs);
+    xb[d] = rfl64((uint64_t)(uintptr_t)(p.x + ((int64_t)b * p.T + fs) * p.H * p.W * p.Cin));
+  }
+  const uint64_t wbase = rfl64((uint64_t)(uintptr_t)p.w);
+  asm volatile(
+#include "convswf_body_n128.inc"
+      OSKSW_OPERANDS : OSKSW256_CLOBBERS);
+#ifndef OSK_CONV_EXP_NOEPI
+  epilogue_all_x<NBJ>(p, bm, wave * 128, 0, 0, l15, q4, smem);
+#endif
   }   // tile loop
 }
 
@@ -479,6 +568,15 @@ int launch_sw(const ConvParams& p0, hipStream_t st) {
   OSK_ENSURE_MAX_SMEM((convsw_kernel<NBJ, UP>), SMEM);
   const int nblk = (p.M / 256) * ((p.Cout + BN - 1) / BN);
   hipLaunchKernelGGL((convsw_kernel<NBJ, UP>), dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
+  return (int)hipGetLastError();
+}
+
+int launch_sw2(const ConvParams& p0, hipStream_t st) {
+  ConvParams p = p0;
+  p.brick = 2;
+  OSK_ENSURE_MAX_SMEM(convsw2_kernel, OSKSWF128_SMEM);
+  const int nblk = p.B * ((p.To + 1) / 2) * (p.Ho / 16) * (p.Wo / 16);
+  hipLaunchKernelGGL(convsw2_kernel, dim3(persistent_grid(nblk)), dim3(256), OSKSWF128_SMEM, st, p);
   return (int)hipGetLastError();
 }
 
@@ -514,6 +612,9 @@ int launch_conv256(const ConvParams& p0, hipStream_t st) {
 #ifndef OSK_CONV_NO_SW   // (A/B builds of tools/: -DOSK_CONV_NO_SW keeps every layer on the implicit-GEMM kernel)
   if (convsw_supported(p)) {
     if (p.up_hw) return p.Cout >= 256 ? launch_sw<8, true>(p, st) : launch_sw<4, true>(p, st);
+#ifndef OSK_CONV_NO_SW2
+    if (p.Cout == 128 && p.To >= 2) return launch_sw2(p, st);
+#endif
     return p.Cout >= 256 ? launch_sw<8, false>(p, st) : launch_sw<4, false>(p, st);
   }
 #endif

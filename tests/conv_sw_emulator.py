@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_conv_sw_asm as G  # noqa: E402
 
 WBASE = 1 << 41
-XBASE = [(1 << 40) + d * (1 << 36) for d in range(3)]
+XBASE = [(1 << 40) + d * (1 << 36) for d in range(4)]
 M32, M64 = (1 << 32) - 1, (1 << 64) - 1
 
 
@@ -106,19 +106,19 @@ def run_stream(ops, on_op, scal):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-def check_schedule(nbj, cin, wave=0, up=False):
-    c = G.Cfg(nbj, up)
+def check_schedule(nbj, cin, wave=0, up=False, f2=False):
+    c = G.Cfg(nbj, up, f2)
     ops = G.generate(c)
     ncb = cin // 32
-    scal = Scalars(dict(wbase=WBASE, xb0=XBASE[0], xb1=XBASE[1], xb2=XBASE[2], cin2=2 * cin, nbody=cin // 64,
+    scal = Scalars(dict(wbase=WBASE, xb0=XBASE[0], xb1=XBASE[1], xb2=XBASE[2], xb3=XBASE[3], cin2=2 * cin, nbody=cin // 64,
                         wdst=wave * 1024, hdst=wave * 1024, hdst5=min(4 + wave, 6) * 1024 if up else 20 * 1024))
     st = dict(epoch=0, m0_fresh=False)
     reads, lg = [], []                 # every ds_read record; indices still in flight (in order)
     dmas, vmq = [], []
-    content = {("H", d): None for d in range(3)}
+    content = {("H", d): None for d in range(c.NSLOT)}
     content.update({("W", k): None for k in range(c.NS)})
     dirty = {r: False for r in content}     # a multi-step refill (halo slot) is in progress
-    hpieces = {d: set() for d in range(3)}
+    hpieces = {d: set() for d in range(c.NSLOT)}
     reg_sym, reg_read = {}, {}
     acc = {}
     blocks = {}                        # region -> set of 1-KiB blocks this wave's pieces covered in the current refill
@@ -141,9 +141,9 @@ def check_schedule(nbj, cin, wave=0, up=False):
             rel = scal.m0 - base - region[1] * size
             assert 0 <= rel < size and rel % 1024 == 0, ("M0 outside its region", o.text, scal.m0, region)
             for r in reads:                                     # WAR: every earlier read of the region retired before the last barrier
-                if r["region"] == region and not r.get("cleared"):
+                if region in r["regions"] and region not in r["cleared"]:
                     assert r.get("retired") is not None and r["retired"] < st["epoch"], ("LDS-DMA into a region a wave may still read", o.text, r)
-                    r["cleared"] = True
+                    r["cleared"].add(region)
             if region[0] == "W":
                 off = scal.pair(G.S_WB) - WBASE
                 tap, rem = divmod(off, 2 * cin)
@@ -155,7 +155,7 @@ def check_schedule(nbj, cin, wave=0, up=False):
             else:
                 off = scal.pair(G.S_X[region[1]]) - XBASE[region[1]]
                 assert off % 64 == 0 and 0 <= off // 64 < ncb, ("halo pointer out of range", off)
-                sym = (off // 64, region[1])
+                sym = (off // 64, "frame")
                 k = o.meta["piece"]
                 if not hpieces[region[1]]:
                     dirty[region] = True
@@ -164,22 +164,28 @@ def check_schedule(nbj, cin, wave=0, up=False):
             vmq.append(len(dmas) - 1)
             content[region] = None if region[0] == "H" else content[region]
         elif o.kind == "R":
-            region = o.meta["region"]
-            pend_fill = [d for d in dmas if d["region"] == region and not d.get("done")]
-            for d in pend_fill:
-                assert d["landed"] is not None and d["landed"] < st["epoch"], ("fragment read of a region whose fill is not published", o.text, d)
-            # publish: the region's content is what its last complete refill carried
-            if pend_fill:
-                syms = {d["sym"] for d in pend_fill}
-                assert len(syms) == 1, ("mixed contents", region, syms)
-                if region[0] == "H":
-                    assert hpieces[region[1]] == set(range(2 * c.NT)), ("halo slot read while its refill is incomplete", region, hpieces[region[1]])
-                    hpieces[region[1]] = set()
-                    dirty[region] = False
-                content[region] = syms.pop()
+            # the regions some wave reads with this instruction: in the two-frame form the second frame's waves read slot dt + 1
+            regions = [("H", d) for d in o.meta["slots"]] if o.meta["region"][0] == "H" else [o.meta["region"]]
+            for region in regions:
+                pend_fill = [d for d in dmas if d["region"] == region and not d.get("done")]
                 for d in pend_fill:
-                    d["done"] = True
-            assert not dirty[region], ("halo slot read during its refill", o.text)
+                    assert d["landed"] is not None and d["landed"] < st["epoch"], ("fragment read of a region whose fill is not published", o.text, d)
+                if pend_fill:      # publish: the region's content is what its last complete refill carried
+                    syms = {d["sym"] for d in pend_fill}
+                    assert len(syms) == 1, ("mixed contents", region, syms)
+                    if region[0] == "H":
+                        assert hpieces[region[1]] == set(range(2 * c.NT)), ("halo slot read while its refill is incomplete", region, hpieces[region[1]])
+                        hpieces[region[1]] = set()
+                        dirty[region] = False
+                    content[region] = syms.pop()
+                    for d in pend_fill:
+                        d["done"] = True
+                assert not dirty[region], ("halo slot read during its refill", o.text)
+            region = regions[0]
+            if len(regions) == 2:      # both frames' waves must see the same channel block
+                assert content[regions[0]] is None or content[regions[1]] is None or content[regions[0]][0] == content[regions[1]][0], \
+                    ("the two frames read different channel blocks", o.text, content[regions[0]], content[regions[1]])
+                assert (content[regions[0]] is None) == (content[regions[1]] is None), o.text
             sym = content[region]
             dst = o.meta["dst"]
             if o.meta["frag"][0] == "A":
@@ -201,7 +207,7 @@ def check_schedule(nbj, cin, wave=0, up=False):
                 j = o.meta["frag"][1]
                 assert dst == c.VB + 4 * j
                 reg_sym[dst] = None if sym is None else ("B", sym[0], sym[1], j)
-            reads.append(dict(region=region, dst=dst, issued=st["epoch"], retired=None))
+            reads.append(dict(regions=regions, dst=dst, issued=st["epoch"], retired=None, cleared=set()))
             lg.append(len(reads) - 1)
             reg_read[dst] = len(reads) - 1
         elif o.kind == "M":
@@ -223,9 +229,9 @@ def check_schedule(nbj, cin, wave=0, up=False):
     return dict(instructions=len(ops), reads=len(reads), pieces=len(dmas), barriers=st["epoch"])
 
 
-def piece_coverage(nbj, up=False):
+def piece_coverage(nbj, up=False, f2=False):
     """the pieces the four waves issue for one refill cover every 1-KiB block of the stage / frame slot"""
-    c = G.Cfg(nbj, up)
+    c = G.Cfg(nbj, up, f2)
     w = sorted({4 * k + wv for k in range(c.NWP) for wv in range(4)})
     h = sorted({min(4 * k + wv, c.NPIECE - 1) for k in range(2 * c.NT) for wv in range(4)})
     return w == list(range(c.W_STAGE // 1024)), h == list(range(c.NPIECE))
@@ -238,6 +244,37 @@ def up_key(ww):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+def wrapper_operands_f2(wave, geom, tile):
+    """convsw2_kernel's operands: tile = (frame pair tp, brick row, brick column, 0); wave = (frame, brick half)"""
+    T, H, W, Cin, Cout, wrs = geom
+    tp, hb, wb, _ = tile
+    lane = np.arange(64)
+    q4, l15 = lane >> 4, lane & 15
+    fr, half = wave >> 1, wave & 1
+    sub, pos = lane >> 2, lane & 3
+    op = {}
+    slot = G.Cfg(8, f2=True).SLOT
+    for dw in range(3):
+        op["xa%d" % dw] = fr * slot + (144 * half + l15) * 64 + ((q4 ^ (((l15 + dw) >> 1) & 3)) << 4)
+    op["yb"] = l15 * 64 + ((q4 ^ ((l15 >> 1) & 3)) << 4)
+    for k in range(4):
+        nl = 16 * (4 * (k & 1) + wave) + sub
+        n = np.minimum(nl, Cout - 1)
+        op["woff%d" % k] = (n * wrs + (pos ^ ((nl >> 1) & 3)) * 8) * 2
+    for k in range(6):
+        q = min(4 * k + wave, 20)
+        v = np.minimum(16 * q + sub, 323)
+        hh, ww = v // 18, v % 18
+        hs = np.clip(hb * 16 - 1 + hh, 0, H - 1)
+        ws = np.clip(wb * 16 - 1 + ww, 0, W - 1)
+        op["hoff%d" % k] = ((hs * W + ws) * Cin + (pos ^ ((ww >> 1) & 3)) * 8) * 2
+    for d in range(4):
+        fs = min(max(2 * tp + d - 2, 0), T - 1)
+        op["xb%d" % d] = XBASE[0] + fs * H * W * Cin * 2
+    op.update(wbase=WBASE, cin2=2 * Cin, nbody=Cin // 64, wdst=wave * 1024, hdst=wave * 1024, hdst5=20 * 1024)
+    return op
+
+
 def wrapper_operands(nbj, wave, geom, tile, up=(False, False)):
     """per-lane / per-wave asm operands of convsw_kernel<NBJ, UP> for one tile -- the C++ formulas, re-stated.
     geom = SOURCE dims (T, H, W, Cin, Cout, wrs); up = (up_t, up_hw); tile = (output frame, brick row, brick column, n0)"""
@@ -280,6 +317,7 @@ def wrapper_operands(nbj, wave, geom, tile, up=(False, False)):
         tu = max(t + dt - 2, 0)
         fs = (0 if tu == 0 else 1 + ((tu - 1) >> 1)) if up_t else tu
         op["xb%d" % dt] = XBASE[0] + fs * H * W * Cin * 2          # one tensor: frame fs of batch item 0
+    op["xb3"] = op["xb2"]
     op.update(wbase=WBASE, cin2=2 * Cin, nbody=Cin // 64, wdst=wave * 1024, hdst=wave * 1024,
               hdst5=(min(4 + wave, 6) if up_hw else 20) * 1024)
     return op
@@ -292,15 +330,16 @@ def _bf16_pairs(u32):
     return np.stack([lo, hi], axis=-1).reshape(*u32.shape[:-1], -1)
 
 
-def emulate_tile(nbj, x_bits, w_bits, geom, tile, up=(False, False)):
-    """x_bits [T, H, W, Cin] uint16, w_bits [Cout, wrs] uint16 -> out [256 tile rows, 32 nbj channels] float32 (no bias)"""
-    c = G.Cfg(nbj, up[1])
+def emulate_tile(nbj, x_bits, w_bits, geom, tile, up=(False, False), f2=False):
+    """x_bits [T, H, W, Cin] uint16, w_bits [Cout, wrs] uint16 -> out [256 tile rows, 32 nbj channels] float32 (no bias);
+    f2: the two-frame form, out [512 rows = (frame, brick row, brick column), 128 channels]"""
+    c = G.Cfg(nbj, up[1], f2)
     ops = G.generate(c)
     xb, wbts = x_bits.reshape(-1).view(np.uint8), w_bits.reshape(-1).view(np.uint8)
     lds = np.zeros(c.SMEM, np.uint8)
     waves = []
     for wv in range(4):
-        opv = wrapper_operands(nbj, wv, geom, tile, up)
+        opv = wrapper_operands_f2(wv, geom, tile) if f2 else wrapper_operands(nbj, wv, geom, tile, up)
         waves.append(dict(op=opv, scal=Scalars({k: int(v) for k, v in opv.items() if np.ndim(v) == 0}),
                           v=np.zeros((256, 64), np.uint32), a=np.zeros((256, 64), np.float32)))
     lane = np.arange(64)
@@ -374,9 +413,9 @@ def emulate_tile(nbj, x_bits, w_bits, geom, tile, up=(False, False)):
                 else:
                     assert o.text.startswith("s_nop"), o.text
         pc += 1
-    out = np.zeros((256, 32 * nbj), np.float32)
+    out = np.zeros((512 if f2 else 256, 128 if f2 else 32 * nbj), np.float32)
     for wv, wd in enumerate(waves):
-        wm, wn = wv >> 1, wv & 1
+        wm, wn = (wv, 0) if f2 else (wv >> 1, wv & 1)
         for j in range(nbj):
             for i in range(G.NB):
                 for e in range(4):

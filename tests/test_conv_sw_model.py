@@ -18,10 +18,18 @@ def test_schedule_is_hazard_free_and_complete(nbj, cin, up):
         assert r["barriers"] == 1 + (54 // E.G.Cfg(nbj).BAR) * (cin // 64)
 
 
+@pytest.mark.parametrize("cin", [64, 128, 256])
+def test_two_frame_schedule_is_hazard_free_and_complete(cin):
+    for wave in (0, 3):
+        r = E.check_schedule(8, cin, wave, f2=True)
+        assert r["barriers"] == 1 + 54 * (cin // 64)
+
+
 @pytest.mark.parametrize("up", [False, True])
 @pytest.mark.parametrize("nbj", [8, 4])
 def test_pieces_of_the_four_waves_cover_a_stage_and_a_frame_slot(nbj, up):
     assert E.piece_coverage(nbj, up) == (True, True)
+    assert E.piece_coverage(8, f2=True) == (True, True)
 
 
 def test_lds_budget():
@@ -78,3 +86,20 @@ def test_generated_stream_computes_the_convolution(nbj, cin, cout, tile, up):
     ref = E.reference_tile(x, w, geom, tile, ncols, up)
     err = np.abs(got[:, :ncols] - ref).max()
     assert err <= 2e-4 * max(1.0, np.abs(ref).max()), err
+
+
+@pytest.mark.parametrize("cin,tile", [
+    (64, (0, 0, 0, 0)),       # frames 0, 1: slots 0, 1 hold frame 0 twice (causal clamp); corner brick
+    (128, (1, 1, 2, 0)),      # frames 2, 3, two body iterations, right-edge brick
+    (64, (2, 2, 1, 0)),       # last pair of an odd T = 5: frame 4 + a frame that does not exist (its rows are never stored)
+])
+def test_two_frame_stream_computes_the_convolution(cin, tile):
+    x, w, xb, wb, geom = _case(5, 5, 48, 48, cin, 128)
+    got = E.emulate_tile(8, xb, wb, geom, tile, f2=True)
+    for f in range(2):
+        t = 2 * tile[0] + f
+        if t >= 5:
+            continue
+        ref = E.reference_tile(x, w, geom, (t, tile[1], tile[2], 0), 128)
+        err = np.abs(got[256 * f: 256 * f + 256] - ref).max()
+        assert err <= 2e-4 * max(1.0, np.abs(ref).max()), (f, err)

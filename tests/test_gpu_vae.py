@@ -67,10 +67,12 @@ CONV_CASES = [
     (256, 256, 3, (1, 1, 1), (True, True), 1, 2, 7, 9, False),       # upsample T,H,W folded into the gather
     (128, 384, 3, (1, 1, 1), (False, True), 1, 2, 8, 8, False),      # H,W upsample only, ragged N for the 256-wide tile
     # stride 1, no upsample, whole 16 x 16 bricks, Cin % 128 == 0: the sliding-window kernel (convsw_kernel, halo brick in LDS)
-    (128, 128, 3, (1, 1, 1), (False, False), 1, 3, 32, 48, True),    # 128-wide tile, 2 body iterations, corner / edge / interior bricks
+    (128, 128, 3, (1, 1, 1), (False, False), 1, 3, 32, 48, True),    # Cout == 128: two-frame tiles, odd T (the last pair has one frame), all brick kinds
     (256, 256, 3, (1, 1, 1), (False, False), 2, 2, 16, 32, False),   # 256-wide tile, two batch items, 4 body iterations
     (128, 384, 3, (1, 1, 1), (False, False), 1, 4, 16, 16, True),    # one brick per frame (every side clamps), ragged N (256 + 128)
-    (512, 128, 3, (1, 1, 1), (False, False), 1, 1, 16, 16, False),   # single frame: all three frame slots hold frame 0; 8 iterations
+    (512, 128, 3, (1, 1, 1), (False, False), 1, 1, 16, 16, False),   # single frame (one-frame 128-wide form): all three slots hold frame 0
+    (128, 192, 3, (1, 1, 1), (False, False), 1, 2, 16, 16, False),   # 128 < Cout < 256: the one-frame 128-wide form, ragged second N tile
+    (256, 128, 3, (1, 1, 1), (False, False), 2, 4, 16, 16, True),    # Cout == 128: the two-frame form (convsw2_kernel), even T, two batch items
     # the same kernel with the decoder's upsample folded into the halo (10 x 10 source patch per frame slot)
     (256, 256, 3, (1, 1, 1), (True, True), 1, 2, 8, 16, False),      # T, H, W upsample: 3 output frames of 16 x 32
     (128, 128, 3, (1, 1, 1), (False, True), 2, 2, 16, 8, True),      # H, W only, 128-wide tile, residual, two batch items

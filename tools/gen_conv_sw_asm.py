@@ -41,9 +41,11 @@ BODY = 2 * TAPS             # steps per loop body (two channel blocks)
 # body step at which the refill of a halo frame slot starts (three steps, two pieces per wave each): right behind the first
 # barrier after the slot's last reader (tap 9 slot + 8 of either block) has retired its fragment reads
 REFILL_START = {1: {0: 2, 9: 0, 18: 1, 27: 2, 36: 0, 45: 1}, 2: {0: 2, 10: 0, 18: 1, 28: 2, 36: 0, 46: 1}}
+# two-frame form (4 frame slots; the second frame's waves read slot dt + 1 where the first frame's read slot dt)
+REFILL_START_F2 = {0: 2, 3: 3, 9: 0, 18: 1, 27: 2, 30: 3, 36: 0, 45: 1}
 
 V_OPERANDS = ["xa0", "xa1", "xa2", "yb", "woff0", "woff1", "woff2", "woff3", "hoff0", "hoff1", "hoff2", "hoff3", "hoff4", "hoff5"]
-S_OPERANDS = ["wbase", "xb0", "xb1", "xb2", "cin2", "nbody", "wdst", "hdst", "hdst5"]
+S_OPERANDS = ["wbase", "xb0", "xb1", "xb2", "xb3", "cin2", "nbody", "wdst", "hdst", "hdst5"]
 OPERANDS = V_OPERANDS + S_OPERANDS
 OPN = {n: "%%%d" % i for i, n in enumerate(OPERANDS)}
 
@@ -53,8 +55,9 @@ S_CIN2, S_NBODY, S_IT = 48, 49, 50
 S_WDST, S_HDST, S_HDST5 = 51, 52, 53
 S_WRAP, S_WRAPL = 54, 56                         # 64-bit: 64 - 26 cin2 (next block, tap 0) / -26 cin2 (same block, tap 0)
 S_TMP, S_T2, S_T3 = 58, 59, 60
-S_FIRST, S_LAST = 40, 61
-S_X = [S_X0, S_X1, S_X2]
+S_X3 = 62
+S_FIRST, S_LAST = 40, 63
+S_X = [S_X0, S_X1, S_X2, S_X3]
 
 
 def vr(b, n=1):
@@ -66,27 +69,32 @@ def ar(b, n=1):
 
 
 class Cfg:
-    def __init__(self, nbj, up=False):
+    def __init__(self, nbj, up=False, f2=False):
         self.NBJ = nbj
         self.UP = up                              # the decoder's nearest 2x (H, W) upsample folded into the halo (see a_offset)
-        self.BN = 32 * nbj                        # output channels per workgroup tile
+        # F2: the tile is the 16 x 16 brick of TWO consecutive output frames x 128 channels: waves (frame, brick half), each
+        # 128 voxels x 128 channels; four frame slots; per-tile fixed costs and the weight traffic are shared by 512 voxels
+        self.F2 = f2
+        assert not f2 or (nbj == 8 and not up)
+        self.NSLOT = 4 if f2 else 3
+        self.BN = 128 if f2 else 32 * nbj         # output channels per workgroup tile
         # one halo frame slot: 18 x 18 voxels padded to 21 LDS-DMA pieces; upsampled: the 10 x 10 SOURCE voxels, 7 pieces
         self.PITCH, self.SLOTV, self.NPIECE = (10, 112, 7) if up else (18, 336, 21)
         self.SLOT = self.SLOTV * 64
-        self.HALO = 3 * self.SLOT
+        self.HALO = self.NSLOT * self.SLOT
         self.NT = 1 if up else 3                  # steps per slot refill (two pieces per wave and step)
         self.BAR = 1 if nbj == 8 else 2           # steps per barrier (64 MFMAs per wave between barriers in both forms)
         self.NS = 6 if nbj == 8 else 9            # W ring stages (one step each); BODY % NS == 0: stage numbers are static
         self.LEAD = self.NS - self.BAR            # step s fetches the weights of step s + LEAD into the stage of step s + LEAD - NS,
         assert BODY % self.NS == 0                # whose last reader retired before the latest barrier (<= s - s % BAR)
         self.HALO_STEPS = {}                      # body step -> (slot, third, the pointer advance behind it is conditional)
-        for start, slot in REFILL_START[self.BAR].items():
+        for start, slot in (REFILL_START_F2 if f2 else REFILL_START[self.BAR]).items():
             for third in range(self.NT):
-                self.HALO_STEPS[start + third] = (slot, third, (slot == 2) == (start >= TAPS))
+                self.HALO_STEPS[start + third] = (slot, third, (slot >= 2) == (start >= TAPS))
         self.W_STAGE = self.BN * 64
         self.W_BASE = self.HALO
         self.SMEM = self.HALO + self.NS * self.W_STAGE
-        self.NWP = nbj // 2                       # weight LDS-DMA pieces per wave and step
+        self.NWP = self.BN // 64                  # weight LDS-DMA pieces per wave and step
         self.NM = NB * nbj                        # MFMAs per step
         self.NACC = 4 * self.NM
         self.V0 = 96
@@ -94,7 +102,7 @@ class Cfg:
         self.VB = self.V0 + 64                    # one rolling weight fragment set
         self.VY = self.VB + 4 * nbj               # weight fragment address of each ring stage (ds_read immediates are 16 bits)
         self.VN = 64 + 4 * nbj + self.NS
-        self.tag = "sw%s%d" % ("u" if up else "", self.BN)
+        self.tag = "sw%s%d" % ("u" if up else "f" if f2 else "", self.BN)
 
     def a_offset(self, tap, i):
         """immediate of activation fragment i (brick rows 8 wm + i) of tap (dt, dh, dw), and the address operand it adds to.
@@ -139,7 +147,8 @@ def generate(c):
     def a_read(step, i):       # activation fragment i of step `step` (body-relative, may be BODY = next body's step 0)
         tap = step % TAPS
         off, dw = c.a_offset(tap, i)
-        ds_read(c.VA[step % 2] + 4 * i, OPN["xa%d" % dw], off, ("A", step, i), dict(region=("H", tap // 9), step=step, frag=("A", i), off=off, dw=dw))
+        ds_read(c.VA[step % 2] + 4 * i, OPN["xa%d" % dw], off, ("A", step, i),
+                dict(region=("H", tap // 9), slots=(tap // 9, tap // 9 + 1) if c.F2 else (tap // 9,), step=step, frag=("A", i), off=off, dw=dw))
 
     def b_read(step, j):
         ds_read(c.VB + 4 * j, vr(c.VY + step % NS), j * 1024, ("B", step, j),
@@ -214,7 +223,7 @@ def generate(c):
 
     # ------------------------------------------------------------------------------------------------ prologue
     emit("s_mov_b64 s[%d:%d], %s" % (S_WB, S_WB + 1, OPN["wbase"]), "S")
-    for d in range(3):
+    for d in range(c.NSLOT):
         emit("s_mov_b64 s[%d:%d], %s" % (S_X[d], S_X[d] + 1, OPN["xb%d" % d]), "S")
     emit("s_mov_b32 s%d, %s" % (S_CIN2, OPN["cin2"]), "S")
     emit("s_mov_b32 s%d, %s" % (S_NBODY, OPN["nbody"]), "S")
@@ -331,6 +340,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
     args = ap.parse_args()
+    c = Cfg(8, f2=True)
+    with open(os.path.join(args.out, "convswf_body_n128.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_conv_sw_asm.py -- do not edit.  Sliding-window CausalConv3d K loop, two-frame form: 16 x 16 voxel "
+                "brick of 2 frames x 128 channels, two 32-channel blocks x 27 taps per body.\n")
+        for ln in body_lines(c):
+            f.write('"%s\\n"\n' % ln)
     for up in (False, True):
         for nbj in (8, 4):
             c = Cfg(nbj, up)
@@ -346,6 +361,8 @@ def main():
                 c = Cfg(nbj, up)
                 P = "OSKSW%s%d" % ("U" if up else "", c.BN)
                 f.write("#define %s_SMEM %d\n#define %s_SLOT %d\n" % (P, c.SMEM, P, c.SLOT))
+        c = Cfg(8, f2=True)
+        f.write("#define OSKSWF128_SMEM %d\n#define OSKSWF128_SLOT %d\n" % (c.SMEM, c.SLOT))
         for nbj in (8, 4):                       # the register footprint does not depend on the halo geometry
             c = Cfg(nbj)
             f.write("#define OSKSW%d_CLOBBERS %s\n" % (c.BN, ", ".join(clobbers(c))))

@@ -4,6 +4,11 @@
 set -e
 cd "$(dirname "$0")/.."
 OBJ=open_sora_amd/lib/obj; mkdir -p tools/lib
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -DOSK_CONV_NO_SW -c open_sora_amd/csrc/conv3d_256.hip -o /tmp/conv3d_256_nosw.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lib/libosk_conv_nosw.so $(ls $OBJ/*.o | grep -v "/conv3d_256.o") /tmp/conv3d_256_nosw.o
-echo built tools/lib/libosk_conv_nosw.so
+for v in NO_SW NO_SW2; do   # NO_SW2: sliding window everywhere, but the Cout == 128 layers on the one-frame 128-wide form
+  n=$(echo $v | tr 'A-Z' 'a-z' | tr -d _)
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -DOSK_CONV_$v -c open_sora_amd/csrc/conv3d_256.hip -o /tmp/conv3d_256_$n.o 2>/dev/null &
+done; wait
+for n in nosw nosw2; do
+  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lib/libosk_conv_$n.so $(ls $OBJ/*.o | grep -v "/conv3d_256.o") /tmp/conv3d_256_$n.o
+  echo built tools/lib/libosk_conv_$n.so
+done
