@@ -216,7 +216,7 @@ def vae_line(dev, T, S, steps, warmup, cpu_budget_s):
     rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "kernel_traffic.json")
     if os.path.exists(rec_path) and (T, S) == (33, 256):
         for rec in json.load(open(rec_path)):
-            if rec["kernel"].startswith("conv256"):   # the latest record wins
+            if rec["kernel"].startswith(("conv256", "convsw")):   # the latest record wins
                 traffic, traffic_src = rec["hbm_bytes_per_step"], rec["source"]
     res = {
         "metric": "vae_video_frames_per_sec (encode + decode; ms per encode+decode in ms_per_step)",
@@ -227,9 +227,10 @@ def vae_line(dev, T, S, steps, warmup, cpu_budget_s):
                    "flops_encode": enc_f, "flops_decode": dec_f},
         "step_tflops": round((enc_f + dec_f) / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round((enc_f + dec_f) / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        # all conv launches of one encode + decode: conv3d_256.hip where Cin % 128 == 0 (conv256x_kernel<8> for Cout >= 256,
-        # conv256x_kernel<4> for Cout = 128), conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers
-        "roofline": {"bound": "mfma", "kernel": "conv256x_kernel + conv3d_kernel (by layer shape)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+        # all conv launches of one encode + decode: conv3d_256.hip where Cin % 128 == 0 -- the LDS sliding-window kernels
+        # (convsw_kernel / convsw2_kernel) for the stride-1 3 x 3 x 3 layers incl. the fused-upsample ones, the implicit-GEMM
+        # conv256x_kernel for strided / 1 x 1 x 1 layers --, conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers
+        "roofline": {"bound": "mfma", "kernel": "convsw_kernel + convsw2_kernel + conv256x_kernel + conv3d_kernel (by layer shape)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_kind": "recorded (PMC passes of this command, see traffic_source)", "traffic_source": traffic_src,
                      "launches": len(prof) // args.steps, "total_conv_ms_per_step": round(conv_ms, 3)},

@@ -13,15 +13,17 @@ if [ -n "$PMC_LINEAR_CONV" ]; then   # the round-1 tile mapping of conv256t for 
   run vaelin_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
   run vaelin_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
 fi
-run dit_fetch "FETCH_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-b1
-run dit_write "WRITE_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-b1
+if [ -z "$PMC_ONLY_VAE" ]; then
+run dit_fetch "FETCH_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-b1 --no-extra
+run dit_write "WRITE_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-b1 --no-extra
+fi
 python - "$O" <<'PY' | tee $O/summary.txt
 import csv, glob, collections, sys
 for f in sorted(glob.glob(sys.argv[1] + "/*/*counter_collection.csv")):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        key = next((k for k in ("conv256x_kernel", "conv256w_kernel", "conv256t_kernel", "gemm256x_kernel", "conv256_kernel", "conv3d_kernel", "gemm256w_kernel", "gemm256p_kernel",
+        key = next((k for k in ("convsw2_kernel", "convsw_kernel", "conv256x_kernel", "conv256w_kernel", "conv256t_kernel", "gemm256x_kernel", "conv256_kernel", "conv3d_kernel", "gemm256w_kernel", "gemm256p_kernel",
                                 "gemm256_kernel", "gemm_bf16_kernel", "attn_asm72_kernel", "attn_hd512_kernel", "gn_stats",
                                 "gn_apply", "qknorm_rope", "ln_modulate", "v_transpose") if k in n), None)
         if key:
