@@ -9,6 +9,7 @@ for w in dit vae; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o $w -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-b1 --no-extra > $O/prof_$w.json 2> $O/prof_$w.err
   f=$(find $O/prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${w}_kernel_stats.csv && head -8 "$f" | cut -c1-160; rm -rf $O/prof_$w
 done
+[ -n "$SKIP_ATTN_PMC" ] && { echo "== done (attention PMC skipped)"; exit 0; }
 echo "== PMC attention (FAST body, tail split + merge), separate passes"
 P=$O/pmc_attn; mkdir -p $P; i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
