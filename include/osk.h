@@ -53,6 +53,21 @@ int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride, i
                   const void* res, const float* gate, int64_t gate_batch_stride,
                   int M, int N, int K, int gelu_from, int out_f32, void* stream);
 
+/* ---- TWO Linear layers that differ only in their operands and row count in ONE launch.
+ * replaces the img-stream / txt-stream pairs of DoubleStreamBlockProcessor (layers.py:209-215 img_attn.qkv | txt_attn.qkv,
+ * 247 img_attn.proj | 251 txt_attn.proj, 248 img_mlp | 252 txt_mlp): same N, K and epilogue kind, separate weights, inputs and
+ * outputs.  Exactly osk_gemm_bf16(first...) followed by osk_gemm_bf16(second...) with out_f32 = 0 (the two must not depend on
+ * each other); where both problems take the 256 x 256 tile kernel they are walked as one tile list, so the small text GEMM
+ * (a third of the chip for one round when launched alone) fills the last round of the image GEMM. */
+typedef struct OskGemmOperands {
+  const void* A; int64_t a_batch_stride, a_row_stride; int a_rows_per_batch;
+  const void* W; int64_t w_row_stride; const float* bias;
+  void* C; int64_t c_batch_stride, c_row_stride; int c_rows_per_batch;
+  const void* res; const float* gate; int64_t gate_batch_stride;
+  int M;
+} OskGemmOperands;
+int osk_gemm_bf16_pair(const OskGemmOperands* first, const OskGemmOperands* second, int N, int K, int gelu_from, void* stream);
+
 /* ---- FP8 (OCP e4m3fn) variant of the Linear GEMM: BASELINE configs[4] ("fp8 MFMA"); the reference itself runs its
  * nn.Linear layers (same call sites as osk_gemm_bf16) in bf16, so this is an opt-in mode.
  * osk_quantize_rows_fp8: dynamic per-row quantisation of a bf16 [M, K] activation (rows_per_batch addressing):

@@ -24,6 +24,7 @@ SIGNATURES = {
     "osk_ln_modulate_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_gemm_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
                       _i32, _i32, _i32, _i32, _i32, _vp],
+    "osk_gemm_bf16_pair": [_vp, _vp, _i32, _i32, _i32, _vp],     # two OskGemmOperands structs by pointer
     "osk_ln_modulate_fp8": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_quantize_rows_fp8": [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _i32, _vp],
     "osk_gemm_fp8": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
@@ -164,6 +165,35 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, *, res=None,
                              gate_batch_stride, B * L, N, K, N if gelu_from is None else gelu_from,
                              1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_bf16")
     return out
+
+
+class OskGemmOperands(C.Structure):
+    """include/osk.h::OskGemmOperands"""
+    _fields_ = [("A", _vp), ("a_batch_stride", _i64), ("a_row_stride", _i64), ("a_rows_per_batch", _i32),
+                ("W", _vp), ("w_row_stride", _i64), ("bias", _vp),
+                ("C", _vp), ("c_batch_stride", _i64), ("c_row_stride", _i64), ("c_rows_per_batch", _i32),
+                ("res", _vp), ("gate", _vp), ("gate_batch_stride", _i64), ("M", _i32)]
+
+
+def _gemm_operands(a, w, bias, out, res, gate, gate_batch_stride) -> OskGemmOperands:
+    B, L, K = a.shape
+    assert out.shape[0] == B and out.shape[1] == L and out.shape[2] == w.shape[0] and w.shape[1] == K
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+    if res is not None:
+        assert res.stride() == out.stride() and res.dtype == torch.bfloat16
+    return OskGemmOperands(a.data_ptr(), a.stride(0), a.stride(1), L, w.data_ptr(), w.stride(0), _p(bias), out.data_ptr(),
+                           out.stride(0), out.stride(1), L, _p(res), _p(gate), gate_batch_stride, B * L)
+
+
+def gemm_pair(first: dict, second: dict, *, gelu_from: int | None = None) -> None:
+    """two gemm() calls that share N, K and the epilogue kind in one launch (osk_gemm_bf16_pair): each dict holds gemm()'s
+    arguments a, w, bias, out and optionally res, gate, gate_batch_stride.  The img- / txt-stream Linear pairs of a double block."""
+    ops = [_gemm_operands(d["a"], d["w"], d["bias"], d["out"], d.get("res"), d.get("gate"), d.get("gate_batch_stride", 0))
+           for d in (first, second)]
+    N, K = first["w"].shape
+    assert tuple(second["w"].shape) == (N, K)
+    _check(lib.osk_gemm_bf16_pair(C.cast(C.pointer(ops[0]), C.c_void_p), C.cast(C.pointer(ops[1]), C.c_void_p), N, K, N if gelu_from is None else gelu_from,
+                                  _stream()), "osk_gemm_bf16_pair")
 
 
 def ln_modulate_fp8(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, mod_batch_stride: int, eps: float = 1e-6):

@@ -40,8 +40,16 @@ struct GeoX {
   }
 };
 
-template <bool OUT_F32>
-__global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmParams p) {
+// NP = 2: TWO problems that differ in their operands and M only (the img- and txt-stream Linear of a double block: same N, K,
+// epilogue kind) walked as ONE tile list -- problem 0's tiles, then problem 1's -- so that the small text GEMM (6 row tiles: a
+// third of the chip for one round) fills the last round of the image GEMM instead of launching alone.
+template <int NP>
+struct GemmPack {
+  GemmParams p[NP];
+};
+
+template <bool OUT_F32, int NP>
+__global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk) {
   constexpr int WT = OSKX_NB * 16, BN = 256;   // wave tile side
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -50,12 +58,17 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int q4 = lane >> 4, l15 = lane & 15;
 
-  const int nbm = (p.M + 255) / 256, nbn = (p.N + BN - 1) / BN;
-  const int ntiles = nbm * nbn;
-  const int grp = p.group > 0 ? p.group : 1;
+  const int nbn = (pk.p[0].N + BN - 1) / BN;                       // N, K, group are the pack's (equal in every problem)
+  const int nt0 = ((pk.p[0].M + 255) / 256) * nbn;
+  const int ntiles = NP == 1 ? nt0 : nt0 + ((pk.p[NP - 1].M + 255) / 256) * nbn;
+  const int grp = pk.p[0].group > 0 ? pk.p[0].group : 1;
   const int per_group = grp * nbn;
-  auto tile_of = [&](int it, int& m0, int& n0) {      // tile order of gemm256.hip / gemm256p.hip
-    const int tile = xcd_remap(it, ntiles);
+  // position in the tile list -> (problem, tile origin): tile order of gemm256.hip / gemm256p.hip inside each problem
+  auto tile_of = [&](int it, int& sel, int& m0, int& n0) {
+    int tile = xcd_remap(it, ntiles);
+    sel = (NP > 1 && tile >= nt0) ? 1 : 0;
+    tile -= sel ? nt0 : 0;
+    const int nbm = (pk.p[sel].M + 255) / 256;
     const int g = tile / per_group, r = tile - g * per_group;
     const int rows_here = nbm - g * grp < grp ? nbm - g * grp : grp;
     const int bn = r / rows_here, bm = g * grp + (r - bn * rows_here);
@@ -64,7 +77,7 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmParams p) {
   };
   // LDS-DMA sources: instruction j = wave + 4 i (i = 0..7) covers tile rows [8 j, 8 j + 8); byte offsets from the bases
   const int srow8 = lane >> 3, spos = lane & 7;
-  auto offsets = [&](int m0, int n0, unsigned* aoff, unsigned* woff) {
+  auto offsets = [&](const GemmParams& p, int m0, int n0, unsigned* aoff, unsigned* woff) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = (wave + 4 * i) * 8 + srow8;
@@ -80,10 +93,10 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmParams p) {
   };
   // a tile whose 256 A rows lie inside M and inside one batch, and whose 256 W rows lie inside N: its per-lane source
   // offsets are an affine function of (m0, n0), so the next tile's are this tile's plus a wave-uniform delta
-  auto affine = [&](int m0, int n0) {
+  auto affine = [&](const GemmParams& p, int m0, int n0) {
     return m0 + 256 <= p.M && n0 + 256 <= p.N && m0 / p.arpb == (m0 + 255) / p.arpb;
   };
-  auto a_origin = [&](int m0) -> int64_t {
+  auto a_origin = [&](const GemmParams& p, int m0) -> int64_t {
     const int b = m0 / p.arpb, l = m0 - b * p.arpb;
     return (b * p.abs_ + (int64_t)l * p.ars) * 2;
   };
@@ -92,27 +105,29 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmParams p) {
   const unsigned sz0 = (unsigned)((q4 ^ ((l15 >> 1) & 7)) << 4);
   const unsigned faA0 = lds_base + (wm * WT + l15) * 128 + sz0;
   const unsigned faW0 = lds_base + OSKX_W_BASE + (wn * WT + l15) * 128 + sz0;
-  const uint64_t abase = rfl64((uint64_t)(uintptr_t)p.A), wbase = rfl64((uint64_t)(uintptr_t)p.W);
-  const uint64_t bbase = rfl64((uint64_t)(uintptr_t)p.bias);
-  const unsigned nk = rfl((unsigned)(p.K / 64));
+  const unsigned nk = rfl((unsigned)(pk.p[0].K / 64));
   const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + OSKX_W_BASE + wave * 1024);
 
   unsigned prefetched = 0;
   for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
     const int itn = it + (int)gridDim.x;
-    int m0, n0, m0n = 0, n0n = 0;
-    tile_of(it, m0, n0);
+    int sel, m0, n0, seln = 0, m0n = 0, n0n = 0;
+    tile_of(it, sel, m0, n0);
+    const GemmParams& p = pk.p[NP == 1 ? 0 : sel];                 // wave-uniform: kernel-argument loads at a scalar offset
     bool has_next = itn < ntiles;
     unsigned dA = 0, dW = 0;
     if (has_next) {
-      tile_of(itn, m0n, n0n);
-      // cross-tile prefetch only between two affine tiles (edge tiles start with their own cold fetch)
-      has_next = affine(m0, n0) && affine(m0n, n0n);
-      dA = (unsigned)(a_origin(m0n) - a_origin(m0));
+      tile_of(itn, seln, m0n, n0n);
+      // cross-tile prefetch only between two affine tiles of the SAME problem (the deltas are relative to its bases; edge
+      // tiles and the first tile of the second problem start with their own cold fetch)
+      has_next = seln == sel && affine(p, m0, n0) && affine(p, m0n, n0n);
+      dA = (unsigned)(a_origin(p, m0n) - a_origin(p, m0));
       dW = (unsigned)(((int64_t)n0n - n0) * p.wrs * 2);
     }
+    const uint64_t abase = rfl64((uint64_t)(uintptr_t)p.A), wbase = rfl64((uint64_t)(uintptr_t)p.W);
+    const uint64_t bbase = rfl64((uint64_t)(uintptr_t)p.bias);
     unsigned aoff[8], woff[8];
-    offsets(m0, n0, aoff, woff);
+    offsets(p, m0, n0, aoff, woff);
     const int m0w = m0 + wm * WT, n0w = n0 + wn * WT;
     const bool folded = p.bias != nullptr && n0w + WT <= p.N;                 // wave-uniform
     const unsigned boff = (unsigned)((n0w + q4 * 4) * 4);
@@ -146,16 +161,21 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmParams p) {
   }
 }
 
-template <bool OUT_F32>
-int launch_one(const GemmParams& p, hipStream_t st) {
-  auto kernel = gemm256x_kernel<OUT_F32>;
-  OSK_ENSURE_MAX_SMEM(kernel, OSKX_SMEM);
+int grid_for(int ntiles) {
   int n_cu = osk_device_cus();
   n_cu -= n_cu % 8;    // the tile walk keeps a workgroup inside one XCD's range only for a grid that is a multiple of 8
   if (n_cu < 8) n_cu = 8;
+  return ntiles < n_cu ? ntiles : n_cu;   // one workgroup per CU (LDS: 128 KiB of 160)
+}
+
+template <bool OUT_F32>
+int launch_one(const GemmParams& p, hipStream_t st) {
+  auto kernel = gemm256x_kernel<OUT_F32, 1>;
+  OSK_ENSURE_MAX_SMEM(kernel, OSKX_SMEM);
+  GemmPack<1> pk;
+  pk.p[0] = p;
   const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  const int grid = ntiles < n_cu ? ntiles : n_cu;   // one workgroup per CU (LDS: 128 KiB of 160)
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), OSKX_SMEM, st, p);
+  hipLaunchKernelGGL(kernel, dim3(grid_for(ntiles)), dim3(256), OSKX_SMEM, st, pk);
   return (int)hipGetLastError();
 }
 
@@ -163,6 +183,19 @@ int launch_one(const GemmParams& p, hipStream_t st) {
 
 int launch_gemm256x(const GemmParams& p, int out_f32, hipStream_t st) {
   return out_f32 ? launch_one<true>(p, st) : launch_one<false>(p, st);
+}
+
+// two problems with equal N, K, gelu_from and group in one launch (bf16 output)
+int launch_gemm256x_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t st) {
+  auto kernel = gemm256x_kernel<false, 2>;
+  OSK_ENSURE_MAX_SMEM(kernel, OSKX_SMEM);
+  GemmPack<2> pk;
+  pk.p[0] = p0;
+  pk.p[1] = p1;
+  const int nbn = (p0.N + 255) / 256;
+  const int ntiles = ((p0.M + 255) / 256 + (p1.M + 255) / 256) * nbn;
+  hipLaunchKernelGGL(kernel, dim3(grid_for(ntiles)), dim3(256), OSKX_SMEM, st, pk);
+  return (int)hipGetLastError();
 }
 
 }  // namespace osk_gemm

@@ -173,12 +173,11 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(const GemmParams p) {
 
 }  // namespace
 
-extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride,
-                             int a_rows_per_batch, const void* W, int64_t w_row_stride,
-                             const float* bias, void* C, int64_t c_batch_stride, int64_t c_row_stride,
-                             int c_rows_per_batch, const void* res, const float* gate,
-                             int64_t gate_batch_stride, int M, int N, int K, int gelu_from,
-                             int out_f32, void* stream) {
+// argument checks of osk_gemm_bf16 + the launch parameters
+static int fill_params(GemmParams& p, const void* A, int64_t a_batch_stride, int64_t a_row_stride, int a_rows_per_batch,
+                       const void* W, int64_t w_row_stride, const float* bias, void* C, int64_t c_batch_stride,
+                       int64_t c_row_stride, int c_rows_per_batch, const void* res, const float* gate,
+                       int64_t gate_batch_stride, int M, int N, int K, int gelu_from, int out_f32) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return OSK_EINVAL;
   if (K % BK) return OSK_EINVAL;
   if (a_rows_per_batch <= 0 || c_rows_per_batch <= 0) return OSK_EINVAL;
@@ -187,7 +186,6 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) || ((uintptr_t)bias & 15)) return OSK_EINVAL;
   if (gate && (!res || ((uintptr_t)gate & 15) || (gate_batch_stride & 3) || ((uintptr_t)res & 7))) return OSK_EINVAL;
   if (out_f32 && ((uintptr_t)C & 15)) return OSK_EINVAL;   // the f32 epilogue stores float4
-  GemmParams p;
   p.A = (const unsigned short*)A; p.abs_ = a_batch_stride; p.ars = a_row_stride; p.arpb = a_rows_per_batch;
   p.W = (const unsigned short*)W; p.wrs = w_row_stride; p.bias = bias;
   p.C = C; p.cbs = c_batch_stride; p.crs = c_row_stride; p.crpb = c_rows_per_batch;
@@ -196,24 +194,76 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
   // row bands per tile group (L2 blocking of the large tiles' order; measured at the XL shapes: 8 for wide N, 4 when there
   // are only a few weight tiles)
   p.group = (N + 255) / 256 <= 6 ? 4 : 8;
+  return OSK_OK;
+}
+
+// tile choice by estimated time = rounds of the grid over the chip x time of one tile.  Per-tile throughput measured at the XL
+// shapes (MI355X, random data): 256x256 ~1.0, 256x128 ~0.78, 128x128 (this file) ~0.72 of the large tile's rate; one workgroup
+// per CU for the large tiles, two 256-thread ones for this file's kernel.  -> 2: 256 x 256, 1: 256 x 128, 0: 128 x 128
+static int tile_choice(int M, int N) {
+  auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
+  const int64_t m256 = (M + 255) / 256, m128 = (M + 127) / 128;
+  const double c256 = rounds(m256 * ((N + 255) / 256), 256) * 4.0 / 1.00;
+  const double c128 = rounds(m256 * ((N + 127) / 128), 256) * 2.0 / 0.78;
+  const double cold = rounds(m128 * ((N + 127) / 128), 512) * 1.0 / (0.5 * 0.72);  // 2 co-resident tiles share a CU
+  const bool wide = N >= 256 && c256 <= c128;
+  if (cold < (wide ? c256 : c128)) return 0;
+  return wide ? 2 : 1;
+}
+
+static bool large_tiles_ok(const GemmParams& p) {
+  const int nb = (p.M + p.arpb - 1) / p.arpb;
+  const int64_t a_span = (int64_t)(nb - 1) * p.abs_ + (int64_t)(p.arpb - 1) * p.ars + p.K;
+  const int64_t w_span = (int64_t)(p.N - 1) * p.wrs + p.K;
+  return osk_gemm::gemm256_supported(p, a_span, w_span);
+}
+
+extern "C" int osk_gemm_bf16_pair(const OskGemmOperands* a, const OskGemmOperands* b, int N, int K, int gelu_from, void* stream) {
+  if (!a || !b) return OSK_EINVAL;
+  GemmParams p[2];
+  const OskGemmOperands* o[2] = {a, b};
+  for (int i = 0; i < 2; ++i) {
+    const int rc = fill_params(p[i], o[i]->A, o[i]->a_batch_stride, o[i]->a_row_stride, o[i]->a_rows_per_batch, o[i]->W,
+                               o[i]->w_row_stride, o[i]->bias, o[i]->C, o[i]->c_batch_stride, o[i]->c_row_stride,
+                               o[i]->c_rows_per_batch, o[i]->res, o[i]->gate, o[i]->gate_batch_stride, o[i]->M, N, K, gelu_from, 0);
+    if (rc != OSK_OK) return rc;
+  }
+  // one tile list where BOTH problems take the 256 x 256 tile kernel; the larger problem first (its tiles fill whole rounds, the
+  // smaller one's the tail); otherwise exactly the two single calls
+  const int big = p[0].M >= p[1].M ? 0 : 1;
+#ifndef OSK_GEMM_NO_PAIR   // (A/B builds of tools/: always the two single calls)
+  if (large_tiles_ok(p[0]) && large_tiles_ok(p[1]) && tile_choice(p[big].M, N) == 2)   // the larger problem alone would take this kernel
+    return osk_gemm::launch_gemm256x_pair(p[big], p[big ^ 1], (hipStream_t)stream);
+#endif
+  (void)big;
+  for (int i = 0; i < 2; ++i) {
+    const int rc = osk_gemm_bf16(o[i]->A, o[i]->a_batch_stride, o[i]->a_row_stride, o[i]->a_rows_per_batch, o[i]->W, o[i]->w_row_stride,
+                                 o[i]->bias, o[i]->C, o[i]->c_batch_stride, o[i]->c_row_stride, o[i]->c_rows_per_batch, o[i]->res,
+                                 o[i]->gate, o[i]->gate_batch_stride, o[i]->M, N, K, gelu_from, 0, stream);
+    if (rc != OSK_OK) return rc;
+  }
+  return OSK_OK;
+}
+
+extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride,
+                             int a_rows_per_batch, const void* W, int64_t w_row_stride,
+                             const float* bias, void* C, int64_t c_batch_stride, int64_t c_row_stride,
+                             int c_rows_per_batch, const void* res, const float* gate,
+                             int64_t gate_batch_stride, int M, int N, int K, int gelu_from,
+                             int out_f32, void* stream) {
+  GemmParams p;
+  const int rc = fill_params(p, A, a_batch_stride, a_row_stride, a_rows_per_batch, W, w_row_stride, bias, C, c_batch_stride,
+                             c_row_stride, c_rows_per_batch, res, gate, gate_batch_stride, M, N, K, gelu_from, out_f32);
+  if (rc != OSK_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   {
     const int nb = (M + a_rows_per_batch - 1) / a_rows_per_batch;
     const int64_t a_span = (int64_t)(nb - 1) * a_batch_stride + (int64_t)(a_rows_per_batch - 1) * a_row_stride + K;
     const int64_t w_span = (int64_t)(N - 1) * w_row_stride + K;
     if (osk_gemm::gemm256_supported(p, a_span, w_span)) {
-      // tile choice by estimated time = rounds of the grid over the chip x time of one tile.  Per-tile throughput
-      // measured at the XL shapes (MI355X, random data): 256x256 ~1.0, 256x128 ~0.78, 128x128 (this file) ~0.72 of the
-      // large tile's rate; one workgroup per CU for the large tiles, two 256-thread ones for this file's kernel.
-      auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
-      const int64_t m256 = (M + 255) / 256, m128 = (M + 127) / 128;
-      const double c256 = rounds(m256 * ((N + 255) / 256), 256) * 4.0 / 1.00;
-      const double c128 = rounds(m256 * ((N + 127) / 128), 256) * 2.0 / 0.78;
-      const double cold = rounds(m128 * ((N + 127) / 128), 512) * 1.0 / (0.5 * 0.72);  // 2 co-resident tiles share a CU
-      const bool wide = N >= 256 && c256 <= c128;
-      if (!(cold < (wide ? c256 : c128)))
-        return wide ? osk_gemm::launch_gemm256x(p, out_f32, st)    // 256 x 256 tiles, 4 waves, v_mfma_f32_16x16x32_bf16
-                    : osk_gemm::launch_gemm256p(p, out_f32, st);   // 256 x 128 tiles, 8 waves, v_mfma_f32_32x32x16_bf16
+      const int kind = tile_choice(M, N);
+      if (kind == 2) return osk_gemm::launch_gemm256x(p, out_f32, st);    // 256 x 256 tiles, 4 waves, v_mfma_f32_16x16x32_bf16
+      if (kind == 1) return osk_gemm::launch_gemm256p(p, out_f32, st);    // 256 x 128 tiles, 8 waves, v_mfma_f32_32x32x16_bf16
     }
   }
   const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);

@@ -30,6 +30,8 @@ bool gemm256_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span
 int launch_gemm256p(const GemmParams& p, int out_f32, hipStream_t st);
 // gemm256x.hip: 256 x 256 tiles, 4 waves (one per SIMD, 128 x 128 wave tiles, 256 accumulator AGPRs) on v_mfma_f32_16x16x32_bf16
 int launch_gemm256x(const GemmParams& p, int out_f32, hipStream_t st);
+// the same kernel over TWO problems that share N, K, gelu_from, group (one tile list: the second problem fills the first one's last round)
+int launch_gemm256x_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t st);
 // gemm256.hip: the one-tile-per-workgroup frame on OCP e4m3 operands (A, W point at bytes; strides in elements = bytes)
 bool gemm256_fp8_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
 int launch_gemm256_fp8(const GemmParams& p, int bn, int out_f32, hipStream_t st);

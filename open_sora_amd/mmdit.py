@@ -296,6 +296,20 @@ def _linear(a, w, b, out: Tensor, **epi) -> Tensor:
     return _OPS.gemm(a, w, b, out, **epi)
 
 
+def _linear_pair(first: dict, second: dict, gelu_from: int | None = None) -> None:
+    """the same Linear kind on the img and on the txt stream (dicts of _linear's arguments a, w, bias, out [, res, gate,
+    gate_batch_stride]): one launch (osk_gemm_bf16_pair: the text GEMM fills the image GEMM's last round of tiles) for bf16
+    operands, the two single calls in fp8 mode"""
+    if all(not isinstance(d["a"], tuple) and not isinstance(d["w"], Fp8Weight) for d in (first, second)):
+        _OPS.gemm_pair(first, second, gelu_from=gelu_from)
+        return
+    for d in (first, second):
+        epi = {k: d[k] for k in ("res", "gate", "gate_batch_stride") if k in d}
+        if gelu_from is not None:
+            epi["gelu_from"] = gelu_from
+        _linear(d["a"], d["w"], d["bias"], d["out"], **epi)
+
+
 def _ln_modulate_for(w, x: Tensor, shift: Tensor, scale: Tensor, xm: Tensor, mbs: int):
     """LN + modulate of x as the input of Linear layer(s) with weight w (row slices of w included): the bf16 rows in
     xm, or -- fp8 mode, shapes the fp8 GEMM takes -- quantised on the fly (one pass, nothing written to xm)."""
@@ -572,9 +586,13 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
     acts = [_ln_modulate_for(aw.qkv_w, x_s, sh1, sc1, xm_s, mbs) for aw, x_s, xm_s, y_s, sh1, sc1 in streams]
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D:]
     scales = (plan.txt.q_scale, plan.txt.k_scale, plan.img.q_scale, plan.img.k_scale)
-    if sp is None:
+    paired = sp is None and len(streams) == 2      # both streams on this rank: their Linear layers go out in pairs
+    if paired:
+        _linear_pair(*(dict(a=act, w=aw.qkv_w, bias=aw.qkv_b, out=y_s) for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts)))
+    elif sp is None:
         for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):
             _linear(act, aw.qkv_w, aw.qkv_b, y_s)
+    if sp is None:
         _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         _joint_attention(ws, q, k, v, H, hd, plan.pv8, plan.score_bound)
     else:
@@ -586,6 +604,16 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
             _linear(act, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
         _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         sp.attention(ws, pending, q, v, H, hd)
+    if paired:   # layers.py:247-252 for both streams, Linear by Linear
+        _linear_pair(dict(a=v[:, Lt:], w=plan.img.proj_w, bias=plan.img.proj_b, out=x_img, res=x_img, gate=i_g1, gate_batch_stride=mbs),
+                     dict(a=v[:, :Lt], w=plan.txt.proj_w, bias=plan.txt.proj_b, out=x_txt, res=x_txt, gate=t_g1, gate_batch_stride=mbs))
+        (iw0, ib0, iw2, ib2), (tw0, tb0, tw2, tb2) = plan.img_mlp, plan.txt_mlp
+        a_img = _ln_modulate_for(iw0, x_img, i_sh2, i_sc2, xm_img, mbs)
+        a_txt = _ln_modulate_for(tw0, x_txt, t_sh2, t_sc2, xm_txt, mbs)
+        _linear_pair(dict(a=a_img, w=iw0, bias=ib0, out=ws.h[:, Lt:]), dict(a=a_txt, w=tw0, bias=tb0, out=ws.h[:, :Lt]), gelu_from=0)
+        _linear_pair(dict(a=ws.h[:, Lt:], w=iw2, bias=ib2, out=x_img, res=x_img, gate=i_g2, gate_batch_stride=mbs),
+                     dict(a=ws.h[:, :Lt], w=tw2, bias=tb2, out=x_txt, res=x_txt, gate=t_g2, gate_batch_stride=mbs))
+        return
     if Li:  # img stream
         _linear(v[:, Lt:], plan.img.proj_w, plan.img.proj_b, x_img, res=x_img, gate=i_g1, gate_batch_stride=mbs)
         w0, b0, w2, b2 = plan.img_mlp

@@ -74,6 +74,14 @@ def gemm(a, w, bias, out, *, res=None, gate=None, gate_batch_stride=0, gelu_from
     return out
 
 
+def gemm_pair(first, second, *, gelu_from=None):
+    """osk_gemm_bf16_pair == the two osk_gemm_bf16 calls"""
+    assert tuple(first["w"].shape) == tuple(second["w"].shape)
+    for d in (first, second):
+        gemm(d["a"], d["w"], d["bias"], d["out"], res=d.get("res"), gate=d.get("gate"), gate_batch_stride=d.get("gate_batch_stride", 0),
+             gelu_from=gelu_from)
+
+
 def ln_modulate_fp8(x, shift, scale, mod_batch_stride, eps=1e-6):
     """osk_ln_modulate_fp8 == osk_ln_modulate_bf16 followed by osk_quantize_rows_fp8 (bit-identical by construction)"""
     xm = torch.empty(x.shape, dtype=torch.bfloat16)

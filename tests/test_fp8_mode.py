@@ -29,6 +29,11 @@ class _Counting:
         self.bf16_shapes.append((a.shape[0] * a.shape[1], w.shape[0], a.shape[2]))
         return cpu_ops.gemm(a, w, bias, out, **kw)
 
+    def gemm_pair(self, first, second, *, gelu_from=None):     # bf16 mode: the img / txt Linear pairs of a double block
+        for d in (first, second):
+            self.gemm(d["a"], d["w"], d["bias"], d["out"], gelu_from=gelu_from,
+                      **{k: d[k] for k in ("res", "gate", "gate_batch_stride") if k in d})
+
     def gemm_fp8(self, *a, **kw):
         self.n_fp8 += 1
         return cpu_ops.gemm_fp8(*a, **kw)

@@ -175,6 +175,52 @@ def test_gemm_persistent_multi_tile(hip_lib, M_L, N, K, gelu_from, gated):
         assert (o32 - ref32).abs().max().item() <= 1e-3 * max(1.0, ref32.abs().max().item())
 
 
+@pytest.mark.parametrize("B,Li,Lt,N,K,gelu_from,gated", [
+    (3, 4000, 512, 3456, 1152, None, False),     # double-block QKV at a reduced token count: both problems on the 256 x 256 tiles
+    (3, 8000, 300, 1152, 1152, None, True),      # proj: gate * x + residual written in place, ragged N (4.5 column tiles), ragged M
+    (2, 8000, 512, 1024, 256, 0, False),         # MLP-up kind: GELU over the whole row
+    (1, 200, 77, 384, 128, None, True),          # small: the entry falls back to the two single calls (bit-identical to them)
+])
+def test_gemm_pair_equals_two_calls(hip_lib, B, Li, Lt, N, K, gelu_from, gated):
+    """osk_gemm_bf16_pair on the joint-buffer views of a double block: [txt ; img] rows of one buffer, separate weights."""
+    L = Lt + Li
+    x = rnd("x", (B, L, K), seed=41)
+    w = [rnd("wi", (N, K), std=K ** -0.5, seed=42), rnd("wt", (N, K), std=K ** -0.5, seed=43)]
+    b = [rnd("bi", (N,), std=0.2, dtype=torch.float32, seed=44), rnd("bt", (N,), std=0.2, dtype=torch.float32, seed=45)]
+    gate = [rnd("gi", (B, N), std=0.5, dtype=torch.float32, seed=46), rnd("gt", (B, N), std=0.5, dtype=torch.float32, seed=47)]
+    res0 = rnd("r", (B, L, N), seed=48)
+    views = lambda t: (t[:, Lt:], t[:, :Lt])          # img rows, txt rows
+
+    def run(pair):
+        out = res0.clone() if gated else torch.full((B, L, N), float("nan"), dtype=BF, device=DEV)
+        args = []
+        for i, (a, o) in enumerate(zip(views(x), views(out))):
+            d = dict(a=a, w=w[i], bias=b[i], out=o)
+            if gated:
+                d.update(res=o, gate=gate[i], gate_batch_stride=gate[i].stride(0))
+            args.append(d)
+        if pair:
+            hip_lib.gemm_pair(args[0], args[1], gelu_from=gelu_from)
+        else:
+            for d in args:
+                hip_lib.gemm(d["a"], d["w"], d["bias"], d["out"], gelu_from=gelu_from,
+                             **{k: d[k] for k in ("res", "gate", "gate_batch_stride") if k in d})
+        return out
+
+    got, single = run(True), run(False)
+    for i, (a, o) in enumerate(zip(views(x), views(got))):
+        ref = _gemm_ref(a, w[i], b[i], gelu_from=gelu_from, res=views(res0)[i] if gated else None, gate=gate[i] if gated else None)
+        bf16_ulp_close(o.float().cpu(), ref.float().bfloat16().float(), rel=2 ** -7, abs_=3e-3)
+    # against the single calls: the image problem runs the kernel it would run alone (bit-identical); the text problem may move
+    # from the 128-wide tiles to this launch's 256-wide ones (another accumulation order)
+    assert torch.equal(views(got)[0], views(single)[0])
+    bf16_ulp_close(got.float().cpu(), single.float().cpu(), rel=2 ** -7, abs_=3e-3)
+    if B * L < 1024:
+        assert torch.equal(got, single)
+    again = run(True)
+    assert torch.equal(got, again), "pair launch is not repeatable"
+
+
 def test_gemm_is_transpose_detecting(hip_lib):
     """A = I block, asymmetric W: C must equal W^T rows exactly (guide: A=I-check with asymmetric B)."""
     K = N = 128
