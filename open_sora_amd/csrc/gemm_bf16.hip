@@ -200,14 +200,16 @@ static int fill_params(GemmParams& p, const void* A, int64_t a_batch_stride, int
 // tile choice by estimated time = rounds of the grid over the chip x time of one tile.  Per-tile throughput measured at the XL
 // shapes (MI355X, random data): 256x256 ~1.0, 256x128 ~0.78, 128x128 (this file) ~0.72 of the large tile's rate; one workgroup
 // per CU for the large tiles, two 256-thread ones for this file's kernel.  -> 2: 256 x 256, 1: 256 x 128, 0: 128 x 128
-static int tile_choice(int M, int N) {
+static int tile_choice(int M, int N, double* cost = nullptr) {
   auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
   const int64_t m256 = (M + 255) / 256, m128 = (M + 127) / 128;
   const double c256 = rounds(m256 * ((N + 255) / 256), 256) * 4.0 / 1.00;
   const double c128 = rounds(m256 * ((N + 127) / 128), 256) * 2.0 / 0.78;
   const double cold = rounds(m128 * ((N + 127) / 128), 512) * 1.0 / (0.5 * 0.72);  // 2 co-resident tiles share a CU
   const bool wide = N >= 256 && c256 <= c128;
-  if (cold < (wide ? c256 : c128)) return 0;
+  const double best = wide ? c256 : c128;
+  if (cost) *cost = cold < best ? cold : best;
+  if (cold < best) return 0;
   return wide ? 2 : 1;
 }
 
@@ -232,8 +234,16 @@ extern "C" int osk_gemm_bf16_pair(const OskGemmOperands* a, const OskGemmOperand
   // smaller one's the tail); otherwise exactly the two single calls
   const int big = p[0].M >= p[1].M ? 0 : 1;
 #ifndef OSK_GEMM_NO_PAIR   // (A/B builds of tools/: always the two single calls)
-  if (large_tiles_ok(p[0]) && large_tiles_ok(p[1]) && tile_choice(p[big].M, N) == 2)   // the larger problem alone would take this kernel
-    return osk_gemm::launch_gemm256x_pair(p[big], p[big ^ 1], (hipStream_t)stream);
+  // one tile list when the larger problem alone would take the 256 x 256 kernel AND the estimate says so: the smaller problem's
+  // tiles ride in the larger one's last round (XL: 2688 + 84 tiles = 11 rounds either way) -- but not when they would open a new,
+  // nearly empty round (11B geometry: 2304 tiles are exactly 9 rounds; + 72 tiles would make it 10)
+  double c_big = 0.0, c_small = 0.0;
+  if (large_tiles_ok(p[0]) && large_tiles_ok(p[1]) && tile_choice(p[big].M, N, &c_big) == 2) {
+    tile_choice(p[big ^ 1].M, N, &c_small);
+    const int64_t nbn = (N + 255) / 256, tiles = ((p[0].M + 255) / 256 + (p[1].M + 255) / 256) * nbn;
+    const double c_pair = (double)((tiles + 255) / 256) * 4.0;
+    if (c_pair < c_big + c_small) return osk_gemm::launch_gemm256x_pair(p[big], p[big ^ 1], (hipStream_t)stream);
+  }
 #endif
   (void)big;
   for (int i = 0; i < 2; ++i) {
