@@ -218,6 +218,110 @@ __global__ void __launch_bounds__(256, 2) conv3d_kernel(const ConvParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Cout <= 4 (the decoder's conv_out: 128 -> 3 at full resolution, 2.0 of the VAE's 53 ms on the kernel above, whose 128-column
+// MFMA tile spends 97 % of its work on zero columns).  The layer is 27 * Cin products per output channel: a reduction, not a
+// GEMM.  A wave owns 64 consecutive voxels of one output row; lane = (16-voxel run lane / 16, 16-byte channel chunk lane % 16),
+// so one load instruction fetches four whole 256-byte voxels (coalesced) and a lane meets the SAME 8 channels in every voxel
+// it visits: its 4 weight dwords per (tap, output channel) come from LDS once per (dt, dh) and serve 16 voxels, and an input
+// voxel is loaded once per (dt, dh) for the three dw taps that use it.  Products on
+// v_dot2_f32_bf16 (packed bf16 pairs, f32 accumulate); the 16 chunk partials of a voxel are summed over the lane row at the end.
+// Geometry: 3 x 3 x 3, stride 1, no upsample, Cin == 128, Wo % 64 == 0 (the row of a wave never wraps).
+typedef __bf16 fo_bf16x2_t __attribute__((ext_vector_type(2)));
+
+OSK_DEV float fo_row16_sum(float v) {
+#define OSKF_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+  OSKF_DPP_ADD(0xB1);
+  OSKF_DPP_ADD(0x4E);
+  OSKF_DPP_ADD(0x141);
+  OSKF_DPP_ADD(0x140);
+#undef OSKF_DPP_ADD
+  return v;
+}
+
+template <int NC>
+__global__ void __launch_bounds__(256, 2) conv_fewout_kernel(const ConvParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned wl[27 * NC * 64];   // [tap][cout][64 dwords = 128 channels]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 27 * NC * 64; i += 256) {
+    const int tap = i / (NC * 64), r = i - tap * NC * 64;
+    const int c = r >> 6, d = r & 63;
+    wl[i] = c < p.Cout ? *reinterpret_cast<const unsigned*>(p.w + (int64_t)c * p.wrs + tap * 128 + 2 * d) : 0u;
+  }
+  __syncthreads();
+  const int lane = tid & 63, sub = lane >> 4, ch = lane & 15;
+  const int seg = blockIdx.x * 4 + (tid >> 6);                 // 64-voxel segment of an output row
+  const int segs_per_row = p.Wo >> 6;
+  const int nseg = p.B * p.To * p.Ho * segs_per_row;
+  if (seg >= nseg) return;
+  const int w0 = ((seg % segs_per_row) << 6) + 16 * sub;       // this lane's 16 consecutive output voxels: w0 .. w0 + 15
+  int q = seg / segs_per_row;
+  const int ho = q % p.Ho;
+  q /= p.Ho;
+  const int to = q % p.To, b = q / p.To;
+  float acc[16][NC];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[i][c] = 0.f;
+  for (int dt = 0; dt < 3; ++dt) {
+    int ts = to + dt - 2;
+    ts = ts < 0 ? 0 : ts;                                     // causal padding: the first frame repeats
+    for (int dh = 0; dh < 3; ++dh) {
+      int hs = ho + dh - 1;
+      hs = hs < 0 ? 0 : (hs > p.H - 1 ? p.H - 1 : hs);
+      const unsigned short* row = p.x + (((int64_t)b * p.T + ts) * p.H + hs) * p.W * 128 + ch * 8;
+      uint4 wv[3][NC];                                        // the three dw taps of this (dt, dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wv[dw][c] = *reinterpret_cast<const uint4*>(&wl[(((dt * 3 + dh) * 3 + dw) * NC + c) * 64 + ch * 4]);
+      // input voxel w0 - 1 + jj of this row feeds outputs jj - dw (dw = 0, 1, 2): 18 loads serve 48 (output, tap) pairs -- the 27
+      // taps of an output would otherwise re-read every input voxel through L2 (the first version of this kernel was L2-bound)
+#pragma unroll
+      for (int jj = 0; jj < 18; ++jj) {
+        int ws = w0 + jj - 1;
+        ws = ws < 0 ? 0 : (ws > p.W - 1 ? p.W - 1 : ws);
+        const uint4 xv = *reinterpret_cast<const uint4*>(row + (int64_t)ws * 128);
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+          const int i = jj - dw;
+          if (i < 0 || i > 15) continue;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            float a = acc[i][c];
+            a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fo_bf16x2_t, xv.x), __builtin_bit_cast(fo_bf16x2_t, wv[dw][c].x), a, false);
+            a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fo_bf16x2_t, xv.y), __builtin_bit_cast(fo_bf16x2_t, wv[dw][c].y), a, false);
+            a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fo_bf16x2_t, xv.z), __builtin_bit_cast(fo_bf16x2_t, wv[dw][c].z), a, false);
+            a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fo_bf16x2_t, xv.w), __builtin_bit_cast(fo_bf16x2_t, wv[dw][c].w), a, false);
+            acc[i][c] = a;
+          }
+        }
+      }
+    }
+  }
+  const int64_t m0 = (((int64_t)b * p.To + to) * p.Ho + ho) * p.Wo + w0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float v = fo_row16_sum(acc[i][c]);
+      if (ch == 0 && c < p.Cout) {
+        const int64_t o = (m0 + i) * p.Cout + c;
+        float r = v + (p.bias ? p.bias[c] : 0.f);
+        if (p.res) r += bf16_bits_to_f32(p.res[o]);
+        p.out[o] = f32_to_bf16_bits(r);
+      }
+    }
+  }
+}
+
+bool fewout_supported(const ConvParams& p) {
+  return p.ks == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.up_t && !p.up_hw && p.Cin == 128 && p.Cout <= 4 && (p.Wo & 63) == 0 &&
+         !p.gn_sums;
+}
+
 }  // namespace
 
 static int conv_entry(const void* x, int B, int T, int H, int W, int Cin, const void* w, int64_t w_row_stride,
@@ -266,6 +370,15 @@ static int conv_entry(const void* x, int B, int T, int H, int W, int Cin, const 
       if (!big || !osk_conv::conv256_gn_supported(p) || ((uintptr_t)out & 15)) return OSK_EUNSUPPORTED;
     }
     if (big) return osk_conv::launch_conv256(p, s);
+  }
+  if (fewout_supported(p)) {
+    const int nseg = B * To * Ho * (Wo >> 6);
+    const dim3 g((nseg + 3) / 4), blk(256);
+    if (Cout == 1) hipLaunchKernelGGL((conv_fewout_kernel<1>), g, blk, 0, s, p);
+    else if (Cout == 2) hipLaunchKernelGGL((conv_fewout_kernel<2>), g, blk, 0, s, p);
+    else if (Cout == 3) hipLaunchKernelGGL((conv_fewout_kernel<3>), g, blk, 0, s, p);
+    else hipLaunchKernelGGL((conv_fewout_kernel<4>), g, blk, 0, s, p);
+    return (int)hipGetLastError();
   }
   const int nblk = ((p.M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
   dim3 grid(nblk), block(256);

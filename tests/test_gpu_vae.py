@@ -66,6 +66,9 @@ CONV_CASES = [
     (512, 512, 3, (2, 2, 2), (False, False), 1, 5, 24, 24, True),    # spatio-temporal stride, 8 K steps per tap
     (256, 256, 3, (1, 1, 1), (True, True), 1, 2, 7, 9, False),       # upsample T,H,W folded into the gather
     (128, 384, 3, (1, 1, 1), (False, True), 1, 2, 8, 8, False),      # H,W upsample only, ragged N for the 256-wide tile
+    # Cout <= 4, Cin == 128, W % 64 == 0: the reduction kernel of the decoder's conv_out (conv_fewout_kernel, v_dot2_f32_bf16)
+    (128, 3, 3, (1, 1, 1), (False, False), 2, 3, 6, 64, False),      # two batch items, every row clamps at both ends
+    (128, 4, 3, (1, 1, 1), (False, False), 1, 2, 5, 128, True),      # 4 output channels, residual, two segments per row
     # stride 1, no upsample, whole 16 x 16 bricks, Cin % 128 == 0: the sliding-window kernel (convsw_kernel, halo brick in LDS)
     (128, 128, 3, (1, 1, 1), (False, False), 1, 3, 32, 48, True),    # Cout == 128: two-frame tiles, odd T (the last pair has one frame), all brick kinds
     (256, 256, 3, (1, 1, 1), (False, False), 2, 2, 16, 32, False),   # 256-wide tile, two batch items, 4 body iterations
