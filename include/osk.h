@@ -256,7 +256,11 @@ int osk_cfg_euler_bf16(const void* pred, int64_t n, const void* x, void* x_out,
  *       rows zero-padded to w_row_stride >= round_up(ksize^3 * Cin, 64)
  *   bias f32 [Cout] or NULL;  res bf16 [B, To, Ho, Wo, Cout] or NULL;  out bf16 [B, To, Ho, Wo, Cout]
  *   To = (Tu-1)/stride_t + 1 with Tu = up_t ? 1 + 2(T-1) : T;  Ho = (Hu-1)/stride_h + 1 with Hu = up_hw ? 2H : H
- * f32 accumulate, one rounding (bias and residual added in f32). */
+ * f32 accumulate, one rounding (bias and residual added in f32).
+ * Kernel by shape (same contract for all, chosen inside): 3 x 3 x 3, stride 1, Cin % 128 == 0, Cout >= 128 and whole 16 x 16 output
+ * bricks -> the LDS sliding window (the halo brick of a 32-channel block resident in LDS, taps = immediate offsets; with or
+ * without the fused upsample; two-frame tiles for Cout == 128); other Cin % 128 == 0, Cout >= 128 shapes -> the table-driven implicit
+ * GEMM; Cout <= 4 with Cin == 128 -> a v_dot2_f32_bf16 reduction; everything else -> the 128 x 128 implicit-GEMM tile. */
 int osk_causal_conv3d_ndhwc_bf16(const void* x, int B, int T, int H, int W, int Cin,
                                  const void* w, int64_t w_row_stride, const float* bias, int Cout, int ksize,
                                  int stride_t, int stride_h, int stride_w, int up_t, int up_hw,
