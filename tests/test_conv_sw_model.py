@@ -103,3 +103,24 @@ def test_two_frame_stream_computes_the_convolution(cin, tile):
         ref = E.reference_tile(x, w, geom, (t, tile[1], tile[2], 0), 128)
         err = np.abs(got[256 * f: 256 * f + 256] - ref).max()
         assert err <= 2e-4 * max(1.0, np.abs(ref).max()), (f, err)
+
+
+def test_generated_bodies_name_only_declared_registers():
+    """every v / a / s register a body names is inside the clobber list its asm statement declares (csrc/convsw_regs.inc) -- a
+    register outside it would silently corrupt the compiler's state around the asm statement"""
+    import os
+    import re
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "open_sora_amd", "csrc")
+    regs = open(os.path.join(csrc, "convsw_regs.inc")).read()
+    clob = {n: set(re.findall(r'"([vas]\d+)"', re.search(r"#define OSKSW%d_CLOBBERS (.*)" % n, regs).group(1))) for n in (256, 128)}
+    used_by = {"convsw_body_n256.inc": 256, "convswu_body_n256.inc": 256, "convswf_body_n128.inc": 256,   # the two-frame form: 128 x 128 wave tiles
+               "convsw_body_n128.inc": 128, "convswu_body_n128.inc": 128}
+    for name, n in used_by.items():
+        text = open(os.path.join(csrc, name)).read()
+        named = set()
+        for kind, lo, hi in re.findall(r"\b([vas])\[(\d+):(\d+)\]", text):
+            named |= {"%s%d" % (kind, i) for i in range(int(lo), int(hi) + 1)}
+        named |= {"%s%s" % (k, i) for k, i in re.findall(r"\b([vas])(\d+)\b", text)}
+        assert named and named <= clob[n], (name, sorted(named - clob[n])[:8])
+        assert len(re.findall(r"v_mfma_f32_16x16x32_bf16", text)) == 54 * 8 * (n // 32)
