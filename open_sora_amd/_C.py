@@ -192,7 +192,7 @@ def gemm_pair(first: dict, second: dict, *, gelu_from: int | None = None) -> Non
            for d in (first, second)]
     N, K = first["w"].shape
     assert tuple(second["w"].shape) == (N, K)
-    _check(lib.osk_gemm_bf16_pair(C.cast(C.pointer(ops[0]), C.c_void_p), C.cast(C.pointer(ops[1]), C.c_void_p), N, K, N if gelu_from is None else gelu_from,
+    _check(lib.osk_gemm_bf16_pair(C.addressof(ops[0]), C.addressof(ops[1]), N, K, N if gelu_from is None else gelu_from,
                                   _stream()), "osk_gemm_bf16_pair")
 
 
