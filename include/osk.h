@@ -227,9 +227,15 @@ int osk_attention_fwd_pv8_bf16(const void* q, int64_t q_batch_stride, int64_t q_
                                float scale, int q_prescaled, int kv_batches, void* workspace, int64_t workspace_bytes,
                                void* stream);
 
-/* name of the device kernel osk_attention_fwd_bf16 dispatches to for (hd, seg_len) under the current
- * OSK_ATTN_VARIANT (reporting only: bench.py labels its roofline line and the rocprof stats with it). */
+/* name of the device kernel osk_attention_fwd_bf16 dispatches to for (hd, seg_len) (reporting only: bench.py labels its
+ * roofline line and the rocprof stats with it). */
 const char* osk_attention_kernel_name(int hd, int seg_len);
+/* ... and of the loop BODY a call of osk_attention_fwd_bounded_bf16 with this segment layout and score bound runs (reporting /
+ * tests only): "attn_asm72_kernel<FAST>" = the bounded body (no max tracking; needs 0 < score_bound <= 56 and, with several key
+ * segments, segments of >= 3 tiles), "attn_asm72_kernel<general>" = the running-reference body, "attn_fwd_kernel<64>".  The
+ * choice is data-dependent through score_bound (open_sora_amd/mmdit.py derives it from the QK-norm scale vectors of
+ * opensora/models/mmdit/layers.py:113-135), so bench.py prints it next to the timing. */
+const char* osk_attention_body_name(int hd, int n_seg, int seg_len, float score_bound);
 
 /* ---- classifier-free-guidance combine + Euler step of the rectified-flow sampler (f32 math):
  *   v = u2 + g_img*(u - u2) + g_txt*(c - u);  x_out = x + dt * v

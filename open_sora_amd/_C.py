@@ -21,6 +21,7 @@ SIGNATURES = {
     "osk_abi_version": [],
     "osk_arch": [],
     "osk_attention_kernel_name": [_i32, _i32],
+    "osk_attention_body_name": [_i32, _i32, _i32, _f32],
     "osk_ln_modulate_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_gemm_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
                       _i32, _i32, _i32, _i32, _i32, _vp],
@@ -71,7 +72,7 @@ def _load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = (C.c_char_p if name in ("osk_arch", "osk_attention_kernel_name") else
+        fn.restype = (C.c_char_p if name in ("osk_arch", "osk_attention_kernel_name", "osk_attention_body_name") else
                       _i64 if name == "osk_attention_workspace_bytes" else _i32)
     if lib.osk_abi_version() != 1:
         raise ImportError("libosk_hip.so ABI version mismatch")
@@ -367,6 +368,11 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
         ev1.record()
         prof.append((ev0, ev1))
     return out
+
+
+def attention_body(hd: int, n_seg: int, seg_len: int, score_bound: float) -> str:
+    """which loop body attention_fwd(..., score_bound=...) runs for this key layout (reporting: bench.py, tests)"""
+    return lib.osk_attention_body_name(hd, n_seg, seg_len, float(score_bound)).decode()
 
 
 def vt8_rows(hd: int) -> int:

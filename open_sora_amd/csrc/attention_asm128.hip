@@ -22,7 +22,7 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
-template <bool FAST>   // FAST: score bound + one segment of whole tiles (attention_params.h::attn_fast_path)
+template <bool FAST>   // FAST: a score bound was given (attention_params.h::attn_fast_path); any key count, any segment layout
 __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;

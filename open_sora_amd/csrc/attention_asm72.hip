@@ -30,7 +30,7 @@ OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
-template <bool FAST>   // FAST: score bound + one segment of whole tiles (attention_params.h::attn_fast_path)
+template <bool FAST>   // FAST: a score bound was given (attention_params.h::attn_fast_path); any key count, any segment layout
 __global__ void __launch_bounds__(256, 1) attn_asm72_kernel(const AttnParams p) {
   constexpr int NU = 2;                                        // 32-row query blocks per wave (the generator's 8 waves x 32
   constexpr int NW = 8 / NU;                                   // rows layout tied this one in rounds 1-2 and is not shipped)

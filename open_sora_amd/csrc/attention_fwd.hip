@@ -609,6 +609,21 @@ extern "C" const char* osk_attention_kernel_name(int hd, int seg_len) {
   return hd == 72 ? "attn_asm72_kernel" : hd == 128 ? "attn_asm128_kernel" : "attn_fwd_kernel";
 }
 
+extern "C" const char* osk_attention_body_name(int hd, int n_seg, int seg_len, float score_bound) {
+  if (hd != 72 && hd != 128) return hd == 64 ? "attn_fwd_kernel<64>" : "unsupported";
+  AttnParams p{};
+  p.n_seg = n_seg; p.seg_len = seg_len;
+  p.seg_lp = (seg_len + 63) / 64 * 64;
+  p.tps = p.seg_lp / 64;
+  if (score_bound > 0.f) {   // rounded up to bf16 as osk_attention_fwd_bounded_bf16 does
+    const unsigned bits = __builtin_bit_cast(unsigned, score_bound);
+    p.bound = __builtin_bit_cast(float, (bits + 0xFFFFu) & 0xFFFF0000u);
+  }
+  const bool fast = osk_attn::attn_fast_path(p);
+  if (hd == 72) return fast ? "attn_asm72_kernel<FAST>" : "attn_asm72_kernel<general>";
+  return fast ? "attn_asm128_kernel<FAST>" : "attn_asm128_kernel<general>";
+}
+
 
 // =============================================================================================
 // fp8 P.V variant: V -> e4m3 V^T with the key order, ones row and zero rows the kernels expect; entry point

@@ -1,4 +1,4 @@
-// Launch parameters shared by the flash-attention kernels (attention_fwd.hip, attention_w64.hip).
+// Launch parameters shared by the flash-attention kernels (attention_fwd.hip, attention_asm{72,128}{,p8}.hip).
 #pragma once
 #include "osk_common.h"
 
@@ -17,8 +17,9 @@ struct AttnParams {
   int B, H, Lq, n_seg, seg_len, seg_lp, tps;
   float sc;   // softmax scale * log2(e); 1.0 when q_prescaled
   // caller-supplied bound on the scores as the kernel sees them (|q . k| * sc <= bound, log2 units), rounded UP to a bf16 value;
-  // 0 = unknown.  With a bound <= OSK_ATTN_MAX_BOUND, one key segment and whole 64-key tiles the hand-scheduled kernels run their
-  // FAST body: reference max = bound (a constant in Q's padding dim), no max tracking, branch-free loader advance
+  // 0 = unknown.  With a bound <= OSK_ATTN_MAX_BOUND the hand-scheduled kernels run their FAST body: reference max = bound (a
+  // constant in Q's padding dim), no max tracking, branch-free loader advance; ragged segment-last tiles and segment jumps are
+  // out-of-line events (tools/gen_attn_asm.py::fast_events).  Several segments of fewer than 3 tiles: the general body.
   float bound = 0.f;
   int q_prescaled;
   int Bkv;    // key / value batches: query batch b reads key batch b % Bkv
@@ -38,7 +39,7 @@ struct AttnParams {
 #define OSK_ATTN_MAX_BOUND 56.0f   // P = exp2(s - bound) >= 2^-112 for every admissible score: no underflow to zero
 
 static inline bool attn_fast_path(const AttnParams& p) {   // host side
-  return p.bound > 0.f && p.bound <= OSK_ATTN_MAX_BOUND && p.n_seg == 1 && (p.seg_len & 63) == 0;
+  return p.bound > 0.f && p.bound <= OSK_ATTN_MAX_BOUND && (p.n_seg == 1 || p.tps >= 3);
 }
 
 // (batch*head, query block) of a workgroup.  map 1 hands every XCD (block b runs on XCD b % 8) a contiguous

@@ -26,8 +26,13 @@ FAST bodies (`generate(..., fast=True)`, attention_asm*_n2_f0.inc): the loop the
   * a caller-supplied BOUND on the scores (|q.k| <= B, log2 units; the model path knows it from the QK-norm scale vectors): the
     reference max is the constant B -- Q's padding dim holds -B from the start, P = exp2(s - B) <= 1 can never overflow -- so
     the per-lane max chains (34 VALU per tile), the compare, the branch and the whole rare path disappear;
-  * one key segment of whole 64-key tiles: no ragged-tile lane masks, no ones-row rewrite, no segment jumps -- both loaders
-    advance with six branch-free SALU instructions (clamped at the last tile) instead of ~36 with branches.
+  * segment ends are EVENTS, not per-tile state: both loaders advance with six branch-free SALU instructions (clamped at the last
+    tile) behind one compare + (not taken) branch against the tile index of the loader's next event; the out-of-line event
+    code (after the loop, one copy per advance site) does what the general body does on every tile -- the K loader's per-lane
+    offsets switch to the clamped set (KCUR registers) while it sits on a ragged segment-last tile, the segment jump, the V^T
+    ring slot's ones row becoming that tile's key-validity mask and ones again two tiles later.  Round 4: this made the
+    bounded body usable for every sequence-parallel call (n_seg = P) and for ragged key counts (the reference's 256 px shape
+    L = 8,828 = 137 x 64 + 60); round 3's FAST body took one segment of whole tiles only.
 Body t (starts right after barrier t-1): the last 2 fragment pairs' P.V MFMAs of tile t-1 | QK^T of tile t+1 |
 P.V of tile t (first 10 of 12 fragment pairs); beside them: K / V^T fragment reads (4-deep rings), LDS-DMA of
 K(t+2), V(t+1), exp2 + pack of tile t, max of tile t+1.
@@ -121,6 +126,11 @@ S_KB, S_VB, S_KSTEP, S_KJ, S_VJ = 40, 42, 44, 46, 48
 S_TPS, S_NT, S_KDST, S_VDST, S_NKW, S_NVW = 50, 51, 52, 53, 54, 55
 S_T, S_KTT, S_VTT, S_TMP, S_HIM, S_KL, S_VL = 56, 57, 58, 59, 60, 62, 63
 
+# FAST bodies: tile index (loader numbering) at which the loader's next segment-end event is due / of the current segment's last
+# tile (S_KRG / S_VRG / S_KTT / S_VTT belong to the general body's per-tile bookkeeping and are dead in the FAST bodies)
+S_KNEXT, S_VNEXT, S_KE, S_VE = S_KTT, S_VTT, S_KRG, S_KRG + 1
+
+
 def operand_names(geo, nslot_k, nslot_v):
     """asm operands (order = operand numbers in the wrapper's asm statement); at most 30"""
     names = ["m0out", "m1out"] + ["koff%d" % i for i in range(nslot_k)] + ["voff%d" % i for i in range(nslot_v)] + \
@@ -175,6 +185,7 @@ class Layout:
         self.KR0 = self.PB0 + (8 if pv8 else 16) * nu   # fragment rings, 16 registers each (pv8: V^T 2 slots x 8)
         self.VR0 = self.KR0 + 16
         self.TMP0 = self.VR0 + 16              # 8 temporaries
+        self.KCUR = self.TMP0                  # FAST bodies (no max chains): the K loader's per-lane offsets in force, one per slot
         self.MT = [self.TMP0 + 8, self.TMP0 + 9]
         self.MM = [self.TMP0 + 10, self.TMP0 + 11]
         self.TX = [self.TMP0 + 12 + i for i in range(4)]
@@ -239,6 +250,7 @@ class Stream:
     def __init__(self, ablate=frozenset()):
         self.lines, self.pending, self.table = [], [], []
         self.ablate, self.in_body = ablate, False
+        self.events = []   # FAST bodies: (which, uid, ring slot, V^T step) of every advance site, for fast_events()
 
     def emit(self, text, kind="x"):
         ab = self.ablate if self.in_body else frozenset()
@@ -411,8 +423,8 @@ def k_dma(st, L, slot, i, part=3):
             st.emit("v_cndmask_b32_e64 %s, %s, %s, s[%d:%d]" % (vr(L.TX[3]), L.OP["koff%d" % i], L.OP["koffL%d" % i], S_KRG, S_KRG + 1), "v")
         elif part == 3:
             st.emit("s_nop 0", "n")
-    if part & 2:
-        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (L.OP["koff%d" % i] if FAST else vr(L.TX[3]), S_KB, S_KB + 1), "g")
+    if part & 2:   # FAST: the offsets in force (koff, or koffL while the loader sits on a ragged tile) live in KCUR registers
+        st.emit("global_load_lds_dwordx4 %s, s[%d:%d]" % (vr(L.KCUR + i) if FAST else vr(L.TX[3]), S_KB, S_KB + 1), "g")
 
 
 def v_dma(st, L, slot, i, part=3):
@@ -441,10 +453,14 @@ def dma_last(st, L, which, slot, uid):
     st.label(lab)
 
 
-def advance(st, which, uid, vstep=128):
+def advance(st, which, uid, vstep=128, L=None, slot=0):
     """point the loader at its next tile; past the last tile it stays (harmless re-fetch of the last tile)"""
-    if FAST:   # one segment of whole tiles: branch-free, six SALU instructions
+    if FAST:   # branch-free, six SALU instructions, behind the event check (slow path: fast_events())
         sl, sb = (S_KL, S_KB) if which == "k" else (S_VL, S_VB)
+        st.emit("s_cmp_eq_u32 s%d, s%d" % (sl, S_KNEXT if which == "k" else S_VNEXT), "s")
+        st.emit("s_cbranch_scc1 .L@@_ev%s%s" % (which, uid), "s")
+        st.events.append((which, uid, slot, vstep))
+        st.label(".L@@_ec%s%s" % (which, uid))
         st.emit("s_add_u32 s%d, s%d, 1" % (S_TMP, sl), "s")
         st.emit("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NT), "s")
         st.emit("s_cselect_b32 s%d, s%d, s%d" % (sl, S_TMP, sl), "s")
@@ -454,6 +470,7 @@ def advance(st, which, uid, vstep=128):
             st.emit("s_cselect_b32 s%d, %d, 0" % (S_TMP, vstep), "s")
         st.emit("s_add_u32 s%d, s%d, s%d" % (sb, sb, S_TMP), "s")
         st.emit("s_addc_u32 s%d, s%d, 0" % (sb + 1, sb + 1), "s")
+        st.label(".L@@_ed%s%s" % (which, uid))
         return
     lab = ".L@@_%sa%s" % (which, uid)
     sl, sb, stt, sj = (S_KL, S_KB, S_KTT, S_KJ) if which == "k" else (S_VL, S_VB, S_VTT, S_VJ)
@@ -517,8 +534,90 @@ def dma_group(st, L, which, slot, uid):
     for i in range(nslot(L, which) - 1):
         (k_dma if which == "k" else v_dma)(st, L, slot, i)
     dma_last(st, L, which, slot, uid)
-    advance(st, which, uid, L.G.VSTEP)
+    advance(st, which, uid, L.G.VSTEP, L, slot)
     ragged_masks(st)
+
+
+def row_write(st, L, slot, mask, uid):
+    """FAST event code: the V^T ring slot's ones row (softmax denominator) := the ragged tile's key-validity mask / ones again.
+    The ones-row wave only (flag bit 1, set when the launch has a ragged tile); lanes 32..63 rewrite the zero row behind it."""
+    lab = ".L@@_rw%s" % uid
+    st.emit("s_bitcmp1_b32 s%d, 1" % S_FLG, "s")
+    st.emit("s_cbranch_scc0 %s" % lab, "s")
+    if mask:
+        st.emit("v_mov_b32 %s, %s" % (vr(L.TX[2]), L.OP["maskval"]), "v")
+    else:
+        st.emit("v_mov_b32 %s, 0x3f803f80" % vr(L.TX[2]), "v")
+    st.emit("v_cndmask_b32_e64 %s, %s, 0, s[%d:%d]" % (vr(L.TX[2]), vr(L.TX[2]), L.S_ONESMASK, L.S_ONESMASK + 1), "v")
+    st.emit("ds_write_b32 %s, %s offset:%d" % (L.OP["onesaddr"], vr(L.TX[2]), L.G.VOFF[slot] - L.G.VOFF[0]), "D")
+    st.label(lab)
+
+
+def fast_events(st, L):
+    """Out-of-line event code of the FAST bodies' loaders, one copy per advance site (the site jumps here when the loader's tile
+    index equals its next-event index, and gets a complete advance back).  With E = the index of the current key segment's last
+    tile (S_KE / S_VE; segments are tps tiles; a launch is `ragged` when seg_len % 64 != 0, i.e. every E tile is short):
+      K loader (two tiles ahead of the MFMAs), at old index E-1: the tile it moves to is E -- its LDS-DMA pieces fetch through the
+        clamped per-lane offsets koffL (rows past the segment re-fetch its last key) if ragged; next event at E.  At old index E:
+        back to koff, the segment jump, E += tps, next event at E-1.  Past the last tile the loader does not move (and keeps
+        its offsets: it re-fetches that tile).
+      V^T loader, at old index E: the ring slot that receives tile E in this body gets the validity mask as its ones row (if
+        ragged; next event two tiles later: the same slot receives tile E+2 and gets its ones back), then advance + segment jump,
+        E += tps.  The wrapper falls back to the general body when segments are shorter than 3 tiles and there are several."""
+    for which, uid, slot, vstep in st.events:
+        e = lambda t, kind="s": st.emit(t, kind)
+        done, common = ".L@@_ed%s%s" % (which, uid), ".L@@_ec%s%s" % (which, uid)
+        st.label(".L@@_ev%s%s" % (which, uid))
+        if which == "k":
+            sl, sb = S_KL, S_KB
+            e("s_add_u32 s%d, s%d, 1" % (S_TMP, sl))
+            e("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NT))
+            e("s_cbranch_scc0 %s" % done)                                    # clamped at the last tile: nothing moves
+            e("s_mov_b32 s%d, s%d" % (sl, S_TMP))
+            e("s_add_u32 s%d, s%d, s%d" % (sb, sb, S_KSTEP))
+            e("s_addc_u32 s%d, s%d, 0" % (sb + 1, sb + 1))
+            e("s_cmp_eq_u32 s%d, s%d" % (S_TMP, S_KE))
+            e("s_cbranch_scc0 .L@@_el%s" % uid)
+            # entering the segment's last tile
+            e("s_mov_b32 s%d, s%d" % (S_KNEXT, S_TMP))
+            e("s_cmp_lg_u32 s%d, 0" % S_NRG)
+            e("s_cbranch_scc1 %s" % done)
+            for i in range(L.NSLOT):
+                e("v_mov_b32 %s, %s" % (vr(L.KCUR + i), L.OP["koffL%d" % i]), "v")
+            e("s_branch %s" % done)
+            st.label(".L@@_el%s" % uid)                                      # leaving it: next segment
+            for i in range(L.NSLOT):
+                e("v_mov_b32 %s, %s" % (vr(L.KCUR + i), L.OP["koff%d" % i]), "v")
+            e("s_add_u32 s%d, s%d, s%d" % (sb, sb, S_KJ))
+            e("s_addc_u32 s%d, s%d, s%d" % (sb + 1, sb + 1, S_KJ + 1))
+            e("s_add_u32 s%d, s%d, s%d" % (S_KE, S_KE, S_TPS))
+            e("s_sub_u32 s%d, s%d, 1" % (S_KNEXT, S_KE))
+            e("s_branch %s" % done)
+        else:
+            sl, sb = S_VL, S_VB
+            e("s_cmp_eq_u32 s%d, s%d" % (sl, S_VE))
+            e("s_cbranch_scc0 .L@@_er%s" % uid)
+            # the loader sits on its segment's last tile, whose LDS-DMA pieces this body has issued into ring slot `slot`
+            e("s_add_u32 s%d, s%d, s%d" % (S_VNEXT, sl, S_TPS))
+            e("s_cmp_lg_u32 s%d, 0" % S_NRG)
+            e("s_cbranch_scc1 .L@@_ej%s" % uid)
+            row_write(st, L, slot, True, "m" + uid)
+            e("s_add_u32 s%d, s%d, 2" % (S_VNEXT, sl))
+            st.label(".L@@_ej%s" % uid)
+            e("s_add_u32 s%d, s%d, s%d" % (S_VE, S_VE, S_TPS))
+            e("s_add_u32 s%d, s%d, 1" % (S_TMP, sl))
+            e("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NT))
+            e("s_cbranch_scc0 %s" % done)
+            e("s_mov_b32 s%d, s%d" % (sl, S_TMP))
+            e("s_add_u32 s%d, s%d, %d" % (sb, sb, vstep))
+            e("s_addc_u32 s%d, s%d, 0" % (sb + 1, sb + 1))
+            e("s_add_u32 s%d, s%d, s%d" % (sb, sb, S_VJ))
+            e("s_addc_u32 s%d, s%d, s%d" % (sb + 1, sb + 1, S_VJ + 1))
+            e("s_branch %s" % done)
+            st.label(".L@@_er%s" % uid)                                      # two tiles behind a ragged tile: its slot's ones row back
+            row_write(st, L, slot, False, "o" + uid)
+            e("s_mov_b32 s%d, s%d" % (S_VNEXT, S_VE))
+            e("s_branch %s" % common)
 
 
 def fixup(st, L, sx, init):
@@ -654,8 +753,8 @@ def body(st, L, k, safe):
     later.append((lambda: dma_last(st, L, "v", cur ^ 1, uid), DMACOST))
     if not L.PV8 and not FAST:   # pv8: the ones / key-validity row arrives with the V^T tile itself; fast: whole tiles only
         later.append((lambda: ones_row(st, L, cur ^ 1), 8))   # before the V^T loader moves on: S_VRG is tile t+1's
-    later.append((lambda: advance(st, "k", uid), 12 if FAST else 28))
-    later.append((lambda: (advance(st, "v", uid, L.G.VSTEP), ragged_masks(st)), 12 if FAST else 32))
+    later.append((lambda: advance(st, "k", uid, 128, L, cur), 20 if FAST else 28))
+    later.append((lambda: (advance(st, "v", uid, L.G.VSTEP, L, cur ^ 1), ragged_masks(st)), 20 if FAST else 32))
 
     # -- fillers paced in CYCLES (v_exp 8, other VALU 4): three classes, each spread uniformly over its window
     cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
@@ -797,6 +896,28 @@ def _generate(L, safe, ablate):
     if not FAST:
         ragged_mask(st, "k")
         ragged_mask(st, "v")
+    else:
+        # loader events (fast_events()): the first segment's last tile is tps - 1; a launch that is ONE segment of whole tiles has
+        # no event at all; when tile 0 itself is the ragged last tile the K loader starts on the clamped offsets
+        e("s_sub_u32 s%d, s%d, 1" % (S_KE, S_TPS))
+        e("s_mov_b32 s%d, s%d" % (S_VE, S_KE))
+        e("s_mov_b32 s%d, s%d" % (S_VNEXT, S_KE))
+        e("s_sub_u32 s%d, s%d, 2" % (S_KNEXT, S_TPS))
+        for i in range(L.NSLOT):
+            e("v_mov_b32 %s, %s" % (vr(L.KCUR + i), L.OP["koff%d" % i]))
+        e("s_cmp_lg_u32 s%d, 0" % S_NRG)
+        e("s_cbranch_scc0 .L@@_ini1")
+        e("s_cmp_lg_u32 s%d, s%d" % (S_TPS, S_NT))
+        e("s_cbranch_scc1 .L@@_ini2")
+        e("s_mov_b32 s%d, -1" % S_KNEXT)
+        e("s_mov_b32 s%d, -1" % S_VNEXT)
+        e("s_branch .L@@_ini2")
+        st.label(".L@@_ini1")
+        e("s_cmp_lg_u32 s%d, 1" % S_TPS)
+        e("s_cbranch_scc1 .L@@_ini2")
+        for i in range(L.NSLOT):
+            e("v_mov_b32 %s, %s" % (vr(L.KCUR + i), L.OP["koffL%d" % i]))
+        st.label(".L@@_ini2")
     for u in range(2):
         e("v_mov_b32 %s, 0" % vr(L.MM[u]))
     for r in range(L.A_O0, L.A_Q0):
@@ -842,6 +963,9 @@ def _generate(L, safe, ablate):
         st.label(".L@@_rare%d" % k)
         fixup(st, L, L.SA0 if k == 0 else L.SB0, init=False)
         e("s_branch .L@@_entry%d" % k)
+    if FAST:
+        e("s_branch .L@@_exit")   # (never reached: both bodies end in branches)
+        fast_events(st, L)
     # ---- exit: the trailing P.V MFMAs of the last tile
     st.label(".L@@_exit")
     for n in range(L.NTRAIL):
