@@ -312,8 +312,20 @@ def main():
         out["vae"] = {k: v[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "step_tflops", "step_mfma_frac",
                                         "roofline", "cpu_baseline") if k in v}
         b11 = dit_line(args, dev, None, 0, 1, "11B", 3, 1, with_b1=False)
-        out["11b"] = {k: b11[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "step_tflops", "step_mfma_frac",
-                                          "roofline", "timed")}
+        keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "step_tflops", "step_mfma_frac", "roofline", "timed")
+        out["11b"] = {k: b11[k] for k in keys}
+        # BASELINE configs[4]'s arithmetic (fp8 MFMA: block Linears + attention P.V; opt-in, outside the bf16 parity gate) on both
+        # geometries, same process, same clock; roofline against the mixed bf16 / fp8 peak; rel_l2_vs_bf16 = one forward of the
+        # same weights and inputs in both modes
+        args.fp8 = True
+        try:
+            f8 = {}
+            for name, st_, wu_ in (("xl", 5, 1), ("11b", 3, 1)):
+                r8 = dit_line(args, dev, None, 0, 1, "XL" if name == "xl" else "11B", st_, wu_, with_b1=False)
+                f8[name] = {k: r8[k] for k in keys + ("rel_l2_vs_bf16",) if k in r8}
+            out["fp8"] = f8
+        finally:
+            args.fp8 = False
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -402,6 +414,8 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
             elapsed = time.perf_counter() - t0
             prof, _C.PROFILE_ATTENTION = _C.PROFILE_ATTENTION, None
             x = st["x"]
+        # the attention body the timed steps ran (before any side measurement touches the QK-norm scales)
+        rep = model.attention_report(world if sp_mode and "all-gather" in sp_mode else 1, L // world if world > 1 else L)
         # SURVEY.md section 8(d) cfg 2 asks for B = 1 (the pure step) next to the reference's CFG triple: a second, separately
         # timed run at batch 1 (reported under "b1", never part of `value`)
         b1 = None
@@ -421,6 +435,58 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
                   "step_tflops": round(configs.flops_per_forward(cfg, 1, L_img, L_txt) / (e1 / n1) / 1e12, 1),
                   "timed": "model forward + osk_cfg_euler_bf16 at CFG batch 1 (a private loop: the sampler's loop is the triple)"}
             del step1, st1
+
+        rel8 = None
+        if args.fp8 and nb == 3 and world == 1:   # one forward of the same weights and inputs in fp8 and in bf16 mode
+            t_vec = torch.full((3,), float(ts[0]), dtype=torch.bfloat16, device=dev)
+            cond = torch.zeros(3, L_img, 68, device=dev, dtype=torch.bfloat16)
+            kw = dict(img=x.repeat(3, 1, 1), img_ids=img_ids, txt=txt, txt_ids=txt_ids, timesteps=t_vec, y_vec=y_vec, cond=cond)
+            p8 = model(**kw).float()
+            model.enable_fp8(False)
+            p16 = model(**kw).float()
+            model.enable_fp8(True)
+            rel8 = float((p8 - p16).norm() / p16.norm())
+            del p8, p16
+        # The headline's attention body is chosen from the QK-norm scales (unit scales here).  Two side measurements under the
+        # same clock (never part of `value`): (a) the same steps with the bound withheld -> the general (running-reference) body
+        # a checkpoint with large scale entries would get; (b) SURVEY.md section 8(d)'s second run: scales ~U(0.5, 1.5).
+        side = None
+        if nb == 3 and world == 1 and with_b1 and not args.fp8:
+            side = {}
+            blocks = list(model.double_blocks) + list(model.single_blocks)
+
+            def timed(n):
+                _C.PROFILE_ATTENTION = []
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                run_denoise(x, 0, n)
+                torch.cuda.synchronize()
+                e_ = time.perf_counter() - t0_
+                pr, _C.PROFILE_ATTENTION = _C.PROFILE_ATTENTION, None
+                return e_ / n * 1e3, sum(s_.elapsed_time(e2) for s_, e2 in pr) / len(pr)
+
+            plans = [b_._osk_plan for b_ in blocks]
+            saved = [p_.score_bound for p_ in plans]
+            for p_ in plans:
+                p_.score_bound = 0.0
+            ms_g, at_g = timed(3)
+            for p_, v_ in zip(plans, saved):
+                p_.score_bound = v_
+            side["general_body"] = {"steps": 3, "ms_per_step": round(ms_g, 3), "attn_avg_launch_ms": round(at_g, 4),
+                                    "attention_body": _C.attention_body(hd, 1, L, 0.0), "what": "same weights, score bound withheld"}
+            gs = torch.Generator(device=dev).manual_seed(7)
+            with torch.no_grad():
+                for b_ in blocks:
+                    for nrm in ([b_.img_attn.norm, b_.txt_attn.norm] if hasattr(b_, "img_attn") else [b_.norm]):
+                        for prm in (nrm.query_norm.scale, nrm.key_norm.scale):
+                            prm.copy_(torch.rand(prm.shape, device=dev, generator=gs) + 0.5)
+            model.invalidate_plan()
+            run_denoise(x, 0, 1)
+            ms_s, at_s = timed(3)
+            rep_s = model.attention_report(1, L)
+            side["qk_scales_u05_15"] = {"steps": 3, "ms_per_step": round(ms_s, 3), "attn_avg_launch_ms": round(at_s, 4),
+                                        "attention_body": ", ".join(rep_s["bodies"]), "score_bound": round(rep_s["score_bound_max"], 3),
+                                        "what": "QK-norm scale vectors ~U(0.5, 1.5) instead of 1 (SURVEY 8(d) second run)"}
 
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -457,7 +523,12 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
             # fp8 mode: QK^T (half the FLOPs) on the bf16 MFMA at 2.5 PF, P.V (the other half) on the fp8 MFMA at 5 PF:
             # the time-weighted peak for equal FLOP shares is the harmonic mean, 3.33 PF
             peak = round(2.0 / (1.0 / MFMA_BF16_PEAK_TFLOPS + 1.0 / (2 * MFMA_BF16_PEAK_TFLOPS)), 1)
-        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
+        # which loop body ran is data-dependent (the FAST body needs the plans' score bound <= 56: mmdit._score_bound reads the
+        # QK-norm scale vectors; freshly constructed scales are 1): report it with the bound
+        body = "attn_asm%dp8_kernel<general>" % hd if (args.fp8 and hd in (72, 128)) else ", ".join(rep["bodies"])
+        roofline = {"bound": "mfma", "kernel": kname, "attention_body": body,
+                    "score_bound": round(rep["score_bound_max"], 3), "score_bound_limit": rep["bound_limit"],
+                    "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_kind": "recorded (PMC passes of this kernel at this shape, see traffic_source)",
                     "traffic_source": traffic_src,
@@ -482,6 +553,10 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
     }
     if b1 is not None:
         out["b1"] = b1
+    if side:
+        out["attention_dispatch"] = side
+    if rel8 is not None:
+        out["rel_l2_vs_bf16"] = round(rel8, 5)
     if world > 1:
         out["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "exchange": sp_mode}
     del model

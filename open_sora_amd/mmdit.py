@@ -603,7 +603,7 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
         for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):
             _linear(act, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
         _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
-        sp.attention(ws, pending, q, v, H, hd)
+        sp.attention(ws, pending, q, v, H, hd, plan.score_bound)
     if paired:   # layers.py:247-252 for both streams, Linear by Linear
         _linear_pair(dict(a=v[:, Lt:], w=plan.img.proj_w, bias=plan.img.proj_b, out=x_img, res=x_img, gate=i_g1, gate_batch_stride=mbs),
                      dict(a=v[:, :Lt], w=plan.txt.proj_w, bias=plan.txt.proj_b, out=x_txt, res=x_txt, gate=t_g1, gate_batch_stride=mbs))
@@ -650,7 +650,7 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
         _linear(act, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
         _linear(act, plan.w1[:D], None if b1 is None else b1[:D], q)
         _OPS.qknorm_rope(q, None, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
-        sp.attention(ws, pending, q, v, H, hd)
+        sp.attention(ws, pending, q, v, H, hd, plan.score_bound)
     _linear(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=ws.x, gate=gate, gate_batch_stride=mbs)
 
 
@@ -771,6 +771,16 @@ class MMDiTModel(_OskState, nn.Module):
         return self
 
     # ------------------------------------------------------------------ planning
+    def attention_report(self, n_seg: int = 1, seg_len: int = 0) -> dict:
+        """Which attention loop body the blocks' plans select, and from which score bounds (the choice is data-dependent:
+        _score_bound() reads the QK-norm scale vectors).  Blocks without a plan yet (no forward so far) are planned here."""
+        hd = self.hidden_size // self.num_heads
+        plans = [plan_double(b) for b in self.double_blocks] + [plan_single(b) for b in self.single_blocks]
+        bounds = [float(p.score_bound) for p in plans]
+        bodies = sorted({_OPS.attention_body(hd, n_seg, seg_len, b) for b in bounds}) if hasattr(_OPS, "attention_body") else []
+        return {"score_bound_min": min(bounds), "score_bound_max": max(bounds), "bound_limit": 56.0, "bodies": bodies,
+                "blocks_on_fast_body": sum(1 for b in bounds if 0.0 < b <= 56.0), "blocks": len(bounds)}
+
     def invalidate_plan(self):
         self._plan = None
         for b in list(getattr(self, "double_blocks", ())) + list(getattr(self, "single_blocks", ())):

@@ -190,10 +190,12 @@ class SeqPar:
         wv = self.tp.all_gather(vt_all.view(-1), vt_all[self.rank].view(-1))
         return k_all, vt_all, wk, wv
 
-    def attention(self, ws, pending, q: Tensor, out: Tensor, H: int, hd: int):
-        """Local queries against the gathered keys: one launch, P key segments of L/P keys."""
+    def attention(self, ws, pending, q: Tensor, out: Tensor, H: int, hd: int, score_bound: float = 0.0):
+        """Local queries against the gathered keys: one launch, P key segments of L/P keys.  score_bound: the block's bound on
+        |q . k| (mmdit._score_bound; it holds for every key of the joint sequence whichever rank projected it) -- the kernel's
+        FAST body takes segmented / ragged key layouts since round 4, so sequence-parallel calls run it too."""
         if isinstance(pending[0], str) and pending[0] == "heads":
-            return self._heads_attention(pending, q, out, H, hd)
+            return self._heads_attention(pending, q, out, H, hd, score_bound)
         B, Lloc, D = q.shape
         ops = mmdit.ops()
         if isinstance(pending[0], str):   # "pv8"
@@ -209,7 +211,7 @@ class SeqPar:
         wv.wait()
         ops.attention_fwd(q, k_all[0], vt_all, out, H, hd, hd ** -0.5, n_seg=self.P, seg_len=Lloc,
                           k_seg_stride=k_all.stride(0), vt_seg_stride=vt_all.stride(0), q_prescaled=True,
-                          workspace=ops.attention_workspace(q.device))
+                          workspace=ops.attention_workspace(q.device), score_bound=score_bound)
 
     # ------------------------------------------------------------------ head-parallel exchange (all-to-all)
     def _heads_buffers(self, B: int, Lloc: int, H: int, hd: int, device):
@@ -240,7 +242,7 @@ class SeqPar:
         wv = self.tp.all_to_all(bufs["vr"].view(-1), bufs["vs"].view(-1))
         return "heads", bufs, wk, wv, pv8
 
-    def _heads_attention(self, pending, q: Tensor, out: Tensor, H: int, hd: int):
+    def _heads_attention(self, pending, q: Tensor, out: Tensor, H: int, hd: int, score_bound: float = 0.0):
         _, bufs, wk, wv, pv8 = pending
         B, Lloc, D = q.shape
         P, Hg = self.P, H // self.P
@@ -265,7 +267,7 @@ class SeqPar:
             ops.v_transpose(bufs["vr"].view(P * B, Lloc, Hg * hd), vt.view(P * B, Hg, hd, vt.shape[-1]), Hg, hd)
             ops.attention_fwd(qr, kr[0], vt, os_, Hg, hd, hd ** -0.5, n_seg=P, seg_len=Lloc, k_seg_stride=kr.stride(0),
                               vt_seg_stride=vt.stride(0), q_prescaled=True, kv_batches=B,
-                              workspace=ops.attention_workspace(q.device))
+                              workspace=ops.attention_workspace(q.device), score_bound=score_bound)
         # chunk s of the output belongs to rank s's tokens: straight back, then head groups side by side
         self.tp.all_to_all(bufs["orr"].view(-1), bufs["os"].view(-1)).wait()
         out.view(B, Lloc, P, D // P).permute(2, 0, 1, 3).copy_(bufs["orr"])
