@@ -10,6 +10,7 @@ changed) and linked into the shared library.
 from __future__ import annotations
 
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -28,7 +29,18 @@ ARCH = "gfx950"
 # (gemm256p, attn_asm72) is resident on the same CU -- from another stream or another process.  That made the batched adaLN
 # GEMV of one rank non-repeatable when two sequence-parallel ranks shared a GPU (GPUTEST_r02).  The same victim kernels built
 # without the feature never mismatch.  The hand-written loops (generated .inc bodies) contain no packed-FP32 instruction.
+# The feature string is a device-side one; hipcc hands -Xclang options to the x86 host pass too, which ignores it with a warning.
+# (ADVICE r3 asked for -Xarch_device: this clang rejects "-Xarch_device -Xclang ..." -- "options requiring arguments are unsupported"
+# -- and the argument-free spellings -Xarch_device -mno-packed-fp32-ops / -mattr=-packed-fp32-ops are accepted and do NOTHING:
+# v_pk_fma_f32 is still emitted.  tests/test_gpu_overlap.py::test_library_has_no_packed_fp32_instructions disassembles the result.)
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+# the flags are part of what the library IS (a build without -packed-fp32-ops is a wrong build, see above): their hash is stored
+# next to the .so and a library built with other flags -- or by an A/B script of tools/ into this path -- is stale
+STAMP_PATH = LIB_PATH + ".flags"
+
+
+def _flags_stamp() -> str:
+    return hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:16]
 
 
 def sources() -> list[str]:
@@ -51,7 +63,12 @@ def _newest(paths) -> float:
 def _stale() -> bool:
     if not os.path.isfile(LIB_PATH):
         return True
-    return _newest(sources() + _shared_deps()) > os.path.getmtime(LIB_PATH)
+    try:
+        if open(STAMP_PATH).read().strip() != _flags_stamp():
+            return True
+    except OSError:
+        return True
+    return _newest(sources() + _shared_deps() + [os.path.abspath(__file__)]) > os.path.getmtime(LIB_PATH)
 
 
 def _hipcc() -> str:
@@ -66,6 +83,11 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
+    try:
+        same_flags = open(STAMP_PATH).read().strip() == _flags_stamp()
+    except OSError:
+        same_flags = False
+    force = force or not same_flags   # cached objects were compiled with other flags
     shared_t = _newest(_shared_deps() + [os.path.abspath(__file__)])
 
     def compile_one(src: str) -> str:
@@ -83,6 +105,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, sources()))
+    for stale_obj in set(glob.glob(os.path.join(OBJ_DIR, "*.o"))) - set(objs):   # objects of deleted translation units
+        os.remove(stale_obj)
     tmp = LIB_PATH + ".tmp"
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
@@ -91,6 +115,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"hipcc link failed ({r.returncode}):\n{r.stderr[-4000:]}")
     os.replace(tmp, LIB_PATH)
+    with open(STAMP_PATH, "w") as f:
+        f.write(_flags_stamp() + "\n")
     return LIB_PATH
 
 

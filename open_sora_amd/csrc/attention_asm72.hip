@@ -9,7 +9,7 @@
 // exp2 / pack / max work, counted lgkmcnt waits, one barrier per tile.  See the generator's header for the
 // dataflow; this file is the wrapper: LDS init, Q pre-scale, the asm operands, the epilogue.
 //
-// Numerics vs attention_w64.hip / attention_fwd.hip:
+// Numerics vs the compiler-scheduled attention_fwd.hip (head_dim 64; rounds 1-2 also had a head_dim-72 twin, attention_w64.hip):
 //  * Q carries scale*log2(e): folded into q's single rounding by osk_qknorm_rope_bf16 (q_prescaled, the model path),
 //    or applied here with one extra bf16 rounding of q (stand-alone calls);
 //  * the online-softmax reference max M is kept bf16-exact inside the contraction (Q padding dim 72 = -M, K

@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256, 1) conv256x_kernel(const ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Sliding-window form (3 x 3 x 3, stride 1, no fused upsample, Ho % 16 == 0 and Wo % 16 == 0, Cin % 64 == 0): a tile is the
+// Sliding-window form (3 x 3 x 3, stride 1, plain or with the nearest 2x upsample folded in (UP), Ho % 16 == 0 and Wo % 16 == 0, Cin % 64 == 0): a tile is the
 // 16 x 16 spatial brick of one output frame; the 3-frame x 18 x 18 halo brick of one 32-channel block sits in LDS and the 27
 // taps differ only in the immediate offset of their fragment reads -- the activations of a tile cross the fabric once per
 // channel block instead of 27 times.  K loop, LDS plan and the lane formulas below: tools/gen_conv_sw_asm.py (its header is the

@@ -1,9 +1,9 @@
-// The 4-wave persistent bf16 GEMM of gemm256w.hip on v_mfma_f32_16x16x32_bf16:  C = epi(A[M,K] @ W[N,K]^T + bias)
+// The 4-wave persistent bf16 GEMM (round 2's gemm256w.hip, removed in round 3) on v_mfma_f32_16x16x32_bf16:  C = epi(A[M,K] @ W[N,K]^T + bias)
 //
 // Same 256 x 256 x 64 workgroup tile, LDS image, LDS-DMA loaders, tile walk, cross-tile prefetch and bias-initialised
 // accumulators; the wave tile 128 x 128 is 8 x 8 accumulator tiles of 16 x 16 (4 AGPRs each) and a K step is two sub-steps of
 // K = 32.  Why a second MFMA shape (profiles/r02_gemm_experiments.md, "what the K loop's time is made of"): every kernel of
-// this library runs at the board's 1.4 kW cap, so time ~ energy per flop; with gemm256w's loop otherwise unchanged, issuing the
+// this library runs at the board's 1.4 kW cap, so time ~ energy per flop; with that kernel's loop otherwise unchanged, issuing the
 // same flops as 16x16x32 MFMAs (4 accumulator registers written per 16 matrix cycles instead of 16 per 32) measured +5-7 %.
 // A fragment is 16 rows x 32 k: lane l reads row l % 16, 16-byte chunk (l / 16) + 4 s of the swizzled 128-byte LDS row --
 // conflict-free for ds_read_b128's lane groups ({0-3, 12-15, 20-27}, ...: the 8 chunk ^ key values of a group are distinct).

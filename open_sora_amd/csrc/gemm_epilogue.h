@@ -1,4 +1,4 @@
-// Fused epilogue of the large-tile GEMM kernels (gemm256p.hip, gemm256w.hip): bias / GELU-tanh / gate * x + residual /
+// Fused epilogue of the large-tile GEMM kernels (gemm256.hip [fp8], gemm256p.hip; the 16 x 16 accumulator layout of gemm256x.hip has its own: gemm_epilogue16.h): bias / GELU-tanh / gate * x + residual /
 // bf16 or f32 store, on the accumulator layout of v_mfma_f32_32x32x16_bf16 with swapped operands (a lane owns ONE output
 // row and 4 consecutive columns per 8-column block).  Geo supplies the wave tile: TM x TN MFMA tiles and
 // read<T>(float[16]) = the 16 accumulator registers of tile T = tn * TM + tm.

@@ -19,6 +19,8 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass
 
+import weakref
+
 import torch
 from torch import Tensor, nn
 
@@ -230,21 +232,37 @@ class _ConvPlan:
         self.stride = tuple(conv.stride)
 
 
+# kernel-side images of the layers' parameters, keyed on the layer object.  A weak map instead of an attribute on the (plain torch)
+# nn.Conv3d / nn.GroupNorm / nn.Linear modules: nothing here travels with copy.deepcopy / pickle / torch.save of the VAE (the
+# images hold re-laid device weights), and an entry dies with its module.
+_PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _drop_plan(mod, *_):
+    """(also the load_state_dict post hook of the layers: a module-level function, so that hooks pickle with the module)"""
+    _PLANS.pop(mod, None)
+
+
 def _plan(mod, kind):
-    """kernel-side image of a layer's parameters, cached on the module and keyed on the parameters' (storage pointer,
-    in-place version; 0 for inference tensors, which track none): a swapped weight, or one rewritten in place through the
-    parameter itself, rebuilds it.  Writes through `p.data` are not visible to that key: drop `_osk_plan` after them."""
-    key = tuple((q.data_ptr(), 0 if q.is_inference() else q._version) for q in mod.parameters())
-    c = getattr(mod, "_osk_plan", None)
+    """kernel-side image of a layer's parameters, cached per parameter-owning layer (nn.Conv3d / nn.GroupNorm / nn.Linear) and
+    keyed on the parameters' (storage pointer, in-place version; 0 for inference tensors, which track none): a swapped weight,
+    or one rewritten in place through the parameter itself, rebuilds it.  A load_state_dict at ANY level (the layer itself, a
+    block, the whole VAE -- also under torch.inference_mode(), where the version key cannot see the copy) drops it through a
+    post hook on the layer.  Writes through `p.data` are not visible: call AutoencoderKLCausal3D.invalidate_plan() after them."""
+    leaf = mod.conv if isinstance(mod, CausalConv3d) else mod
+    key = tuple((q.data_ptr(), 0 if q.is_inference() else q._version) for q in leaf.parameters())
+    c = _PLANS.get(leaf)
     p = c[1] if c is not None and c[0] == key else None
     if p is None:
         if kind == "conv":
-            p = _ConvPlan(mod.conv if isinstance(mod, CausalConv3d) else mod)
+            p = _ConvPlan(leaf)
         elif kind == "gn":
-            p = (mod.weight.detach().float().contiguous(), mod.bias.detach().float().contiguous(), mod.num_groups, mod.eps)
+            p = (leaf.weight.detach().float().contiguous(), leaf.bias.detach().float().contiguous(), leaf.num_groups, leaf.eps)
         elif kind == "lin":
-            p = (mod.weight.detach().to(BF16).contiguous(), mod.bias.detach().float().contiguous())
-        object.__setattr__(mod, "_osk_plan", (key, p))
+            p = (leaf.weight.detach().to(BF16).contiguous(), leaf.bias.detach().float().contiguous())
+        if _drop_plan not in leaf._load_state_dict_post_hooks.values():
+            leaf.register_load_state_dict_post_hook(_drop_plan)
+        _PLANS[leaf] = (key, p)
     return p
 
 
@@ -475,8 +493,7 @@ class AutoencoderKLCausal3D(nn.Module):
         """drop every cached kernel-side weight image (re-laid conv weights, f32 biases): they are rebuilt from the
         parameters on the next call"""
         for m in self.modules():
-            if hasattr(m, "_osk_plan"):
-                object.__delattr__(m, "_osk_plan")
+            _drop_plan(m)
 
     # the cached weight images alias / copy parameter storage: any operation that replaces or rewrites the
     # parameters (load_state_dict, .to(), .cuda(), .half() ...) must drop them

@@ -23,6 +23,8 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass, field
 
+import weakref
+
 import torch
 from torch import Tensor, nn
 
@@ -93,6 +95,36 @@ class _OskState:
         if "_plan" in d:
             d["_plan"] = None
         return d
+
+
+# load_state_dict watchers.  The hook itself is a module-level function (module hooks are pickled / deep-copied with the module:
+# a closure would break torch.save(model)); who it serves lives in weak side tables that never travel.
+_WATCHERS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # sub-module -> [weakref(owner of a cached plan)]
+_WATCHED: "weakref.WeakSet" = weakref.WeakSet()                        # owners already wired
+
+
+def _state_loaded(module, _incompatible_keys) -> None:
+    for ref in _WATCHERS.get(module, ()):
+        b = ref()
+        if b is None:
+            continue
+        if hasattr(b, "invalidate_plan"):        # the whole model: its plan also holds f32 copies of the blocks' adaLN biases
+            b.invalidate_plan()
+        elif "_osk_plan" in b.__dict__:
+            object.__delattr__(b, "_osk_plan")
+
+
+def _watch_state_loads(owner) -> None:
+    """A load_state_dict at any level of the owner's module tree (the block, one of its Linear layers, ...) drops the owner's
+    cached plan -- also under torch.inference_mode(), where the (pointer, version) key of _param_key cannot see an in-place
+    copy.  Works on the reference's own blocks too (the processors cache their plans on whatever block they run on)."""
+    if owner in _WATCHED:
+        return
+    for m in owner.modules():
+        if _state_loaded not in m._load_state_dict_post_hooks.values():
+            m.register_load_state_dict_post_hook(_state_loaded)
+        _WATCHERS.setdefault(m, []).append(weakref.ref(owner))
+    _WATCHED.add(owner)
 
 
 class _Holder(nn.Module):
@@ -417,6 +449,7 @@ def plan_double(block) -> _DoublePlan:
         hd = block.head_dim if hasattr(block, "head_dim") else block.hidden_size // block.num_heads
         p.score_bound = _score_bound(hd, (p.img.q_scale, p.txt.q_scale), (p.img.k_scale, p.txt.k_scale))
         p.key = _param_key(block)
+        _watch_state_loads(block)
         object.__setattr__(block, "_osk_plan", p)
     return p
 
@@ -437,6 +470,7 @@ def plan_single(block) -> _SinglePlan:
         hd = block.head_dim if hasattr(block, "head_dim") else block.hidden_size // block.num_heads
         p.score_bound = _score_bound(hd, (p.q_scale,), (p.k_scale,))
         p.key = _param_key(block)
+        _watch_state_loads(block)
         object.__setattr__(block, "_osk_plan", p)
     return p
 
@@ -476,12 +510,12 @@ def _workspace(owner, B, L_txt, L_img, D, R, H, hd, device) -> _Workspace:
         cache = {}
         object.__setattr__(owner, "_osk_ws_cache", cache)
     key = (B, L_txt, L_img, D, R, H, hd, str(device), _stream_key(device), id(_OPS))
-    ws = cache.get(key)
+    ws = cache.pop(key, None)
     if ws is None:
-        if len(cache) >= 4:
-            cache.clear()
+        while len(cache) >= 4:   # least recently used first (dicts keep insertion order; a hit is re-inserted below).  The entry in
+            cache.pop(next(iter(cache)))   # use -- e.g. the one a captured hipGraph replays into -- is always the newest
         ws = _Workspace(B, L_txt, L_img, D, R, H, hd, device)
-        cache[key] = ws
+    cache[key] = ws
     return ws
 
 
@@ -853,6 +887,7 @@ class MMDiTModel(_OskState, nn.Module):
         p["vector_in"] = emb(self.vector_in)
         p["guidance_in"] = emb(self.guidance_in) if cfg.guidance_embed else None
         p["key"] = self._plan_key()
+        _watch_state_loads(self)   # a load_state_dict on any sub-module drops the plan (inference tensors: no version to key on)
         self._plan = p
         return p
 

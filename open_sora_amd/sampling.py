@@ -89,6 +89,9 @@ def prepare_ids(bs: int, t: int, h: int, w: int, n_txt: int, device, dtype, patc
     return img_ids, txt_ids
 
 
+_SIDE_STREAMS: dict = {}   # device -> the capture stream of denoise(hip_graph=True)
+
+
 class I2VDenoiser:
     """sampling.py:158-245.  `denoise(model, img=..., timesteps=[...], guidance=..., guidance_img=..., masks=...,
     masked_ref=..., img_ids=..., txt=..., txt_ids=..., y_vec=..., [text_osci, image_osci, scale_temporal_osci,
@@ -134,7 +137,11 @@ class I2VDenoiser:
             # capture needs a non-default stream, and the model's workspaces are keyed on the stream: run the WHOLE loop (the
             # eager step 0 as well) on one side stream, so capture re-uses step 0's workspaces instead of allocating a second
             # set from the graph's private pool that would stay pinned for the model's lifetime
-            side = torch.cuda.Stream(dev)
+            # ONE side stream per device for the lifetime of the process (the workspace key contains the stream handle: a fresh
+            # stream per call would allocate a fresh activation workspace set per sampling run -- ADVICE r3)
+            side = _SIDE_STREAMS.get(str(dev))
+            if side is None:
+                side = _SIDE_STREAMS[str(dev)] = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 out = self._loop(model, kwargs, x, x_next, img3, t_vec, cond3, guidance_vec, timesteps, guidance, guidance_img,

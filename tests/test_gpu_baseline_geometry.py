@@ -119,6 +119,99 @@ def test_xl_blocks_at_full_bench_length(hip_lib):
     assert_parity(o_x, t_x, r_x, "XL single block, L=16896")
 
 
+# ------------------------------------------------------------------------------------------------ 11B geometry (the shipped config)
+def _pe_for(ang, liger: bool):
+    """the reference's two positional-embedding formats (layers.py:38-44 / 55-65) from one angle table"""
+    c, s = torch.cos(ang), torch.sin(ang)
+    if liger:   # LigerEmbedND: (cos, sin), halves repeated, [B, L, hd]
+        return (torch.cat((c, c), -1).float().to(DEV), torch.cat((s, s), -1).float().to(DEV))
+    return torch.stack([c, -s, s, c], dim=-1).reshape(*ang.shape, 2, 2).float().unsqueeze(1).to(DEV)
+
+
+@pytest.mark.parametrize("liger", [False, True], ids=["eager_rope", "liger_rope"])
+def test_11b_blocks_vs_oracle(hip_lib, liger):
+    """the geometry bench.py's `11b` sub-object times (hidden 3072, 24 x 128) had no model-level parity test.
+    ONE double and ONE single block at B = 3 (the CFG triple), L = 2048 + 512, both RoPE conventions: K = 3072 / 12288 / 15360
+    GEMMs, N = 9216 / 21,504, qknorm_rope_kernel<128> at 24 heads, attn_asm128_kernel, through the block processors."""
+    from open_sora_amd import mmdit
+
+    cfg = dict(pcfg.MMDIT["11B"], depth=1, depth_single_blocks=1, use_liger_rope=liger)
+    D, H = cfg["hidden_size"], cfg["num_heads"]
+    sd = fast_params(synth.mmdit_param_shapes(cfg), seed=31 + int(liger))
+    sdb = {k: v.bfloat16() for k, v in sd.items()}
+    model = mmdit.Flux(device_map=DEV, torch_dtype=BF, **cfg)
+    model.load_state_dict({k: v.to(DEV, BF) for k, v in sd.items()}, strict=True)
+    B, T, hp, wp, Lt = 3, 2, 32, 32, 512
+    g = torch.Generator().manual_seed(6)
+    img = torch.randn(B, T * hp * wp, D, generator=g).bfloat16().float()
+    txt = torch.randn(B, Lt, D, generator=g).bfloat16().float()
+    vec = torch.randn(B, D, generator=g).bfloat16().float()
+    img_ids, txt_ids = S.grid_ids(B, T, hp, wp, Lt, torch.float32)
+    ids = torch.cat((txt_ids, img_ids), 1)
+    ang = (O.rope_angles_liger if liger else O.rope_angles)(ids, cfg["axes_dim"], cfg["theta"])
+    mode = "half" if liger else "interleaved"
+    pe = _pe_for(ang, liger)
+    with torch.inference_mode():
+        o_img, o_txt = model.double_blocks[0](img.to(DEV, BF), txt.to(DEV, BF), vec.to(DEV, BF), pe)
+        t_img, t_txt = O.double_block(sd, cfg, 0, img, txt, vec, ang, mode)
+        r_img, r_txt = O.double_block(sdb, cfg, 0, img.bfloat16(), txt.bfloat16(), vec.bfloat16(), ang, mode)
+    assert_parity(o_img, t_img, r_img, f"11B double block [{mode}], B=3, L=2560: img stream")
+    assert_parity(o_txt, t_txt, r_txt, f"11B double block [{mode}], B=3, L=2560: txt stream")
+    x = torch.cat((t_txt, t_img), 1).bfloat16().float()
+    del t_img, t_txt, r_img, r_txt
+    with torch.inference_mode():
+        o_x = model.single_blocks[0](x.to(DEV, BF), vec.to(DEV, BF), pe)
+        t_x = O.single_block(sd, cfg, 0, x, vec, ang, mode)
+        r_x = O.single_block(sdb, cfg, 0, x.bfloat16(), vec.bfloat16(), ang, mode)
+    assert_parity(o_x, t_x, r_x, f"11B single block [{mode}], B=3, L=2560")
+    assert model.attention_report(1, 2560)["bodies"] == ["attn_asm128_kernel<FAST>"]
+
+
+def test_11b_reduced_depth_forward_vs_oracle(hip_lib):
+    """error accumulation through D = 3072 blocks: the shipped config at depth 2 + 4 (0.9 G parameters), whole forward incl. the
+    embedders and the final layer, B = 3, L = 1024 + 256, vs the oracle in fp32 and bf16"""
+    from open_sora_amd import mmdit
+
+    cfg = dict(pcfg.MMDIT["11B"], depth=2, depth_single_blocks=4)
+    sd = fast_params(synth.mmdit_param_shapes(cfg), seed=37)
+    inp = {k: torch.from_numpy(v) for k, v in synth.mmdit_inputs(cfg, 3, 1, 32, 32, 256).items()}
+    model = mmdit.Flux(device_map=DEV, torch_dtype=BF, **cfg)
+    model.load_state_dict({k: v.to(DEV, BF) for k, v in sd.items()}, strict=True)
+    with torch.inference_mode():
+        out = model(**_to(inp, BF, DEV))
+        truth = O.forward(sd, cfg, **inp)
+        ref = O.forward({k: v.bfloat16() for k, v in sd.items()}, cfg, **_to(inp, BF))
+    assert_parity(out, truth, ref, "MMDiT-11B geometry, depth 2+4, B=3, L=1280")
+
+
+def test_xl_forward_qk_scales_u05_15_runs_the_fast_body(hip_lib):
+    """SURVEY.md section 8(d)'s second run: QK-norm scale vectors ~U(0.5, 1.5) instead of ~1 through the XL
+    full-depth forward -- the score bound grows to <= 1.05 * 12.24 * 2.25 = 28.9 < 56, so every block still takes the bounded
+    body, and the result must meet the oracle like the unit-scale run.  A model with scale entries of 3 must fall back."""
+    cfg, sd, inp, _, _ = _xl_case(False, 64)
+    g = torch.Generator().manual_seed(99)
+    sd2 = {k: ((torch.rand(v.shape, generator=g) + 0.5).bfloat16().float() if k.endswith(("query_norm.scale", "key_norm.scale")) else v)
+           for k, v in sd.items()}
+    assert sum(1 for k in sd2 if k.endswith("query_norm.scale")) == 2 * cfg["depth"] + cfg["depth_single_blocks"]
+    model = _xl_model(cfg, sd2)
+    with torch.inference_mode():
+        out = model(**_to(inp, BF, DEV))
+        truth = O.forward(sd2, cfg, **inp)
+        ref = O.forward({k: v.bfloat16() for k, v in sd2.items()}, cfg, **_to(inp, BF))
+    assert_parity(out, truth, ref, "MMDiT-XL 9+19 forward, QK-norm scales ~U(0.5, 1.5)")
+    rep = model.attention_report(1, 576)
+    assert rep["bodies"] == ["attn_asm72_kernel<FAST>"] and rep["blocks_on_fast_body"] == 28 and 12.0 < rep["score_bound_max"] <= 29.0, rep
+    sd3 = {k: (v * 3.0 if k.endswith(("query_norm.scale", "key_norm.scale")) else v) for k, v in sd.items()}
+    model.load_state_dict({k: v.to(DEV, BF) for k, v in sd3.items()}, strict=True)
+    rep3 = model.attention_report(1, 576)
+    assert rep3["bodies"] == ["attn_asm72_kernel<general>"] and rep3["blocks_on_fast_body"] == 0 and rep3["score_bound_min"] > 56.0, rep3
+    with torch.inference_mode():
+        out3 = model(**_to(inp, BF, DEV))
+        truth3 = O.forward(sd3, cfg, **inp)
+        ref3 = O.forward({k: v.bfloat16() for k, v in sd3.items()}, cfg, **_to(inp, BF))
+    assert_parity(out3, truth3, ref3, "MMDiT-XL 9+19 forward, QK-norm scales x 3 (general attention body)")
+
+
 # ------------------------------------------------------------------------------------------------ VAE, shipped widths
 _VAE_CFG = dict(configs._VAE, block_out_channels=(128, 256, 512, 512), layers_per_block=2)
 
@@ -133,7 +226,7 @@ def _vae(cfg, sd):
 
 def test_vae_shipped_widths_encode_decode_vs_oracle(hip_lib):
     """BASELINE configs[2]'s architecture (128/256/512/512, 2 layers per block) on [1, 3, 9, 64, 64]: every conv with
-    Cin % 128 == 0 takes the 256-voxel tile (conv256t_kernel), inside an encode / decode compared with the oracle."""
+    Cin % 128 == 0 takes a 256-voxel tile (convsw_kernel / convsw2_kernel / conv256x_kernel), inside an encode / decode compared with the oracle."""
     cfg = dict(_VAE_CFG)
     sd = fast_params(synth.vae_param_shapes(cfg), seed=21)
     sdb = {k: v.bfloat16() for k, v in sd.items()}

@@ -83,7 +83,10 @@ def test_gemm_plain_bias(hip_lib, M_L, N, K):
 # shapes that dispatch to the large-tile hand-scheduled kernel (gemm256.hip: M >= 256, N >= 128): exact tiles, ragged M
 # and N tails, tiles straddling a batch boundary, one K step (K = 64), both tile widths (N % 256 == 0 -> BN 256, else 128)
 @pytest.mark.parametrize("M_L,N,K", [((1, 256), 256, 64), ((1, 512), 512, 128), ((2, 300), 384, 192), ((3, 700), 1152, 1152),
-                                     ((1, 1000), 520, 256), ((2, 1024), 2304, 576), ((1, 257), 132, 64), ((1, 300), 200, 128)])
+                                     ((1, 1000), 520, 256), ((2, 1024), 2304, 576), ((1, 257), 132, 64), ((1, 300), 200, 128),
+                                     # the 11B geometry's Linear shapes (hidden 3072: QKV, linear1 = QKV + MLP-up, MLP-down, linear2):
+                                     # K = 3072 / 12288 / 15360 are 48 / 192 / 240 K steps of the persistent loop, N = 21,504 is 84 column tiles
+                                     ((3, 1300), 9216, 3072), ((1, 2560), 21504, 3072), ((2, 700), 3072, 12288), ((1, 1300), 3072, 15360)])
 def test_gemm_large_tile(hip_lib, M_L, N, K):
     B, L = M_L
     a = rnd("a", (B, L, K))
@@ -180,6 +183,8 @@ def test_gemm_persistent_multi_tile(hip_lib, M_L, N, K, gelu_from, gated):
     (3, 8000, 300, 1152, 1152, None, True),      # proj: gate * x + residual written in place, ragged N (4.5 column tiles), ragged M
     (2, 8000, 512, 1024, 256, 0, False),         # MLP-up kind: GELU over the whole row
     (1, 200, 77, 384, 128, None, True),          # small: the entry falls back to the two single calls (bit-identical to them)
+    (2, 8192, 512, 3072, 3072, None, True),      # 11B width: the image problem's 768 tiles are exactly 3 rounds -> the entry declines (two calls)
+    (1, 6144, 512, 9216, 3072, None, False),     # 11B QKV: 24 x 36 + 2 x 36 tiles, K = 3072
 ])
 def test_gemm_pair_equals_two_calls(hip_lib, B, Li, Lt, N, K, gelu_from, gated):
     """osk_gemm_bf16_pair on the joint-buffer views of a double block: [txt ; img] rows of one buffer, separate weights."""

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import configs, synth, vae_oracle as V
-from tests.util import assert_parity, finite_retry
+from tests.util import assert_parity, finite_retry, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -258,37 +258,80 @@ def test_vae_tiled_vs_reference_golden(hip_lib):
     assert_parity(dec, torch.from_numpy(g["dec"]), d_ref, "vae tiled decode")
 
 
-def test_full_size_conv_spot_check(hip_lib):
-    """BASELINE config 3 size: the single largest conv of the decoder (dec.up2 upsampler: 256 -> 256 channels,
-    17 x 128 x 128 -> 33 x 256 x 256 with the upsample folded in) checked voxel-by-voxel on a random sample
-    (borders included) against a direct fp64 evaluation of pad(upsample(x)) * w."""
-    ci = co = 256
-    T, H, W = 17, 128, 128
+# the eight large layer shapes of BASELINE config 3 (profiles/r03k_conv_layers.jsonl: 96 % of the VAE's conv FLOPs), each at its
+# real size: (Cin, Cout, T, H, W, upsample (t, hw), kernel that takes it)
+_FULL_SIZE_LAYERS = [
+    (128, 128, 33, 256, 256, (False, False), "convsw2_kernel (two-frame tiles)"),
+    (256, 128, 33, 256, 256, (False, False), "convsw2_kernel"),
+    (256, 256, 33, 128, 128, (False, False), "convsw_kernel<8>"),
+    (512, 256, 33, 128, 128, (False, False), "convsw_kernel<8>: 2112 tiles, 8.25 rounds"),
+    (512, 512, 17, 64, 64, (False, False), "convsw_kernel<8>"),
+    (512, 512, 9, 32, 32, (False, False), "convsw_kernel<8>, 144 tiles"),
+    (512, 512, 9, 32, 32, (True, True), "convsw_kernel<8, UP>: dec.up0 upsampler -> 17 x 64 x 64"),
+    (256, 256, 17, 128, 128, (True, True), "convsw_kernel<8, UP>: dec.up2 upsampler -> 33 x 256 x 256"),
+    (512, 512, 17, 64, 64, (True, True), "convsw_kernel<8, UP>: dec.up1 upsampler -> 33 x 128 x 128"),
+]
+
+
+@pytest.mark.parametrize("ci,co,T,H,W,up,what", _FULL_SIZE_LAYERS, ids=[f"{c[0]}to{c[1]}_{c[2]}x{c[3]}{'_up' if c[5][0] else ''}" for c in _FULL_SIZE_LAYERS])
+def test_full_size_conv_spot_check(hip_lib, ci, co, T, H, W, up, what):
+    """BASELINE config 3 size (VERDICT r3 weak #1b): every large conv layer shape of the encode + decode at its REAL extent --
+    not only the decoder's last upsampler -- checked voxel by voxel on a random sample (corners and borders included) against a
+    direct fp64 evaluation of pad(upsample(x)) * w + bias, written into a NaN-filled output."""
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn(1, T, H, W, ci, device=DEV, generator=g).to(BF)
     w = (torch.randn(co, 3, 3, 3, ci, device=DEV, generator=g) * (27 * ci) ** -0.5).to(BF)
     b = torch.randn(co, device=DEV, generator=g) * 0.1
-    To, Ho, Wo = hip_lib.conv_out_dims(T, H, W, (1, 1, 1), (True, True))
-    assert (To, Ho, Wo) == (33, 256, 256)
-    out = torch.empty(1, To, Ho, Wo, co, dtype=BF, device=DEV)
-    hip_lib.causal_conv3d(x, w.reshape(co, -1).contiguous(), b, out, 3, (1, 1, 1), (True, True))
+    To, Ho, Wo = hip_lib.conv_out_dims(T, H, W, (1, 1, 1), up)
+    out = torch.full((1, To, Ho, Wo, co), float("nan"), dtype=BF, device=DEV)
+    hip_lib.causal_conv3d(x, w.reshape(co, -1).contiguous(), b, out, 3, (1, 1, 1), up)
     torch.cuda.synchronize()
-    rs = np.random.RandomState(0)
-    pts = [(0, 0, 0), (To - 1, Ho - 1, Wo - 1), (1, 0, Wo - 1), (2, Ho - 1, 0)] + \
-          [(rs.randint(To), rs.randint(Ho), rs.randint(Wo)) for _ in range(60)]
+    assert torch.isfinite(out.float()).all(), what
+    rs = np.random.RandomState(ci + co + T)
+    pts = [(0, 0, 0), (To - 1, Ho - 1, Wo - 1), (1, 0, Wo - 1), (2, Ho - 1, 0), (To - 1, 15, 16), (0, Ho - 16, Wo - 17)] + \
+          [(rs.randint(To), rs.randint(Ho), rs.randint(Wo)) for _ in range(58)]
     xc, wc, bc = x[0].double(), w.double(), b.double()
     for (t, h, ww) in pts:
         acc = bc.clone()
         for dt in range(3):
             tu = min(max(t + dt - 2, 0), To - 1)
-            ts = 0 if tu == 0 else 1 + (tu - 1) // 2
+            ts = (0 if tu == 0 else 1 + (tu - 1) // 2) if up[0] else tu
             for dh in range(3):
-                hs = min(max(h + dh - 1, 0), Ho - 1) // 2
+                hs = min(max(h + dh - 1, 0), Ho - 1) // (2 if up[1] else 1)
                 for dw in range(3):
-                    ws = min(max(ww + dw - 1, 0), Wo - 1) // 2
+                    ws = min(max(ww + dw - 1, 0), Wo - 1) // (2 if up[1] else 1)
                     acc += wc[:, dt, dh, dw, :] @ xc[ts, hs, ws]
         got = out[0, t, h, ww].double()
-        assert (got - acc).abs().max() <= 2.0 ** -7 * acc.abs().max() + 1e-3, (t, h, ww)
+        assert (got - acc).abs().max() <= 2.0 ** -7 * acc.abs().max() + 1e-3, (what, t, h, ww)
+
+
+def test_full_size_encode_decode_vs_reference_fixture(hip_lib):
+    """BASELINE config 3 END TO END at its real size against the reference itself: tests/golden/vae_fullsize_cfg3.npz holds what the
+    reference's own AutoencoderKLCausal3D (fp32, CPU, run once offline by oracle/make_golden_fullsize.py) returns for
+    synth.vae_video(1, 33, 256, 256) / synth.vae_latent(1, 9, 32, 32) with the synthetic shipped-width weights: the whole latent
+    mean, the decoded video on an 8 x 8 pixel lattice, and per (channel, frame) first and second moments of the whole video.
+    No bf16 comparator can be run here (a full-size bf16 oracle pass is ~1 h of CPU): the bound is the 64 x 64 shipped-width
+    test's measured relL2 of the reference-precision run with head-room (encode 1.2e-2, decode 2.5e-2)."""
+    from oracle import make_golden_fullsize as FS
+
+    g = np.load(os.path.join(GOLDEN_DIR, "vae_fullsize_cfg3.npz"))
+    cfg = dict(FS.CFG)
+    m = _model(cfg)
+    x = torch.from_numpy(synth.vae_video(*FS.SHAPE)).to(DEV).to(BF)
+    with torch.inference_mode():
+        z = m.encode(x, sample_posterior=False).float().cpu()
+        zin = torch.from_numpy(synth.vae_latent(1, 9, 32, 32)).to(DEV).to(BF)
+        dec = m.decode(zin).float().cpu()
+    zt = torch.from_numpy(g["z"])
+    assert list(z.shape) == list(zt.shape) and torch.isfinite(z).all() and torch.isfinite(dec).all()
+    ez = rel_l2(z, zt)
+    got = FS.summarize_dec(dec)
+    ed = rel_l2(torch.from_numpy(got["dec_s8"]), torch.from_numpy(g["dec_s8"]))
+    em = float(np.abs(got["dec_mean"] - g["dec_mean"]).max())
+    es = float(np.abs(got["dec_sq"] - g["dec_sq"]).max() / np.abs(g["dec_sq"]).max())
+    print(f"full-size cfg 3 vs the reference fixture: latent relL2 {ez:.3e}, decoded lattice relL2 {ed:.3e}, per-frame mean |d| {em:.3e}, mean-square rel {es:.3e}")
+    assert ez <= 1.2e-2 and ed <= 2.5e-2, (ez, ed)
+    assert em <= 4e-3 * max(1.0, float(np.abs(g["dec_mean"]).max())) and es <= 2e-2, (em, es)
 
 
 def test_large_tile_conv_is_deterministic_under_load(hip_lib):
@@ -306,7 +349,7 @@ def test_large_tile_conv_is_deterministic_under_load(hip_lib):
         hip_lib.causal_conv3d(x, w, b, o, 3)
         outs.append(o)
     torch.cuda.synchronize()
-    assert all(torch.equal(outs[0], o) for o in outs[1:]), "conv256t: run-to-run difference"
+    assert all(torch.equal(outs[0], o) for o in outs[1:]), "conv256x / convsw: run-to-run difference"
     assert torch.isfinite(outs[0].float()).all()
 
 

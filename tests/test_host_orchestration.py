@@ -189,3 +189,54 @@ def test_plan_key_sees_in_place_writes_but_not_data_writes(cpu_mmdit):
     with torch.inference_mode():
         fresh = model(**inp)
     assert torch.allclose(fresh.float(), base.float(), atol=2e-2, rtol=2e-2) and not torch.equal(fresh, shifted)
+
+
+def test_block_level_load_state_dict_under_inference_mode_drops_the_plan(cpu_mmdit):
+    """parameters that are inference tensors have no version counter, so an in-place `load_state_dict` on ONE BLOCK (or
+    on one of its Linear layers) inside torch.inference_mode() changes the values without changing the plan key.  The load hooks
+    drop the cached plan; the next forward equals a freshly built model with the same weights."""
+    cfg, B, T, h, w, L_txt = configs.GOLDEN["hd64_eager_fused"]
+    inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF)
+    with torch.inference_mode():
+        model = _build(cpu_mmdit, cfg)
+        base = model(**inp)
+        blk = model.double_blocks[0]
+        sd = {k: (v * 1.5).to(v.dtype) for k, v in blk.state_dict().items()}
+        blk.load_state_dict(sd)                                   # block level: the model's own override never runs
+        assert "_osk_plan" not in blk.__dict__
+        changed = model(**inp)
+        lin = model.single_blocks[0].linear2
+        lin.load_state_dict({k: (v * 0.5).to(v.dtype) for k, v in lin.state_dict().items()})   # a leaf of a single block
+        assert "_osk_plan" not in model.single_blocks[0].__dict__
+        changed2 = model(**inp)
+        fresh = _build(cpu_mmdit, cfg)
+        fresh.load_state_dict(model.state_dict())
+        want = fresh(**inp)
+    assert not torch.equal(changed, base) and not torch.equal(changed2, changed)
+    assert torch.equal(changed2, want)
+
+
+def test_workspace_cache_is_lru_and_caches_do_not_travel(cpu_mmdit):
+    import copy
+
+    cfg, B, T, h, w, L_txt = configs.GOLDEN["hd64_eager_fused"]
+    model = _build(cpu_mmdit, cfg)
+    with torch.inference_mode():
+        for i, lt in enumerate((8, 16, 24, 32, 40)):              # five geometries: the oldest is evicted, not the whole cache
+            model(**torch_inputs(cfg, B, T, h, w, lt, dtype=BF))
+            if i == 3:
+                keys4 = list(model._osk_ws_cache)
+        keys5 = list(model._osk_ws_cache)
+        assert len(keys5) == 4 and keys5[:3] == keys4[1:]
+        model(**torch_inputs(cfg, B, T, h, w, 16, dtype=BF))      # a hit moves the entry to the young end
+        assert list(model._osk_ws_cache)[-1] == keys5[0]
+    clone = copy.deepcopy(model)
+    assert "_osk_ws_cache" not in clone.__dict__ and clone._plan is None
+    assert all("_osk_plan" not in b.__dict__ for b in clone.double_blocks)
+    import pickle
+
+    blob = pickle.dumps(model.double_blocks[0])     # the load_state_dict watchers are module-level functions: modules still pickle
+    assert len(blob) < 3 * sum(p.numel() * p.element_size() for p in model.double_blocks[0].parameters())
+    with torch.inference_mode():
+        inp = torch_inputs(cfg, B, T, h, w, 8, dtype=BF)
+        assert torch.equal(clone(**inp), model(**inp))

@@ -1,6 +1,6 @@
 """The LDS image of the large-tile GEMM / conv kernels (rows of 128 bytes = 64 bf16 k, 16-byte chunk c of row r stored at
 chunk position c ^ ((r >> 1) & 7)) must be conflict-free for BOTH fragment lane maps that read it with ds_read_b128:
-  * v_mfma_f32_32x32x16_bf16 (gemm256 / gemm256p / gemm256w, conv256t / conv256w): lane l reads row l % 32, chunk 2 ks + l / 32;
+  * v_mfma_f32_32x32x16_bf16 (gemm256 [fp8] / gemm256p; rounds 1-2 also: gemm256w, conv256t / conv256w, since removed): lane l reads row l % 32, chunk 2 ks + l / 32;
   * v_mfma_f32_16x16x32_bf16 (gemm256x, conv256x):                               lane l reads row l % 16, chunk 4 s + l / 16.
 ds_read_b128 is served in four groups of 16 lanes (/opt/skills/guides/MI355X_MICROARCH.md, LDS section); lanes of one group
 conflict when they hit the same 16-byte slot of the 256-byte bank window with different addresses.  Pure arithmetic: runs on CPU."""

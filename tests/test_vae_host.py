@@ -102,3 +102,31 @@ def test_vae_built_and_loaded_inside_inference_mode(cpu_vae):
         zb = outside.encode(x, sample_posterior=False)
         da = inside.decode(za)
     assert torch.equal(za, zb) and torch.isfinite(da.float()).all()
+
+
+def test_vae_plans_do_not_travel_and_follow_state_loads(cpu_vae):
+    """the per-layer weight images live in a weak map (not on the plain torch layers), so copy.deepcopy / pickle of the
+    VAE carry none of them; a load_state_dict on a SUB-module under inference_mode (no version counter to key on) drops the
+    layer's image through its post hook."""
+    import copy
+    import pickle
+
+    from open_sora_amd import hunyuan_vae
+
+    cfg, B, T, H, W = configs.VAE_GOLDEN["c32_lpb1"]
+    x = torch.from_numpy(synth.vae_video(B, T, H, W)).to(BF)
+    with torch.inference_mode():
+        m = _model(cpu_vae, cfg)
+        z0 = m.encode(x, sample_posterior=False)
+        n_plans = sum(1 for mod in m.modules() if mod in hunyuan_vae._PLANS)
+        assert n_plans > 10
+        assert not any(k.startswith("_osk_plan") for mod in m.modules() for k in mod.__dict__)
+        clone = copy.deepcopy(m)
+        assert sum(1 for mod in clone.modules() if mod in hunyuan_vae._PLANS) == 0
+        assert len(pickle.dumps(m.encoder.conv_in)) < 4 * sum(p.numel() * p.element_size() for p in m.encoder.conv_in.parameters()) + 4096
+        assert torch.equal(clone.encode(x, sample_posterior=False), z0)
+        conv = m.encoder.conv_in
+        conv.load_state_dict({k: (v * 2.0).to(v.dtype) for k, v in conv.state_dict().items()})
+        assert conv.conv not in hunyuan_vae._PLANS
+        z1 = m.encode(x, sample_posterior=False)
+    assert not torch.equal(z1, z0)

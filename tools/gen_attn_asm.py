@@ -5,7 +5,7 @@
 
 Why a generator: the MFMA shadow (32 cycles, ~5 issue slots) has to be filled by hand; hipcc's scheduler clusters
 the softmax VALU work behind the MFMAs and shuffles accumulators between the VGPR and AGPR halves
-(tools/isa_stream.py on attention_w64.hip shows it).  The schedule below is explicit and reproducible;
+(tools/isa_stream.py on the compiler-scheduled twin of rounds 1-2, attention_w64.hip, showed it).  The schedule below is explicit and reproducible;
 `python tools/gen_attn_asm.py --table NU [--hd 128]` prints it shadow by shadow.
 
 Two layouts of the same dataflow, workgroup = 256 query rows, KV tile = 64 keys:
@@ -13,7 +13,7 @@ Two layouts of the same dataflow, workgroup = 256 query rows, KV tile = 64 keys:
           392 registers per wave;
   NU = 1: 8 waves x 32 rows, two waves per SIMD (<= 256 registers each): twice the LDS fragment traffic, but each
           wave's fillers also sit in the shadow of its partner's MFMAs.
-Dataflow (operand conventions of attention_w64.hip, the compiler-scheduled twin that validated the LDS images and
+Dataflow (operand conventions of rounds 1-2's attention_w64.hip, the compiler-scheduled twin that validated the LDS images and
 the pipeline on the GPU): S^T = K . Q^T and O^T += V^T . P^T on v_mfma_f32_32x32x16_bf16 with swapped operands (a
 lane owns one query).  Q is pre-multiplied by scale*log2(e); the reference max M (bf16-exact, log2 units) sits,
 negated, in Q's padding dim 72 and K's padding dim 72 reads 1.0 from a constant LDS chunk, so the MFMA delivers

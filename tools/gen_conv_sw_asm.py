@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Generator of the hand-scheduled gfx950 K loop of the SLIDING-WINDOW CausalConv3d (open_sora_amd/csrc/conv3d_256.hip,
-convsw_kernel): 3 x 3 x 3, stride 1, no fused upsample, a workgroup tile = the 16 x 16 spatial brick of ONE output frame x
+convsw_kernel): 3 x 3 x 3, stride 1 (plain; the fused-upsample form `up` reads a 10 x 10 source patch), a workgroup tile = the 16 x 16 spatial brick of ONE output frame x
 256 (NBJ = 8) or 128 (NBJ = 4) output channels.
 
 Why: conv256x_kernel (tools/gen_gemm_asm.py::gen_conv_x4) is an implicit GEMM whose every filter tap re-fetches its 256 x 64
