@@ -46,6 +46,38 @@ def test_kernel_repeats_while_mfma_kernel_runs_on_second_stream(hip_lib, victim,
     assert bad == 0, f"{victim}: {bad} of {iters} launches differ from the first while {aggressor} runs on a second stream"
 
 
+@gpu
+@pytest.mark.parametrize("aggressor", AGGRESSORS)
+def test_foreign_torch_elementwise_victim_under_mfma_aggressor(hip_lib, aggressor):
+    """kernels of OTHER libraries are still compiled with packed FP32.  A torch f32 elementwise kernel
+    (addcmul: a fused multiply-add per element, the v_pk_fma_f32 pattern) runs on the main stream while one of this library's
+    MFMA kernels runs on a second stream.  This library cannot fix a foreign kernel: a mismatch here is the documented
+    co-residency constraint observed, reported as xfail with its count -- not a defect of the
+    product path, whose own kernels are covered by the test above."""
+    from tools.xproc_probe import make_kernel
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        alaunch, _, akeep = make_kernel(aggressor)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a, b, c = (torch.randn(1 << 22, device="cuda", generator=g) for _ in range(3))
+    first = torch.addcmul(c, a, b, value=1.5)
+    torch.cuda.synchronize()
+    iters = 400
+    flags = torch.zeros(iters, dtype=torch.int32, device="cuda")
+    for i in range(iters):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                alaunch()
+        out = torch.addcmul(c, a, b, value=1.5)
+        flags[i] = (out != first).sum()
+    torch.cuda.synchronize()
+    bad = int((flags > 0).sum())
+    if bad:
+        pytest.xfail(f"torch.addcmul (foreign, packed-FP32 build): {bad} of {iters} launches differ, {int(flags.sum())} elements, while "
+                     f"{aggressor} runs on a second stream -- the co-residency constraint of INTEGRATION.md section 4")
+
+
 def test_library_has_no_packed_fp32_instructions(hip_lib):
     """the build flag that removes the victim pattern is in force: no v_pk_*_f32 / v_pk_mov_b32 in the shipped code object"""
     import os

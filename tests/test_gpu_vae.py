@@ -310,8 +310,8 @@ def test_full_size_encode_decode_vs_reference_fixture(hip_lib):
     reference's own AutoencoderKLCausal3D (fp32, CPU, run once offline by oracle/make_golden_fullsize.py) returns for
     synth.vae_video(1, 33, 256, 256) / synth.vae_latent(1, 9, 32, 32) with the synthetic shipped-width weights: the whole latent
     mean, the decoded video on an 8 x 8 pixel lattice, and per (channel, frame) first and second moments of the whole video.
-    No bf16 comparator can be run here (a full-size bf16 oracle pass is ~1 h of CPU): the bound is the 64 x 64 shipped-width
-    test's measured relL2 of the reference-precision run with head-room (encode 1.2e-2, decode 2.5e-2)."""
+    No bf16 comparator is run here (a full-size bf16 oracle pass is tens of minutes of CPU): fixed bounds with head-room over
+    the measured values (MI355X, round 4: latent 1.10e-2, decoded lattice 1.15e-2, per-frame mean 3.5e-4, mean square 7.5e-4)."""
     from oracle import make_golden_fullsize as FS
 
     g = np.load(os.path.join(GOLDEN_DIR, "vae_fullsize_cfg3.npz"))
@@ -330,7 +330,7 @@ def test_full_size_encode_decode_vs_reference_fixture(hip_lib):
     em = float(np.abs(got["dec_mean"] - g["dec_mean"]).max())
     es = float(np.abs(got["dec_sq"] - g["dec_sq"]).max() / np.abs(g["dec_sq"]).max())
     print(f"full-size cfg 3 vs the reference fixture: latent relL2 {ez:.3e}, decoded lattice relL2 {ed:.3e}, per-frame mean |d| {em:.3e}, mean-square rel {es:.3e}")
-    assert ez <= 1.2e-2 and ed <= 2.5e-2, (ez, ed)
+    assert ez <= 1.6e-2 and ed <= 2.0e-2, (ez, ed)
     assert em <= 4e-3 * max(1.0, float(np.abs(g["dec_mean"]).max())) and es <= 2e-2, (em, es)
 
 
