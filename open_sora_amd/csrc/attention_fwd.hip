@@ -433,7 +433,7 @@ int launch_kernel(KernelT kernel, int smem, const AttnParams& p, hipStream_t st)
 template <int HD>
 int launch(const AttnParams& p, hipStream_t st) {
   if constexpr (HD == 72) {
-    const int rc = osk_attn::launch_asm72(p, st);
+    const int rc = p.rows == 512 ? osk_attn::launch_asm72w(p, st) : osk_attn::launch_asm72(p, st);
     return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, HD, st);
   } else if constexpr (HD == 128) {
     const int rc = osk_attn::launch_asm128(p, st);
@@ -454,24 +454,24 @@ namespace {
 template <int HD>
 __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
   constexpr int CPR = HD / 4;                    // float4 chunks per row
-  const int nqb = (p.Lq + 255) / 256;
+  const int nqb = (p.Lq + p.rows - 1) / p.rows;
   int bh, qb;
   unit_to_work(p, nqb, p.tail_first + (int)blockIdx.x, bh, qb);
   const int b = bh / p.H, h = bh - b * p.H;
   const int S = p.tail_split;
   for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
     const int r = blockIdx.y * 64 + i / CPR, c = i % CPR;
-    const int row = qb * 256 + r;
+    const int row = qb * p.rows + r;
     if (row >= p.Lq) continue;
-    const int64_t slot0 = (int64_t)blockIdx.x * S * 256 + r;
+    const int64_t slot0 = (int64_t)blockIdx.x * S * p.rows + r;
     float l[8], m = -INFINITY;
-    for (int s = 0; s < S; ++s) { l[s] = p.ws_lse[slot0 + s * 256]; m = fmaxf(m, l[s]); }
+    for (int s = 0; s < S; ++s) { l[s] = p.ws_lse[slot0 + s * p.rows]; m = fmaxf(m, l[s]); }
     float tot = 0.f;
     for (int s = 0; s < S; ++s) { l[s] = exp2f(l[s] - m); tot += l[s]; }
     const float inv = 1.0f / tot;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < S; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(p.ws_o + (slot0 + s * 256) * HD + c * 4);
+      const float4 v = *reinterpret_cast<const float4*>(p.ws_o + (slot0 + (int64_t)s * p.rows) * HD + c * 4);
       acc.x += l[s] * v.x; acc.y += l[s] * v.y; acc.z += l[s] * v.z; acc.w += l[s] * v.w;
     }
     uint2 w2;
@@ -500,7 +500,7 @@ void split_tail(AttnParams& p, int units, int hd, void* workspace, int64_t works
   int best = 1;
   for (int s = 2; s <= 8; ++s) {
     if (p.n_seg > 1 ? (p.n_seg % s != 0) : (s > p.tps)) continue;
-    const int64_t need = (int64_t)R * s * 256 * (hd + 1) * 4;
+    const int64_t need = (int64_t)R * s * p.rows * (hd + 1) * 4;
     if (need > workspace_bytes) continue;
     if (cost(s) < cost(best) - 1e-9) best = s;
   }
@@ -508,12 +508,12 @@ void split_tail(AttnParams& p, int units, int hd, void* workspace, int64_t works
   p.tail_split = best;
   p.tail_first = units - R;
   p.ws_o = (float*)workspace;
-  p.ws_lse = p.ws_o + (int64_t)R * best * 256 * hd;
+  p.ws_lse = p.ws_o + (int64_t)R * best * p.rows * hd;
 }
 
 int launch_merge(const AttnParams& p, int hd, hipStream_t st) {
-  const int units = ((p.Lq + 255) / 256) * p.B * p.H;
-  dim3 grid(units - p.tail_first, 4), block(256);
+  const int units = ((p.Lq + p.rows - 1) / p.rows) * p.B * p.H;
+  dim3 grid(units - p.tail_first, p.rows / 64), block(256);
   if (hd == 72) hipLaunchKernelGGL(attn_merge_kernel<72>, grid, block, 0, st, p);
   else if (hd == 128) hipLaunchKernelGGL(attn_merge_kernel<128>, grid, block, 0, st, p);
   else return OSK_EUNSUPPORTED;
@@ -582,7 +582,8 @@ extern "C" int osk_attention_fwd_bounded_bf16(const void* q, int64_t q_batch_str
   p.Bkv = kv_batches > 0 ? kv_batches : B;
   p.map = 1;   // XCD-contiguous work order (each XCD walks one head's K / V^T stream)
   if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 0)) return OSK_EINVAL;
-  if (hd == 72 || hd == 128) osk_attn::split_tail(p, ((Lq + 255) / 256) * B * H, hd, workspace, workspace_bytes);
+  if (osk_attn::attn_wide_path(p, hd)) p.rows = 512;
+  if (hd == 72 || hd == 128) osk_attn::split_tail(p, ((Lq + p.rows - 1) / p.rows) * B * H, hd, workspace, workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   switch (hd) {
     case 64: return launch<64>(p, st);
@@ -620,7 +621,7 @@ extern "C" const char* osk_attention_body_name(int hd, int n_seg, int seg_len, f
     p.bound = __builtin_bit_cast(float, (bits + 0xFFFFu) & 0xFFFF0000u);
   }
   const bool fast = osk_attn::attn_fast_path(p);
-  if (hd == 72) return fast ? "attn_asm72_kernel<FAST>" : "attn_asm72_kernel<general>";
+  if (hd == 72) return fast ? "attn_asm72_kernel<FAST>" : "attn_asm72_kernel<general>";   // (Lq >= 1024: the FAST body's wide layout, attn_asm72w_kernel)
   return fast ? "attn_asm128_kernel<FAST>" : "attn_asm128_kernel<general>";
 }
 

@@ -22,6 +22,7 @@ struct AttnParams {
   // out-of-line events (tools/gen_attn_asm.py::fast_events).  Several segments of fewer than 3 tiles: the general body.
   float bound = 0.f;
   int q_prescaled;
+  int rows = 256;   // query rows per work unit (workgroup): 256, or 512 for the wide head_dim-72 layout (attention_asm72w.hip)
   int Bkv;    // key / value batches: query batch b reads key batch b % Bkv
   int map;    // block -> (head, query block) order: 0 = heads fastest, 1 = XCD-contiguous, query blocks fastest
   // tail split (hand-scheduled kernels only; see split_tail()): the workgroups of the last, partial round of the grid
@@ -118,6 +119,17 @@ int launch_merge(const AttnParams& p, int hd, hipStream_t st);
 
 // attention_asm72.hip: head_dim 72, 4 waves x 64 query rows, hand-scheduled (generated) main loop
 int launch_asm72(const AttnParams& p, hipStream_t st);
+// attention_asm72w.hip: head_dim 72, the bounded body in the wide layout (4 waves x 128 rows, one 32-key half per loop body); p.rows == 512
+int launch_asm72w(const AttnParams& p, hipStream_t st);
+// host: does a bounded head_dim-72 call take the wide layout?  (enough query rows for 512-row work units to fill the chip evenly)
+static inline bool attn_wide_path(const AttnParams& p, int hd) {
+#ifdef OSK_ATTN_NO_WIDE   // (A/B builds of tools/make_attn_nowide_lib.sh: always the 256-row layout)
+  (void)p; (void)hd;
+  return false;
+#else
+  return hd == 72 && attn_fast_path(p) && p.Lq >= 1024;
+#endif
+}
 // attention_asm128.hip: head_dim 128, the same layout and generator
 int launch_asm128(const AttnParams& p, hipStream_t st);
 // attention_asm128p8.hip / attention_asm72p8.hip: the same with the P.V product on the fp8 MFMA

@@ -25,7 +25,8 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 BODIES = sorted(p for p in glob.glob(os.path.join(CSRC, "*.inc"))
                 if ("_body" in p or "_segment" in p) and "attention" not in os.path.basename(p)
                 and "convsw" not in os.path.basename(p))   # the sliding-window conv has its own executable model: tests/test_conv_sw_model.py
-ATTN_BODIES = sorted(p for p in glob.glob(os.path.join(CSRC, "attention_asm*_n*_[vf]0.inc")))   # general (v0) and fast (f0) bodies
+ATTN_BODIES = sorted(p for p in glob.glob(os.path.join(CSRC, "attention_asm*_n*_[vf]0.inc")) +   # general (v0) and fast (f0) bodies
+                     glob.glob(os.path.join(CSRC, "attention_asm72w_f0.inc")))                   # + the wide layout's
 S_ADST, S_WDST = "s45", "s46"
 A_STAGE = 32768
 

@@ -480,6 +480,32 @@ def test_attention_bounded_short_segments_fall_back_and_shared_batches_tail_spli
     _bounded_segments_case(hip_lib, 1, 17, hd, 4096, 1000, 1, ws=True)                 # tail parts = tile runs, the last one ragged
 
 
+@pytest.mark.parametrize("Lq,seg,nseg", [(1024, 64, 1), (1024, 128, 1), (1100, 192, 1), (1536, 1000, 1), (2000, 4133, 1), (1024, 60, 1),
+                                         (1300, 130, 1), (1024, 192, 3), (2048, 200, 2), (1111, 260, 4), (1024, 129, 5)])
+def test_attention_wide_layout_head_dim_72(hip_lib, Lq, seg, nseg):
+    """attn_asm72w_kernel (bounded calls with Lq >= 1024: 512-row workgroups, one 32-key half per loop body): 1, 2, 3 and many
+    key tiles (prologue only / each of the four bodies as the last one), ragged query blocks, ragged keys, segments"""
+    _bounded_segments_case(hip_lib, 2, 3, 72, Lq, seg, nseg, seed=71)
+
+
+def test_attention_wide_layout_tail_split_and_determinism(hip_lib):
+    _bounded_segments_case(hip_lib, 1, 16, 72, 8448, 1024, 1, ws=True, seed=73)         # 272 units: 16 tail units split by tile runs
+    _bounded_segments_case(hip_lib, 3, 16, 72, 2048, 700, 3, ws=True, seed=74)          # segments as tail parts
+    hd, B, H, Lq, Lk = 72, 2, 8, 2000, 4133
+    D = H * hd
+    q = (rnd("q", (B, Lq, D), seed=81).float() * (hd ** -0.5 * 1.4426950408889634)).to(BF)
+    k, v = rnd("k", (B, Lk, D), seed=82), rnd("v", (B, Lk, D), seed=83)
+    vt = torch.empty(B, H, hd, (Lk + 63) // 64 * 64, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+    outs = []
+    for _ in range(12):
+        o = torch.empty(B, Lq, D, dtype=BF, device=DEV)
+        hip_lib.attention_fwd(q, k, vt, o, H, hd, hd ** -0.5, q_prescaled=True, score_bound=40.0)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:]), "wide attention: run-to-run difference"
+
+
 @pytest.mark.parametrize("hd,H,L", [(72, 16, 8828), (128, 6, 8828)])
 def test_attention_bounded_reference_256px_length(hip_lib, hd, H, L):
     """the reference's own 256 px shape (configs/diffusion/inference/256px.py: L = 8,316 + 512 = 137 x 64 + 60)"""

@@ -620,6 +620,32 @@ def fast_events(st, L):
             e("s_branch %s" % common)
 
 
+def fast_preamble(st, L):
+    """FAST bodies: initial state of the loader events (fast_events())"""
+    e = st.emit
+    # loader events (fast_events()): the first segment's last tile is tps - 1; a launch that is ONE segment of whole tiles has
+    # no event at all; when tile 0 itself is the ragged last tile the K loader starts on the clamped offsets
+    e("s_sub_u32 s%d, s%d, 1" % (S_KE, S_TPS))
+    e("s_mov_b32 s%d, s%d" % (S_VE, S_KE))
+    e("s_mov_b32 s%d, s%d" % (S_VNEXT, S_KE))
+    e("s_sub_u32 s%d, s%d, 2" % (S_KNEXT, S_TPS))
+    for i in range(L.NSLOT):
+        e("v_mov_b32 %s, %s" % (vr(L.KCUR + i), L.OP["koff%d" % i]))
+    e("s_cmp_lg_u32 s%d, 0" % S_NRG)
+    e("s_cbranch_scc0 .L@@_ini1")
+    e("s_cmp_lg_u32 s%d, s%d" % (S_TPS, S_NT))
+    e("s_cbranch_scc1 .L@@_ini2")
+    e("s_mov_b32 s%d, -1" % S_KNEXT)
+    e("s_mov_b32 s%d, -1" % S_VNEXT)
+    e("s_branch .L@@_ini2")
+    st.label(".L@@_ini1")
+    e("s_cmp_lg_u32 s%d, 1" % S_TPS)
+    e("s_cbranch_scc1 .L@@_ini2")
+    for i in range(L.NSLOT):
+        e("v_mov_b32 %s, %s" % (vr(L.KCUR + i), L.OP["koffL%d" % i]))
+    st.label(".L@@_ini2")
+
+
 def fixup(st, L, sx, init):
     """move the reference max M to (M + max(mt, 0)) [init: to mt], rounded to bf16: shift the pending scores,
     rescale O (not at init: O == 0), rewrite Q's padding dim 72 with -M."""
@@ -897,27 +923,7 @@ def _generate(L, safe, ablate):
         ragged_mask(st, "k")
         ragged_mask(st, "v")
     else:
-        # loader events (fast_events()): the first segment's last tile is tps - 1; a launch that is ONE segment of whole tiles has
-        # no event at all; when tile 0 itself is the ragged last tile the K loader starts on the clamped offsets
-        e("s_sub_u32 s%d, s%d, 1" % (S_KE, S_TPS))
-        e("s_mov_b32 s%d, s%d" % (S_VE, S_KE))
-        e("s_mov_b32 s%d, s%d" % (S_VNEXT, S_KE))
-        e("s_sub_u32 s%d, s%d, 2" % (S_KNEXT, S_TPS))
-        for i in range(L.NSLOT):
-            e("v_mov_b32 %s, %s" % (vr(L.KCUR + i), L.OP["koff%d" % i]))
-        e("s_cmp_lg_u32 s%d, 0" % S_NRG)
-        e("s_cbranch_scc0 .L@@_ini1")
-        e("s_cmp_lg_u32 s%d, s%d" % (S_TPS, S_NT))
-        e("s_cbranch_scc1 .L@@_ini2")
-        e("s_mov_b32 s%d, -1" % S_KNEXT)
-        e("s_mov_b32 s%d, -1" % S_VNEXT)
-        e("s_branch .L@@_ini2")
-        st.label(".L@@_ini1")
-        e("s_cmp_lg_u32 s%d, 1" % S_TPS)
-        e("s_cbranch_scc1 .L@@_ini2")
-        for i in range(L.NSLOT):
-            e("v_mov_b32 %s, %s" % (vr(L.KCUR + i), L.OP["koffL%d" % i]))
-        st.label(".L@@_ini2")
+        fast_preamble(st, L)
     for u in range(2):
         e("v_mov_b32 %s, 0" % vr(L.MM[u]))
     for r in range(L.A_O0, L.A_Q0):
@@ -970,6 +976,260 @@ def _generate(L, safe, ablate):
     st.label(".L@@_exit")
     for n in range(L.NTRAIL):
         pv_mfma(st, L, (L.G.NPV - L.NTP) * L.MPP + n)
+    e("s_nop 15")
+    e("s_nop 15")
+    e("v_mov_b32 %s, %s" % (L.OP["m0out"], vr(L.MM[0])))
+    e("v_mov_b32 %s, %s" % (L.OP["m1out"], vr(L.MM[1])))
+    return st
+
+
+# ================================================================================================ WIDE layout (round 4)
+class LayoutW(Layout):
+    """head_dim 72, FAST (bounded) body only: 4 waves x 128 query rows = 512-row workgroups, 32-key SUB-tiles.
+
+    A wave owns FOUR 32-row query blocks u'' = 2 ph + u (ph = "phase", u in {0, 1}) and a loop body handles ONE 32-key half h of
+    a 64-key tile.  Per body and wave that is the same 20 + 40 MFMAs, the same 64 exp2 / 32 packs / 16 lane-row swaps and the
+    same register budget as the 2-block layout's body over a whole tile (what that layout indexes by key half t2 is the phase
+    here: score set S(set, u, ph), packed P of block u'' in PB(u, 2 ph + qb)) -- but every K fragment now feeds 4 MFMAs instead
+    of 2 and every V^T fragment 8 instead of 4 (five resident V^T slots: phase 1 re-uses the fragments phase 0 read), and a
+    64-key tile's LDS-DMA pieces and loader advances are spread over two bodies: per 1280 matrix cycles 10 fragment reads instead
+    of 20, ~2.4 LDS-DMA pieces instead of ~4.8, one loader advance instead of two.  O^T: 160 AGPRs (4 blocks), Q: 80.
+    Ring protocol (2 K slots, 2 V^T slots, one barrier per body): body (t, h) = P.V of half h of tile t (V^T slot t % 2) beside
+    QK^T of the NEXT half -- (t, 1) from K slot t % 2 when h == 0, (t + 1, 0) from the other slot when h == 1.  K(t + 2) streams
+    into K(t)'s slot during (t, 1) (K(t) was last read in (t, 0)); V^T(t + 1) into V^T(t - 1)'s slot during (t, 0)."""
+
+    def __init__(self):
+        Layout.__init__(self, 2, 72, pv16=True)
+        G = self.G
+        self.WIDE = True
+        self.NUW = 4                                   # query blocks per wave
+        self.A_O0 = 0
+        self.A_Q0 = 4 * G.NDB * 2 * self.NUW           # 160
+        self.A_END = self.A_Q0 + 4 * G.NKS * self.NUW  # 240
+        self.VR0 = self.KR0 + 16                       # five V^T fragment slots (20 registers)
+        self.TMP0 = self.VR0 + 20
+        self.KCUR = self.TMP0
+        self.MM = [self.TMP0 + 4, self.TMP0 + 5]
+        self.MT = [self.TMP0 + 6, self.TMP0 + 7]
+        self.TX = [self.TMP0 + 8 + i for i in range(4)]
+        self.V_END = self.TMP0 + 12
+        assert self.V_END <= 256 and self.A_END <= 256
+
+    def AO16W(self, u2, qb, db):
+        return self.A_O0 + ((u2 * 2 + qb) * self.G.NDB + db) * 4
+
+    def AQW(self, u2, ks):
+        return self.A_Q0 + (u2 * self.G.NKS + ks) * 4
+
+
+def kw_read(st, L, slot, half, ks, tag):
+    """K fragment (32 keys of `half`, k-step ks) of the tile in ring slot `slot` -> K ring slot ks % 4"""
+    dst = L.KR0 + (ks % 4) * 4
+    if ks < 4:
+        st.ds_read(dst, L.OP["fo%d" % ks], L.G.KOFF[slot] + half * 4096, tag)
+    else:
+        st.ds_read(dst, L.OP["kc%d" % half], L.G.KOFF[slot], tag)
+
+
+def qkw_mfma(st, L, sn, a):
+    p, u = a // 2, a % 2
+    ks, ph = p // 2, p % 2
+    dst = vr(L.S(sn, u, ph), 16)
+    st.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, vr(L.KR0 + (ks % 4) * 4, 4), ar(L.AQW(2 * ph + u, ks), 4),
+                                                       "0" if ks == 0 else dst), "M")
+
+
+def pvw_mfma(st, L, b):
+    r, sub = b // 4, b % 4
+    u, qb = sub // 2, sub % 2
+    ph, db = r // L.G.NDB, r % L.G.NDB
+    dst = ar(L.AO16W(2 * ph + u, qb, db), 4)
+    st.emit("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (dst, vr(L.VR0 + db * 4, 4), vr(L.PB(u, 2 * ph + qb), 4), dst), "X")
+
+
+def body_wide(st, L, k, h, safe=False):
+    """body (k, h): P.V of key half h of the tile in ring slot k (its scores: set A when h == 0, set B when h == 1) beside QK^T
+    of the next half into the other set"""
+    G = L.G
+    sc, sn = (L.SA0, L.SB0) if h == 0 else (L.SB0, L.SA0)
+    nslot_, nhalf = (k, 1) if h == 0 else (k ^ 1, 0)
+    uid = "w%d%d" % (k, h)
+    which = "v" if h == 0 else "k"                 # the loader this body drives: V^T(t + 1) -> slot k ^ 1 / K(t + 2) -> slot k
+    dslot = (k ^ 1) if h == 0 else k
+    st.label(".L@@_body%d%d" % (k, h))
+    for ks in range(4):
+        kw_read(st, L, nslot_, nhalf, ks, ("k", ks))
+    dma = k_dma if which == "k" else v_dma
+    pieces = list(range(nslot(L, which) - 1))[:L.NTRAIL]
+    for n in range(L.NTRAIL):
+        if n < len(pieces):
+            dma(st, L, dslot, pieces[n], 1)
+        pvw_mfma(st, L, 32 + n)                    # pairs 8, 9 = (phase 1, row blocks 3, 4) of the previous body
+        if n < len(pieces):
+            dma(st, L, dslot, pieces[n], 2)
+    st.label(".L@@_entry%d%d" % (k, h))
+    later = []
+    for i in range(len(pieces), nslot(L, which) - 1):
+        later.append((lambda i=i: dma(st, L, dslot, i), DMACOST))
+    later.append((lambda: dma_last(st, L, which, dslot, uid), DMACOST))
+    later.append((lambda: advance(st, which, uid, G.VSTEP, L, dslot), 20))
+    cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
+    clsA, clsB = [], []
+    for g in range(4):
+        for u in range(2):
+            (clsA if g < 2 else clsB).extend(exp_group(L, sc, u, g))
+        if g % 2 == 1:
+            for u in range(2):
+                (clsA if g < 2 else clsB).extend(swap_group(L, u, g // 2))
+    W = L.FAST_WINDOWS
+    classes = [[clsA, W[0], W[1], 0, 0.0], [clsB, W[2], W[3], 0, 0.0]]
+    totals = [sum(cost(o[0]) for o in c[0]) for c in classes]
+    mf = [("qk", a) for a in range(20)] + [("pv", b) for b in range(32)]
+    for n, (kind, idx) in enumerate(mf):
+        i = L.I_QK0 + n
+        used = 0.0
+        if kind == "qk":
+            p, u = idx // 2, idx % 2
+            ks, ph = p // 2, p % 2
+            if u == 0 and ph == 0:
+                st.need(("k", ks))
+            qkw_mfma(st, L, sn, idx)
+            if u == 1 and ph == 1:                 # both phases of this k-step issued: its K ring slot is free
+                if ks + 4 < G.NKS:
+                    kw_read(st, L, nslot_, nhalf, ks + 4, ("k", ks + 4))
+                    used += 4
+                if ks >= 1:                        # V^T fragments of row blocks 0..3 behind k-steps 1..4 (slots 3, 4: free since the trailing MFMAs)
+                    st.ds_read(L.VR0 + (ks - 1) * 4, L.OP["vo%d" % h], G.VOFF[k] + (ks - 1) * 2048, ("v", ks - 1))
+                    used += 4
+        else:
+            r, sub = idx // 4, idx % 4
+            if sub == 0 and r < G.NDB and r % 2 == 0:
+                st.need(("v", min(r + 1, G.NDB - 1)))
+            pvw_mfma(st, L, idx)
+            if r == 0 and sub == 3:                # the fifth V^T fragment (row block 4: dims 64..71, ones row)
+                st.ds_read(L.VR0 + 4 * 4, L.OP["vo%d" % h], G.VOFF[k] + 4 * 2048, ("v", 4))
+                used += 4
+        if safe:
+            st.emit("s_nop 7", "n")
+        if later:
+            fn, cyc = later.pop(0)
+            fn()
+            used += cyc
+        for ci, c in enumerate(classes):
+            items, first, last = c[0], c[1], c[2]
+            if i < first:
+                continue
+            frac = min(1.0, (i - first + 1) / float(last - first + 1))
+            while c[3] < len(items):
+                kind_, text = items[c[3]]
+                if totals[ci] * frac - c[4] <= 0 and i < last:
+                    break
+                if used >= (13 if kind == "pv" else 30) and i < last:
+                    break
+                st.emit(text, kind_)
+                used += cost(kind_)
+                c[4] += cost(kind_)
+                c[3] += 1
+    for c in classes:
+        assert c[3] == len(c[0]), "unscheduled filler work"
+    assert not later
+    _check_p_ready_wide(st, k, h)
+    st.emit("s_waitcnt vmcnt(0) lgkmcnt(0)", "w")
+    st.pending = []
+    st.emit("s_barrier", "B")
+    if h == 1:
+        st.emit("s_add_u32 s%d, s%d, 1" % (S_T, S_T), "s")
+        st.emit("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NT), "s")
+        st.emit("s_cbranch_scc0 .L@@_exit", "s")
+        if k == 1:
+            st.emit("s_branch .L@@_body00", "s")
+    return which, dslot, pieces
+
+
+def _check_p_ready_wide(st, k, h):
+    """body_wide's filler windows are hand-set: every P.V MFMA of the body's own half comes after the packs and the lane-row swap of
+    its P operand; every MFMA after the s_waitcnt that covers its LDS operand is checked by Stream.need's bookkeeping"""
+    import re as _re
+    start = max(i for i, (kind, text) in enumerate(st.table) if kind == "L" and text.endswith("_entry%d%d" % (k, h)))
+    written, swapped = set(), set()
+    for kind, text in st.table[start:]:
+        if text.startswith("v_cvt_pk"):
+            written.add(int(_re.match(r"v_cvt_pk_\w+ v(\d+),", text).group(1)))
+        elif text.startswith("v_permlane16_swap"):
+            a_, b_ = (int(x) for x in _re.match(r"v_permlane16_swap_b32 v(\d+), v(\d+)", text).groups())
+            assert {a_, b_} <= written, "lane-row swap before its registers are packed: " + text
+            swapped |= {a_, b_}
+        elif text.startswith("v_mfma_f32_16x16x32"):
+            m = _re.match(r"v_mfma_\w+ a\[\d+:\d+\], v\[\d+:\d+\], v\[(\d+):(\d+)\]", text)
+            need = set(range(int(m.group(1)), int(m.group(2)) + 1))
+            assert need <= written and need <= swapped, "P.V MFMA before its P operand is ready: " + text
+
+
+def generate_wide(L, safe=False):
+    global FAST
+    FAST = True
+    try:
+        return _generate_wide(L, safe)
+    finally:
+        FAST = False
+
+
+def _generate_wide(L, safe):
+    st = Stream()
+    e = st.emit
+    G = L.G
+    e("s_mov_b64 s[%d:%d], %s" % (S_KB, S_KB + 1, L.OP["kbase"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_VB, S_VB + 1, L.OP["vbase"]))
+    e("s_mov_b32 s%d, %s" % (S_KSTEP, L.OP["kstep"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_KJ, S_KJ + 1, L.OP["kjump"]))
+    e("s_mov_b64 s[%d:%d], %s" % (S_VJ, S_VJ + 1, L.OP["vjump"]))
+    e("s_mov_b32 s%d, %s" % (S_KDST, L.OP["kdst"]))
+    e("s_mov_b32 s%d, %s" % (S_VDST, L.OP["vdst"]))
+    e("s_and_b32 s%d, %s, 0xffff" % (S_TPS, L.OP["tpsnt"]))
+    e("s_lshr_b32 s%d, %s, 16" % (S_NT, L.OP["tpsnt"]))
+    e("s_lshr_b32 s%d, %s, 16" % (S_NKW, L.OP["nkvw"]))
+    e("s_and_b32 s%d, %s, 0xffff" % (S_NVW, L.OP["nkvw"]))
+    for sreg in (S_T, S_KL, S_VL):
+        e("s_mov_b32 s%d, 0" % sreg)
+    e("s_mov_b32 s%d, 0" % S_HIM)
+    e("s_mov_b32 s%d, -1" % (S_HIM + 1))
+    e("s_lshr_b32 s%d, s%d, 8" % (S_FLG, S_NVW))
+    e("s_and_b32 s%d, s%d, 1" % (S_NRG, S_FLG))
+    e("s_and_b32 s%d, s%d, 0xff" % (S_NVW, S_NVW))
+    fast_preamble(st, L)
+    for u in range(2):
+        e("v_mov_b32 %s, 0" % vr(L.MM[u]))
+    for r in range(L.A_O0, L.A_Q0):
+        e("v_accvgpr_write_b32 %s, 0" % ar(r))
+    dma_group(st, L, "k", 0, "p0")
+    dma_group(st, L, "v", 0, "p1")
+    dma_group(st, L, "k", 1, "p2")
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    for ks in range(G.NKS):                     # scores of (tile 0, half 0) -> set A
+        kw_read(st, L, 0, 0, ks, ("k", ks))
+        st.need(("k", ks))
+        for ph in range(2):
+            for u in range(2):
+                qkw_mfma(st, L, L.SA0, (ks * 2 + ph) * 2 + u)
+    e("s_nop 15")
+    e("s_nop 15")
+    which, dslot, pieces = body_wide(Stream(), L, 0, 0)
+    for i in pieces:                            # what body (0, 0) does before its entry point
+        (k_dma if which == "k" else v_dma)(st, L, dslot, i)
+    for ks in range(4):
+        kw_read(st, L, 0, 1, ks, ("k", ks))
+    e("s_branch .L@@_entry00")
+    st.in_body = True
+    for k in range(2):
+        for h in range(2):
+            st.pending = []
+            body_wide(st, L, k, h, safe)
+    st.in_body = False
+    fast_events(st, L)
+    st.label(".L@@_exit")
+    for n in range(L.NTRAIL):
+        pvw_mfma(st, L, 32 + n)
     e("s_nop 15")
     e("s_nop 15")
     e("v_mov_b32 %s, %s" % (L.OP["m0out"], vr(L.MM[0])))
@@ -1049,9 +1309,27 @@ def main():
                         "segment of whole tiles): %s\n" % (hd, nu, what))
                 for ln in stf.lines:
                     f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%df0" % (tagof(hd, pv8), nu)))
+    # the wide layout of head_dim 72 (4 query blocks per wave, 32-key sub-tiles): FAST body only
+    LW = LayoutW()
+    stw = generate_wide(LW, safe)
+    with open(os.path.join(args.out, "attention_asm72w_f0.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim 72, WIDE layout (4 waves x 128 query rows, one 32-key half per "
+                "body), FAST body: %s\n" % ("production" if not args.exp else "experiment " + args.exp))
+        for ln in stw.lines:
+            f.write('"%s\\n"\n' % ln.replace("@@", "osk72wf0"))
     # register / operand contract for the wrapper
     with open(os.path.join(args.out, "attention_asm_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.\n")
+        clobw = ['"v%d"' % i for i in range(LW.V_FIRST, LW.V_END)] + ['"a%d"' % i for i in range(0, LW.A_END)] + \
+                ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+        f.write("#define OSK72W_CLOBBERS %s\n" % ", ".join(clobw))
+        f.write("#define OSK72W_A_CLOBBERS %s\n" % ", ".join('"a%d"' % i for i in range(0, LW.A_END)))
+        f.write("#define OSK72W_NSLOT %d\n" % LW.NSLOT)
+        for u in range(LW.NUW):
+            f.write("#define OSK72W_QW%d %s\n" % (u, " ".join('"v_accvgpr_write_b32 a%d, %%%d\\n"' % (LW.AQW(u, 0) + i, i) for i in range(4 * LW.G.NKS))))
+            for qb in range(2):
+                f.write("#define OSK72W_OR%d %s\n" % (u * 2 + qb, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (db * 4 + i, LW.AO16W(u, qb, db) + i)
+                                                                           for db in range(LW.G.NDB) for i in range(4))))
         for hd, pv8 in sorted({(h, p8) for h, _, p8 in layouts}):
             G = mk(2, hd, pv8).G
             P = "OSK%s_" % tagof(hd, pv8).upper()
