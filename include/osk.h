@@ -68,6 +68,20 @@ typedef struct OskGemmOperands {
 } OskGemmOperands;
 int osk_gemm_bf16_pair(const OskGemmOperands* first, const OskGemmOperands* second, int N, int K, int gelu_from, void* stream);
 
+/* ---- GEGLU up-projection (the STDiT-generation block's "GEGLU MLP" of BASELINE.json's
+ * north_star; the mounted v2.0 reference has no GEGLU call site -- its MLP is Linear -> GELU(tanh) -> Linear, layers.py:277-281 --
+ * so this entry is PARITY-UNPINNED: semantics = diffusers' FeedForward(activation_fn="geglu") with the library's tanh GELU):
+ *   C[m, j] = (A W_v^T + b_v)[m, j] * gelu_tanh((A W_g^T + b_g)[m, j]),   j < N_out
+ * as ONE GEMM with N = 2 N_out whose epilogue multiplies value and gate in registers.  W_packed [2 N_out, K] / bias_packed
+ * [2 N_out]: value and gate rows interleaved in blocks of 16 -- packed row 32 j2 + i (i < 16) = value row 16 j2 + i, packed row
+ * 32 j2 + 16 + i = gate row 16 j2 + i (open_sora_amd/_C.py::geglu_pack builds it once at plan time); N_out % 16 == 0.
+ * Shapes the 256 x 256 tile kernel does not take (M < 256, narrow N, ...) run the plain GEMM into `workspace` (>= M * 2 N_out * 2
+ * bytes, 16-byte aligned) followed by a row kernel; without a workspace they return OSK_EUNSUPPORTED and launch nothing. */
+int osk_gemm_geglu_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride, int a_rows_per_batch,
+                        const void* W_packed, int64_t w_row_stride, const float* bias_packed, void* C,
+                        int64_t c_batch_stride, int64_t c_row_stride, int c_rows_per_batch, int M, int N_out, int K,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- FP8 (OCP e4m3fn) variant of the Linear GEMM: BASELINE configs[4] ("fp8 MFMA"); the reference itself runs its
  * nn.Linear layers (same call sites as osk_gemm_bf16) in bf16, so this is an opt-in mode.
  * osk_quantize_rows_fp8: dynamic per-row quantisation of a bf16 [M, K] activation (rows_per_batch addressing):
@@ -226,6 +240,19 @@ int osk_attention_fwd_pv8_bf16(const void* q, int64_t q_batch_stride, int64_t q_
                                float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
                                float scale, int q_prescaled, int kv_batches, void* workspace, int64_t workspace_bytes,
                                void* stream);
+
+/* ---- short-sequence attention with an optional ALiBi bias (the STDiT-generation block's temporal
+ * self-attention over T <= 64 frames, B * H * W independent sequences, "RoPE/ALiBi" in BASELINE.json's north_star).  The mounted
+ * v2.0 reference passes alibi_slopes=None at every flash-attn call site (opensora/models/mmdit/math.py:22-36), so this entry is
+ * PARITY-UNPINNED; semantics = flash-attn's documented `alibi_slopes`:
+ *   out[b, i, h] = softmax_j(scale * q_i . k_j - alibi_slopes[h] * |i + Lk - Lq - j|) v_j ,   Lq, Lk <= 64
+ * q, k, v, out bf16 [B, L, H * hd] views (row strides in elements, last dim contiguous), alibi_slopes f32 [H] or NULL (no bias).
+ * One wave per (batch, head), registers only, HBM-bound; V is taken as is (no osk_v_transpose_bf16).  hd in {64, 72, 128};
+ * longer sequences: OSK_EUNSUPPORTED (use osk_attention_fwd_bf16). */
+int osk_attention_short_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride, const void* k, int64_t k_batch_stride,
+                             int64_t k_row_stride, const void* v, int64_t v_batch_stride, int64_t v_row_stride, void* out,
+                             int64_t o_batch_stride, int64_t o_row_stride, const float* alibi_slopes, int B, int H, int Lq, int Lk,
+                             int hd, float scale, void* stream);
 
 /* name of the device kernel osk_attention_fwd_bf16 dispatches to for (hd, seg_len) (reporting only: bench.py labels its
  * roofline line and the rocprof stats with it). */

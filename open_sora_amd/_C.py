@@ -20,6 +20,9 @@ _i64, _i32, _f32, _f64, _vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_v
 SIGNATURES = {
     "osk_abi_version": [],
     "osk_arch": [],
+    "osk_gemm_geglu_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
+    "osk_attention_short_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
+                                 _f32, _vp],
     "osk_attention_kernel_name": [_i32, _i32],
     "osk_attention_body_name": [_i32, _i32, _i32, _f32],
     "osk_ln_modulate_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
@@ -165,6 +168,31 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, *, res=None,
                              out.data_ptr(), out.stride(0), out.stride(1), L, _p(res), _p(gate),
                              gate_batch_stride, B * L, N, K, N if gelu_from is None else gelu_from,
                              1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_bf16")
+    return out
+
+
+def geglu_pack(w_value: torch.Tensor, w_gate: torch.Tensor, b_value=None, b_gate=None):
+    """Weights of a GEGLU up-projection in the row order osk_gemm_geglu_bf16 wants: value and gate rows interleaved in blocks of 16
+    (include/osk.h).  w_* [N_out, K] -> [2 N_out, K]; biases f32 [N_out] -> [2 N_out] (or None).  Done once, at plan time."""
+    n, k = w_value.shape
+    assert w_gate.shape == (n, k) and n % 16 == 0
+    w = torch.stack((w_value.reshape(n // 16, 16, k), w_gate.reshape(n // 16, 16, k)), 1).reshape(2 * n, k).contiguous()
+    b = None
+    if b_value is not None:
+        b = torch.stack((b_value.float().reshape(n // 16, 16), b_gate.float().reshape(n // 16, 16)), 1).reshape(2 * n).contiguous()
+    return w, b
+
+
+def gemm_geglu(a: torch.Tensor, w_packed: torch.Tensor, bias_packed, out: torch.Tensor, workspace: torch.Tensor | None = None):
+    """out[b, l, j] = value * gelu_tanh(gate) of the packed projection (geglu_pack); a bf16 [B, L, K], out bf16 [B, L, N_out].
+    workspace (uint8 / bf16, >= B L 2 N_out 2 bytes): only shapes off the 256 x 256 tile path need it."""
+    B, L, K = a.shape
+    n_out = w_packed.shape[0] // 2
+    assert out.shape == (B, L, n_out) and a.dtype == out.dtype == w_packed.dtype == torch.bfloat16
+    _check(lib.osk_gemm_geglu_bf16(a.data_ptr(), a.stride(0), a.stride(1), L, w_packed.data_ptr(), w_packed.stride(0), _p(bias_packed),
+                                   out.data_ptr(), out.stride(0), out.stride(1), L, B * L, n_out, K, _p(workspace),
+                                   0 if workspace is None else workspace.numel() * workspace.element_size(), _stream()),
+           "osk_gemm_geglu_bf16")
     return out
 
 
@@ -367,6 +395,20 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))
+    return out
+
+
+def attention_short(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, H: int, hd: int, scale: float,
+                    alibi_slopes: torch.Tensor | None = None) -> torch.Tensor:
+    """softmax(scale q k^T - slope_h |i + Lk - Lq - j|) v for sequences of at most 64 tokens (osk_attention_short_bf16: the
+    temporal-attention call shape); q [B, Lq, H*hd], k / v [B, Lk, H*hd] bf16 views, alibi_slopes f32 [H] or None."""
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+    if alibi_slopes is not None:
+        assert alibi_slopes.dtype == torch.float32 and alibi_slopes.is_contiguous() and alibi_slopes.numel() == H
+    _check(lib.osk_attention_short_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1), v.data_ptr(),
+                                        v.stride(0), v.stride(1), out.data_ptr(), out.stride(0), out.stride(1), _p(alibi_slopes),
+                                        B, H, Lq, Lk, hd, scale, _stream()), "osk_attention_short_bf16")
     return out
 
 

@@ -220,6 +220,52 @@ static bool large_tiles_ok(const GemmParams& p) {
   return osk_gemm::gemm256_supported(p, a_span, w_span);
 }
 
+// ---- GEGLU (f4): the fused path is gemm256x's epilogue class; shapes the 256 x 256 tiles do not take run the plain GEMM into the
+// caller's workspace ([M, 2 N_out] bf16, packed column order) and this row kernel
+namespace {
+__global__ void __launch_bounds__(256) geglu_rows_kernel(const unsigned short* __restrict__ t, unsigned short* __restrict__ c,
+                                                         int64_t cbs, int64_t crs, int crpb, int M, int n_out) {
+  const int per_row = n_out / 4;
+  const int64_t total = (int64_t)M * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / per_row), c4 = (int)(i - (int64_t)m * per_row) * 4;
+    const int j2 = c4 >> 4, r = c4 & 15;
+    const unsigned short* row = t + (int64_t)m * 2 * n_out + j2 * 32 + r;
+    const uint2 v = *reinterpret_cast<const uint2*>(row), g = *reinterpret_cast<const uint2*>(row + 16);
+    uint2 o;
+    o.x = pack_bf16x2(bf16_lo(v.x) * gelu_tanh(bf16_lo(g.x)), bf16_hi(v.x) * gelu_tanh(bf16_hi(g.x)));
+    o.y = pack_bf16x2(bf16_lo(v.y) * gelu_tanh(bf16_lo(g.y)), bf16_hi(v.y) * gelu_tanh(bf16_hi(g.y)));
+    const int b = m / crpb, l = m - b * crpb;
+    *reinterpret_cast<uint2*>(c + b * cbs + (int64_t)l * crs + c4) = o;
+  }
+}
+}  // namespace
+
+extern "C" int osk_gemm_geglu_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride, int a_rows_per_batch,
+                                   const void* W_packed, int64_t w_row_stride, const float* bias_packed, void* C,
+                                   int64_t c_batch_stride, int64_t c_row_stride, int c_rows_per_batch, int M, int N_out, int K,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+  if (N_out <= 0 || (N_out & 15)) return OSK_EINVAL;
+  GemmParams p;
+  const int N = 2 * N_out;
+  const int rc = fill_params(p, A, a_batch_stride, a_row_stride, a_rows_per_batch, W_packed, w_row_stride, bias_packed, C,
+                             c_batch_stride, c_row_stride, c_rows_per_batch, nullptr, nullptr, 0, M, N, K, N, 0);
+  if (rc != OSK_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  p.geglu = 1;
+  if (large_tiles_ok(p) && tile_choice(M, N) == 2) return osk_gemm::launch_gemm256x(p, 0, st);
+  // small / odd shapes: plain GEMM (bias added, no activation) into the workspace, then the row kernel
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < (int64_t)M * N * 2) return OSK_EUNSUPPORTED;
+  const int rc2 = osk_gemm_bf16(A, a_batch_stride, a_row_stride, a_rows_per_batch, W_packed, w_row_stride, bias_packed, workspace,
+                                (int64_t)M * N, N, M, nullptr, nullptr, 0, M, N, K, N, 0, stream);
+  if (rc2 != OSK_OK) return rc2;
+  const int64_t total = (int64_t)M * (N_out / 4);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(geglu_rows_kernel, dim3(blocks), dim3(256), 0, st, (const unsigned short*)workspace, (unsigned short*)C,
+                     c_batch_stride, c_row_stride, c_rows_per_batch, M, N_out);
+  return (int)hipGetLastError();
+}
+
 extern "C" int osk_gemm_bf16_pair(const OskGemmOperands* a, const OskGemmOperands* b, int N, int K, int gelu_from, void* stream) {
   if (!a || !b) return OSK_EINVAL;
   GemmParams p[2];

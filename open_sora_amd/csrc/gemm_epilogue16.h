@@ -119,10 +119,88 @@ OSK_DEV void tiles_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, 
   (tile_edge<Geo, OUT_F32, Ts>(p, m0w, n0w, l15, q4, folded), ...);
 }
 
+// ---- GEGLU class (f4; north_star's "GEGLU MLP"): column blocks come in (value, gate) pairs 2 J2, 2 J2 + 1 -- the same lane holds
+// the same output row and the same 4 relative channels of both -- and the wave tile's 128 GEMM columns become 64 output columns at
+// n0w / 2.  bf16 output only; bias folded into the accumulators (interior) or added here (edge), in the packed column order.
+template <class Geo, int J2, int I>
+OSK_DEV void geglu_pair_interior(const GemmParams& p, const int64_t* storeoff, int n0o) {
+  constexpr int NB = Geo::NB;
+  float v0[4], g0[4], v1[4], g1[4];
+  Geo::template read<(2 * J2) * NB + I>(v0);
+  Geo::template read<(2 * J2 + 1) * NB + I>(g0);
+  Geo::template read<(2 * J2) * NB + I + 1>(v1);
+  Geo::template read<(2 * J2 + 1) * NB + I + 1>(g1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v0[i] *= gelu_tanh(g0[i]);
+    v1[i] *= gelu_tanh(g1[i]);
+  }
+  auto sx = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+  auto sy = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+  *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.C) + storeoff[I / 2] + n0o + J2 * 16) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+}
+
+template <class Geo, int I, int... J2s>
+OSK_DEV void geglu_row_pair(const GemmParams& p, const int64_t* storeoff, int n0o, std::integer_sequence<int, J2s...>) {
+  (geglu_pair_interior<Geo, J2s, I>(p, storeoff, n0o), ...);
+}
+
+template <class Geo, int... Is>
+OSK_DEV void geglu_interior(const GemmParams& p, const int64_t* storeoff, int n0o, std::integer_sequence<int, Is...>) {
+  (geglu_row_pair<Geo, 2 * Is>(p, storeoff, n0o, std::make_integer_sequence<int, Geo::NB / 2>{}), ...);
+}
+
+template <class Geo, int T2>   // T2 = J2 * NB + I
+OSK_DEV void geglu_tile_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded) {
+  constexpr int NB = Geo::NB;
+  constexpr int J2 = T2 / NB, I = T2 % NB;
+  float v[4], g[4];
+  Geo::template read<(2 * J2) * NB + I>(v);
+  Geo::template read<(2 * J2 + 1) * NB + I>(g);
+  const int m = m0w + I * 16 + l15;
+  if (m >= p.M) return;
+  const int b = m / p.crpb, l = m - b * p.crpb;
+  const int64_t roff = b * p.cbs + (int64_t)l * p.crs;
+  const int nv = n0w + (2 * J2) * 16 + q4 * 4;          // packed GEMM column of the value; its gate sits 16 columns on
+  const int no = n0w / 2 + J2 * 16 + q4 * 4;            // output column
+  for (int j = 0; j < 4 && no + j < p.N / 2; ++j) {
+    float tv = v[j], tg = g[j];
+    if (!folded && p.bias) { tv += p.bias[nv + j]; tg += p.bias[nv + 16 + j]; }
+    reinterpret_cast<unsigned short*>(p.C)[roff + no + j] = f32_to_bf16_bits(tv * gelu_tanh(tg));
+  }
+}
+
+template <class Geo, int... Ts>
+OSK_DEV void geglu_tiles_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded, std::integer_sequence<int, Ts...>) {
+  (geglu_tile_edge<Geo, Ts>(p, m0w, n0w, l15, q4, folded), ...);
+}
+
+template <class Geo>
+OSK_DEV void geglu_all(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool interior, bool folded) {
+  constexpr int NB = Geo::NB;
+  if (m0w >= p.M || n0w >= p.N) return;
+  const bool wide = ((((uintptr_t)p.C) & 15) == 0) && ((p.crs & 7) == 0) && ((p.cbs & 7) == 0);
+  if (!interior || !wide || (p.bias && !folded)) {
+    geglu_tiles_edge<Geo>(p, m0w, n0w, l15, q4, folded, std::make_integer_sequence<int, (NB / 2) * NB>{});
+    return;
+  }
+  int64_t storeoff[NB / 2];
+  const int b = m0w / p.crpb, l0 = m0w - b * p.crpb + l15;
+#pragma unroll
+  for (int i = 0; i < NB / 2; ++i) storeoff[i] = b * p.cbs + (int64_t)(l0 + 16 * (2 * i + (q4 & 1))) * p.crs + (q4 >> 1) * 8;
+  geglu_interior<Geo>(p, storeoff, n0w / 2, std::make_integer_sequence<int, NB / 2>{});
+}
+
 // the whole 128 x 128 wave tile
 template <class Geo, bool OUT_F32>
 OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool interior, bool folded) {
   constexpr int NB = Geo::NB;
+  if constexpr (!OUT_F32) {
+    if (p.geglu) {   // (kernel-argument uniform)
+      geglu_all<Geo>(p, m0w, n0w, l15, q4, interior, folded);
+      return;
+    }
+  }
   if (m0w >= p.M || n0w >= p.N) return;   // the whole wave tile lies outside C (ragged last tile row / column): wave-uniform
   // the fast path stores 16 bytes per lane (bf16) / reads 8-byte residual pieces: C, its strides and the tile origin must allow it
   const bool wide = OUT_F32 || (((((uintptr_t)p.C) & 15) == 0) && ((p.crs & 7) == 0) && ((p.cbs & 7) == 0));

@@ -20,6 +20,9 @@ struct GemmParams {
   int64_t gbs;
   int M, N, K, gelu_from;
   int group;   // gemm256: row bands per tile group (L2 blocking of the tile order)
+  // GEGLU (gemm256x.hip only): the N GEMM columns are N / 2 (value, gate) pairs in alternating 16-column blocks -- W / bias rows
+  // packed by osk_geglu_pack_index -- and C has N / 2 columns: C[m, 16 j + i] = value * gelu_tanh(gate)   (gemm_epilogue16.h)
+  int geglu = 0;
   const float* sa = nullptr;   // fp8 instantiation: per-row scales of A [M] and of W [N]
   const float* sw = nullptr;
 };

@@ -1047,6 +1047,9 @@ def pvw_mfma(st, L, b):
     st.emit("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (dst, vr(L.VR0 + db * 4, 4), vr(L.PB(u, 2 * ph + qb), 4), dst), "X")
 
 
+WIDE_EXP = {"gap": 1, "win": None, "lateswap": False}   # --wide-exp (experiments): DMA piece spacing in the trailing shadows, filler windows, swap placement
+
+
 def body_wide(st, L, k, h, safe=False):
     """body (k, h): P.V of key half h of the tile in ring slot k (its scores: set A when h == 0, set B when h == 1) beside QK^T
     of the next half into the other set"""
@@ -1060,13 +1063,15 @@ def body_wide(st, L, k, h, safe=False):
     for ks in range(4):
         kw_read(st, L, nslot_, nhalf, ks, ("k", ks))
     dma = k_dma if which == "k" else v_dma
-    pieces = list(range(nslot(L, which) - 1))[:L.NTRAIL]
+    gap = WIDE_EXP["gap"]
+    pieces = list(range(nslot(L, which) - 1))[:(L.NTRAIL + gap - 1) // gap]
     for n in range(L.NTRAIL):
-        if n < len(pieces):
-            dma(st, L, dslot, pieces[n], 1)
+        pn = n // gap if n % gap == 0 else len(pieces)
+        if pn < len(pieces):
+            dma(st, L, dslot, pieces[pn], 1)
         pvw_mfma(st, L, 32 + n)                    # pairs 8, 9 = (phase 1, row blocks 3, 4) of the previous body
-        if n < len(pieces):
-            dma(st, L, dslot, pieces[n], 2)
+        if pn < len(pieces):
+            dma(st, L, dslot, pieces[pn], 2)
     st.label(".L@@_entry%d%d" % (k, h))
     later = []
     for i in range(len(pieces), nslot(L, which) - 1):
@@ -1081,7 +1086,7 @@ def body_wide(st, L, k, h, safe=False):
         if g % 2 == 1:
             for u in range(2):
                 (clsA if g < 2 else clsB).extend(swap_group(L, u, g // 2))
-    W = L.FAST_WINDOWS
+    W = WIDE_EXP["win"] or L.FAST_WINDOWS
     classes = [[clsA, W[0], W[1], 0, 0.0], [clsB, W[2], W[3], 0, 0.0]]
     totals = [sum(cost(o[0]) for o in c[0]) for c in classes]
     mf = [("qk", a) for a in range(20)] + [("pv", b) for b in range(32)]
@@ -1251,7 +1256,15 @@ def main():
                     "rounds 1-2; changes the V^T key order the kernel expects, so only for timing runs with matching wrappers")
     ap.add_argument("--fast-windows", default="", help="experiment: hd:a0,a1,b0,b1 filler windows of the FAST body (layout NU = 2), e.g. 72:1,33,30,42")
     ap.add_argument("--fast-exp", default="", help="experiment: like --exp, applied to the FAST bodies only")
+    ap.add_argument("--wide-exp", default="", help="experiment on the WIDE head_dim-72 body: gapN (LDS-DMA pieces every N trailing shadows) and / or "
+                    "win:a0,a1,b0,b1 (filler windows), joined by +")
     args = ap.parse_args()
+    for tok in [t for t in args.wide_exp.split("+") if t]:
+        if tok.startswith("gap"):
+            WIDE_EXP["gap"] = int(tok[3:])
+        elif tok.startswith("win:"):
+            w_ = [int(x) for x in tok[4:].split(",")]
+            WIDE_EXP["win"] = w_ + [w_[3], w_[3]]
     if args.fast_windows:
         for spec_ in args.fast_windows.split(";"):
             hd_, w_ = spec_.split(":")
@@ -1266,7 +1279,7 @@ def main():
     safe = args.exp == "safe"
     gap = args.exp.startswith("dmagap")
     ablate = frozenset() if (safe or gap or not args.exp) else frozenset(args.exp.split("+"))
-    if (args.exp or args.fast_windows or args.fast_exp or args.no_pv16) and os.path.realpath(args.out) == os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc")):
+    if (args.exp or args.fast_windows or args.fast_exp or args.no_pv16 or args.wide_exp) and os.path.realpath(args.out) == os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc")):
         raise SystemExit("--exp bodies are experiments: give --out a scratch directory, not the shipped csrc")
     if args.table:
         L = mk(args.table, args.hd, args.pv8) if args.table == 2 else Layout(args.table, args.hd, args.pv8)

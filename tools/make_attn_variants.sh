@@ -10,10 +10,10 @@ for v in "${VS[@]}"; do
   name=${v%%|*}; gargs=${v#*|}
   T=/tmp/attnvar_$name; rm -rf $T; mkdir -p $T/x/open_sora_amd $T/x/include; cp -r open_sora_amd/csrc $T/x/open_sora_amd/csrc; cp include/*.h $T/x/include/
   python tools/gen_attn_asm.py --out $T/x/open_sora_amd/csrc $gargs
-  objs=$(ls $OBJ/*.o | grep -v "/attention_asm72.o\|/attention_asm128.o")
-  for f in attention_asm72 attention_asm128; do
+  objs=$(ls $OBJ/*.o | grep -v "/attention_asm72.o\|/attention_asm128.o\|/attention_asm72w.o")
+  for f in attention_asm72 attention_asm128 attention_asm72w; do
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -c $T/x/open_sora_amd/csrc/$f.hip -o $T/$f.o 2>/dev/null &
   done; wait
-  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lib/libosk_attn_$name.so $objs $T/attention_asm72.o $T/attention_asm128.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lib/libosk_attn_$name.so $objs $T/attention_asm72.o $T/attention_asm128.o $T/attention_asm72w.o
   echo "built tools/lib/libosk_attn_$name.so  ($gargs)"
 done
