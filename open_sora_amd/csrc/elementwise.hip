@@ -250,8 +250,8 @@ __global__ void __launch_bounds__(256) qknorm_rope_kernel(
 // the block's tokens and the four scale vectors are staged in LDS once.  Same rounding points as above.
 // LDS row stride hd*2 (+16 when hd % 32 == 0) bytes keeps the per-thread 16-byte row reads off each other's banks.
 // ---------------------------------------------------------------------------------------------
-template <int HD, int MODE>
-__global__ void __launch_bounds__(256) qknorm_rope_rows_kernel(
+template <int HD, int MODE, int NT>   // NT threads = NT (token, head) rows per block
+__global__ void __launch_bounds__(NT) qknorm_rope_rows_kernel(
     unsigned short* __restrict__ q, unsigned short* __restrict__ k, int64_t bs, int64_t rs,
     const unsigned short* __restrict__ qs0, const unsigned short* __restrict__ ks0,
     const unsigned short* __restrict__ qs1, const unsigned short* __restrict__ ks1, int l_split,
@@ -260,32 +260,41 @@ __global__ void __launch_bounds__(256) qknorm_rope_rows_kernel(
   constexpr int RS = HD * 2 + ((HD % 32) == 0 ? 16 : 0);  // LDS row stride, bytes
   constexpr int CPR = HD / 8;                              // 16-byte chunks per row
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-  const int tpb = 256 / H, rows = tpb * H;
+  const int tpb = NT / H, rows = tpb * H;
   unsigned char* s_rows = sm;                                            // [rows][RS]
-  float* s_cs = reinterpret_cast<float*>(sm + 256 * RS);                 // [tpb][2][HD/2]
+  float* s_cs = reinterpret_cast<float*>(sm + NT * RS);                 // [tpb][2][HD/2]
   unsigned short* s_sc = reinterpret_cast<unsigned short*>(s_cs + tpb * HD);  // [4][HD]
   const int tid = threadIdx.x;
-  const int64_t tok0 = (int64_t)blockIdx.x * tpb;                        // first token (over B * L)
-  const int64_t ntok = (int64_t)B * L;
-  // ---- stage cos / sin rows of the block's tokens and the scale vectors
-  for (int i = tid; i < tpb * HD; i += 256) {
-    const int t = i / HD, j = i - t * HD;
-    int64_t tok = tok0 + t;
+  // token arithmetic in 32 bits (the entry point checks B * L < 2^31): a 64-bit division is ~10x the instructions of a 32-bit one,
+  // and round 3's version ran 2 of them per staged cos / sin element -- more integer work than the norm + rotation itself
+  const int tok0 = (int)blockIdx.x * tpb;                                // first token (over B * L)
+  const int ntok = B * L;
+  int* s_bl = reinterpret_cast<int*>(s_sc + 4 * HD);                     // [tpb][2]: (batch, position) of the block's tokens
+  if (tid < tpb) {
+    int tok = tok0 + tid;
     tok = tok < ntok ? tok : ntok - 1;
-    const int l = (int)(tok % L), b = (int)(tok / L);
-    const int64_t off = b * csb + (int64_t)l * (HD / 2);
-    s_cs[i] = j < HD / 2 ? cos_t[off + j] : sin_t[off + j - HD / 2];
+    const int b = (int)((unsigned)tok / (unsigned)L);
+    s_bl[2 * tid] = b;
+    s_bl[2 * tid + 1] = tok - b * L;
   }
-  for (int i = tid; i < 4 * HD; i += 256) {
+  for (int i = tid; i < 4 * HD; i += NT) {
     const unsigned short* src = i < HD ? qs0 : (i < 2 * HD ? ks0 : (i < 3 * HD ? qs1 : ks1));
     s_sc[i] = src[i % HD];
   }
+  __syncthreads();
+  // ---- stage cos / sin rows of the block's tokens
+  const float stage_mult = (q && k ? (int)blockIdx.y : (k ? 1 : 0)) ? 1.0f : q_mult;
+  for (int i = tid; i < tpb * HD; i += NT) {
+    const int t = i / HD, j = i - t * HD;                                // (HD is a compile-time constant: multiply + shift)
+    const int64_t off = s_bl[2 * t] * csb + (int64_t)s_bl[2 * t + 1] * (HD / 2);
+    // (the q pass: softmax scale * log2(e) rides on the staged rotation, once per token instead of once per head; the two
+    //  orders of the products differ by f32 rounding only, far below the bf16 rounding that follows)
+    s_cs[i] = (j < HD / 2 ? cos_t[off + j] : sin_t[off + j - HD / 2]) * stage_mult;
+  }
   const int r = tid;                       // this thread's row
-  const int t_loc = r / H, h = r - t_loc * H;
-  int64_t tok_r = tok0 + t_loc;
-  const bool rvalid = r < rows && tok_r < ntok;
-  tok_r = tok_r < ntok ? tok_r : ntok - 1;
-  const int l_r = (int)(tok_r % L);
+  const int t_loc = (int)((unsigned)r / (unsigned)H), h = r - t_loc * H;
+  const bool rvalid = r < rows && tok0 + t_loc < ntok;
+  const int l_r = s_bl[2 * (t_loc < tpb ? t_loc : tpb - 1) + 1];
   const int span_chunks = H * CPR;         // 16-byte chunks of one token's [H * hd] span
   {
     // blockIdx.y picks the tensor: q and k are independent passes, two blocks instead of two serial phases
@@ -294,12 +303,11 @@ __global__ void __launch_bounds__(256) qknorm_rope_rows_kernel(
     __syncthreads();                       // staging visible
     // copy loops: TPT = 256 / tpb consecutive threads walk ONE token's span (TPT x 16 contiguous bytes per step), so the
     // token -> (batch, position) division happens once per thread instead of once per 16-byte chunk
-    const int tpt = 256 / tpb;
-    const int ct = tid / tpt, cj = tid - ct * tpt;
-    int64_t ctok = tok0 + ct;
-    const bool cvalid = ct < tpb && ctok < ntok;
-    ctok = ctok < ntok ? ctok : ntok - 1;
-    unsigned short* cspan = tb + (ctok / L) * bs + (ctok % L) * rs;
+    const int tpt = NT / tpb;
+    const int ct = (int)((unsigned)tid / (unsigned)tpt), cj = tid - ct * tpt;
+    const bool cvalid = ct < tpb && tok0 + ct < ntok;
+    const int cti = ct < tpb ? ct : tpb - 1;
+    unsigned short* cspan = tb + s_bl[2 * cti] * bs + (int64_t)s_bl[2 * cti + 1] * rs;
     if (ct < tpb) {
       for (int w = cj; w < span_chunks; w += tpt) {
         const uint4 u = *reinterpret_cast<const uint4*>(cspan + w * 8);
@@ -329,7 +337,6 @@ __global__ void __launch_bounds__(256) qknorm_rope_rows_kernel(
       }
       const float* cr = s_cs + t_loc * HD;
       const float* sr = cr + HD / 2;
-      const float qm = which ? 1.0f : q_mult;
       float csv[HD / 2], snv[HD / 2];        // 4 angles per 16-byte LDS read (HD / 2 is a multiple of 4)
 #pragma unroll
       for (int c = 0; c < HD / 8; ++c) {
@@ -343,12 +350,12 @@ __global__ void __launch_bounds__(256) qknorm_rope_rows_kernel(
         const float cs = csv[pj], sn = snv[pj];
         if constexpr (MODE == 0) {           // pairs (2j, 2j+1)
           const float a = v[2 * pj], b2 = v[2 * pj + 1];
-          v[2 * pj] = (cs * a - sn * b2) * qm;
-          v[2 * pj + 1] = (sn * a + cs * b2) * qm;
+          v[2 * pj] = cs * a - sn * b2;
+          v[2 * pj + 1] = sn * a + cs * b2;
         } else {                             // pairs (j, j + hd/2)
           const float a = v[pj], b2 = v[pj + HD / 2];
-          v[pj] = (a * cs - b2 * sn) * qm;
-          v[pj + HD / 2] = (b2 * cs + a * sn) * qm;
+          v[pj] = a * cs - b2 * sn;
+          v[pj + HD / 2] = b2 * cs + a * sn;
         }
       }
 #pragma unroll
@@ -374,16 +381,25 @@ extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, co
   const int64_t total = (int64_t)B * L * H;
   {
     // row-per-thread kernel (coalesced spans through LDS)
-    if (H <= 256 && (hd == 64 || hd == 72) && (rope_mode == 0 || rope_mode == 1)) {  // hd 128: the lane-group
+    if (H <= 256 && (hd == 64 || hd == 72) && (rope_mode == 0 || rope_mode == 1) && (int64_t)B * L < (1ll << 31)) {  // hd 128: the lane-group
       // kernel below already uses every lane (16 x 16 B per row) and a whole row per thread would need 256 VGPRs
-      const int tpb = 256 / H;
+      // 128-row blocks (round 4: 21 KB of LDS -> 7 blocks per CU instead of 3 x 42 KB: the copy-in / compute / copy-out phases of
+      // more, smaller blocks interleave better) unless the head count needs the 256-row block to hold a whole token
+      const int NT_ = H <= 128 ? 128 : 256;
+      const int tpb = NT_ / H;
       const int64_t ntok = (int64_t)B * L;
-      dim3 grid((unsigned)((ntok + tpb - 1) / tpb), (q && k) ? 2 : 1), block(256);
+      dim3 grid((unsigned)((ntok + tpb - 1) / tpb), (q && k) ? 2 : 1), block(NT_);
 #define LAUNCH_ROWS(HD, MODE)                                                                                   \
   {                                                                                                             \
     constexpr int RS_ = HD * 2 + ((HD % 32) == 0 ? 16 : 0);                                                     \
-    const size_t smem = 256 * RS_ + (size_t)tpb * HD * 4 + 4 * HD * 2;                                          \
-    hipLaunchKernelGGL((qknorm_rope_rows_kernel<HD, MODE>), grid, block, smem, st, (unsigned short*)q,          \
+    const size_t smem = (size_t)NT_ * RS_ + (size_t)tpb * HD * 4 + 4 * HD * 2 + (size_t)tpb * 8;                \
+    if (NT_ == 128)                                                                                             \
+      hipLaunchKernelGGL((qknorm_rope_rows_kernel<HD, MODE, 128>), grid, block, smem, st, (unsigned short*)q,   \
+                         (unsigned short*)k, bs, rs, (const unsigned short*)qs0, (const unsigned short*)ks0,    \
+                         (const unsigned short*)qs1, (const unsigned short*)ks1, l_split, cos_t, sin_t, csb, B, \
+                         L, H, eps, q_mult);                                                                    \
+    else                                                                                                        \
+    hipLaunchKernelGGL((qknorm_rope_rows_kernel<HD, MODE, 256>), grid, block, smem, st, (unsigned short*)q,     \
                        (unsigned short*)k, bs, rs, (const unsigned short*)qs0, (const unsigned short*)ks0,      \
                        (const unsigned short*)qs1, (const unsigned short*)ks1, l_split, cos_t, sin_t, csb, B,   \
                        L, H, eps, q_mult);                                                                      \
