@@ -380,11 +380,7 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   const unsigned yb = lds_base + (unsigned)((wn * WTN + l15) * 64 + ((q4 ^ ((l15 >> 1) & 3)) << 4));
   // the last halo piece of a slot: block 20 of 21 (every wave) / block min(4 + wave, 6) of 7
   const unsigned dst = rfl(lds_base + wave * 1024), dst5 = rfl(lds_base + (UP ? (4 + wave < 6 ? 4 + wave : 6) : 20) * 1024);
-#ifdef OSK_CONV_EXP_ONEBODY   // timing experiments only (tools/make_conv_exp_libs.sh): WRONG RESULTS
-  const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = 1;
-#else
   const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = rfl((unsigned)p.Cin / 64);
-#endif
   const int sub = lane >> 2, pos = lane & 3;                     // an LDS-DMA piece = 16 rows of 64 bytes: lane -> (row, position)
 
   for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
@@ -464,9 +460,7 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
 #include "convswu_body_n128.inc"
         OSKSW_OPERANDS : OSKSW128_CLOBBERS);
   }
-#ifndef OSK_CONV_EXP_NOEPI
   epilogue_all_x<NBJ>(p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
-#endif
   }   // tile loop
 }
 
@@ -492,11 +486,7 @@ __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
     xa[dw] = lds_base + (unsigned)(fr * OSKSWF128_SLOT + (144 * half + l15) * 64 + ((q4 ^ (((l15 + dw) >> 1) & 3)) << 4));
   const unsigned yb = lds_base + (unsigned)(l15 * 64 + ((q4 ^ ((l15 >> 1) & 3)) << 4));
   const unsigned dst = rfl(lds_base + wave * 1024), dst5 = rfl(lds_base + 20 * 1024);
-#ifdef OSK_CONV_EXP_ONEBODY
-  const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = 1;
-#else
   const unsigned cin2 = rfl((unsigned)p.Cin * 2), nbody = rfl((unsigned)p.Cin / 64);
-#endif
   const int sub = lane >> 2, pos = lane & 3;
 
   for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
@@ -536,9 +526,7 @@ __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
   asm volatile(
 #include "convswf_body_n128.inc"
       OSKSW_OPERANDS : OSKSW256_CLOBBERS);
-#ifndef OSK_CONV_EXP_NOEPI
   epilogue_all_x<NBJ>(p, bm, wave * 128, 0, 0, l15, q4, smem);
-#endif
   }   // tile loop
 }
 

@@ -279,7 +279,6 @@ extern "C" int osk_gemm_bf16_pair(const OskGemmOperands* a, const OskGemmOperand
   // one tile list where BOTH problems take the 256 x 256 tile kernel; the larger problem first (its tiles fill whole rounds, the
   // smaller one's the tail); otherwise exactly the two single calls
   const int big = p[0].M >= p[1].M ? 0 : 1;
-#ifndef OSK_GEMM_NO_PAIR   // (A/B builds of tools/: always the two single calls)
   // one tile list when the larger problem alone would take the 256 x 256 kernel AND the estimate says so: the smaller problem's
   // tiles ride in the larger one's last round (XL: 2688 + 84 tiles = 11 rounds either way) -- but not when they would open a new,
   // nearly empty round (11B geometry: 2304 tiles are exactly 9 rounds; + 72 tiles would make it 10)
@@ -290,7 +289,6 @@ extern "C" int osk_gemm_bf16_pair(const OskGemmOperands* a, const OskGemmOperand
     const double c_pair = (double)((tiles + 255) / 256) * 4.0;
     if (c_pair < c_big + c_small) return osk_gemm::launch_gemm256x_pair(p[big], p[big ^ 1], (hipStream_t)stream);
   }
-#endif
   (void)big;
   for (int i = 0; i < 2; ++i) {
     const int rc = osk_gemm_bf16(o[i]->A, o[i]->a_batch_stride, o[i]->a_row_stride, o[i]->a_rows_per_batch, o[i]->W, o[i]->w_row_stride,

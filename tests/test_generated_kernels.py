@@ -70,6 +70,61 @@ def test_wide_attention_schedule_invariants():
     assert len(quads) == 40
 
 
+def test_generated_loops_fit_the_instruction_cache():
+    """the hot loop of every hand-scheduled kernel has to stay inside the 64 KB instruction cache (shared by
+    two CUs) with room to spare.  Measured on the BUILT library: per kernel of the disassembled gfx950 code objects, the longest
+    backward branch (target .. branch) = the largest loop.  Budget 52 KB; the fully unrolled two-channel-block sliding-window conv
+    bodies are the largest (~47 KB), the attention loops are 3-7 KB, the GEMM K loops ~8 KB."""
+    import shutil
+    import tempfile
+
+    import pytest
+
+    from open_sora_amd.build import build_lib
+
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("ROCm LLVM tools not found")
+    lib_path = build_lib()
+    loops = {}
+    with tempfile.TemporaryDirectory() as d:
+        lib = shutil.copy(lib_path, os.path.join(d, "libosk_hip.so"))
+        subprocess.run([objdump, "--offloading", lib], capture_output=True, text=True, cwd=d)
+        for co in sorted(os.path.join(d, f) for f in os.listdir(d) if "gfx950" in f):
+            cur, mfma_at, back = None, [], []
+
+            def close():
+                # the K loop of a kernel = its SMALLEST backward-branch span that holds at least 32 MFMAs (the persistent kernels'
+                # outer tile loop also spans the epilogue -- 100+ KB executed once per tile -- and is not what has to stay resident)
+                spans = [e - b for b, e in back if sum(1 for a_ in mfma_at if b <= a_ < e) >= 32]
+                if cur and spans:
+                    loops[cur] = min(spans)
+
+            for ln in subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+                if m:
+                    close()
+                    cur, mfma_at, back = m.group(1), [], []
+                    continue
+                m = re.search(r"// ([0-9A-F]+):", ln)
+                if not m or not cur:
+                    continue
+                addr = int(m.group(1), 16)
+                if "v_mfma" in ln:
+                    mfma_at.append(addr)
+                m2 = re.match(r"\s+s_c?branch\w* (\d+)\s", ln)
+                if m2 and int(m2.group(1)) >= 0x8000:                # 16-bit signed dword offset: backward
+                    back.append((addr + 4 - (0x10000 - int(m2.group(1))) * 4, addr + 4))
+            close()
+    hand = {k: v for k, v in loops.items() if re.search(r"attn_asm|gemm256|convsw|conv256x", k)}
+    assert len(hand) >= 12, sorted(loops)
+    worst = max(hand.values())
+    assert 30 * 1024 < worst <= 52 * 1024, {k[:60]: v for k, v in hand.items() if v == worst}
+    for k, v in hand.items():
+        if "attn_asm" in k:
+            assert v <= 16 * 1024, (k, v)
+
+
 def test_no_orphan_generated_files():
     made = set()
     for p in glob.glob(os.path.join(CSRC, "*.inc")):

@@ -170,3 +170,77 @@ def test_seqpar_ranks_as_threads_overlapped_exchange_equals_serial_order(hip_lib
     e_ref, e_sp = rel_l2(ref_bf16.float(), truth), rel_l2(over[0][0][0], truth)
     assert e_sp <= max(1.5 * e_ref, 2.0 ** -8), (e_sp, e_ref)
     assert rel_l2(over[0][0][0], single) <= 2.0 ** -7
+
+
+@gpu
+@pytest.mark.parametrize("P,mode", [(2, "allgather"), (4, "allgather"), (4, "ulysses")])
+def test_seqpar_ranks_as_threads_at_the_bench_length(hip_lib, P, mode):
+    """sequence parallelism had only been exercised at L <= 320.  Here at the BENCH token count
+    (MMDiT-XL width, L = 16,384 + 512, B = 1; depth 2 + 4 so that the test stays short -- the exchange protocol does not depend
+    on the depth) with P ranks as threads of this process on the one GPU: every rank's attention call has Lq = L / P >= 4,224
+    rows against P key segments of 66 / 132 tiles, i.e. the wide FAST body with loader events at every segment end, beside the
+    other ranks' GEMMs and copy "collectives" on 2 P streams.  Overlapped exchange == serial order bit for bit, all ranks agree,
+    repeatable, and equal to the single-GPU forward at the kernels' own rounding level.  The per-forward times (serial vs
+    overlapped, all ranks sharing ONE GPU: not a scaling measurement) go to gpurun_out/ for profiles/."""
+    import copy
+    import json
+    import os
+    import time
+
+    from open_sora_amd import configs as pcfg, mmdit, seqpar
+    from oracle import synth
+    from tests.local_transport import LocalTransport, run_ranks
+    from tests.util import fast_params, rel_l2
+
+    cfg = dict(pcfg.MMDIT["XL"], depth=2, depth_single_blocks=4)
+    dev = "cuda:0"
+    model = mmdit.Flux(device_map=dev, torch_dtype=torch.bfloat16, **cfg)
+    model.load_state_dict({k: v.to(dev, torch.bfloat16) for k, v in fast_params(synth.mmdit_param_shapes(cfg), seed=5).items()}, strict=True)
+    inp = {k: torch.from_numpy(v) for k, v in synth.mmdit_inputs(cfg, 1, 16, 32, 32, 512).items()}
+    inp = {k: (v.to(dev) if "ids" in k else v.to(dev, torch.bfloat16)) for k, v in inp.items()}
+    with torch.inference_mode():
+        single = model(**inp).float().cpu()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model(**inp)
+        torch.cuda.synchronize()
+        t_single = (time.perf_counter() - t0) / 3 * 1e3
+    assert model.attention_report(1, 16896)["bodies"] == ["attn_asm72_kernel<FAST>"]
+
+    def run(overlap):
+        def rank_fn(rank, world):
+            m = copy.copy(model)
+            m.forward = m.forward_ckpt
+            object.__setattr__(m, "_osk_ws_cache", {})
+            tp = LocalTransport(world, rank, dev, overlap=overlap)
+            sp = seqpar.enable(m, mode=mode, transport=tp)
+            with torch.inference_mode():
+                outs = [m(**inp).float()]                               # warm-up: workspaces, exchange buffers
+                torch.cuda.current_stream().synchronize()
+                world.barrier.wait()
+                t1 = time.perf_counter()
+                outs += [m(**inp).float() for _ in range(2)]
+                torch.cuda.current_stream().synchronize()
+                world.barrier.wait()
+                dt = (time.perf_counter() - t1) / 2 * 1e3
+            return [o.cpu() for o in outs], dt, sp.head_parallel(cfg["num_heads"])
+
+        return run_ranks(P, rank_fn, dev)
+
+    serial, over = run(False), run(True)
+    for res in (serial, over):
+        for outs, _, heads in res:
+            assert heads == (mode == "ulysses")
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), "sequence-parallel forward is not repeatable"
+            assert torch.equal(outs[0], res[0][0][0]), "ranks disagree on the gathered prediction"
+    assert torch.equal(over[0][0][0], serial[0][0][0]), "overlapped exchange differs from the serial order"
+    assert rel_l2(over[0][0][0], single) <= 2.0 ** -7
+    rec = dict(test="seqpar ranks-as-threads, XL width depth 2+4, L=16896, B=1, ONE GPU shared by all ranks", P=P, mode=mode,
+               single_gpu_forward_ms=round(t_single, 2), serial_exchange_ms=round(max(r[1] for r in serial), 2),
+               overlapped_exchange_ms=round(max(r[1] for r in over), 2))
+    print(json.dumps(rec))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "sp_onegpu_bench_length.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
