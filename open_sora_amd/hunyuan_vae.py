@@ -19,6 +19,7 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass
 
+import threading
 import weakref
 
 import torch
@@ -266,6 +267,42 @@ def _plan(mod, kind):
     return p
 
 
+class _GnSumsPool:
+    """The f64 [B, G, 2] accumulators of the fused GroupNorm statistics have to arrive zeroed (the conv epilogue ADDS into them).
+    One buffer for a whole encoder / decoder pass, zeroed by ONE fill, handed out slice by slice -- round 3 zeroed one tensor per
+    GroupNorm (56 fill launches per encode + decode).  Stream-ordered like every other buffer: the fill precedes the convs."""
+
+    SLOTS = 64
+
+    def __init__(self):
+        self.buf, self.used = None, 0
+
+    def begin(self, B: int, G: int, device):
+        n = B * G * 2
+        self.buf = torch.zeros(self.SLOTS, n, dtype=torch.float64, device=device)
+        self.used = 0
+
+    def take(self, B: int, G: int, device) -> Tensor:
+        if self.buf is None or self.used >= self.SLOTS or self.buf.shape[1] != B * G * 2 or self.buf.device != torch.device(device):
+            return torch.zeros(B, G, 2, dtype=torch.float64, device=device)
+        t = self.buf[self.used].view(B, G, 2)
+        self.used += 1
+        return t
+
+    def end(self):
+        self.buf, self.used = None, 0
+
+
+_GN_POOL = threading.local()
+
+
+def _gn_pool() -> _GnSumsPool:
+    p = getattr(_GN_POOL, "pool", None)
+    if p is None:
+        p = _GN_POOL.pool = _GnSumsPool()
+    return p
+
+
 def _conv(mod, x: Tensor, up=(False, False), res: Tensor | None = None, gn: int = 0) -> Tensor:
     """gn = G > 0: the output feeds an nn.GroupNorm(G, ...) next -- its statistics are taken in the conv's epilogue
     (osk_causal_conv3d_gn_ndhwc_bf16) and travel with the tensor (`_osk_gn`) to `_gn`, which then skips its read pass."""
@@ -275,7 +312,7 @@ def _conv(mod, x: Tensor, up=(False, False), res: Tensor | None = None, gn: int 
     To, Ho, Wo = _ops().conv_out_dims(T, H, W, p.stride, up)
     out = torch.empty(B, To, Ho, Wo, p.cout, dtype=BF16, device=x.device)
     if gn and p.cout % gn == 0:
-        sums = torch.zeros(B, gn, 2, dtype=torch.float64, device=x.device)
+        sums = _gn_pool().take(B, gn, x.device)
         _, fused = _ops().causal_conv3d(x, p.w, p.b, out, p.k, p.stride, up, res, gn_sums=sums)
         if fused:
             out._osk_gn = (gn, sums)
@@ -373,29 +410,39 @@ def _to_ncthw(x: Tensor, dtype) -> Tensor:
 def run_encoder(enc: EncoderCausal3D, x: Tensor) -> Tensor:
     """EncoderCausal3D.forward (vae.py:128-155) on NDHWC input (channels padded to 8)."""
     G = enc.conv_norm_out.num_groups
-    h = _conv(enc.conv_in, x, gn=G)
-    for blk in enc.down_blocks:
-        for r in blk.resnets:
-            h = _resnet(r, h)
-        if blk.downsamplers is not None:
-            h = _conv(blk.downsamplers[0].conv, h, gn=G)
-    h = _mid(enc.mid_block, h)
-    return _conv(enc.conv_out, _gn(enc.conv_norm_out, h, True))
+    pool = _gn_pool()
+    pool.begin(x.shape[0], G, x.device)
+    try:
+        h = _conv(enc.conv_in, x, gn=G)
+        for blk in enc.down_blocks:
+            for r in blk.resnets:
+                h = _resnet(r, h)
+            if blk.downsamplers is not None:
+                h = _conv(blk.downsamplers[0].conv, h, gn=G)
+        h = _mid(enc.mid_block, h)
+        return _conv(enc.conv_out, _gn(enc.conv_norm_out, h, True))
+    finally:
+        pool.end()
 
 
 def run_decoder(dec: DecoderCausal3D, z: Tensor) -> Tensor:
     """DecoderCausal3D.forward (vae.py:246-277); the nearest upsample is folded into the upsampler conv."""
     G = dec.conv_norm_out.num_groups
-    h = _conv(dec.conv_in, z, gn=G)
-    h = _mid(dec.mid_block, h)
-    for blk in dec.up_blocks:
-        for r in blk.resnets:
-            h = _resnet(r, h)
-        if blk.upsamplers is not None:
-            ft, fh, fw = blk.upsamplers[0].upsample_factor
-            assert fh == fw and fh in (1, 2) and ft in (1, 2)
-            h = _conv(blk.upsamplers[0].conv, h, up=(ft == 2, fh == 2), gn=G)
-    return _conv(dec.conv_out, _gn(dec.conv_norm_out, h, True))
+    pool = _gn_pool()
+    pool.begin(z.shape[0], G, z.device)
+    try:
+        h = _conv(dec.conv_in, z, gn=G)
+        h = _mid(dec.mid_block, h)
+        for blk in dec.up_blocks:
+            for r in blk.resnets:
+                h = _resnet(r, h)
+            if blk.upsamplers is not None:
+                ft, fh, fw = blk.upsamplers[0].upsample_factor
+                assert fh == fw and fh in (1, 2) and ft in (1, 2)
+                h = _conv(blk.upsamplers[0].conv, h, up=(ft == 2, fh == 2), gn=G)
+        return _conv(dec.conv_out, _gn(dec.conv_norm_out, h, True))
+    finally:
+        pool.end()
 
 
 # =============================================================================================
