@@ -510,8 +510,10 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
         kname = _C.lib.osk_attention_kernel_name(hd, L // world).decode()
         if args.fp8 and hd in (72, 128):
             kname = f"attn_asm{hd}p8_kernel"   # fp8 mode: the fp8 P.V variant
+        elif hd == 72 and L // world >= 1024 and all("FAST" in b_ for b_ in rep["bodies"]):
+            kname = "attn_asm72w_kernel"       # bounded calls with >= 1024 query rows: the wide layout of the FAST body
         # HBM bytes per launch: RECORDED, not measured in this run -- PMC passes (FETCH_SIZE doubled per the gfx950 correction,
-        # + WRITE_SIZE) of the same kernel at the same shape, collected by tools/gpu_final_r3.sh (its PMC passes over tools/attn_only.py) and committed under profiles/
+        # + WRITE_SIZE) of the same kernel at the same shape, collected by tools/gpu_final_r4.sh (its PMC passes over tools/attn_only.py) and committed under profiles/
         traffic, traffic_src = None, None
         rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "attn_traffic.json")
         if os.path.exists(rec_path):
