@@ -361,16 +361,45 @@ def exp_group(L, sc, u, g):
     return ops
 
 
-def swap_group(L, u, t2):
+def swap_group(L, u, t2, guard=True):
     """pv16: the 8 packed P registers of one 32-key half (lane = one query of the 32-row block, 16 keys) -> two 16x16x32 B operands
     (queries 0..15 in PB(u, 2 t2), queries 16..31 in PB(u, 2 t2 + 1); lane row r holds the keys PV16_KEYS[r]): v_permlane16_swap
     exchanges the odd lane rows of the first register with the even rows of the second.  s_nop: VALU write -> permlane read,
     permlane write -> MFMA operand read."""
-    ops = [("n", "s_nop 1")]
+    # guard = False (the wide body): no nops -- the order of the fillers keeps the packs >= 3 instructions in front of the swap and
+    # the swap >= 3 in front of its MFMA, which _check_swap_distance() verifies on the emitted stream (in-step A/B: -1.5 .. -2.6 % per launch)
+    nop = [] if (NO_SWAP_NOPS or not guard) else [("n", "s_nop 1")]
+    ops = list(nop)
     for i in range(4):
         ops.append(("v", "v_permlane16_swap_b32 %s, %s" % (vr(L.PB(u, 2 * t2, i)), vr(L.PB(u, 2 * t2 + 1, i)))))
-    ops.append(("n", "s_nop 1"))
-    return ops
+    return ops + nop
+
+
+NO_SWAP_NOPS = False   # experiment (--wide-exp noswapnop): rely on the distance the filler order gives (checked by _check_swap_distance)
+
+
+def _check_swap_distance(st):
+    """without the guard nops: >= 2 instructions between the v_cvt_pk that writes a P register and the lane-row swap that reads it,
+    and between a swap and the MFMA that reads its registers"""
+    import re as _re
+    last_write, last_swap = {}, {}
+    n = 0
+    for kind, text in st.table:
+        if kind == "L":
+            continue
+        n += 1
+        m = _re.match(r"v_cvt_pk_\w+ v(\d+),", text)
+        if m:
+            last_write[int(m.group(1))] = n
+        m = _re.match(r"v_permlane16_swap_b32 v(\d+), v(\d+)", text)
+        if m:
+            for r in (int(m.group(1)), int(m.group(2))):
+                assert n - last_write.get(r, -99) > 2, "swap too close behind the pack of v%d" % r
+                last_swap[r] = n
+        m = _re.match(r"v_mfma_f32_16x16x32_bf16 a\[\d+:\d+\], v\[\d+:\d+\], v\[(\d+):(\d+)\]", text)
+        if m:
+            for r in range(int(m.group(1)), int(m.group(2)) + 1):
+                assert n - last_swap.get(r, -99) > 2, "MFMA too close behind the swap of v%d" % r
 
 
 def max_chain(L, sn, u, t2, tmp):
@@ -1047,7 +1076,7 @@ def pvw_mfma(st, L, b):
     st.emit("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (dst, vr(L.VR0 + db * 4, 4), vr(L.PB(u, 2 * ph + qb), 4), dst), "X")
 
 
-WIDE_EXP = {"gap": 1, "win": None, "lateswap": False}   # --wide-exp (experiments): DMA piece spacing in the trailing shadows, filler windows, swap placement
+WIDE_EXP = {"gap": 1, "win": None, "vm": 0, "swapnop": False, "kwait2": True, "dmafill": True}   # production values; --wide-exp flips them   # --wide-exp (experiments): DMA piece spacing in the trailing shadows, filler windows, swap placement
 
 
 def body_wide(st, L, k, h, safe=False):
@@ -1074,8 +1103,12 @@ def body_wide(st, L, k, h, safe=False):
             dma(st, L, dslot, pieces[pn], 2)
     st.label(".L@@_entry%d%d" % (k, h))
     later = []
+    deferred = []      # the LDS-DMA instruction of a piece whose M0 write was just emitted: goes behind the next filler instruction
     for i in range(len(pieces), nslot(L, which) - 1):
-        later.append((lambda i=i: dma(st, L, dslot, i), DMACOST))
+        if WIDE_EXP["dmafill"]:
+            later.append((lambda i=i: (dma(st, L, dslot, i, 1), deferred.append(lambda i=i: dma(st, L, dslot, i, 2))), DMACOST))
+        else:
+            later.append((lambda i=i: dma(st, L, dslot, i), DMACOST))
     later.append((lambda: dma_last(st, L, which, dslot, uid), DMACOST))
     later.append((lambda: advance(st, which, uid, G.VSTEP, L, dslot), 20))
     cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
@@ -1085,7 +1118,7 @@ def body_wide(st, L, k, h, safe=False):
             (clsA if g < 2 else clsB).extend(exp_group(L, sc, u, g))
         if g % 2 == 1:
             for u in range(2):
-                (clsA if g < 2 else clsB).extend(swap_group(L, u, g // 2))
+                (clsA if g < 2 else clsB).extend(swap_group(L, u, g // 2, guard=WIDE_EXP["swapnop"]))
     W = WIDE_EXP["win"] or L.FAST_WINDOWS
     classes = [[clsA, W[0], W[1], 0, 0.0], [clsB, W[2], W[3], 0, 0.0]]
     totals = [sum(cost(o[0]) for o in c[0]) for c in classes]
@@ -1097,7 +1130,10 @@ def body_wide(st, L, k, h, safe=False):
             p, u = idx // 2, idx % 2
             ks, ph = p // 2, p % 2
             if u == 0 and ph == 0:
-                st.need(("k", ks))
+                if not WIDE_EXP["kwait2"]:
+                    st.need(("k", ks))
+                elif ks % 2 == 0:          # one wait per two k-steps (the fragments of both were issued long before)
+                    st.need(("k", min(ks + 1, G.NKS - 1)))
             qkw_mfma(st, L, sn, idx)
             if u == 1 and ph == 1:                 # both phases of this k-step issued: its K ring slot is free
                 if ks + 4 < G.NKS:
@@ -1135,11 +1171,18 @@ def body_wide(st, L, k, h, safe=False):
                 used += cost(kind_)
                 c[4] += cost(kind_)
                 c[3] += 1
+                if deferred:               # one instruction now sits between the M0 write and its LDS-DMA
+                    deferred.pop(0)()
+        if deferred:                       # no filler in this shadow: the wait state the hardware needs
+            st.emit("s_nop 0", "n")
+            deferred.pop(0)()
     for c in classes:
         assert c[3] == len(c[0]), "unscheduled filler work"
-    assert not later
+    assert not later and not deferred
     _check_p_ready_wide(st, k, h)
-    st.emit("s_waitcnt vmcnt(0) lgkmcnt(0)", "w")
+    # the pieces this body issued are not needed before the body after next (K(t + 2) from (t, 1): read from (t + 1, 1) on; V^T(t + 1)
+    # from (t, 0): read from (t + 1, 0) on): the wait in front of the barrier only has to retire the PREVIOUS body's pieces
+    st.emit("s_waitcnt vmcnt(%d) lgkmcnt(0)" % WIDE_EXP["vm"], "w")
     st.pending = []
     st.emit("s_barrier", "B")
     if h == 1:
@@ -1232,6 +1275,8 @@ def _generate_wide(L, safe):
             body_wide(st, L, k, h, safe)
     st.in_body = False
     fast_events(st, L)
+    if not WIDE_EXP["swapnop"]:
+        _check_swap_distance(st)
     st.label(".L@@_exit")
     for n in range(L.NTRAIL):
         pvw_mfma(st, L, 32 + n)
@@ -1262,6 +1307,10 @@ def main():
     for tok in [t for t in args.wide_exp.split("+") if t]:
         if tok.startswith("gap"):
             WIDE_EXP["gap"] = int(tok[3:])
+        elif tok in ("swapnop", "kwait1", "nodmafill"):
+            WIDE_EXP[{"swapnop": "swapnop", "kwait1": "kwait2", "nodmafill": "dmafill"}[tok]] = tok == "swapnop"
+        elif tok.startswith("vm"):
+            WIDE_EXP["vm"] = int(tok[2:])
         elif tok.startswith("win:"):
             w_ = [int(x) for x in tok[4:].split(",")]
             WIDE_EXP["win"] = w_ + [w_[3], w_[3]]
