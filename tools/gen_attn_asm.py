@@ -1132,6 +1132,9 @@ def body_wide(st, L, k, h, safe=False):
             if u == 0 and ph == 0:
                 if not WIDE_EXP["kwait2"]:
                     st.need(("k", ks))
+                elif WIDE_EXP["kwait2"] == 4:
+                    if ks in (0, 4):       # experiment: one wait for the four fragments read at the top, one for the fifth
+                        st.need(("k", 3 if ks == 0 else 4))
                 elif ks % 2 == 0:          # one wait per two k-steps (the fragments of both were issued long before)
                     st.need(("k", min(ks + 1, G.NKS - 1)))
             qkw_mfma(st, L, sn, idx)
@@ -1307,6 +1310,8 @@ def main():
     for tok in [t for t in args.wide_exp.split("+") if t]:
         if tok.startswith("gap"):
             WIDE_EXP["gap"] = int(tok[3:])
+        elif tok == "kwait4":
+            WIDE_EXP["kwait2"] = 4
         elif tok in ("swapnop", "kwait1", "nodmafill"):
             WIDE_EXP[{"swapnop": "swapnop", "kwait1": "kwait2", "nodmafill": "dmafill"}[tok]] = tok == "swapnop"
         elif tok.startswith("vm"):
