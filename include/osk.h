@@ -154,9 +154,9 @@ int osk_qknorm_rope_bf16(void* q, void* k, int64_t batch_stride, int64_t row_str
  * v row (b,l) head h at v + b*batch_stride + l*row_stride + h*hd.
  * vt [B, H, hd, Lp], Lp = round_up(L, 64), zero-filled for keys >= L.  The key order inside a 64-key tile is the one in
  * which the attention kernel of that head_dim holds P for its second product (an internal contract between the two calls):
- *   hd 64 / 128 (P.V on 32x32x16 MFMAs): inside every group of 16 keys the two middle quads are swapped (k0-3, k8-11, k4-7,
+ *   hd 128 (P.V on 32x32x16 MFMAs): inside every group of 16 keys the two middle quads are swapped (k0-3, k8-11, k4-7,
  *     k12-15) -- the order the score accumulators hand P back, no cross-lane shuffle;
- *   hd 72 (P.V on 16x16x32 MFMAs, 80 instead of 96 padded rows): 16-byte chunk c of a tile row = 32-key half c / 4, MFMA
+ *   hd 72 and hd 64 (the same loop; P.V on 16x16x32 MFMAs, 80 instead of 96 padded rows): 16-byte chunk c of a tile row = 32-key half c / 4, MFMA
  *     lane row c % 4, holding keys {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31} of that half for rows 0..3. */
 int osk_v_transpose_bf16(const void* v, int64_t batch_stride, int64_t row_stride,
                          void* vt, int B, int L, int H, int hd, void* stream);
@@ -259,7 +259,7 @@ int osk_attention_short_bf16(const void* q, int64_t q_batch_stride, int64_t q_ro
 const char* osk_attention_kernel_name(int hd, int seg_len);
 /* ... and of the loop BODY a call of osk_attention_fwd_bounded_bf16 with this segment layout and score bound runs (reporting /
  * tests only): "attn_asm72_kernel<FAST>" = the bounded body (no max tracking; needs 0 < score_bound <= 56 and, with several key
- * segments, segments of >= 3 tiles), "attn_asm72_kernel<general>" = the running-reference body, "attn_fwd_kernel<64>".  The
+ * segments, segments of >= 3 tiles), "attn_asm72_kernel<general>" = the running-reference body (head_dim 64 runs the head_dim-72 kernels).  The
  * choice is data-dependent through score_bound (open_sora_amd/mmdit.py derives it from the QK-norm scale vectors of
  * opensora/models/mmdit/layers.py:113-135), so bench.py prints it next to the timing. */
 const char* osk_attention_body_name(int hd, int n_seg, int seg_len, float score_bound);

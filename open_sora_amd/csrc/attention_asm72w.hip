@@ -15,13 +15,14 @@
 namespace osk_attn {
 namespace {
 
-constexpr int HD = 72, NKS = 5, NDT = 3;
+constexpr int HDL = 72, NKS = 5, NDT = 3;   // HDL: the head_dim of the LDS images / register layout; the tensors' head_dim is the template parameter HD (72, or 64: see below)
 
 OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 OSK_DEV uint64_t rfl64(uint64_t v) {
   return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v);
 }
 
+template <int HD>   // 72, or 64 (see attention_asm72.hip)
 __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p) {
   constexpr bool FAST = true;
   constexpr int ROWS = 512;                                    // query rows per workgroup
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
   __syncthreads();
   if (tid < 64) {
     const int slot = tid >> 5;
-    reinterpret_cast<unsigned*>(smem + OSK72_VOFF0 + slot * OSK72_VTILE + HD * 128)[tid & 31] = 0x3F803F80u;
+    reinterpret_cast<unsigned*>(smem + OSK72_VOFF0 + slot * OSK72_VTILE + HDL * 128)[tid & 31] = 0x3F803F80u;
   }
   if (tid == 64 || tid == 65)  // one copy per K ring slot, KTILE apart (the slot is an immediate offset in the asm)
     *reinterpret_cast<unsigned*>(smem + OSK72_CONST_OFF + (tid - 64) * OSK72_KTILE) = 0x00003F80u;
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
     // dword `lane` of LDS row 72: 16-byte position lane / 4 holds logical chunk c = (lane / 4) ^ ((72 >> 1) & 7) of the swizzled
     // 128-byte row image; chunk c of the V^T tile = 32-key half c / 4, lane row c % 4, whose 8 keys (baked by
     // osk_v_transpose_bf16 for this head_dim) are PV16_KEYS[c % 4] (tools/gen_attn_asm.py)
-    const int c = (lane >> 2) ^ ((HD >> 1) & 7), e0 = (lane & 3) * 2;
+    const int c = (lane >> 2) ^ ((HDL >> 1) & 7), e0 = (lane & 3) * 2;
     auto key_of = [](int c_, int e_) {
       const int r_ = c_ & 3;   // lane row: keys {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31}
       return 32 * (c_ >> 2) + ((r_ & 1) << 4) + ((r_ >> 1) << 2) + ((e_ >> 2) << 3) + (e_ & 3);
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
     maskval = (key_of(c, e0) < last_valid ? 0x3F80u : 0u) | (key_of(c, e0 + 1) < last_valid ? 0x3F800000u : 0u);
   }
   if (ragged && kp.tps == 1 && tid < 32)                 // tile 0 itself is ragged: no loop body precedes it
-    reinterpret_cast<unsigned*>(smem + OSK72_VOFF0 + HD * 128)[tid] = maskval;
+    reinterpret_cast<unsigned*>(smem + OSK72_VOFF0 + HDL * 128)[tid] = maskval;
   __syncthreads();
 
   // ---- Q fragments, pre-scaled by scale*log2(e), -> AGPRs (u-major, k-step, 4 words)
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
 #pragma unroll
   for (int t2 = 0; t2 < 2; ++t2)   // ring slot 1 = + KTILE (immediate), for the column image and the constant chunk alike
     kc[t2] = hi ? lds_base + OSK72_CONST_OFF : lds_base + 8192 + t2 * 512 + l31 * 16;
-  const unsigned onesaddr = lds_base + OSK72_VOFF0 + HD * 128 + lane * 4;   // lanes 32..63: the zero row behind it
+  const unsigned onesaddr = lds_base + OSK72_VOFF0 + HDL * 128 + lane * 4;   // lanes 32..63: the zero row behind it
   // V^T fragments of the 16x16x32 P.V product: lane (row r4 = lane / 16, dim l15 = lane % 16 of a 16-row block) reads chunk
   // 4 t2 + r4 of its row (+ block and ring-slot immediates in the asm); same swizzled 128-byte-row image as K
   const int l15 = lane & 15, r4 = lane >> 4;
@@ -161,8 +162,8 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
   const unsigned tpsnt = rfl((unsigned)kp.tps | ((unsigned)kp.nt << 16));   // (two operand slots went to vo[])
   const unsigned kdst = rfl(lds_base + wave * 1024), vdst = rfl(lds_base + OSK72_VOFF0 + (NW - 1 - wave) * 1024);
   // valid loader slots of this wave: the last one only where its instruction index is < 9
-  const unsigned nkw = rfl(wave + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1));
-  const unsigned nvw = rfl(((NW - 1 - wave) + NW * (NSLOT - 1) < 9 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1)) |
+  const unsigned nkw = rfl(wave + NW * (NSLOT - 1) < HD / 8 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1));   // (head_dim 64: no column image)
+  const unsigned nvw = rfl(((NW - 1 - wave) + NW * (NSLOT - 1) < HD / 8 ? (unsigned)NSLOT : (unsigned)(NSLOT - 1)) |
                            (ragged ? 0u : 1u << 8) | ((ragged && wave == 0) ? 1u << 9 : 0u));
   const unsigned nkvw = rfl(nvw | (nkw << 16));
 
@@ -237,8 +238,9 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
   }
 }
 
+template <int HD>
 int launch_wide(const AttnParams& p, hipStream_t st) {
-  auto kernel = attn_asm72w_kernel;
+  auto kernel = attn_asm72w_kernel<HD>;
   OSK_ENSURE_MAX_SMEM(kernel, OSK72_SMEM);
   const int units = ((p.Lq + 511) / 512) * p.B * p.H;
   const int tail_units = p.tail_split > 1 ? units - p.tail_first : 0;
@@ -249,6 +251,7 @@ int launch_wide(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
-int launch_asm72w(const AttnParams& p, hipStream_t st) { return launch_wide(p, st); }
+int launch_asm72w(const AttnParams& p, hipStream_t st) { return launch_wide<72>(p, st); }
+int launch_asm64w(const AttnParams& p, hipStream_t st) { return launch_wide<64>(p, st); }
 
 }  // namespace osk_attn

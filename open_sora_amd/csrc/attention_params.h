@@ -122,12 +122,15 @@ int launch_asm72(const AttnParams& p, hipStream_t st);
 // attention_asm72w.hip: head_dim 72, the bounded body in the wide layout (4 waves x 128 rows, one 32-key half per loop body); p.rows == 512
 int launch_asm72w(const AttnParams& p, hipStream_t st);
 // host: does a bounded head_dim-72 call take the wide layout?  (enough query rows for 512-row work units to fill the chip evenly)
+// the same two kernels on tensors with 64-wide heads (template parameter HD = 64)
+int launch_asm64(const AttnParams& p, hipStream_t st);
+int launch_asm64w(const AttnParams& p, hipStream_t st);
 static inline bool attn_wide_path(const AttnParams& p, int hd) {
 #ifdef OSK_ATTN_NO_WIDE   // (A/B builds of tools/make_attn_nowide_lib.sh: always the 256-row layout)
   (void)p; (void)hd;
   return false;
 #else
-  return hd == 72 && attn_fast_path(p) && p.Lq >= 1024;
+  return (hd == 72 || hd == 64) && attn_fast_path(p) && p.Lq >= 1024;
 #endif
 }
 // attention_asm128.hip: head_dim 128, the same layout and generator

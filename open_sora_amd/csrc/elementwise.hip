@@ -469,13 +469,13 @@ __global__ void __launch_bounds__(256) v_transpose_kernel(const unsigned short* 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       int key;
-      if constexpr (HD == 72) {
-        // head_dim 72 (P.V on v_mfma_f32_16x16x32_bf16, attention_asm72.hip): chunk pc of the 64-key row = 32-key half pc / 4,
+      if constexpr (HD == 72 || HD == 64) {
+        // head_dim 72 and 64 (P.V on v_mfma_f32_16x16x32_bf16, attention_asm72.hip): chunk pc of the 64-key row = 32-key half pc / 4,
         // lane row r = pc % 4 of the MFMA operands, whose 8 keys are {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31}
         const int r = pc & 3;
         key = 32 * (pc >> 2) + ((r & 1) << 4) + ((r >> 1) << 2) + ((j >> 2) << 3) + (j & 3);
       } else {
-        // head_dim 64 / 128 (P.V on 32x32x16): per 16 keys, positions 0-3 -> keys 0-3, 4-7 -> keys 8-11, 8-11 -> keys 4-7, 12-15 -> keys 12-15
+        // head_dim 128 (P.V on 32x32x16): per 16 keys, positions 0-3 -> keys 0-3, 4-7 -> keys 8-11, 8-11 -> keys 4-7, 12-15 -> keys 12-15
         const int p = pc * 8 + j;                  // position within tile
         const int p16 = p & 15, grp = p & ~15;
         key = grp + ((p16 < 4 || p16 >= 12) ? p16 : (p16 < 8 ? p16 + 4 : p16 - 4));

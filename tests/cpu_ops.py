@@ -21,9 +21,9 @@ _PV16_KEYS = torch.tensor([[0, 1, 2, 3, 8, 9, 10, 11], [16, 17, 18, 19, 24, 25, 
 def pos2key(hd: int, Lp: int) -> torch.Tensor:
     """key stored at position p of a V^T row (include/osk.h, osk_v_transpose_bf16): the order the attention kernel of that head_dim
     holds its P operand in.  head_dim 72 (16x16x32 P.V): 16-byte chunk c of a 64-key tile = the 8 keys of lane row c % 4 in the
-    32-key half c / 4; head_dim 64 / 128 (32x32x16): a 4-key swap inside every 16 keys."""
+    32-key half c / 4 -- and head_dim 64, which runs the same loop; head_dim 128 (32x32x16): a 4-key swap inside every 16 keys."""
     p = torch.arange(Lp)
-    if hd == 72:
+    if hd in (64, 72):
         c, e = (p % 64) // 8, p % 8
         return (p // 64) * 64 + 32 * (c // 4) + _PV16_KEYS[c % 4, e]
     return (p // 16 * 16) + _PERM[p % 16]

@@ -365,7 +365,9 @@ def _attn_case(hip_lib, B, H, hd, Lq, Lk, seed=3, spike=False, lse_tol=2e-3, pre
 @pytest.mark.parametrize("hd", [64, 72, 128])
 @pytest.mark.parametrize("Lq,Lk", [(256, 256), (300, 1000), (64, 65), (33, 700)])
 def test_attention_vs_oracle(hip_lib, hd, Lq, Lk):
-    _attn_case(hip_lib, 2, 2, hd, Lq, Lk)
+    # a stand-alone call: the kernels fold scale*log2(e) into Q and re-round it to bf16 (2^-9 relative on the logits) -- LSE tolerance
+    # 4e-3 (measured 1.3e-3 .. 1.9e-3 at these shapes for every head_dim; round 3's compiler-scheduled head_dim-64 kernel did not re-round)
+    _attn_case(hip_lib, 2, 2, hd, Lq, Lk, lse_tol=4e-3)
 
 
 @pytest.mark.parametrize("hd", [72, 128])
@@ -414,7 +416,7 @@ def _bounded_case(hip_lib, B, H, hd, Lq, Lk, bound_at_least=0.0, ws=False, seed=
     return bound
 
 
-@pytest.mark.parametrize("hd", [72, 128])
+@pytest.mark.parametrize("hd", [64, 72, 128])
 @pytest.mark.parametrize("Lq,Lk", [(256, 64), (300, 128), (64, 192), (257, 1024), (33, 4096)])
 def test_attention_bounded_fast_body_vs_f64(hip_lib, hd, Lq, Lk):
     _bounded_case(hip_lib, 2, 2, hd, Lq, Lk)
@@ -463,7 +465,7 @@ def _bounded_segments_case(hip_lib, B, H, hd, Lq, seg, nseg, ws=False, Bkv=None,
     assert ((got - out_t.double()).norm() / ref.norm()).item() <= 6e-3
 
 
-@pytest.mark.parametrize("hd", [72, 128])
+@pytest.mark.parametrize("hd", [64, 72, 128])
 @pytest.mark.parametrize("seg,nseg", [(1000, 1), (60, 1), (65, 1), (130, 1), (190, 1), (4133, 1), (192, 3), (200, 2), (260, 4), (320, 2), (129, 5)])
 def test_attention_bounded_ragged_tiles_and_segments_run_the_fast_body(hip_lib, hd, seg, nseg):
     """VERDICT r3 'missing' 3: ragged key counts (one tile, the prologue's tiles, both loop bodies) and several key segments
@@ -482,10 +484,12 @@ def test_attention_bounded_short_segments_fall_back_and_shared_batches_tail_spli
 
 @pytest.mark.parametrize("Lq,seg,nseg", [(1024, 64, 1), (1024, 128, 1), (1100, 192, 1), (1536, 1000, 1), (2000, 4133, 1), (1024, 60, 1),
                                          (1300, 130, 1), (1024, 192, 3), (2048, 200, 2), (1111, 260, 4), (1024, 129, 5)])
-def test_attention_wide_layout_head_dim_72(hip_lib, Lq, seg, nseg):
+@pytest.mark.parametrize("hd", [72, 64])
+def test_attention_wide_layout_head_dim_72(hip_lib, Lq, seg, nseg, hd):
     """attn_asm72w_kernel (bounded calls with Lq >= 1024: 512-row workgroups, one 32-key half per loop body): 1, 2, 3 and many
-    key tiles (prologue only / each of the four bodies as the last one), ragged query blocks, ragged keys, segments"""
-    _bounded_segments_case(hip_lib, 2, 3, 72, Lq, seg, nseg, seed=71)
+    key tiles (prologue only / each of the four bodies as the last one), ragged query blocks, ragged keys, segments; head_dim 64
+    runs the same kernel with zero dims 64..71"""
+    _bounded_segments_case(hip_lib, 2, 3, hd, Lq, seg, nseg, seed=71)
 
 
 def test_attention_wide_layout_tail_split_and_determinism(hip_lib):
@@ -529,7 +533,7 @@ def test_attention_prescaled_q_other_head_dims(hip_lib, hd):
     _attn_case(hip_lib, 1, 2, hd, 200, 333, seed=5, prescaled=True)
 
 
-@pytest.mark.parametrize("hd", [72, 128])
+@pytest.mark.parametrize("hd", [64, 72, 128])
 @pytest.mark.parametrize("spike_key", [5, 64 + 7, 128 + 63, 448 + 1, 959])
 def test_attention_asm_reference_max_jump(hip_lib, spike_key, hd):
     """one key whose score exceeds every earlier one by far more than the kernel's 2^8 deferral threshold: the
@@ -559,7 +563,7 @@ def test_attention_asm_reference_max_jump(hip_lib, spike_key, hd):
     assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() <= 1.5e-3 * s.abs().max().item()
 
 
-@pytest.mark.parametrize("hd", [72, 128])
+@pytest.mark.parametrize("hd", [64, 72, 128])
 @pytest.mark.parametrize("seg,nseg", [(100, 3), (40, 2), (200, 2)])
 def test_attention_asm_ragged_segments(hip_lib, seg, nseg, hd):
     """hand-scheduled kernel with ragged key segments (sequence-parallel all-gather layout with L/P % 64 != 0): every
@@ -809,7 +813,7 @@ def test_errors_raise(hip_lib):
 
 
 # ----------------------------------------------------------------------------- tail split (workspace variant)
-@pytest.mark.parametrize("hd", [72, 128])
+@pytest.mark.parametrize("hd", [64, 72, 128])
 @pytest.mark.parametrize("case", ["one_segment_ragged", "few_units", "segments", "shared_key_batches", "one_tile_per_part"])
 def test_attention_tail_split_matches_unsplit(hip_lib, hd, case):
     """osk_attention_fwd_ws_bf16: the work units of the grid's last partial round are cut into key parts and merged by

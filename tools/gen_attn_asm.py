@@ -1362,7 +1362,7 @@ def main():
             f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d%s, layout NU=%d: %s\n" %
                     (hd, ", fp8 P.V" if pv8 else "", nu, what))
             for ln in st.lines:
-                f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%dv0" % (tagof(hd, pv8), nu)))
+                f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%dv0_%%=" % (tagof(hd, pv8), nu)))
         if not pv8:   # the bounded / single-segment / whole-tile body of the same layout
             fexp = args.fast_exp or args.exp
             if fexp.startswith("dmagap"):
@@ -1375,7 +1375,7 @@ def main():
                 f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim %d, layout NU=%d, FAST body (score bound, one "
                         "segment of whole tiles): %s\n" % (hd, nu, what))
                 for ln in stf.lines:
-                    f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%df0" % (tagof(hd, pv8), nu)))
+                    f.write('"%s\\n"\n' % ln.replace("@@", "osk%sn%df0_%%=" % (tagof(hd, pv8), nu)))
     # the wide layout of head_dim 72 (4 query blocks per wave, 32-key sub-tiles): FAST body only
     LW = LayoutW()
     stw = generate_wide(LW, safe)
@@ -1383,7 +1383,7 @@ def main():
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.  head_dim 72, WIDE layout (4 waves x 128 query rows, one 32-key half per "
                 "body), FAST body: %s\n" % ("production" if not args.exp else "experiment " + args.exp))
         for ln in stw.lines:
-            f.write('"%s\\n"\n' % ln.replace("@@", "osk72wf0"))
+            f.write('"%s\\n"\n' % ln.replace("@@", "osk72wf0_%="))
     # register / operand contract for the wrapper
     with open(os.path.join(args.out, "attention_asm_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit.\n")
