@@ -382,6 +382,8 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
     B, Lq, _ = q.shape
     if seg_len is None:
         seg_len = k.shape[1]
+    if CHECK_SCORE_BOUND and score_bound > 0:
+        _assert_score_bound(q, k, H, hd, scale, n_seg, seg_len, k_seg_stride, q_prescaled, kv_batches, score_bound)
     prof = PROFILE_ATTENTION
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -415,6 +417,28 @@ def attention_short(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
 def attention_body(hd: int, n_seg: int, seg_len: int, score_bound: float) -> str:
     """which loop body attention_fwd(..., score_bound=...) runs for this key layout (reporting: bench.py, tests)"""
     return lib.osk_attention_body_name(hd, n_seg, seg_len, float(score_bound)).decode()
+
+
+# OSK_TRACE=1 (debugging runs): every bounded attention call checks the caller's promise on the device before it launches -- the
+# bounded loop body has no running maximum, so a violated bound silently loses accuracy (or, far beyond it, overflows).  The check is
+# the sufficient condition the model's own bound is derived from (Cauchy-Schwarz per head): max |q_h| * max |k_h| <= bound.
+CHECK_SCORE_BOUND = bool(os.environ.get("OSK_TRACE"))
+
+
+def _assert_score_bound(q, k, H, hd, scale, n_seg, seg_len, k_seg_stride, q_prescaled, kv_batches, bound):
+    Bq, Lq, _ = q.shape
+    Bk = kv_batches if kv_batches else Bq
+    qn = q.float().reshape(Bq, Lq, H, hd).norm(dim=-1).amax()
+    if not q_prescaled:
+        qn = qn * (scale * 1.4426950408889634)
+    kn = torch.zeros((), dtype=torch.float32, device=q.device)
+    for s_ in range(n_seg):
+        ks = torch.as_strided(k, (Bk, seg_len, H * hd), (k.stride(0), k.stride(1), 1), k.storage_offset() + s_ * k_seg_stride)
+        kn = torch.maximum(kn, ks.float().reshape(Bk, seg_len, H, hd).norm(dim=-1).amax())
+    worst = float(qn * kn)
+    if worst > bound * (1 + 2.0 ** -7):
+        raise RuntimeError(f"osk_attention_fwd_bounded_bf16: the caller's score bound {bound:.4g} does not hold: max |q| max |k| = {worst:.4g} "
+                           "(log2 units) -- the QK-norm scale vectors changed after the plan was built?")
 
 
 def vt8_rows(hd: int) -> int:

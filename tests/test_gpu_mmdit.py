@@ -229,3 +229,27 @@ def test_two_models_and_two_streams_do_not_share_workspaces(hip_lib):
     ws1 = {id(v) for v in m1._osk_ws_cache.values()}
     ws2 = {id(v) for v in m2._osk_ws_cache.values()}
     assert len(ws1) >= 2 and not (ws1 & ws2)
+
+
+def test_score_bound_debug_check_on_device(hip_lib, monkeypatch):
+    """the bounded attention body trusts the caller's score bound.  With the debug switch on (OSK_TRACE=1 sets
+    open_sora_amd._C.CHECK_SCORE_BOUND) every bounded call first checks the promise on the device: a golden model's forward passes
+    it in every block; a call whose bound is too small raises instead of silently losing the tail of the softmax."""
+    from open_sora_amd import _C, mmdit
+
+    monkeypatch.setattr(_C, "CHECK_SCORE_BOUND", True)
+    name = "hd72_eager_split"
+    cfg, B, T, h, w, L_txt = configs.GOLDEN[name]
+    model = mmdit.Flux(device_map="cuda", torch_dtype=torch.bfloat16, **cfg)
+    model.load_state_dict(torch_params(cfg, dtype=torch.bfloat16, device="cuda"), strict=True)
+    inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=torch.bfloat16, device="cuda")
+    with torch.inference_mode():
+        out = model(**inp)                                      # every block's bound holds
+    assert torch.isfinite(out.float()).all()
+    H, hd, L = 2, 72, 256
+    q = torch.randn(1, L, H * hd, device="cuda").to(torch.bfloat16)
+    k = torch.randn(1, L, H * hd, device="cuda").to(torch.bfloat16)
+    vt = torch.zeros(1, H, hd, L, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty_like(q)
+    with pytest.raises(RuntimeError, match="score bound"):
+        _C.attention_fwd(q, k, vt, o, H, hd, hd ** -0.5, score_bound=1.0)     # |q||k| scale log2e ~ 12 >> 1
