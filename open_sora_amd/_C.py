@@ -99,7 +99,9 @@ class _TracingLib:
             v = int(v)
             k = self._ids.setdefault(v, len(self._ids))
             return f"p{k}@{v & 0xFF:02x}"
-        return round(float(v), 9) if kind is _f32 else int(v)
+        if isinstance(v, C.Array):                 # small by-pointer arrays (osk_rope_table's axes): their contents
+            return tuple(int(x) for x in v)
+        return round(float(v), 9) if kind in (_f32, _f64) else int(v)
 
     def __getattr__(self, name):
         fn = getattr(self._inner, name)
