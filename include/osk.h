@@ -346,6 +346,16 @@ int osk_attention_hd512_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t 
                                  int64_t k_batch_stride, int64_t k_row_stride, const void* vt, int64_t vt_batch_stride,
                                  int64_t vt_row_stride, const float* bias_v, void* out, int64_t out_batch_stride,
                                  int64_t out_row_stride, int B, int S, int keys_per_frame, float scale, void* stream);
+/* ... with a caller-owned workspace (>= osk_attention_hd512_workspace_bytes(B, S), 16-byte aligned): the launch is only
+ * ceil(S / 128) x B x 2 workgroups and its time is the key-tile chain of the last frame's query blocks, so with a workspace every
+ * chain is cut into up to 4 runs of key tiles that run side by side (partial rows in f32 + LSE, combined by a merge kernel).
+ * Same result up to the f32 rounding of the combination; NULL / too small a workspace = the single-chain launch. */
+int osk_attention_hd512_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride, const void* k,
+                                    int64_t k_batch_stride, int64_t k_row_stride, const void* vt, int64_t vt_batch_stride,
+                                    int64_t vt_row_stride, const float* bias_v, void* out, int64_t out_batch_stride,
+                                    int64_t out_row_stride, int B, int S, int keys_per_frame, float scale, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
+int64_t osk_attention_hd512_workspace_bytes(int B, int S);
 
 /* ---- tile cross-fade of the tiled VAE paths, in place in b (f32 math, one rounding):
  *   b[o, e, i] = a[o, Da - extent + e, i] * (1 - e/extent) + b[o, e, i] * (e/extent),  e < extent

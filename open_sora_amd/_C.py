@@ -60,6 +60,9 @@ SIGNATURES = {
     "osk_groupnorm_apply_ndhwc_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _vp],
     "osk_masked_softmax_f32_bf16": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_blend_bf16": [_vp, _vp, _i64, _i32, _i32, _i32, _i64, _vp],
+    "osk_attention_hd512_fwd_ws_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
+                                        _i32, _f32, _vp, _i64, _vp],
+    "osk_attention_hd512_workspace_bytes": [_i32, _i32],
     "osk_attention_hd512_fwd_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
                                      _i32, _f32, _vp],
 }
@@ -76,7 +79,7 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name in ("osk_arch", "osk_attention_kernel_name", "osk_attention_body_name") else
-                      _i64 if name == "osk_attention_workspace_bytes" else _i32)
+                      _i64 if name in ("osk_attention_workspace_bytes", "osk_attention_hd512_workspace_bytes") else _i32)
     if lib.osk_abi_version() != 1:
         raise ImportError("libosk_hip.so ABI version mismatch")
     return lib
@@ -598,14 +601,30 @@ def blend(a: torch.Tensor, b: torch.Tensor, extent: int, dim: int) -> torch.Tens
     return b
 
 
+_HD512_WS: dict = {}
+
+
+def attention_hd512_workspace(B: int, S: int, device) -> torch.Tensor:
+    """workspace of the key-split launch, one per (device, stream, size); reused by every call"""
+    dev = torch.device(device)
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0, B, S)
+    ws = _HD512_WS.get(key)
+    if ws is None:
+        if len(_HD512_WS) >= 4:
+            _HD512_WS.pop(next(iter(_HD512_WS)))
+        ws = _HD512_WS[key] = torch.empty(int(lib.osk_attention_hd512_workspace_bytes(B, S)), dtype=torch.uint8, device=dev)
+    return ws
+
+
 def attention_hd512(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, bias_v, out: torch.Tensor, keys_per_frame: int,
-                    scale: float) -> torch.Tensor:
+                    scale: float, workspace: torch.Tensor | None = None) -> torch.Tensor:
     """the VAE mid block's one-head attention: q, k, out bf16 [B, S, 512] views; vt bf16 [B, 512, ld] (natural key order,
     zero beyond S, ld >= round_up(S, 32)); bias_v f32 [512] | None; frame-causal over groups of keys_per_frame keys."""
     B, S, C = q.shape
     assert C == 512 and vt.shape[1] == 512 and vt.stride(2) == 1 and q.stride(2) == 1 and k.stride(2) == 1 and out.stride(2) == 1
-    _check(lib.osk_attention_hd512_fwd_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
-                                            vt.data_ptr(), vt.stride(0), vt.stride(1), _p(bias_v), out.data_ptr(),
-                                            out.stride(0), out.stride(1), B, S, keys_per_frame, scale, _stream()),
-           "osk_attention_hd512_fwd_bf16")
+    _check(lib.osk_attention_hd512_fwd_ws_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                                               vt.data_ptr(), vt.stride(0), vt.stride(1), _p(bias_v), out.data_ptr(),
+                                               out.stride(0), out.stride(1), B, S, keys_per_frame, scale, _p(workspace),
+                                               0 if workspace is None else workspace.numel() * workspace.element_size(), _stream()),
+           "osk_attention_hd512_fwd_ws_bf16")
     return out

@@ -47,6 +47,11 @@ struct P512 {
   unsigned short* out; int64_t obs, ors;
   int S, kpf;
   float scale_log2;
+  // key split (round 4): every (query block, dim pass) is cut into `parts` runs of key tiles that run as separate workgroups and
+  // write normalised partial rows (f32) + log2-domain LSE into the workspace; attn_hd512_merge_kernel combines them
+  int parts = 1;
+  float* ws_o = nullptr;     // [B][query blocks][parts][QB rows][512]
+  float* ws_lse = nullptr;   // [B][query blocks][parts][QB rows]
 };
 
 OSK_DEV void glds16(const unsigned short* g, unsigned char* lds_wave_base) {
@@ -61,7 +66,7 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
   const int hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.y;
   const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QB;   // longest key range first
-  const int pass = blockIdx.z;
+  const int pass = (int)blockIdx.z % NPASS, part = (int)blockIdx.z / NPASS;
   const int qi = q0 + wave * QW + l31;
   const int qc = qi < p.S ? qi : p.S - 1;
 
@@ -81,7 +86,10 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
   q_last = q_last < p.S ? q_last : p.S - 1;
   int wg_limit = (q_last / kpf + 1) * kpf;
   wg_limit = wg_limit < p.S ? wg_limit : p.S;
-  const int ntiles = (wg_limit + KT - 1) / KT;
+  const int ntiles_all = (wg_limit + KT - 1) / KT;
+  // this workgroup's run of key tiles [t_first, t_first + ntiles)
+  const int t_first = (int)((int64_t)part * ntiles_all / p.parts);
+  const int ntiles = (int)((int64_t)(part + 1) * ntiles_all / p.parts) - t_first;
 
   const unsigned short* kb = p.k + b * p.kbs;
   const unsigned short* vb = p.vt + b * p.vbs;
@@ -89,7 +97,7 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
   auto issue = [&](int t, int bi, int pass) {
     unsigned char* kbuf = smem + bi * BUF;
     unsigned char* vbuf = kbuf + KTILE;
-    const int key0 = t * KT;
+    const int key0 = (t_first + t) * KT;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = wave + 4 * i;                                  // key row of the tile: one 1 KiB row per instruction
@@ -114,7 +122,7 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;   // running max (shared by the two half-waves of a query), this lane's partial sum
 
-  issue(0, 0, pass);
+  if (ntiles > 0) issue(0, 0, pass);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
     }
     // ---- mask + online softmax: register r = 4 g + j of this lane is key 8 g + 4 hi + j of the tile
-    const int key0 = t * KT;
+    const int key0 = (t_first + t) * KT;
     float tmax = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -180,8 +188,26 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
   }
 
   // ---- normalise, add the V bias, store: register r = 4 g + j of row tile d is dim 32 d + 8 g + 4 hi + j of this query
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
+  // a key part that lies entirely behind this row's visible keys (only possible when a query block spans two frames): every score
+  // was the mask value AND so was the running maximum, i.e. P = exp2(0) = 1 for masked keys -- the part must weigh nothing
+  const bool dead = ntiles == 0 || (int64_t)t_first * KT >= my_limit;
+  const float l_sum = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = dead ? 0.f : l_sum;
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (p.parts > 1) {
+    // partial result of this key part: normalised rows in f32 + LSE (log2 units) -> workspace
+    const int64_t slot = (((int64_t)b * gridDim.x + blockIdx.x) * p.parts + part) * QB + wave * QW + l31;
+    float* wo = p.ws_o + slot * HD;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dim = pass * (HD / NPASS) + 32 * d + 8 * g + 4 * hi;
+        *reinterpret_cast<float4*>(wo + dim) = make_float4(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+      }
+    if (pass == 0 && hi == 0) p.ws_lse[slot] = l_tot > 0.f ? m_run + __builtin_amdgcn_logf(l_tot) : -1e30f;
+    return;
+  }
   if (qi < p.S) {
     unsigned short* orow = p.out + b * p.obs + (int64_t)qi * p.ors;
 #pragma unroll
@@ -199,13 +225,45 @@ __global__ void __launch_bounds__(256, 1) attn_hd512_kernel(const P512 p) {
   }
 }
 
+// out = sum_p 2^(lse_p - lse) O_p + bias_v over the key parts of a query block (lse = log2 sum_p 2^lse_p); grid (query blocks, B,
+// MSPLIT row groups), thread = (row, float4 chunk of the 512 dims): the partial rows are contiguous f32 [row][512] per part.
+// HBM-bound: parts x 2 KiB read + 1 KiB written per row; the row groups are there to put > 256 workgroups on the chip.
+constexpr int MSPLIT = 8, MROWS = QB / MSPLIT;
+__global__ void __launch_bounds__(256) attn_hd512_merge_kernel(const P512 p) {
+  const int b = blockIdx.y;
+  const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QB;
+  const int64_t base = ((int64_t)b * gridDim.x + blockIdx.x) * p.parts * QB;
+  for (int i = (int)blockIdx.z * MROWS * (HD / 4) + threadIdx.x; i < ((int)blockIdx.z + 1) * MROWS * (HD / 4); i += 256) {
+    const int r = i / (HD / 4), c = i - r * (HD / 4);
+    const int qi = q0 + r;
+    if (qi >= p.S) continue;
+    float w[8], m = -1e30f;
+    for (int s = 0; s < p.parts; ++s) { w[s] = p.ws_lse[base + (int64_t)s * QB + r]; m = fmaxf(m, w[s]); }
+    float tot = 0.f;
+    for (int s = 0; s < p.parts; ++s) { w[s] = __builtin_amdgcn_exp2f(w[s] - m); tot += w[s]; }
+    const float inv = 1.0f / tot;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < p.parts; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(p.ws_o + (base + (int64_t)s * QB + r) * HD + c * 4);
+      acc.x += w[s] * v.x; acc.y += w[s] * v.y; acc.z += w[s] * v.z; acc.w += w[s] * v.w;
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias_v) bv = *reinterpret_cast<const float4*>(p.bias_v + c * 4);
+    uint2 u;
+    u.x = pack_bf16x2(acc.x * inv + bv.x, acc.y * inv + bv.y);
+    u.y = pack_bf16x2(acc.z * inv + bv.z, acc.w * inv + bv.w);
+    *reinterpret_cast<uint2*>(p.out + b * p.obs + (int64_t)qi * p.ors + c * 4) = u;
+  }
+}
+
 }  // namespace
 
-extern "C" int osk_attention_hd512_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride, const void* k,
-                                            int64_t k_batch_stride, int64_t k_row_stride, const void* vt,
-                                            int64_t vt_batch_stride, int64_t vt_row_stride, const float* bias_v, void* out,
-                                            int64_t out_batch_stride, int64_t out_row_stride, int B, int S,
-                                            int keys_per_frame, float scale, void* stream) {
+extern "C" int osk_attention_hd512_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride, const void* k,
+                                               int64_t k_batch_stride, int64_t k_row_stride, const void* vt,
+                                               int64_t vt_batch_stride, int64_t vt_row_stride, const float* bias_v, void* out,
+                                               int64_t out_batch_stride, int64_t out_row_stride, int B, int S,
+                                               int keys_per_frame, float scale, void* workspace, int64_t workspace_bytes,
+                                               void* stream) {
   if (!q || !k || !vt || !out || B <= 0 || S <= 0 || keys_per_frame < 0) return OSK_EINVAL;
   if ((q_row_stride & 7) || (k_row_stride & 7) || (vt_row_stride & 7) || (out_row_stride & 3) || (q_batch_stride & 7) ||
       (k_batch_stride & 7) || (vt_batch_stride & 7) || (out_batch_stride & 3))
@@ -213,6 +271,7 @@ extern "C" int osk_attention_hd512_fwd_bf16(const void* q, int64_t q_batch_strid
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)vt & 15) || ((uintptr_t)out & 7) || ((uintptr_t)bias_v & 15))
     return OSK_EINVAL;
   if (vt_row_stride < (int64_t)((S + KT - 1) / KT) * KT) return OSK_EINVAL;   // whole 32-key tiles are fetched
+  if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 0)) return OSK_EINVAL;
   OSK_ENSURE_MAX_SMEM(attn_hd512_kernel, SMEM);
   P512 p;
   p.q = (const unsigned short*)q; p.qbs = q_batch_stride; p.qrs = q_row_stride;
@@ -222,7 +281,36 @@ extern "C" int osk_attention_hd512_fwd_bf16(const void* q, int64_t q_batch_strid
   p.out = (unsigned short*)out; p.obs = out_batch_stride; p.ors = out_row_stride;
   p.S = S; p.kpf = keys_per_frame;
   p.scale_log2 = scale * 1.4426950408889634f;
-  dim3 grid((S + QB - 1) / QB, B, NPASS), block(256);
-  hipLaunchKernelGGL(attn_hd512_kernel, grid, block, SMEM, (hipStream_t)stream, p);
+  const int nqb = (S + QB - 1) / QB;
+  // The launch is nqb x B x 2 workgroups and its time is the key-tile chain of the longest one (at 33 x 256 x 256: 144 workgroups
+  // on 256 CUs, 288 tiles).  With a workspace the chains are cut into up to 4 parts of >= 64 tiles that run side by side.
+  const int longest = (S + KT - 1) / KT;
+  int parts = longest / 64;
+  parts = parts < 1 ? 1 : (parts > 4 ? 4 : parts);
+  while (parts > 1 && (!workspace || (int64_t)B * nqb * parts * QB * (HD + 1) * 4 > workspace_bytes)) --parts;
+  p.parts = parts;
+  if (parts > 1) {
+    p.ws_o = (float*)workspace;
+    p.ws_lse = p.ws_o + (int64_t)B * nqb * parts * QB * HD;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nqb, B, NPASS * parts), block(256);
+  hipLaunchKernelGGL(attn_hd512_kernel, grid, block, SMEM, st, p);
+  if (parts > 1) hipLaunchKernelGGL(attn_hd512_merge_kernel, dim3(nqb, B, MSPLIT), dim3(256), 0, st, p);
   return (int)hipGetLastError();
+}
+
+extern "C" int64_t osk_attention_hd512_workspace_bytes(int B, int S) {
+  if (B <= 0 || S <= 0) return 0;
+  return (int64_t)B * ((S + QB - 1) / QB) * 4 * QB * (HD + 1) * 4;
+}
+
+extern "C" int osk_attention_hd512_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride, const void* k,
+                                            int64_t k_batch_stride, int64_t k_row_stride, const void* vt,
+                                            int64_t vt_batch_stride, int64_t vt_row_stride, const float* bias_v, void* out,
+                                            int64_t out_batch_stride, int64_t out_row_stride, int B, int S,
+                                            int keys_per_frame, float scale, void* stream) {
+  return osk_attention_hd512_fwd_ws_bf16(q, q_batch_stride, q_row_stride, k, k_batch_stride, k_row_stride, vt, vt_batch_stride,
+                                         vt_row_stride, bias_v, out, out_batch_stride, out_row_stride, B, S, keys_per_frame, scale,
+                                         nullptr, 0, stream);
 }

@@ -366,7 +366,7 @@ def _mid_attention(att: Attention, x: Tensor) -> Tensor:
         o.gemm(hn, wk, bk, k)
         for b in range(B):
             o.gemm(wv.view(1, C, C), hn[b], None, vt[b: b + 1, :, :S])     # V^T [C, S] = Wv hn^T
-        o.attention_hd512(q, k, vt, bv, att_o, n_hw, C ** -0.5)
+        o.attention_hd512(q, k, vt, bv, att_o, n_hw, C ** -0.5, workspace=o.attention_hd512_workspace(B, S, x.device))
         o.gemm(att_o, wo, bo, out, res=tok, gate=ones, gate_batch_stride=0)
         return out.view(B, T, H, W, C)
     S4 = (S + 3) // 4 * 4

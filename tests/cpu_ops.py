@@ -383,7 +383,11 @@ def blend(a, b, extent, dim):
     return b
 
 
-def attention_hd512(q, k, vt, bias_v, out, keys_per_frame, scale):
+def attention_hd512_workspace(B, S, device):
+    return None
+
+
+def attention_hd512(q, k, vt, bias_v, out, keys_per_frame, scale, workspace=None):
     """osk_attention_hd512_fwd_bf16: f32 frame-causal softmax(q k^T scale) v (+ bias), P rounded to bf16 before P.V"""
     B, S, C = q.shape
     f = torch.arange(S) // (keys_per_frame if keys_per_frame > 0 else S)

@@ -401,7 +401,8 @@ def test_blend_kernel_vs_reference_formula(hip_lib, dim, shape_a, shape_b, exten
     assert torch.equal(b[tuple(rest)], b0[tuple(rest)])
 
 
-@pytest.mark.parametrize("B,T,hw,masked", [(1, 3, 64, True), (2, 5, 37, True), (1, 1, 300, True), (1, 4, 96, False), (1, 9, 256, True)])
+@pytest.mark.parametrize("B,T,hw,masked", [(1, 3, 64, True), (2, 5, 37, True), (1, 1, 300, True), (1, 4, 96, False), (1, 9, 256, True),
+                                           (1, 9, 1024, True), (2, 5, 1000, True), (1, 3, 2100, False)])
 def test_attention_hd512_vs_f64(hip_lib, B, T, hw, masked):
     """osk_attention_hd512_fwd_bf16 (one head of dim 512, frame-causal) against an f64 softmax(q k^T / sqrt(512) + mask) v + b
     with the reference's mask rule (unet_causal_3d_blocks.py:52-60: key frame <= query frame); ragged S (not a multiple of
@@ -430,3 +431,16 @@ def test_attention_hd512_vs_f64(hip_lib, B, T, hw, masked):
     out2 = torch.empty_like(out)
     hip_lib.attention_hd512(q, k, vt, bias, out2, hw if masked else 0, scale)
     assert torch.equal(out, out2)
+    # key-split launch (round 4; it engages from S >= 4096: the last three cases -- frames of 1024 tokens = BASELINE config 3's mid
+    # block, frames of 1000 tokens so that 128-row query blocks span two frames and a key part can be masked out entirely for some of
+    # their rows, and the unmasked mode): same result up to the f32 combination of the parts, repeatable
+    ws = hip_lib.attention_hd512_workspace(B, S, DEV)
+    out3 = torch.full_like(out, float("nan"))
+    hip_lib.attention_hd512(q, k, vt, bias, out3, hw if masked else 0, scale, workspace=ws)
+    err3 = (out3.double() - ref).abs()
+    assert torch.isfinite(out3.float()).all() and (err3 <= tol).all(), (err3.max().item(), (err3 / tol).max().item())
+    if S < 4096:
+        assert torch.equal(out3, out)            # short chains are not split
+    out4 = torch.empty_like(out)
+    hip_lib.attention_hd512(q, k, vt, bias, out4, hw if masked else 0, scale, workspace=ws)
+    assert torch.equal(out3, out4)
