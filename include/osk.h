@@ -327,6 +327,24 @@ int osk_groupnorm_stats_ndhwc_bf16(const void* x, int B, int64_t S, int C, int G
 int osk_groupnorm_apply_ndhwc_bf16(const void* x, const double* sums, const float* gamma, const float* beta,
                                    void* out, int B, int64_t S, int C, int G, float eps, int silu, void* stream);
 
+/* ---- GroupNorm + SiLU folded into the CONSUMING convolution (round 4): the norm1 -> SiLU -> conv1 and norm2 -> SiLU -> conv2
+ * chains of ResnetBlockCausal3D.forward (unet_causal_3d_blocks.py:247-256) without the normalised tensor ever existing in HBM.
+ * osk_groupnorm_table_f32: sums (osk_groupnorm_stats_ndhwc_bf16 / a producing conv's gn_sums) + gamma, beta ->
+ *   table f32 [B][C / 8][16]: per 8-channel chunk 8 scales a_c = rstd_g gamma_c, then 8 shifts d_c = beta_c - mean_g a_c
+ *   (exactly the per-channel constants osk_groupnorm_apply_ndhwc_bf16 derives; 16-byte aligned).
+ * osk_causal_conv3d_gnin_ndhwc_bf16: osk_causal_conv3d_ndhwc_bf16 (no upsample) of
+ *   bf16(silu(bf16(x * a + d))) -- the same rounding points as apply(silu = 1) followed by the conv -- reading x itself: the
+ *   sliding-window kernels fetch their halo pieces into registers, transform them in the MFMA shadows and write them to LDS.
+ *   gn_sums != NULL: + the fused statistics of the OUTPUT as osk_causal_conv3d_gn_ndhwc_bf16 (gn_groups groups; zeroed by the caller).
+ *   Shapes: 3 x 3 x 3, stride 1, Cin % 128 == 0, whole 16 x 16 output bricks, Cout >= 256 or (Cout == 128 and T >= 2); anything
+ *   else returns OSK_EUNSUPPORTED and launches NOTHING -- the caller then runs apply + the plain conv. */
+int osk_groupnorm_table_f32(const double* sums, const float* gamma, const float* beta, float* table, int B, int64_t S,
+                            int C, int G, float eps, void* stream);
+int osk_causal_conv3d_gnin_ndhwc_bf16(const void* x, const float* gn_in_table, int B, int T, int H, int W, int Cin,
+                                      const void* w, int64_t w_row_stride, const float* bias, int Cout, int ksize,
+                                      int stride_t, int stride_h, int stride_w, const void* res, void* out, int To, int Ho,
+                                      int Wo, double* gn_sums, int gn_groups, void* stream);
+
 /* ---- frame-causal masked softmax over attention score rows (mid-block attention, one head of dim C):
  *   probs[i][j] = softmax_j(scale * scores[i][j])  over keys j < (i / keys_per_frame + 1) * keys_per_frame,
  *   0 elsewhere (columns up to ld_probs are written, so probs is a K-padded GEMM operand).

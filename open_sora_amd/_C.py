@@ -56,6 +56,9 @@ SIGNATURES = {
                                      _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
     "osk_causal_conv3d_gn_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                         _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    "osk_causal_conv3d_gnin_ndhwc_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32,
+                                          _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    "osk_groupnorm_table_f32": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp],
     "osk_groupnorm_stats_ndhwc_bf16": [_vp, _i32, _i64, _i32, _i32, _vp, _vp],
     "osk_groupnorm_apply_ndhwc_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _vp],
     "osk_masked_softmax_f32_bf16": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
@@ -552,6 +555,57 @@ def causal_conv3d(x: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, ksi
         ev1.record()
         prof.append((ev0, ev1, 2.0 * Cin * Cout * ksize ** 3 * B * To * Ho * Wo))
     return out if gn_sums is None else (out, fused)
+
+
+def causal_conv3d_gn_in(x: torch.Tensor, table: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, ksize: int,
+                        stride=(1, 1, 1), res=None, gn_sums: torch.Tensor | None = None):
+    """conv(silu(GroupNorm(x))) reading x itself: `table` (groupnorm_table) carries the norm's per-(batch, channel) scale / shift and
+    the sliding-window kernels apply it -- with the rounding points of groupnorm_apply(silu=True) -- while they refill their halo.
+    -> (ran, fused): ran False = the shape is not one those kernels take and NOTHING was launched (the caller runs
+    groupnorm_apply + causal_conv3d); fused = gn_sums was accumulated in the epilogue as in causal_conv3d."""
+    B, T, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    To, Ho, Wo = conv_out_dims(T, H, W, stride)
+    assert x.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (B, To, Ho, Wo, Cout), (out.shape, (B, To, Ho, Wo, Cout))
+    assert res is None or (res.is_contiguous() and res.shape == out.shape)
+    assert table.dtype == torch.float32 and table.is_contiguous() and tuple(table.shape) == (B, Cin // 8, 16), table.shape
+    prof = PROFILE_CONV
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+
+    def call(sums):
+        return lib.osk_causal_conv3d_gnin_ndhwc_bf16(x.data_ptr(), table.data_ptr(), B, T, H, W, Cin, w.data_ptr(), w.stride(0),
+                                                     _p(bias), Cout, ksize, stride[0], stride[1], stride[2], _p(res),
+                                                     out.data_ptr(), To, Ho, Wo, _p(sums), 0 if sums is None else sums.shape[1],
+                                                     _stream())
+
+    fused = False
+    rc = OSK_EUNSUPPORTED
+    if gn_sums is not None:
+        assert gn_sums.dtype == torch.float64 and gn_sums.is_contiguous() and gn_sums.shape[0] == B and gn_sums.shape[2] == 2
+        rc = call(gn_sums)
+        fused = rc == 0
+    if rc == OSK_EUNSUPPORTED:
+        rc = call(None)
+    if rc == OSK_EUNSUPPORTED:
+        return False, False
+    _check(rc, "osk_causal_conv3d_gnin_ndhwc_bf16")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * Cin * Cout * ksize ** 3 * B * To * Ho * Wo))
+    return True, fused
+
+
+def groupnorm_table(sums: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, table: torch.Tensor, S: int, G: int,
+                    eps: float = 1e-6) -> torch.Tensor:
+    """sums f64 [B, G, 2] over S voxels -> table f32 [B, C / 8, 16]: per 8-channel chunk 8 scales rstd gamma, 8 shifts beta - mean
+    rstd gamma (the constants groupnorm_apply derives), for causal_conv3d_gn_in."""
+    B, C = sums.shape[0], gamma.numel()
+    assert table.dtype == torch.float32 and table.is_contiguous() and tuple(table.shape) == (B, C // 8, 16), table.shape
+    _check(lib.osk_groupnorm_table_f32(sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), table.data_ptr(), B, S, C, G, eps,
+                                       _stream()), "osk_groupnorm_table_f32")
+    return table
 
 
 def groupnorm_stats(x: torch.Tensor, G: int, sums: torch.Tensor) -> torch.Tensor:

@@ -326,7 +326,8 @@ bool fewout_supported(const ConvParams& p) {
 
 static int conv_entry(const void* x, int B, int T, int H, int W, int Cin, const void* w, int64_t w_row_stride,
                       const float* bias, int Cout, int ksize, int stride_t, int stride_h, int stride_w, int up_t, int up_hw,
-                      const void* res, void* out, int To, int Ho, int Wo, double* gn_sums, int gn_groups, void* stream) {
+                      const void* res, void* out, int To, int Ho, int Wo, double* gn_sums, int gn_groups, void* stream,
+                      const float* gn_in = nullptr) {
   if (!x || !w || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return OSK_EINVAL;
   if (ksize != 1 && ksize != 3) return OSK_EUNSUPPORTED;
   if (stride_t < 1 || stride_h < 1 || stride_w < 1 || stride_t > 2 || stride_h > 2 || stride_w > 2) return OSK_EINVAL;
@@ -369,6 +370,10 @@ static int conv_entry(const void* x, int B, int T, int H, int W, int Cin, const 
       // (the statistics ride in the 16-byte-store path of the epilogue: the output must be 16-byte aligned)
       if (!big || !osk_conv::conv256_gn_supported(p) || ((uintptr_t)out & 15)) return OSK_EUNSUPPORTED;
     }
+    if (gn_in) {     // input GroupNorm + SiLU folded into the halo refill: sliding-window kernels only; nothing is launched otherwise
+      p.gn_in = gn_in;
+      if (!big || !osk_conv::conv256_gn_in_supported(p)) return OSK_EUNSUPPORTED;
+    }
     if (big) return osk_conv::launch_conv256(p, s);
   }
   if (fewout_supported(p)) {
@@ -403,4 +408,14 @@ extern "C" int osk_causal_conv3d_gn_ndhwc_bf16(const void* x, int B, int T, int 
   if (!gn_sums || gn_groups <= 0 || ((uintptr_t)gn_sums & 7)) return OSK_EINVAL;
   return conv_entry(x, B, T, H, W, Cin, w, w_row_stride, bias, Cout, ksize, stride_t, stride_h, stride_w, up_t, up_hw, res, out,
                     To, Ho, Wo, gn_sums, gn_groups, stream);
+}
+
+extern "C" int osk_causal_conv3d_gnin_ndhwc_bf16(const void* x, const float* gn_in_table, int B, int T, int H, int W, int Cin,
+                                                 const void* w, int64_t w_row_stride, const float* bias, int Cout, int ksize,
+                                                 int stride_t, int stride_h, int stride_w, const void* res, void* out, int To,
+                                                 int Ho, int Wo, double* gn_sums, int gn_groups, void* stream) {
+  if (!gn_in_table || ((uintptr_t)gn_in_table & 15)) return OSK_EINVAL;
+  if (gn_sums && (gn_groups <= 0 || ((uintptr_t)gn_sums & 7))) return OSK_EINVAL;
+  return conv_entry(x, B, T, H, W, Cin, w, w_row_stride, bias, Cout, ksize, stride_t, stride_h, stride_w, 0, 0, res, out, To, Ho, Wo,
+                    gn_sums, gn_sums ? gn_groups : 0, stream, gn_in_table);
 }

@@ -352,8 +352,12 @@ __global__ void __launch_bounds__(256, 1) conv256x_kernel(const ConvParams p) {
 // SOURCE patch per frame slot (output row o reads source row o >> 1), pairs of lanes share a source voxel.
 OSK_DEV int swu_key(int ww) { return ww >= 6 ? 2 : 0; }   // swizzle key of source halo column ww (tests/conv_sw_emulator.py::up_key)
 
-template <int NBJ, bool UP>
+// GN (NBJ == 8, plain geometry): p.gn_in != null -- the input is silu(GroupNorm(x)); the halo pieces travel through registers
+// (global_load_dwordx4, a lane always holds chunk lane % 4 of its voxel), are transformed in the MFMA shadows and written to the
+// swizzled LDS position with ds_write_b128 (generator: the GN form in tools/gen_conv_sw_asm.py's header)
+template <int NBJ, bool UP, bool GN = false>
 __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
+  static_assert(!GN || (NBJ == 8 && !UP), "the GN form exists for the 256-channel plain geometry");
   constexpr int WT = OSKX_NB * 16, WTN = NBJ * 16, BN = 32 * NBJ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -404,10 +408,11 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   // ---- halo pieces: piece k of this wave = halo voxels 16 q .. + 15 of a frame slot, q = min(4 k + wave, 20); voxel v = 18 hh + ww
   // reads input (hb 16 - 1 + hh, wb 16 - 1 + ww) clamped into the frame (replicate padding)
   // (UP: two pieces per wave, q = min(4 k + wave, 6), of the 10 x 10 source patch from (hb 8 - 1, wb 8 - 1))
-  unsigned hoff[6];
+  unsigned hoff[6], hdw[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     int hs, ws, key;
+    hdw[k] = 0;
     if constexpr (UP) {
       int q = 4 * (k & 1) + wave;
       q = q < 6 ? q : 6;
@@ -422,6 +427,10 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
       v = v < 323 ? v : 323;
       const int hh = v / 18, ww = v - hh * 18;
       hs = hb * 16 - 1 + hh; ws = wb * 16 - 1 + ww; key = (ww >> 1) & 3;
+      if constexpr (GN) {          // the swizzle moves from the global offset to the LDS write address
+        hdw[k] = lds_base + (unsigned)(v * 64 + ((pos ^ key) << 4));
+        key = 0;
+      }
     }
     hs = hs < 0 ? 0 : (hs > p.H - 1 ? p.H - 1 : hs);
     ws = ws < 0 ? 0 : (ws > p.W - 1 ? p.W - 1 : ws);
@@ -443,7 +452,19 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   ::"v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(yb), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(hoff[0]),       \
       "v"(hoff[1]), "v"(hoff[2]), "v"(hoff[3]), "v"(hoff[4]), "v"(hoff[5]), "s"(wbase), "s"(xb[0]), "s"(xb[1]), "s"(xb[2]),  \
       "s"(xb[3]), "s"(cin2), "s"(nbody), "s"(dst), "s"(dst), "s"(dst5)
-  if constexpr (NBJ == 8 && !UP) {
+  // GN form: + the LDS write address of each halo piece, this lane's 64 bytes inside a channel block's table rows, the table of batch b
+#define OSKSWG_OPERANDS                                                                                                      \
+  ::"v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(yb), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(hoff[0]),       \
+      "v"(hoff[1]), "v"(hoff[2]), "v"(hoff[3]), "v"(hoff[4]), "v"(hoff[5]), "v"(hdw[0]), "v"(hdw[1]), "v"(hdw[2]),           \
+      "v"(hdw[3]), "v"(hdw[4]), "v"(hdw[5]), "v"(goff), "s"(wbase), "s"(xb[0]), "s"(xb[1]), "s"(xb[2]), "s"(xb[3]),          \
+      "s"(cin2), "s"(nbody), "s"(dst), "s"(dst), "s"(dst5), "s"(gbase)
+  if constexpr (GN) {
+    const unsigned goff = (unsigned)pos * 64;
+    const uint64_t gbase = rfl64((uint64_t)(uintptr_t)(p.gn_in + (int64_t)b * p.Cin * 2));
+    asm volatile(
+#include "convswg_body_n256.inc"
+        OSKSWG_OPERANDS : OSKSWG256_CLOBBERS);
+  } else if constexpr (NBJ == 8 && !UP) {
     asm volatile(
 #include "convsw_body_n256.inc"
         OSKSW_OPERANDS : OSKSW256_CLOBBERS);
@@ -469,6 +490,7 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
 // accumulator tiles), four frame slots in LDS (frame f's taps read slots f .. f + 2).  Per 512 voxels ONE prologue / epilogue
 // ramp and one pass of the weights instead of two, 16 fragment reads per 64 MFMAs instead of 12 per 32: the 128-channel layers at
 // full resolution (a third of the VAE's conv FLOPs) lost 37 % of their time to per-tile fixed costs in the one-frame form.
+template <bool GN>
 __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
   constexpr int NBJ = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -502,7 +524,7 @@ __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
     const int n = nl < p.Cout ? nl : p.Cout - 1;
     woff[k] = (unsigned)(((int64_t)n * p.wrs + (pos ^ ((nl >> 1) & 3)) * 8) * 2);
   }
-  unsigned hoff[6];
+  unsigned hoff[6], hdw[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     int q = 4 * k + wave;
@@ -513,7 +535,9 @@ __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
     int hs = hb * 16 - 1 + hh, ws = wb * 16 - 1 + ww;
     hs = hs < 0 ? 0 : (hs > p.H - 1 ? p.H - 1 : hs);
     ws = ws < 0 ? 0 : (ws > p.W - 1 ? p.W - 1 : ws);
-    hoff[k] = (unsigned)((((int64_t)hs * p.W + ws) * p.Cin + (pos ^ ((ww >> 1) & 3)) * 8) * 2);
+    const int key = (ww >> 1) & 3;
+    hdw[k] = lds_base + (unsigned)(v * 64 + ((pos ^ key) << 4));           // (GN form only)
+    hoff[k] = (unsigned)((((int64_t)hs * p.W + ws) * p.Cin + (GN ? pos : pos ^ key) * 8) * 2);
   }
   uint64_t xb[4];                                                  // slot d = input frame clamp(2 tp + d - 2) (the last one exists
 #pragma unroll                                                     // only if the pair's second frame does: clamped to T - 1 otherwise)
@@ -523,9 +547,17 @@ __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
     xb[d] = rfl64((uint64_t)(uintptr_t)(p.x + ((int64_t)b * p.T + fs) * p.H * p.W * p.Cin));
   }
   const uint64_t wbase = rfl64((uint64_t)(uintptr_t)p.w);
-  asm volatile(
+  if constexpr (GN) {
+    const unsigned goff = (unsigned)pos * 64;
+    const uint64_t gbase = rfl64((uint64_t)(uintptr_t)(p.gn_in + (int64_t)b * p.Cin * 2));
+    asm volatile(
+#include "convswgf_body_n128.inc"
+        OSKSWG_OPERANDS : OSKSWGF128_CLOBBERS);
+  } else {
+    asm volatile(
 #include "convswf_body_n128.inc"
-      OSKSW_OPERANDS : OSKSW256_CLOBBERS);
+        OSKSW_OPERANDS : OSKSW256_CLOBBERS);
+  }
   epilogue_all_x<NBJ>(p, bm, wave * 128, 0, 0, l15, q4, smem);
   }   // tile loop
 }
@@ -547,24 +579,25 @@ int launch_x(const ConvParams& p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-template <int NBJ, bool UP>
+template <int NBJ, bool UP, bool GN = false>
 int launch_sw(const ConvParams& p0, hipStream_t st) {
   constexpr int BN = 32 * NBJ;
   constexpr int SMEM = UP ? (NBJ == 8 ? OSKSWU256_SMEM : OSKSWU128_SMEM) : (NBJ == 8 ? OSKSW256_SMEM : OSKSW128_SMEM);
   ConvParams p = p0;
   p.brick = 1;
-  OSK_ENSURE_MAX_SMEM((convsw_kernel<NBJ, UP>), SMEM);
+  OSK_ENSURE_MAX_SMEM((convsw_kernel<NBJ, UP, GN>), SMEM);
   const int nblk = (p.M / 256) * ((p.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL((convsw_kernel<NBJ, UP>), dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
+  hipLaunchKernelGGL((convsw_kernel<NBJ, UP, GN>), dim3(persistent_grid(nblk)), dim3(256), SMEM, st, p);
   return (int)hipGetLastError();
 }
 
+template <bool GN>
 int launch_sw2(const ConvParams& p0, hipStream_t st) {
   ConvParams p = p0;
   p.brick = 2;
-  OSK_ENSURE_MAX_SMEM(convsw2_kernel, OSKSWF128_SMEM);
+  OSK_ENSURE_MAX_SMEM(convsw2_kernel<GN>, OSKSWF128_SMEM);
   const int nblk = p.B * ((p.To + 1) / 2) * (p.Ho / 16) * (p.Wo / 16);
-  hipLaunchKernelGGL(convsw2_kernel, dim3(persistent_grid(nblk)), dim3(256), OSKSWF128_SMEM, st, p);
+  hipLaunchKernelGGL(convsw2_kernel<GN>, dim3(persistent_grid(nblk)), dim3(256), OSKSWF128_SMEM, st, p);
   return (int)hipGetLastError();
 }
 
@@ -577,6 +610,15 @@ bool convsw_supported(const ConvParams& p) {
 }
 
 }  // namespace
+
+// input GroupNorm + SiLU folded in: the sliding-window kernels in plain geometry, 256-channel tiles or the two-frame form
+bool conv256_gn_in_supported(const ConvParams& p) {
+#ifdef OSK_CONV_NO_SW
+  return false;
+#else
+  return convsw_supported(p) && !p.up_hw && (p.Cout >= 256 || (p.Cout == 128 && p.To >= 2));
+#endif
+}
 
 // 32-bit per-lane byte offsets: both tensors must span < 4 GiB; whole K steps per tap in pairs: Cin % 128 == 0
 bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes) {
@@ -598,10 +640,14 @@ bool conv256_gn_supported(const ConvParams& p) {
 int launch_conv256(const ConvParams& p0, hipStream_t st) {
   ConvParams p = p0;
 #ifndef OSK_CONV_NO_SW   // (A/B builds of tools/: -DOSK_CONV_NO_SW keeps every layer on the implicit-GEMM kernel)
+  if (p.gn_in) {
+    if (!conv256_gn_in_supported(p)) return OSK_EUNSUPPORTED;
+    return p.Cout >= 256 ? launch_sw<8, false, true>(p, st) : launch_sw2<true>(p, st);
+  }
   if (convsw_supported(p)) {
     if (p.up_hw) return p.Cout >= 256 ? launch_sw<8, true>(p, st) : launch_sw<4, true>(p, st);
 #ifndef OSK_CONV_NO_SW2
-    if (p.Cout == 128 && p.To >= 2) return launch_sw2(p, st);
+    if (p.Cout == 128 && p.To >= 2) return launch_sw2<false>(p, st);
 #endif
     return p.Cout >= 256 ? launch_sw<8, false>(p, st) : launch_sw<4, false>(p, st);
   }

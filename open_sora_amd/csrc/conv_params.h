@@ -23,12 +23,17 @@ struct ConvParams {
   // outputs of group g (gn_G groups of Cout / gn_G adjacent channels); null = off
   double* gn_sums = nullptr;
   int gn_G = 0;
+  // GroupNorm + SiLU of the INPUT folded into the halo refill (conv3d_256.hip, sliding-window kernels, plain geometry): the conv
+  // sees bf16(silu(bf16(x a + d))); table f32 [B][Cin / 8][16] = 8 scales a then 8 shifts d per 8-channel chunk
+  // (osk_groupnorm_table_f32); null = the input as stored
+  const float* gn_in = nullptr;
 };
 
 
 // conv3d_256.hip: 256 voxels x {256,128} channels x 64 tile, 4 waves, all 27 taps in one hand-scheduled asm K loop
 bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes);
 bool conv256_gn_supported(const ConvParams& p);   // the fused-statistics epilogue takes this output geometry
+bool conv256_gn_in_supported(const ConvParams& p);   // a kernel with the input GroupNorm + SiLU folded in takes this shape
 int launch_conv256(const ConvParams& p, hipStream_t st);
 
 }  // namespace osk_conv

@@ -223,6 +223,37 @@ extern "C" int osk_groupnorm_apply_ndhwc_bf16(const void* x, const double* sums,
   return (int)hipGetLastError();
 }
 
+// (scale, shift) rows for the conv kernels that fold GroupNorm + SiLU into their input path (conv3d_256.hip, GN form): the same
+// a = rstd gamma, d = beta - mean a as gn_apply_kernel's prologue, laid out [B][C / 8][8 a | 8 d]
+namespace {
+__global__ void __launch_bounds__(256) gn_table_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ table, int64_t S,
+                                                      int C, int G, float eps) {
+  const int b = blockIdx.x;
+  const int cpg = C / G;
+  const double cnt = (double)S * cpg;
+  for (int ch = threadIdx.x; ch < C; ch += 256) {
+    const double* sg = sums + ((int64_t)b * G + ch / cpg) * 2;
+    const double mean = sg[0] / cnt;
+    double var = sg[1] / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = rsqrtf((float)var + eps);
+    const float a = rstd * gamma[ch];
+    float* row = table + ((int64_t)b * (C >> 3) + (ch >> 3)) * 16 + (ch & 7);
+    row[0] = a;
+    row[8] = beta[ch] - (float)mean * a;
+  }
+}
+}  // namespace
+
+extern "C" int osk_groupnorm_table_f32(const double* sums, const float* gamma, const float* beta, float* table, int B,
+                                       int64_t S, int C, int G, float eps, void* stream) {
+  if (!sums || !gamma || !beta || !table || B <= 0 || S <= 0 || C <= 0 || G <= 0 || C % G || (C & 7)) return OSK_EINVAL;
+  if (((uintptr_t)table & 15) || ((uintptr_t)sums & 7)) return OSK_EINVAL;
+  hipLaunchKernelGGL(gn_table_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, table, S, C, G, eps);
+  return (int)hipGetLastError();
+}
+
 extern "C" int osk_masked_softmax_f32_bf16(const float* scores, int64_t ld_scores, void* probs, int64_t ld_probs,
                                            int Sq, int Sk, int keys_per_frame, float scale, void* stream) {
   if (!scores || !probs || Sq <= 0 || Sk <= 0 || ld_scores < Sk || ld_probs < Sk || keys_per_frame < 0) return OSK_EINVAL;

@@ -331,12 +331,39 @@ def _gn(mod: nn.GroupNorm, x: Tensor, silu: bool) -> Tensor:
     return _ops().groupnorm_apply(x, sums, gamma, beta, torch.empty_like(x), G, eps, silu)
 
 
+def _gn_silu_conv(norm: nn.GroupNorm, conv, x: Tensor, res: Tensor | None = None, gn: int = 0) -> Tensor:
+    """conv(silu(norm(x))) (unet_causal_3d_blocks.py:247-256).  Where the sliding-window kernels take the conv
+    (osk_causal_conv3d_gnin_ndhwc_bf16: 3 x 3 x 3, whole 16 x 16 bricks, Cout >= 256 or the two-frame form) the normalised tensor
+    never exists: the norm becomes a [B, C / 8, 16] table of per-channel scale / shift pairs and the conv applies it -- same
+    rounding points -- while it refills its halo from x.  Otherwise: the apply pass, then the conv."""
+    gamma, beta, G, eps = _plan(norm, "gn")
+    p = _plan(conv, "conv")
+    B, T, H, W, C = x.shape
+    have = getattr(x, "_osk_gn", None)
+    if have is not None and have[0] == G:
+        sums = have[1]
+    else:
+        sums = torch.empty(B, G, 2, dtype=torch.float64, device=x.device)
+        _ops().groupnorm_stats(x, G, sums)
+    if p.k == 3 and tuple(p.stride) == (1, 1, 1) and C == p.cin_p and C % 128 == 0:
+        table = torch.empty(B, C // 8, 16, dtype=torch.float32, device=x.device)
+        _ops().groupnorm_table(sums, gamma, beta, table, T * H * W, G, eps)
+        out = torch.empty(B, T, H, W, p.cout, dtype=BF16, device=x.device)
+        out_sums = _gn_pool().take(B, gn, x.device) if gn and p.cout % gn == 0 else None
+        ran, fused = _ops().causal_conv3d_gn_in(x, table, p.w, p.b, out, p.k, p.stride, res, gn_sums=out_sums)
+        if ran:
+            if fused:
+                out._osk_gn = (gn, out_sums)
+            return out
+    h = _ops().groupnorm_apply(x, sums, gamma, beta, torch.empty_like(x), G, eps, True)
+    return _conv(conv, h, res=res, gn=gn)
+
+
 def _resnet(blk: ResnetBlockCausal3D, x: Tensor) -> Tensor:
     """ResnetBlockCausal3D.forward (unet_causal_3d_blocks.py:247-259); the residual add rides in conv2's epilogue."""
-    h = _conv(blk.conv1, _gn(blk.norm1, x, True), gn=blk.norm2.num_groups)
-    h = _gn(blk.norm2, h, True)
+    h = _gn_silu_conv(blk.norm1, blk.conv1, x, gn=blk.norm2.num_groups)
     sc = x if blk.conv_shortcut is None else _conv(blk.conv_shortcut, x)
-    return _conv(blk.conv2, h, res=sc, gn=blk.norm1.num_groups)   # the next consumer is a GroupNorm of the same grouping
+    return _gn_silu_conv(blk.norm2, blk.conv2, h, res=sc, gn=blk.norm1.num_groups)   # the next consumer is a GroupNorm of the same grouping
 
 
 def _mid_attention(att: Attention, x: Tensor) -> Tensor:

@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_conv_sw_asm as G  # noqa: E402
 
 WBASE = 1 << 41
+GBASE = 1 << 42                       # GN form: the (scale, shift) table
 XBASE = [(1 << 40) + d * (1 << 36) for d in range(4)]
 M32, M64 = (1 << 32) - 1, (1 << 64) - 1
 
@@ -29,19 +30,20 @@ M32, M64 = (1 << 32) - 1, (1 << 64) - 1
 class Scalars:
     """the SALU subset the generated stream uses, on concrete values"""
 
-    def __init__(self, operands):
+    def __init__(self, operands, names=None):
         self.s = {}
         self.scc = 0
         self.m0 = 0
         self.op = operands            # operand name -> int (64-bit for the pointer operands)
+        self.names = names or G.OPERANDS
 
     def val(self, tok):
         tok = tok.strip().rstrip(",")
         if tok.startswith("%"):
-            return self.op[G.OPERANDS[int(tok[1:])]]
+            return self.op[self.names[int(tok[1:])]]
         if tok.startswith("s"):
             return self.s[int(tok[1:])]
-        return int(tok) & M32
+        return int(tok, 0) & M32
 
     def run(self, text):
         m = re.match(r"(\S+)\s+(.*)", text)
@@ -106,14 +108,17 @@ def run_stream(ops, on_op, scal):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-def check_schedule(nbj, cin, wave=0, up=False, f2=False):
-    c = G.Cfg(nbj, up, f2)
+def check_schedule(nbj, cin, wave=0, up=False, f2=False, gn=False):
+    c = G.Cfg(nbj, up, f2, gn)
     ops = G.generate(c)
     ncb = cin // 32
     scal = Scalars(dict(wbase=WBASE, xb0=XBASE[0], xb1=XBASE[1], xb2=XBASE[2], xb3=XBASE[3], cin2=2 * cin, nbody=cin // 64,
-                        wdst=wave * 1024, hdst=wave * 1024, hdst5=min(4 + wave, 6) * 1024 if up else 20 * 1024))
+                        wdst=wave * 1024, hdst=wave * 1024, hdst5=min(4 + wave, 6) * 1024 if up else 20 * 1024, gbase=GBASE),
+                   c.OPERANDS)
     st = dict(epoch=0, m0_fresh=False)
-    reads, lg = [], []                 # every ds_read record; indices still in flight (in order)
+    reads, lg = [], []                 # every ds_read record; LDS operations still in flight, in order: ("r", read index) / ("w", fill index)
+    quads = {}                         # GN form: ring position -> the halo piece it holds (load record index, transformed dwords)
+    tab = []                           # GN form: the table loads, in order (fill record indices)
     dmas, vmq = [], []
     content = {("H", d): None for d in range(c.NSLOT)}
     content.update({("W", k): None for k in range(c.NS)})
@@ -129,7 +134,11 @@ def check_schedule(nbj, cin, wave=0, up=False, f2=False):
         elif o.kind == "W":
             if "lgkm" in o.meta:
                 while len(lg) > o.meta["lgkm"]:
-                    reads[lg.pop(0)]["retired"] = st["epoch"]
+                    kind, idx = lg.pop(0)
+                    if kind == "r":
+                        reads[idx]["retired"] = st["epoch"]
+                    else:
+                        dmas[idx]["landed"] = st["epoch"]
             if "vm" in o.meta:
                 while len(vmq) > o.meta["vm"]:
                     dmas[vmq.pop(0)]["landed"] = st["epoch"]
@@ -163,6 +172,50 @@ def check_schedule(nbj, cin, wave=0, up=False, f2=False):
             dmas.append(dict(region=region, sym=sym, issued=st["epoch"], landed=None, piece=o.meta.get("piece"), rel=rel // 1024))
             vmq.append(len(dmas) - 1)
             content[region] = None if region[0] == "H" else content[region]
+        elif o.kind == "G" and o.meta.get("table"):
+            off = scal.pair(G.S_G) - GBASE
+            assert off % 256 == 0 and 0 <= off // 256 < ncb, ("table pointer out of range", off)
+            if o.meta["tag"][1] == 0:
+                for q in quads.values():                        # the rows are not rewritten under a transform that still needs them
+                    assert q["fma"] in (0, 8), ("table load while a piece is half transformed", o.text)
+                tab.append([])
+            dmas.append(dict(region=None, sym=off // 256, landed=None))
+            tab[-1].append(len(dmas) - 1)
+            vmq.append(len(dmas) - 1)
+        elif o.kind == "G":
+            slot = o.meta["region"][1]
+            off = scal.pair(G.S_X[slot]) - XBASE[slot]
+            assert off % 64 == 0 and 0 <= off // 64 < ncb, ("halo pointer out of range", off)
+            assert o.meta["ring"] not in quads, ("register quad loaded while it holds an unwritten piece", o.text)
+            dmas.append(dict(region=None, sym=(off // 64, "frame"), landed=None))
+            quads[o.meta["ring"]] = dict(load=len(dmas) - 1, slot=slot, piece=o.meta["piece"], fma=0, done=set(), key=o.meta["tag"][1:])
+            vmq.append(len(dmas) - 1)
+        elif o.kind == "V":
+            q = quads[o.meta["quad"]]
+            assert q["key"] == o.meta["key"], ("transform of a quad that holds another piece", o.text, q)
+            if "src" in o.meta:
+                assert dmas[q["load"]]["landed"] is not None, ("transform reads a piece that has not been waited for", o.text)
+            if o.meta.get("tab"):
+                assert tab and len(tab[-1]) == 4 and all(dmas[i]["landed"] is not None for i in tab[-1]), ("scale / shift rows in flight", o.text)
+                assert dmas[tab[-1][0]]["sym"] == dmas[q["load"]]["sym"][0], ("rows of another channel block", o.text,
+                                                                             dmas[tab[-1][0]]["sym"], dmas[q["load"]]["sym"])
+                q["fma"] += 1
+            if "dstw" in o.meta:
+                q["done"].add(o.meta["dstw"])
+        elif o.kind == "Wd":
+            region = o.meta["region"]
+            q = quads.pop((o.meta["src"] - c.VST) // 4)
+            assert q["done"] == {0, 1, 2, 3} and q["fma"] == 8 and q["slot"] == region[1] and q["piece"] == o.meta["piece"], (o.text, q)
+            for r in reads:                                     # WAR, as for an LDS-DMA piece
+                if region in r["regions"] and region not in r["cleared"]:
+                    assert r.get("retired") is not None and r["retired"] < st["epoch"], ("LDS write into a region a wave may still read", o.text, r)
+                    r["cleared"].add(region)
+            if not hpieces[region[1]]:
+                dirty[region] = True
+            hpieces[region[1]].add(o.meta["piece"])
+            dmas.append(dict(region=region, sym=dmas[q["load"]]["sym"], issued=st["epoch"], landed=None, piece=o.meta["piece"]))
+            lg.append(("w", len(dmas) - 1))
+            content[region] = None
         elif o.kind == "R":
             # the regions some wave reads with this instruction: in the two-frame form the second frame's waves read slot dt + 1
             regions = [("H", d) for d in o.meta["slots"]] if o.meta["region"][0] == "H" else [o.meta["region"]]
@@ -208,7 +261,7 @@ def check_schedule(nbj, cin, wave=0, up=False, f2=False):
                 assert dst == c.VB + 4 * j
                 reg_sym[dst] = None if sym is None else ("B", sym[0], sym[1], j)
             reads.append(dict(regions=regions, dst=dst, issued=st["epoch"], retired=None, cleared=set()))
-            lg.append(len(reads) - 1)
+            lg.append(("r", len(reads) - 1))
             reg_read[dst] = len(reads) - 1
         elif o.kind == "M":
             for reg in (o.meta["a"], o.meta["b"]):
@@ -225,7 +278,7 @@ def check_schedule(nbj, cin, wave=0, up=False, f2=False):
     assert len(acc) == c.NBJ * G.NB
     for key, got in acc.items():
         assert got == want, (key, sorted(want - got)[:4], sorted(got - want)[:4])
-    assert not lg and not vmq, "the loop exits with LDS reads or LDS-DMA pieces in flight"
+    assert not lg and not vmq and not quads, "the loop exits with LDS reads, LDS-DMA pieces or halo pieces in flight"
     return dict(instructions=len(ops), reads=len(reads), pieces=len(dmas), barriers=st["epoch"])
 
 
@@ -244,7 +297,26 @@ def up_key(ww):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-def wrapper_operands_f2(wave, geom, tile):
+def _gn_operands(op, wave, brick, dims):
+    """GN form (plain halo geometry): a lane always fetches chunk lane % 4 of its voxel (hoff: no swizzle) and writes it to the swizzled
+    LDS position itself (hdw); goff = this lane's 64 bytes (8 scales, 8 shifts) inside a channel block's 256-byte table rows"""
+    hb, wb = brick
+    H, W, Cin = dims
+    lane = np.arange(64)
+    sub, pos = lane >> 2, lane & 3
+    for k in range(6):
+        q = min(4 * k + wave, 20)
+        v = np.minimum(16 * q + sub, 323)
+        hh, ww = v // 18, v % 18
+        hs = np.clip(hb * 16 - 1 + hh, 0, H - 1)
+        ws = np.clip(wb * 16 - 1 + ww, 0, W - 1)
+        op["hoff%d" % k] = ((hs * W + ws) * Cin + pos * 8) * 2
+        op["hdw%d" % k] = v * 64 + ((pos ^ ((ww >> 1) & 3)) << 4)
+    op["goff"] = pos * 64
+    op["gbase"] = GBASE
+
+
+def wrapper_operands_f2(wave, geom, tile, gn=False):
     """convsw2_kernel's operands: tile = (frame pair tp, brick row, brick column, 0); wave = (frame, brick half)"""
     T, H, W, Cin, Cout, wrs = geom
     tp, hb, wb, _ = tile
@@ -272,10 +344,12 @@ def wrapper_operands_f2(wave, geom, tile):
         fs = min(max(2 * tp + d - 2, 0), T - 1)
         op["xb%d" % d] = XBASE[0] + fs * H * W * Cin * 2
     op.update(wbase=WBASE, cin2=2 * Cin, nbody=Cin // 64, wdst=wave * 1024, hdst=wave * 1024, hdst5=20 * 1024)
+    if gn:
+        _gn_operands(op, wave, (hb, wb), (H, W, Cin))
     return op
 
 
-def wrapper_operands(nbj, wave, geom, tile, up=(False, False)):
+def wrapper_operands(nbj, wave, geom, tile, up=(False, False), gn=False):
     """per-lane / per-wave asm operands of convsw_kernel<NBJ, UP> for one tile -- the C++ formulas, re-stated.
     geom = SOURCE dims (T, H, W, Cin, Cout, wrs); up = (up_t, up_hw); tile = (output frame, brick row, brick column, n0)"""
     T, H, W, Cin, Cout, wrs = geom
@@ -320,6 +394,9 @@ def wrapper_operands(nbj, wave, geom, tile, up=(False, False)):
     op["xb3"] = op["xb2"]
     op.update(wbase=WBASE, cin2=2 * Cin, nbody=Cin // 64, wdst=wave * 1024, hdst=wave * 1024,
               hdst5=(min(4 + wave, 6) if up_hw else 20) * 1024)
+    if gn:
+        assert not up_hw
+        _gn_operands(op, wave, (hb, wb), (H, W, Cin))
     return op
 
 
@@ -330,35 +407,91 @@ def _bf16_pairs(u32):
     return np.stack([lo, hi], axis=-1).reshape(*u32.shape[:-1], -1)
 
 
-def emulate_tile(nbj, x_bits, w_bits, geom, tile, up=(False, False), f2=False):
+def bf16_rne(f):
+    """float32 array -> bf16 bits (round to nearest even; finite inputs), as v_cvt_pk_bf16_f32 / f32_to_bf16_bits"""
+    u = np.asarray(f, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint32)
+
+
+def gn_silu(x, scale, shift):
+    """the transform the GN form applies to a conv input (csrc/groupnorm.hip::gn_apply_kernel with silu): float32 in, float32
+    (bf16-exact) out; the SAME numpy operations the emulated instructions run, so the conv inputs of both sides are bit-equal"""
+    y = (x.astype(np.float64) * scale.astype(np.float64) + shift.astype(np.float64)).astype(np.float32)      # v_fma_f32
+    y = (bf16_rne(y) << 16).astype(np.uint32).view(np.float32)
+    e = np.exp2((y * np.float32(-1.4426950408889634)).astype(np.float32)).astype(np.float32)
+    r = (np.float32(1.0) / (np.float32(1.0) + e)).astype(np.float32)
+    return (bf16_rne((y * r).astype(np.float32)) << 16).astype(np.uint32).view(np.float32)
+
+
+def gn_table(scale, shift):
+    """[Cin] scales, shifts -> the table of one batch item: [Cin / 8][16] float32 = 8 scales then 8 shifts per 8-channel chunk"""
+    return np.concatenate([scale.reshape(-1, 8), shift.reshape(-1, 8)], axis=1).astype(np.float32)
+
+
+def emulate_tile(nbj, x_bits, w_bits, geom, tile, up=(False, False), f2=False, gn_tab=None):
     """x_bits [T, H, W, Cin] uint16, w_bits [Cout, wrs] uint16 -> out [256 tile rows, 32 nbj channels] float32 (no bias);
-    f2: the two-frame form, out [512 rows = (frame, brick row, brick column), 128 channels]"""
-    c = G.Cfg(nbj, up[1], f2)
+    f2: the two-frame form, out [512 rows = (frame, brick row, brick column), 128 channels];
+    gn_tab (gn_table()): the GN form -- the conv input is gn_silu(x)"""
+    gn = gn_tab is not None
+    c = G.Cfg(nbj, up[1], f2, gn)
     ops = G.generate(c)
     xb, wbts = x_bits.reshape(-1).view(np.uint8), w_bits.reshape(-1).view(np.uint8)
+    gbts = np.ascontiguousarray(gn_tab, np.float32).reshape(-1).view(np.uint8) if gn else None
     lds = np.zeros(c.SMEM, np.uint8)
     waves = []
     for wv in range(4):
-        opv = wrapper_operands_f2(wv, geom, tile) if f2 else wrapper_operands(nbj, wv, geom, tile, up)
-        waves.append(dict(op=opv, scal=Scalars({k: int(v) for k, v in opv.items() if np.ndim(v) == 0}),
+        opv = wrapper_operands_f2(wv, geom, tile, gn) if f2 else wrapper_operands(nbj, wv, geom, tile, up, gn)
+        waves.append(dict(op=opv, scal=Scalars({k: int(v) for k, v in opv.items() if np.ndim(v) == 0}, c.OPERANDS),
                           v=np.zeros((256, 64), np.uint32), a=np.zeros((256, 64), np.float32)))
     lane = np.arange(64)
 
     def vsrc(wd, tok):
         tok = tok.strip().rstrip(",")
         if tok.startswith("%"):
-            return np.asarray(wd["op"][G.OPERANDS[int(tok[1:])]], dtype=np.int64)
-        return wd["v"][int(tok[1:])].astype(np.int64)
+            return np.asarray(wd["op"][c.OPERANDS[int(tok[1:])]], dtype=np.int64)
+        if tok.startswith("s"):
+            return np.full(64, wd["scal"].s[int(tok[1:])], np.int64)
+        if tok.startswith("v"):
+            return wd["v"][int(tok[1:])].astype(np.int64)
+        return np.full(64, int(tok, 0) if not tok.endswith(".0") else int(np.float32(tok).view(np.uint32)), np.int64)
 
     def gather16(addr):
         out = np.zeros((64, 16), np.uint8)
         for ln in range(64):
             a = int(addr[ln])
-            if a >= WBASE:
+            if a >= GBASE:
+                out[ln] = gbts[a - GBASE: a - GBASE + 16]
+            elif a >= WBASE:
                 out[ln] = wbts[a - WBASE: a - WBASE + 16]
             else:
                 out[ln] = xb[a - XBASE[0]: a - XBASE[0] + 16]
         return out
+
+    f32 = lambda a: np.asarray(a, np.int64).astype(np.uint32).view(np.float32)
+    u32 = lambda f: np.asarray(f, np.float32).view(np.uint32)
+
+    def valu(wd, text):
+        m = re.match(r"(\S+)\s+v(\d+), (.*)", text)
+        opc, dst, src = m.group(1), int(m.group(2)), [vsrc(wd, t) for t in m.group(3).split(",")]
+        if opc == "v_lshlrev_b32_e32":
+            r = ((src[1] << src[0]) & M32).astype(np.uint32)
+        elif opc == "v_and_b32_e32":
+            r = (src[0] & src[1]).astype(np.uint32)
+        elif opc == "v_fma_f32":
+            r = u32((f32(src[0]).astype(np.float64) * f32(src[1]).astype(np.float64) + f32(src[2]).astype(np.float64)).astype(np.float32))
+        elif opc == "v_cvt_pk_bf16_f32":
+            r = (bf16_rne(f32(src[0])) | (bf16_rne(f32(src[1])) << 16)).astype(np.uint32)
+        elif opc == "v_mul_f32_e32":
+            r = u32((f32(src[0]) * f32(src[1])).astype(np.float32))
+        elif opc == "v_add_f32_e32":
+            r = u32((f32(src[0]) + f32(src[1])).astype(np.float32))
+        elif opc == "v_exp_f32_e32":
+            r = u32(np.exp2(f32(src[0])).astype(np.float32))
+        elif opc == "v_rcp_f32_e32":
+            r = u32((np.float32(1.0) / f32(src[0])).astype(np.float32))
+        else:
+            raise AssertionError("unmodelled vector instruction: " + text)
+        wd["v"][dst] = r
 
     labels = {o.meta["name"]: i for i, o in enumerate(ops) if o.kind == "L"}
     pc = 0
@@ -378,6 +511,24 @@ def emulate_tile(nbj, x_bits, w_bits, geom, tile, up=(False, False), f2=False):
                 data = gather16(addr)
                 m0 = wd["scal"].m0
                 lds[m0: m0 + 1024] = data.reshape(-1)
+        elif o.kind == "G":
+            m = re.match(r"global_load_dwordx4 v\[(\d+):\d+\], (\S+), s\[(\d+):\d+\](?: offset:(\d+))?", o.text)
+            for wd in waves:
+                addr = wd["scal"].pair(int(m.group(3))) + vsrc(wd, m.group(2)) + int(m.group(4) or 0)
+                words = gather16(addr).view(np.uint32)                                            # [64, 4]
+                wd["v"][int(m.group(1)): int(m.group(1)) + 4] = words.T
+        elif o.kind == "V":
+            for wd in waves:
+                valu(wd, o.text)
+        elif o.kind == "Wd":
+            m = re.match(r"ds_write_b128 (\S+), v\[(\d+):\d+\] offset:(\d+)", o.text)
+            src = int(m.group(2))
+            for wd in waves:
+                addr = vsrc(wd, m.group(1)) + int(m.group(3))
+                assert (addr % 16 == 0).all() and (addr + 16 <= c.HALO).all()
+                data = np.ascontiguousarray(wd["v"][src: src + 4].T)                              # [64, 4] uint32
+                for ln in range(64):
+                    lds[int(addr[ln]): int(addr[ln]) + 16] = data[ln].view(np.uint8)
         elif o.kind == "R":
             m = re.match(r"ds_read_b128 v\[(\d+):\d+\], (\S+) offset:(\d+)", o.text)
             dst, imm = int(m.group(1)), int(m.group(3))

@@ -330,6 +330,36 @@ def causal_conv3d(x, w, bias, out, ksize, stride=(1, 1, 1), up=(False, False), r
     return out
 
 
+def groupnorm_table(sums, gamma, beta, table, S, G, eps=1e-6):
+    B, C = sums.shape[0], gamma.numel()
+    n = S * (C // G)
+    mean = sums[:, :, 0] / n
+    var = (sums[:, :, 1] / n - mean * mean).clamp_min(0)
+    rstd = torch.rsqrt(var.float() + eps)
+    a = rstd.repeat_interleave(C // G, 1) * gamma.float()[None]
+    d = beta.float()[None] - mean.float().repeat_interleave(C // G, 1) * a
+    table.copy_(torch.cat((a.reshape(B, C // 8, 8), d.reshape(B, C // 8, 8)), 2))
+    return table
+
+
+def gn_in_supported(x_shape, Cout, ksize, stride):
+    """the shapes csrc/conv3d_256.hip::conv256_gn_in_supported takes"""
+    B, T, H, W, Cin = x_shape
+    return ksize == 3 and tuple(stride) == (1, 1, 1) and H % 16 == 0 and W % 16 == 0 and Cin % 128 == 0 and \
+        (Cout >= 256 or (Cout == 128 and T >= 2)) and B * T * H * W >= 256
+
+
+def causal_conv3d_gn_in(x, table, w, bias, out, ksize, stride=(1, 1, 1), res=None, gn_sums=None):
+    B, Cin = x.shape[0], x.shape[-1]
+    if not gn_in_supported(x.shape, w.shape[0], ksize, stride):
+        return False, False
+    a = table[:, :, :8].reshape([B] + [1] * (x.ndim - 2) + [Cin])
+    d = table[:, :, 8:].reshape([B] + [1] * (x.ndim - 2) + [Cin])
+    y = F.silu((x.float() * a + d).to(BF).float()).to(BF)
+    r = causal_conv3d(y, w, bias, out, ksize, stride, (False, False), res, gn_sums)
+    return True, gn_sums is not None and r[1]
+
+
 def groupnorm_stats(x, G, sums):
     B, C = x.shape[0], x.shape[-1]
     xf = x.double().reshape(B, -1, G, C // G)

@@ -160,6 +160,98 @@ def test_conv_fused_groupnorm_statistics(hip_lib, case):
     assert torch.allclose(var, var_x, rtol=1e-4, atol=1e-6)
 
 
+GN_IN_CASES = [
+    # Cin, Cout, B, T, H, W, residual, G of the OUTPUT statistics (0 = none)      kernel
+    (128, 128, 1, 4, 32, 32, False, 32),     # convsw2_kernel<GN>: two body iterations, fused output statistics
+    (256, 128, 1, 5, 32, 48, True, 0),       # convsw2_kernel<GN>: odd T (the last pair's second frame does not exist), residual
+    (128, 256, 2, 3, 32, 32, True, 32),      # convsw_kernel<8, false, GN>: batch 2 (one table per item), residual + statistics
+    (256, 512, 1, 2, 16, 32, False, 0),      # two 256-channel tiles per brick, a single brick row (both H borders in one halo)
+    (512, 512, 1, 3, 16, 16, False, 32),     # eight channel-block pairs: the table pointer walks 16 blocks
+    (128, 320, 1, 2, 32, 16, False, 0),      # ragged last channel tile (64 of 256)
+]
+
+
+@pytest.mark.parametrize("case", GN_IN_CASES, ids=lambda c: f"{c[0]}to{c[1]}B{c[2]}T{c[3]}")
+def test_conv_with_the_input_groupnorm_folded_in(hip_lib, case):
+    """osk_causal_conv3d_gnin_ndhwc_bf16 (norm -> SiLU -> conv of ResnetBlockCausal3D, unet_causal_3d_blocks.py:247-256, with the
+    normalised tensor never written): (1) against the two-launch path it replaces -- osk_groupnorm_apply_ndhwc_bf16 then the plain
+    conv -- the conv INPUTS are produced with the same instructions and rounding points, so the outputs may differ only through
+    the f32 accumulation order: <= 2^-7 of the output scale element-wise and relL2 <= 2e-3; (2) against the fp64 evaluation of
+    conv(silu(GroupNorm(x))) under the usual parity bound; (3) the fused OUTPUT statistics against a stats pass over the result."""
+    ci, co, B, T, H, W, use_res, G_out = case
+    g = torch.Generator(device=DEV).manual_seed(ci + co + T)
+    x = (torch.randn(B, T, H, W, ci, device=DEV, generator=g) * 1.7 + 0.4).to(BF)
+    w = (torch.randn(co, 27 * ci, device=DEV, generator=g) * (27 * ci) ** -0.5).to(BF)
+    b = torch.randn(co, device=DEV, generator=g) * 0.1
+    gamma = 1.0 + 0.3 * torch.randn(ci, device=DEV, generator=g)
+    beta = 0.2 * torch.randn(ci, device=DEV, generator=g)
+    res = torch.randn(B, T, H, W, co, device=DEV, generator=g).to(BF) if use_res else None
+    G = 32
+    sums = torch.empty(B, G, 2, dtype=torch.float64, device=DEV)
+    hip_lib.groupnorm_stats(x, G, sums)
+    # the path being replaced
+    h = hip_lib.groupnorm_apply(x, sums, gamma, beta, torch.empty_like(x), G, 1e-6, True)
+    want = hip_lib.causal_conv3d(h, w, b, torch.empty(B, T, H, W, co, dtype=BF, device=DEV), 3, res=res)
+    # the folded path
+    table = hip_lib.groupnorm_table(sums, gamma, beta, torch.empty(B, ci // 8, 16, device=DEV), T * H * W, G, 1e-6)
+    got = torch.full((B, T, H, W, co), float("nan"), dtype=BF, device=DEV)
+    osum = torch.zeros(B, G_out, 2, dtype=torch.float64, device=DEV) if G_out else None
+    ran, fused = hip_lib.causal_conv3d_gn_in(x, table, w, b, got, 3, res=res, gn_sums=osum)
+    torch.cuda.synchronize()
+    assert ran and fused == bool(G_out)
+    assert torch.isfinite(got.float()).all()
+    d = (got.float() - want.float()).abs().max().item()
+    assert d <= 2.0 ** -7 * want.float().abs().max().item(), d
+    assert rel_l2(got.float().cpu(), want.float().cpu()) <= 2e-3
+    # fp64 reference of the whole chain
+    xf = x.double().cpu()
+    n = T * H * W * (ci // G)
+    xg = xf.reshape(B, -1, G, ci // G)
+    mean = xg.mean((1, 3))
+    var = (xg * xg).mean((1, 3)) - mean * mean
+    rstd = (var + 1e-6).rsqrt()
+    y = (xg - mean[:, None, :, None]) * rstd[:, None, :, None]
+    y = y.reshape(B, T, H, W, ci) * gamma.double().cpu() + beta.double().cpu()
+    y = y * torch.sigmoid(y)
+    wk = w.double().cpu().reshape(co, 3, 3, 3, ci).permute(0, 4, 1, 2, 3)
+    ref = _conv_ref(y.permute(0, 4, 1, 2, 3), wk, b.cpu(), (1, 1, 1), (False, False),
+                    None if res is None else res.cpu().permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
+    assert_parity(got, ref, want, "conv(silu(gn(x))) folded into the conv (comparator: apply + conv)")
+    if G_out:
+        chk = hip_lib.groupnorm_stats(got, G_out, torch.empty_like(osum))
+        assert torch.allclose(osum, chk, rtol=1e-5, atol=1e-2), (osum - chk).abs().max()
+
+
+def test_conv_with_folded_groupnorm_declines_other_shapes(hip_lib):
+    """shapes the sliding-window GN kernels do not take: ran is False and NOTHING is launched (the output keeps its sentinel) --
+    hunyuan_vae._gn_silu_conv then runs apply + conv"""
+    for (ci, co, T, H, W) in [(128, 128, 1, 32, 32),      # Cout == 128 needs frame pairs
+                              (128, 256, 2, 24, 32),      # H is not whole 16-row bricks
+                              (64, 256, 2, 16, 16)]:      # Cin % 128
+        x = torch.randn(1, T, H, W, ci, device=DEV).to(BF)
+        w = torch.randn(co, 27 * ci, device=DEV).to(BF)
+        table = torch.ones(1, ci // 8, 16, device=DEV)
+        out = torch.full((1, T, H, W, co), 7.0, dtype=BF, device=DEV)
+        assert hip_lib.causal_conv3d_gn_in(x, table, w, None, out, 3) == (False, False)
+        torch.cuda.synchronize()
+        assert (out == 7.0).all()
+
+
+def test_groupnorm_table_matches_the_apply_kernels_constants(hip_lib):
+    """osk_groupnorm_table_f32: y = x a + d with the table's constants IS groupnorm_apply's y (same f32 expressions)"""
+    B, S, C, G = 2, 777, 256, 32
+    x = (torch.randn(B, S, C, device=DEV) * 2 + 1).to(BF)
+    gamma, beta = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+    sums = hip_lib.groupnorm_stats(x, G, torch.empty(B, G, 2, dtype=torch.float64, device=DEV))
+    table = hip_lib.groupnorm_table(sums, gamma, beta, torch.empty(B, C // 8, 16, device=DEV), S, G, 1e-6)
+    a = table[:, :, :8].reshape(B, 1, C)
+    d = table[:, :, 8:].reshape(B, 1, C)
+    want = hip_lib.groupnorm_apply(x, sums, gamma, beta, torch.empty_like(x), G, 1e-6, False)
+    got = torch.addcmul(d, x.float(), a).to(BF)          # (torch may or may not contract to an fma: one bf16 ulp at most)
+    assert (got.float() - want.float()).abs().max() <= 2.0 ** -7 * want.float().abs().max()
+    assert (got != want).float().mean() < 1e-3
+
+
 def test_conv3d_rejects_bad_arguments(hip_lib):
     x = torch.zeros(1, 2, 4, 4, 24, dtype=BF, device=DEV)
     w = torch.zeros(8, 27 * 24 + 8, dtype=BF, device=DEV)

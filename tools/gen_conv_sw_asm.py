@@ -28,6 +28,13 @@ One step of a wave:   s_waitcnt vmcnt(N) ; s_barrier          -- the weights of 
     the 8 activation fragment reads of step s + 1 (other fragment set), weight fragment j of step s + 1 into the register quad
     group j has just released (one set of weight fragments, rolling), the LDS-DMA pieces of step s + 5's weights and -- on 9 of
     27 steps -- two halo pieces, the scalar address advances.
+GN form (`gn`, round 4; plain NBJ = 8 and two-frame geometry): the conv's INPUT is silu(GroupNorm(x)) and the kernel reads x itself --
+the normalise + SiLU pass (gn_apply_kernel: 4 bytes of HBM per element and norm) is folded into the halo refill.  The halo pieces are
+fetched into a ring of VGPR quads (global_load_dwordx4, same voxel order, a lane always holds chunk lane % 4 = 8 fixed channels of
+the 32-channel block), transformed LAT steps later in the MFMA shadows with the reference's rounding points
+(bf16(x a_c + d_c) -> y sigmoid(y) -> bf16; a, d from a per-(batch, channel) table, 16 VGPRs reloaded per channel block) and
+written with ds_write_b128 to the swizzled position the LDS-DMA form fills (the swizzle moves from the global offset to the LDS
+address); the write is published by the barrier two steps later.  72 VALU (16 transcendental) per piece: ~1 per MFMA on average.
 The generator keeps its own model of what every instruction does (`Op.meta`); tests/test_conv_sw_model.py executes that model
 symbolically (every accumulator tile receives every (channel block, tap) product exactly once, no fragment is used before its
 wait, no LDS region is refilled before a barrier behind its last read or read before its fill is published).
@@ -47,7 +54,9 @@ REFILL_START_F2 = {0: 2, 3: 3, 9: 0, 18: 1, 27: 2, 30: 3, 36: 0, 45: 1}
 V_OPERANDS = ["xa0", "xa1", "xa2", "yb", "woff0", "woff1", "woff2", "woff3", "hoff0", "hoff1", "hoff2", "hoff3", "hoff4", "hoff5"]
 S_OPERANDS = ["wbase", "xb0", "xb1", "xb2", "xb3", "cin2", "nbody", "wdst", "hdst", "hdst5"]
 OPERANDS = V_OPERANDS + S_OPERANDS
-OPN = {n: "%%%d" % i for i, n in enumerate(OPERANDS)}
+# GN form: per-lane LDS write address of each halo piece, per-lane byte offset into a channel block's (scale, shift) rows; table base
+GN_V_OPERANDS = ["hdw0", "hdw1", "hdw2", "hdw3", "hdw4", "hdw5", "goff"]
+GN_S_OPERANDS = ["gbase"]
 
 # asm-owned scalars
 S_WB, S_X0, S_X1, S_X2 = 40, 42, 44, 46          # 64-bit running pointers: weights of the next step to fetch, halo frame bases
@@ -56,6 +65,8 @@ S_WDST, S_HDST, S_HDST5 = 51, 52, 53
 S_WRAP, S_WRAPL = 54, 56                         # 64-bit: 64 - 26 cin2 (next block, tap 0) / -26 cin2 (same block, tap 0)
 S_TMP, S_T2, S_T3 = 58, 59, 60
 S_X3 = 62
+S_G = 64                                         # GN form, 64-bit: the (scale, shift) rows of the channel block loaded last
+S_MASK, S_NL2E = 66, 67                          # GN form: 0xffff0000, -log2(e) (4-byte encodings instead of 8 with a literal)
 S_FIRST, S_LAST = 40, 63
 S_X = [S_X0, S_X1, S_X2, S_X3]
 
@@ -69,8 +80,10 @@ def ar(b, n=1):
 
 
 class Cfg:
-    def __init__(self, nbj, up=False, f2=False):
+    def __init__(self, nbj, up=False, f2=False, gn=False):
         self.NBJ = nbj
+        self.GN = gn                              # silu(GroupNorm(.)) of the input folded into the halo refill (module docstring)
+        assert not gn or (nbj == 8 and not up)
         self.UP = up                              # the decoder's nearest 2x (H, W) upsample folded into the halo (see a_offset)
         # F2: the tile is the 16 x 16 brick of TWO consecutive output frames x 128 channels: waves (frame, brick half), each
         # 128 voxels x 128 channels; four frame slots; per-tile fixed costs and the weight traffic are shared by 512 voxels
@@ -102,7 +115,30 @@ class Cfg:
         self.VB = self.V0 + 64                    # one rolling weight fragment set
         self.VY = self.VB + 4 * nbj               # weight fragment address of each ring stage (ds_read immediates are 16 bits)
         self.VN = 64 + 4 * nbj + self.NS
-        self.tag = "sw%s%d" % ("u" if up else "f" if f2 else "", self.BN)
+        self.tag = "sw%s%s%d" % ("g" if gn else "", "u" if up else "f" if f2 else "", self.BN)
+        self.OPERANDS = V_OPERANDS + (GN_V_OPERANDS if gn else []) + S_OPERANDS + (GN_S_OPERANDS if gn else [])
+        self.OPN = {n: "%%%d" % i for i, n in enumerate(self.OPERANDS)}
+        self.S_LAST = S_NL2E if gn else S_LAST
+        if gn:
+            # steps between a halo piece's load and its transform (two-frame form: refill groups 3 steps apart, 8 steps from a
+            # refill's first load to the slot's first reader) and the ring of register quads that holds the pieces in flight;
+            # pieces per body (36 / 48) % NRING == 0: ring positions are static
+            self.LAT, self.NRING = (3, 8) if f2 else (4, 6)
+            self.VST = self.V0 + self.VN
+            self.VSC = self.VST + 4 * self.NRING  # 8 scales, 8 shifts of this lane's channels, 8 temporaries
+            self.VSH, self.VT = self.VSC + 8, self.VSC + 16
+            self.VN += 4 * self.NRING + 24
+            assert self.V0 + self.VN <= 256
+            # (scale, shift) rows of the next channel block: fetched one step behind the last transform that uses the old ones
+            starts = sorted((st, sl) for st, sl in (REFILL_START_F2 if f2 else REFILL_START[self.BAR]).items())
+            label = lambda st, sl: (0 if sl >= 2 else 1) if st < TAPS else (1 if sl >= 2 else 2)
+            self.TAB_STEPS = {}                   # body step -> the advance is conditional (first block of the NEXT body)
+            for (s0, l0), (s1, l1) in zip(starts, starts[1:]):
+                if label(s0, l0) != label(s1, l1):
+                    step = s0 + self.NT - 1 + self.LAT + 1
+                    assert step < s1 + self.LAT and label(s1, l1) == label(s0, l0) + 1
+                    self.TAB_STEPS[step] = label(s1, l1) == 2
+            assert len(self.TAB_STEPS) == 2
 
     def a_offset(self, tap, i):
         """immediate of activation fragment i (brick rows 8 wm + i) of tap (dt, dh, dw), and the address operand it adds to.
@@ -126,9 +162,12 @@ class Op:
 def generate(c):
     """-> list of Op.  kinds: M mfma, R ds_read, D lds-dma, m0, S salu, W waitcnt, B barrier, L label, J branch, X other"""
     ops = []
+    OPN = c.OPN
     NS, LEAD, HALO_STEPS = c.NS, c.LEAD, c.HALO_STEPS
-    pend = []          # LDS reads in flight, in order (tags)
-    vm = []            # LDS-DMA pieces in flight, in order (tags)
+    pend = []          # LDS reads (GN form: and halo writes) in flight, in order (tags)
+    vm = []            # LDS-DMA pieces (GN form: and register loads) in flight, in order (tags)
+    ring = {}          # GN form: (load step, piece) -> ring position of the register quad
+    nring = [0]
 
     def emit(text, kind="X", meta=None):
         ops.append(Op(text, kind, meta))
@@ -141,8 +180,9 @@ def generate(c):
     def need(tag):
         if tag in pend:
             idx = len(pend) - 1 - pend[::-1].index(tag)
-            emit("s_waitcnt lgkmcnt(%d)" % (len(pend) - 1 - idx), "W", dict(lgkm=len(pend) - 1 - idx))
-            del pend[: idx + 1]
+            n = min(len(pend) - 1 - idx, 15)                 # (a 4-bit counter: the wait retires at least what is asked for)
+            emit("s_waitcnt lgkmcnt(%d)" % n, "W", dict(lgkm=n))
+            del pend[: len(pend) - n]
 
     def a_read(step, i):       # activation fragment i of step `step` (body-relative, may be BODY = next body's step 0)
         tap = step % TAPS
@@ -165,6 +205,60 @@ def generate(c):
             out.append((Op("s_add_u32 m0, s%d, %d" % (S_WDST, c.W_BASE + (fstep % NS) * c.W_STAGE + k * 4096), "m0"),
                         Op("global_load_lds_dwordx4 %s, s[%d:%d]" % (OPN["woff%d" % k], S_WB, S_WB + 1), "D",
                            dict(region=("W", fstep % NS), fstep=fstep, tag=("W", fstep)))))
+        return out
+
+    def g_load(slot, k, key):
+        """GN form: halo piece k of frame slot `slot` into the next quad of the register ring"""
+        r = nring[0] % c.NRING
+        nring[0] += 1
+        ring[key] = r
+        return Op("global_load_dwordx4 %s, %s, s[%d:%d]" % (vr(c.VST + 4 * r, 4), OPN["hoff%d" % k], S_X[slot], S_X[slot] + 1), "G",
+                  dict(region=("H", slot), tag=("G",) + key, piece=k, ring=r, dst=c.VST + 4 * r))
+
+    def xform(slot, keys):
+        """GN form: the pieces `keys` (one or two, interleaved instruction by instruction: a transcendental's result is never read
+        by the next instruction) -> list of Op: 18 VALU per dword pair, then the ds_write_b128 of each piece.
+        y = bf16(x a + d); out = bf16(y / (1 + 2^(-y log2 e)))  (csrc/groupnorm.hip::gn_apply_kernel, osk_common.h::silu)"""
+        out = []
+        P = [(c.VST + 4 * ring[key], c.VT + 4 * n, key) for n, key in enumerate(keys)]
+
+        def each(fmt, kind="V", **meta):
+            for d, t, key in P:
+                out.append(Op(fmt(d, t), kind, dict(meta, key=key, quad=(d - c.VST) // 4)))
+
+        for w in range(4):
+            each(lambda d, t: "v_lshlrev_b32_e32 %s, 16, %s" % (vr(t), vr(d + w)), src=w)
+            each(lambda d, t: "v_and_b32_e32 %s, s%d, %s" % (vr(t + 1), S_MASK, vr(d + w)), src=w)
+            each(lambda d, t: "v_fma_f32 %s, %s, %s, %s" % (vr(t), vr(t), vr(c.VSC + 2 * w), vr(c.VSH + 2 * w)), tab=True)
+            each(lambda d, t: "v_fma_f32 %s, %s, %s, %s" % (vr(t + 1), vr(t + 1), vr(c.VSC + 2 * w + 1), vr(c.VSH + 2 * w + 1)), tab=True)
+            each(lambda d, t: "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(t), vr(t), vr(t + 1)))
+            each(lambda d, t: "v_and_b32_e32 %s, s%d, %s" % (vr(t + 1), S_MASK, vr(t)))
+            each(lambda d, t: "v_lshlrev_b32_e32 %s, 16, %s" % (vr(t), vr(t)))
+            each(lambda d, t: "v_mul_f32_e32 %s, s%d, %s" % (vr(t + 2), S_NL2E, vr(t)))
+            each(lambda d, t: "v_mul_f32_e32 %s, s%d, %s" % (vr(t + 3), S_NL2E, vr(t + 1)))
+            each(lambda d, t: "v_exp_f32_e32 %s, %s" % (vr(t + 2), vr(t + 2)))
+            each(lambda d, t: "v_exp_f32_e32 %s, %s" % (vr(t + 3), vr(t + 3)))
+            each(lambda d, t: "v_add_f32_e32 %s, 1.0, %s" % (vr(t + 2), vr(t + 2)))
+            each(lambda d, t: "v_add_f32_e32 %s, 1.0, %s" % (vr(t + 3), vr(t + 3)))
+            each(lambda d, t: "v_rcp_f32_e32 %s, %s" % (vr(t + 2), vr(t + 2)))
+            each(lambda d, t: "v_rcp_f32_e32 %s, %s" % (vr(t + 3), vr(t + 3)))
+            each(lambda d, t: "v_mul_f32_e32 %s, %s, %s" % (vr(t), vr(t), vr(t + 2)))
+            each(lambda d, t: "v_mul_f32_e32 %s, %s, %s" % (vr(t + 1), vr(t + 1), vr(t + 3)))
+            each(lambda d, t: "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(d + w), vr(t), vr(t + 1)), dstw=w)
+        for d, t, key in P:
+            k = key[-1]
+            out.append(Op("ds_write_b128 %s, %s offset:%d" % (OPN["hdw%d" % k], vr(d, 4), slot * c.SLOT), "Wd",
+                          dict(region=("H", slot), tag=("HW",) + key, piece=k, src=d, key=key)))
+        return out
+
+    def table_load(cond):
+        """GN form: advance the table pointer by one channel block (256 bytes; `cond`: only if another body iteration follows) and
+        fetch this lane's 8 scales + 8 shifts"""
+        out = list(add64(S_G, "256")) if not cond else cond_next() + [Op("s_cselect_b32 s%d, 256, 0" % S_T2, "S")] + add64(S_G, "s%d" % S_T2)
+        for q in range(4):
+            out.append(Op("global_load_dwordx4 %s, %s, s[%d:%d]%s" % (vr(c.VSC + 4 * q, 4), OPN["goff"], S_G, S_G + 1,
+                                                                     " offset:%d" % (16 * q) if q else ""), "G",
+                          dict(table=True, tag=("T", q), dst=c.VSC + 4 * q)))
         return out
 
     def h_pieces(slot, third, tag):
@@ -240,19 +334,56 @@ def generate(c):
         emit("v_add_u32_e32 %s, %d, %s" % (vr(c.VY + k), c.W_BASE + k * c.W_STAGE, OPN["yb"]), "X")
     for r in range(c.NACC):
         emit("v_accvgpr_write_b32 %s, 0" % ar(r))
-    for slot in (0, 1):                                                    # halo frames 0, 1 of channel block 0
-        for third in range(c.NT):
-            for p in h_pieces(slot, third, ("H", slot, "pro")):
-                dma_issue(p)
-        for o in add64(S_X[slot], "64"):
+    if c.GN:
+        emit("s_mov_b64 s[%d:%d], %s" % (S_G, S_G + 1, OPN["gbase"]), "S")
+        emit("s_mov_b32 s%d, 0xffff0000" % S_MASK, "S")
+        emit("s_mov_b32 s%d, 0xbfb8aa3b" % S_NL2E, "S")
+        for o in table_load(False)[2:]:                                    # channel block 0's rows: no advance
             ops.append(o)
-    for p in w_pieces(0):                                                  # the prologue's own fragment reads need step 0's weights
-        dma_issue(p)
-    for o in w_advance(0):
-        ops.append(o)
-    emit("s_waitcnt vmcnt(0)", "W", dict(vm=0))
-    del vm[:]
-    emit("s_barrier", "B")
+            vm.append(o.meta["tag"])
+        for p in w_pieces(0):
+            dma_issue(p)
+        for o in w_advance(0):
+            ops.append(o)
+        # halo frames 0, 1 of channel block 0 through the register ring, two pieces at a time: slot 1's pair p is fetched into
+        # the quads slot 0's pair p has just left
+        pairs = [(slot, pr) for slot in (0, 1) for pr in range(3)]
+        def pro_load(slot, pr):
+            for k in (2 * pr, 2 * pr + 1):
+                o = g_load(slot, k, ("pro", slot, k))
+                ops.append(o)
+                vm.append(o.meta["tag"])
+            if pr == 2:
+                ops.extend(add64(S_X[slot], "64"))
+        for slot, pr in pairs[:3]:
+            pro_load(slot, pr)
+        for n, (slot, pr) in enumerate(pairs):
+            vm_need(("G", "pro", slot, 2 * pr + 1))
+            for o in xform(slot, [("pro", slot, 2 * pr), ("pro", slot, 2 * pr + 1)]):
+                ops.append(o)
+                if o.kind == "Wd":
+                    pend.append(o.meta["tag"])
+            if n + 3 < len(pairs):
+                pro_load(*pairs[n + 3])
+        nring[0] = 0                                                       # every quad is free again: the body starts at ring position 0
+        emit("s_waitcnt vmcnt(0) lgkmcnt(0)", "W", dict(vm=0, lgkm=0))
+        del vm[:]
+        del pend[:]
+        emit("s_barrier", "B")
+    else:
+        for slot in (0, 1):                                                # halo frames 0, 1 of channel block 0
+            for third in range(c.NT):
+                for p in h_pieces(slot, third, ("H", slot, "pro")):
+                    dma_issue(p)
+            for o in add64(S_X[slot], "64"):
+                ops.append(o)
+        for p in w_pieces(0):                                              # the prologue's own fragment reads need step 0's weights
+            dma_issue(p)
+        for o in w_advance(0):
+            ops.append(o)
+        emit("s_waitcnt vmcnt(0)", "W", dict(vm=0))
+        del vm[:]
+        emit("s_barrier", "B")
     for f in range(1, LEAD):                                               # the pieces a steady-state body top finds in flight
         for p in w_pieces(f):
             dma_issue(p)
@@ -268,9 +399,12 @@ def generate(c):
     emit("s_waitcnt lgkmcnt(0)", "W", dict(lgkm=0))                        # canonical state at the loop top (once per 54 steps)
     del pend[:]
     vm_top = list(vm)
+    publish = {}                           # GN form: step -> halo write tags that must have retired before its barrier
     for s in range(BODY):
         if s % c.BAR == 0:
             vm_need(("W", s + c.BAR))      # every step whose fragment reads are issued before the next barrier
+            for tag in publish.pop(s, []):
+                need(tag)
             emit("s_barrier", "B", dict(step=s))
         # fillers by MFMA index
         fill = [[] for _ in range(c.NM)]
@@ -282,15 +416,39 @@ def generate(c):
         pieces = [("w", p) for p in w_pieces(s + LEAD)]
         if s in HALO_STEPS:
             slot, third = HALO_STEPS[s][:2]
-            pieces += [("h", p) for p in h_pieces(slot, third, ("H", slot, s))]
+            if c.GN:
+                pieces += [("g", g_load(slot, k, (s, slot, k))) for k in (2 * third, 2 * third + 1)]
+            else:
+                pieces += [("h", p) for p in h_pieces(slot, third, ("H", slot, s))]
         gap = c.NM // max(len(pieces), 4)
         for n, (kind, p) in enumerate(pieces):
-            fill[3 + n * gap].append(("m0", p[0]))
-            fill[4 + n * gap].append(("dma", p[1]))
+            if kind == "g":
+                fill[4 + n * gap].append(("vmem", p))
+            else:
+                fill[3 + n * gap].append(("m0", p[0]))
+                fill[4 + n * gap].append(("dma", p[1]))
             if kind == "w" and n == c.NWP - 1:
                 fill[4 + n * gap].append(("salu", w_advance(s + LEAD)))
-            if kind == "h" and n == len(pieces) - 1 and HALO_STEPS[s][1] == c.NT - 1:
+            if kind in "hg" and n == len(pieces) - 1 and HALO_STEPS[s][1] == c.NT - 1:
                 fill[4 + n * gap].append(("salu", h_advance(s)))
+        if c.GN:
+            if s in c.TAB_STEPS:           # behind the last fma of the old rows (step s - 1), ahead of the next group's first wait
+                tl = table_load(c.TAB_STEPS[s])
+                fill[20].append(("salu", [o for o in tl if o.kind != "G"]))
+                for q, o in enumerate(o for o in tl if o.kind == "G"):
+                    fill[21 + q].append(("vmem", o))
+            s0 = s - c.LAT
+            if s0 in HALO_STEPS:           # transform + LDS write of the two pieces fetched at step s0
+                slot, third = HALO_STEPS[s0][:2]
+                keys = [(s0, slot, 2 * third), (s0, slot, 2 * third + 1)]
+                xo = xform(slot, keys)
+                fill[1].append(("vmwait", [("T", 3), ("G",) + keys[1]]))
+                nv = len(xo) - 2
+                for n, o in enumerate(xo[:nv]):
+                    fill[2 + (n * 60) // nv].append(("valu", o))
+                for o in xo[nv:]:
+                    fill[62].append(("dswrite", o))
+                    publish.setdefault(s + 2, []).append(o.meta["tag"])
         m = 0
         for j in range(c.NBJ):
             for i in range(NB):
@@ -304,9 +462,17 @@ def generate(c):
                         b_read(f[1], f[2])
                     elif f[0] == "m0":
                         ops.append(f[1])
-                    elif f[0] == "dma":
+                    elif f[0] in ("dma", "vmem"):
                         ops.append(f[1])
                         vm.append(f[1].meta["tag"])
+                    elif f[0] == "vmwait":
+                        for tag in f[1]:
+                            vm_need(tag)
+                    elif f[0] == "valu":
+                        ops.append(f[1])
+                    elif f[0] == "dswrite":
+                        ops.append(f[1])
+                        pend.append(f[1].meta["tag"])
                     else:
                         ops.extend(f[1])
                 m += 1
@@ -324,6 +490,7 @@ def generate(c):
         last = len(norm) - 1 - norm[::-1].index(("W", c.BAR))
         return norm[last + 1:]
     assert behind_first_wait(vm) == behind_first_wait(vm_top), (vm, vm_top)
+    assert not publish and (not c.GN or nring[0] % c.NRING == 0)
     return ops
 
 
@@ -333,7 +500,7 @@ def body_lines(c):
 
 def clobbers(c):
     return ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN)] + ['"a%d"' % i for i in range(c.NACC)] + \
-           ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+           ['"s%d"' % i for i in range(S_FIRST, c.S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
 
 
 def main():
@@ -354,6 +521,14 @@ def main():
                         "%d channels, two 32-channel blocks x 27 taps per body.\n" % (" (nearest 2x upsample folded in)" if up else "", c.BN))
                 for ln in body_lines(c):
                     f.write('"%s\\n"\n' % ln)
+    for f2 in (False, True):
+        c = Cfg(8, f2=f2, gn=True)
+        with open(os.path.join(args.out, "convswg%s_body_n%d.inc" % ("f" if f2 else "", c.BN)), "w") as f:
+            f.write("// GENERATED by tools/gen_conv_sw_asm.py -- do not edit.  Sliding-window CausalConv3d K loop, GN form (the input is "
+                    "silu(GroupNorm(x)), applied in the halo refill)%s: 16 x 16 voxel brick x %d channels, two 32-channel blocks x 27 taps per body.\n"
+                    % (", two-frame form" if f2 else "", c.BN))
+            for ln in body_lines(c):
+                f.write('"%s\\n"\n' % ln)
     with open(os.path.join(args.out, "convsw_regs.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_conv_sw_asm.py -- do not edit.\n")
         for up in (False, True):
@@ -366,6 +541,9 @@ def main():
         for nbj in (8, 4):                       # the register footprint does not depend on the halo geometry
             c = Cfg(nbj)
             f.write("#define OSKSW%d_CLOBBERS %s\n" % (c.BN, ", ".join(clobbers(c))))
+        for f2 in (False, True):                 # GN form: + the register ring (6 / 8 quads), 16 scale / shift registers, 8 temporaries
+            c = Cfg(8, f2=f2, gn=True)
+            f.write("#define OSKSWG%s_CLOBBERS %s\n" % ("F128" if f2 else "256", ", ".join(clobbers(c))))
 
 
 if __name__ == "__main__":
