@@ -331,6 +331,13 @@ def _gn(mod: nn.GroupNorm, x: Tensor, silu: bool) -> Tensor:
     return _ops().groupnorm_apply(x, sums, gamma, beta, torch.empty_like(x), G, eps, silu)
 
 
+# norm -> SiLU -> conv of the resnet blocks as ONE conv launch that reads the un-normalised tensor (_gn_silu_conv).  Opt-in: on the
+# 1.4 kW MI355X the encode + decode takes the same time either way (the transform's VALU work beside the MFMAs costs the convs what
+# the apply pass cost the HBM: profiles/r04m_vae_gn_fold_ab.jsonl); what it buys is 12 GB less HBM traffic per encode + decode and
+# one full-resolution activation buffer less.
+FOLD_GN = False
+
+
 def _gn_silu_conv(norm: nn.GroupNorm, conv, x: Tensor, res: Tensor | None = None, gn: int = 0) -> Tensor:
     """conv(silu(norm(x))) (unet_causal_3d_blocks.py:247-256).  Where the sliding-window kernels take the conv
     (osk_causal_conv3d_gnin_ndhwc_bf16: 3 x 3 x 3, whole 16 x 16 bricks, Cout >= 256 or the two-frame form) the normalised tensor
@@ -345,7 +352,7 @@ def _gn_silu_conv(norm: nn.GroupNorm, conv, x: Tensor, res: Tensor | None = None
     else:
         sums = torch.empty(B, G, 2, dtype=torch.float64, device=x.device)
         _ops().groupnorm_stats(x, G, sums)
-    if p.k == 3 and tuple(p.stride) == (1, 1, 1) and C == p.cin_p and C % 128 == 0:
+    if FOLD_GN and p.k == 3 and tuple(p.stride) == (1, 1, 1) and C == p.cin_p and C % 128 == 0:
         table = torch.empty(B, C // 8, 16, dtype=torch.float32, device=x.device)
         _ops().groupnorm_table(sums, gamma, beta, table, T * H * W, G, eps)
         out = torch.empty(B, T, H, W, p.cout, dtype=BF16, device=x.device)

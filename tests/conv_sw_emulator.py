@@ -204,7 +204,7 @@ def check_schedule(nbj, cin, wave=0, up=False, f2=False, gn=False):
                 q["done"].add(o.meta["dstw"])
         elif o.kind == "Wd":
             region = o.meta["region"]
-            q = quads.pop((o.meta["src"] - c.VST) // 4)
+            q = quads.pop(o.meta["quad"])
             assert q["done"] == {0, 1, 2, 3} and q["fma"] == 8 and q["slot"] == region[1] and q["piece"] == o.meta["piece"], (o.text, q)
             for r in reads:                                     # WAR, as for an LDS-DMA piece
                 if region in r["regions"] and region not in r["cleared"]:

@@ -74,7 +74,7 @@ def test_generated_loops_fit_the_instruction_cache():
     """the hot loop of every hand-scheduled kernel has to stay inside the 64 KB instruction cache (shared by
     two CUs) with room to spare.  Measured on the BUILT library: per kernel of the disassembled gfx950 code objects, the longest
     backward branch (target .. branch) = the largest loop.  Budget 52 KB; the fully unrolled two-channel-block sliding-window conv
-    bodies are the largest (~47 KB), the attention loops are 3-7 KB, the GEMM K loops ~8 KB."""
+    bodies are the largest (~47 KB), the attention loops are 3-7 KB, the GEMM K loops ~8 KB; the opt-in GN forms of those conv bodies: <= 60 KB."""
     import shutil
     import tempfile
 
@@ -118,6 +118,10 @@ def test_generated_loops_fit_the_instruction_cache():
             close()
     hand = {k: v for k, v in loops.items() if re.search(r"attn_asm|gemm256|convsw|conv256x", k)}
     assert len(hand) >= 12, sorted(loops)
+    # the opt-in GN forms of the sliding-window conv (input GroupNorm + SiLU folded in: + 72 VALU per halo piece) are the two
+    # largest loops of the library: still inside the cache, with less room
+    gn = {k: hand.pop(k) for k in list(hand) if re.search(r"convsw2_kernelILb1E|convsw_kernelILi8ELb0ELb1E", k)}
+    assert len(gn) == 2 and max(gn.values()) <= 60 * 1024, gn
     worst = max(hand.values())
     assert 30 * 1024 < worst <= 52 * 1024, {k[:60]: v for k, v in hand.items() if v == worst}
     for k, v in hand.items():

@@ -397,23 +397,30 @@ def test_full_size_conv_spot_check(hip_lib, ci, co, T, H, W, up, what):
         assert (got - acc).abs().max() <= 2.0 ** -7 * acc.abs().max() + 1e-3, (what, t, h, ww)
 
 
-def test_full_size_encode_decode_vs_reference_fixture(hip_lib):
-    """BASELINE config 3 END TO END at its real size against the reference itself: tests/golden/vae_fullsize_cfg3.npz holds what the
+@pytest.mark.parametrize("fold", [False, True], ids=["apply+conv", "gn_folded"])
+def test_full_size_encode_decode_vs_reference_fixture(hip_lib, fold):
+    """(fold: hunyuan_vae.FOLD_GN -- the opt-in path whose resnet convs read the un-normalised tensor -- meets the same bounds.)
+    BASELINE config 3 END TO END at its real size against the reference itself: tests/golden/vae_fullsize_cfg3.npz holds what the
     reference's own AutoencoderKLCausal3D (fp32, CPU, run once offline by oracle/make_golden_fullsize.py) returns for
     synth.vae_video(1, 33, 256, 256) / synth.vae_latent(1, 9, 32, 32) with the synthetic shipped-width weights: the whole latent
     mean, the decoded video on an 8 x 8 pixel lattice, and per (channel, frame) first and second moments of the whole video.
     No bf16 comparator is run here (a full-size bf16 oracle pass is tens of minutes of CPU): fixed bounds with head-room over
     the measured values (MI355X, round 4: latent 1.10e-2, decoded lattice 1.15e-2, per-frame mean 3.5e-4, mean square 7.5e-4)."""
     from oracle import make_golden_fullsize as FS
+    from open_sora_amd import hunyuan_vae
 
     g = np.load(os.path.join(GOLDEN_DIR, "vae_fullsize_cfg3.npz"))
     cfg = dict(FS.CFG)
     m = _model(cfg)
     x = torch.from_numpy(synth.vae_video(*FS.SHAPE)).to(DEV).to(BF)
-    with torch.inference_mode():
-        z = m.encode(x, sample_posterior=False).float().cpu()
-        zin = torch.from_numpy(synth.vae_latent(1, 9, 32, 32)).to(DEV).to(BF)
-        dec = m.decode(zin).float().cpu()
+    hunyuan_vae.FOLD_GN = fold
+    try:
+        with torch.inference_mode():
+            z = m.encode(x, sample_posterior=False).float().cpu()
+            zin = torch.from_numpy(synth.vae_latent(1, 9, 32, 32)).to(DEV).to(BF)
+            dec = m.decode(zin).float().cpu()
+    finally:
+        hunyuan_vae.FOLD_GN = False
     zt = torch.from_numpy(g["z"])
     assert list(z.shape) == list(zt.shape) and torch.isfinite(z).all() and torch.isfinite(dec).all()
     ez = rel_l2(z, zt)

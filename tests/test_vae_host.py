@@ -130,3 +130,38 @@ def test_vae_plans_do_not_travel_and_follow_state_loads(cpu_vae):
         assert conv.conv not in hunyuan_vae._PLANS
         z1 = m.encode(x, sample_posterior=False)
     assert not torch.equal(z1, z0)
+
+
+def test_groupnorm_fold_is_opt_in_and_equivalent(cpu_vae):
+    """hunyuan_vae.FOLD_GN (default off: equal encode + decode time on the 1.4 kW board): norm -> SiLU -> conv through
+    osk_groupnorm_table_f32 + osk_causal_conv3d_gnin_ndhwc_bf16 gives the resnet block's output of the apply + conv path, takes
+    the fused output statistics along, and falls back where the sliding-window kernels do not take the shape"""
+    vae = cpu_vae
+    assert vae.FOLD_GN is False
+    torch.manual_seed(0)
+    blk = vae.ResnetBlockCausal3D(in_channels=128, out_channels=128).to(BF)
+    x = torch.randn(1, 3, 16, 16, 128).to(BF)
+    calls = []
+    orig = cpu_ops.causal_conv3d_gn_in
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        calls.append(r)
+        return r
+
+    cpu_ops.causal_conv3d_gn_in = spy
+    try:
+        with torch.inference_mode():
+            plain = vae._resnet(blk, x)
+            assert not calls
+            vae.FOLD_GN = True
+            fold = vae._resnet(blk, x)
+            assert calls == [(True, True), (True, True)]           # both convs folded, both with fused output statistics
+            assert getattr(fold, "_osk_gn", None) is not None
+            small = vae._resnet(blk, x[:, :1])                     # Cout == 128 needs frame pairs: declined, apply + conv runs
+            assert calls[2:] == [(False, False), (False, False)] and small.shape == (1, 1, 16, 16, 128)
+    finally:
+        cpu_ops.causal_conv3d_gn_in = orig
+        vae.FOLD_GN = False
+    d = (fold.float() - plain.float()).abs().max()
+    assert d <= 2.0 ** -6 * plain.float().abs().max(), d

@@ -54,6 +54,7 @@ REFILL_START_F2 = {0: 2, 3: 3, 9: 0, 18: 1, 27: 2, 30: 3, 36: 0, 45: 1}
 V_OPERANDS = ["xa0", "xa1", "xa2", "yb", "woff0", "woff1", "woff2", "woff3", "hoff0", "hoff1", "hoff2", "hoff3", "hoff4", "hoff5"]
 S_OPERANDS = ["wbase", "xb0", "xb1", "xb2", "xb3", "cin2", "nbody", "wdst", "hdst", "hdst5"]
 OPERANDS = V_OPERANDS + S_OPERANDS
+GN_EXP = {}                                      # experiments (tools only): {"windows": {f2: {start: (slot, T0, T1)}}, "valu": "none" | "notrans"}
 # GN form: per-lane LDS write address of each halo piece, per-lane byte offset into a channel block's (scale, shift) rows; table base
 GN_V_OPERANDS = ["hdw0", "hdw1", "hdw2", "hdw3", "hdw4", "hdw5", "goff"]
 GN_S_OPERANDS = ["gbase"]
@@ -101,7 +102,22 @@ class Cfg:
         self.LEAD = self.NS - self.BAR            # step s fetches the weights of step s + LEAD into the stage of step s + LEAD - NS,
         assert BODY % self.NS == 0                # whose last reader retired before the latest barrier (<= s - s % BAR)
         self.HALO_STEPS = {}                      # body step -> (slot, third, the pointer advance behind it is conditional)
-        for start, slot in (REFILL_START_F2 if f2 else REFILL_START[self.BAR]).items():
+        starts = REFILL_START_F2 if f2 else REFILL_START[self.BAR]
+        if gn:
+            # GN form: the loads go to registers, so a refill group's fetch may start before the slot's last reader has retired
+            # (only the LDS write must not); the groups are placed so that the transform work is EVENLY spread over the body --
+            # a filler beside 16-cycle MFMAs is only hidden while a gap carries <= ~3 of them -- and the register ring never holds
+            # more than NRING pieces.  GN_WINDOWS: block-relative first load step of a group -> (frame slot, [T0, T1) = the steps
+            # (fractional: 64 MFMA gaps per step) over which its 6 pieces per wave are transformed and written, one after the other)
+            self.GN_WINDOWS = ({0: (2, 2.0, 7.5), 5: (3, 8.0, 13.0), 10: (0, 14.0, 19.5), 16: (1, 19.5, 25.5)} if f2 else
+                               {0: (2, 3.0, 10.5), 9: (0, 12.0, 19.5), 18: (1, 21.0, 26.5)})
+            for k, v in GN_EXP.get("windows", {}).get(f2, {}).items():
+                self.GN_WINDOWS[k] = v
+            starts = {}
+            for blk in (0, 1):
+                for st, (sl, _, _) in self.GN_WINDOWS.items():
+                    starts[st + blk * TAPS] = sl
+        for start, slot in starts.items():
             for third in range(self.NT):
                 self.HALO_STEPS[start + third] = (slot, third, (slot >= 2) == (start >= TAPS))
         self.W_STAGE = self.BN * 64
@@ -120,25 +136,26 @@ class Cfg:
         self.OPN = {n: "%%%d" % i for i, n in enumerate(self.OPERANDS)}
         self.S_LAST = S_NL2E if gn else S_LAST
         if gn:
-            # steps between a halo piece's load and its transform (two-frame form: refill groups 3 steps apart, 8 steps from a
-            # refill's first load to the slot's first reader) and the ring of register quads that holds the pieces in flight;
-            # pieces per body (36 / 48) % NRING == 0: ring positions are static
-            self.LAT, self.NRING = (3, 8) if f2 else (4, 6)
+            # the ring of register quads that holds the pieces between load and LDS write; pieces per body (36 / 48) % NRING == 0:
+            # ring positions are static
+            self.NRING = 8 if f2 else 6
             self.VST = self.V0 + self.VN
             self.VSC = self.VST + 4 * self.NRING  # 8 scales, 8 shifts of this lane's channels, 8 temporaries
             self.VSH, self.VT = self.VSC + 8, self.VSC + 16
             self.VN += 4 * self.NRING + 24
             assert self.V0 + self.VN <= 256
-            # (scale, shift) rows of the next channel block: fetched one step behind the last transform that uses the old ones
-            starts = sorted((st, sl) for st, sl in (REFILL_START_F2 if f2 else REFILL_START[self.BAR]).items())
+            # groups in body order: (first load step, slot, T0, T1, channel block it fetches: 0 = this body's first, 1 = its second,
+            # 2 = the next body's first); the (scale, shift) rows change right behind the last transform of a block's groups
             label = lambda st, sl: (0 if sl >= 2 else 1) if st < TAPS else (1 if sl >= 2 else 2)
-            self.TAB_STEPS = {}                   # body step -> the advance is conditional (first block of the NEXT body)
-            for (s0, l0), (s1, l1) in zip(starts, starts[1:]):
-                if label(s0, l0) != label(s1, l1):
-                    step = s0 + self.NT - 1 + self.LAT + 1
-                    assert step < s1 + self.LAT and label(s1, l1) == label(s0, l0) + 1
-                    self.TAB_STEPS[step] = label(s1, l1) == 2
-            assert len(self.TAB_STEPS) == 2
+            self.GN_GROUPS = sorted((st + blk * TAPS, sl, t0 + blk * TAPS, t1 + blk * TAPS, label(st + blk * TAPS, sl))
+                                    for blk in (0, 1) for st, (sl, t0, t1) in self.GN_WINDOWS.items())
+            self.TAB_TIMES = {}                   # body time -> the advance is conditional (first block of the NEXT body)
+            for g0, g1 in zip(self.GN_GROUPS, self.GN_GROUPS[1:]):
+                assert g0[3] <= g1[2], "transform windows overlap"
+                if g0[4] != g1[4]:
+                    assert g1[4] == g0[4] + 1
+                    self.TAB_TIMES[g0[3] + 0.05] = g1[4] == 2
+            assert len(self.TAB_TIMES) == 2 and self.GN_GROUPS[-1][3] < BODY
 
     def a_offset(self, tap, i):
         """immediate of activation fragment i (brick rows 8 wm + i) of tap (dt, dh, dw), and the address operand it adds to.
@@ -166,7 +183,8 @@ def generate(c):
     NS, LEAD, HALO_STEPS = c.NS, c.LEAD, c.HALO_STEPS
     pend = []          # LDS reads (GN form: and halo writes) in flight, in order (tags)
     vm = []            # LDS-DMA pieces (GN form: and register loads) in flight, in order (tags)
-    ring = {}          # GN form: (load step, piece) -> ring position of the register quad
+    ring = {}          # GN form: (load step, slot, piece) -> ring position of the register quad
+    ring_pre = {}      # ... as the transform schedule assumed it
     nring = [0]
 
     def emit(text, kind="X", meta=None):
@@ -207,48 +225,66 @@ def generate(c):
                            dict(region=("W", fstep % NS), fstep=fstep, tag=("W", fstep)))))
         return out
 
-    def g_load(slot, k, key):
-        """GN form: halo piece k of frame slot `slot` into the next quad of the register ring"""
+    def g_load(slot, k, key, pro=None):
+        """GN form: halo piece k of frame slot `slot` into the next quad of the register ring (pro = n: the prologue's n-th piece, into
+        the fragment registers v[V0 + 4 n ..] -- nothing reads fragments before the prologue's barrier)"""
+        if pro is not None:
+            return Op("global_load_dwordx4 %s, %s, s[%d:%d]" % (vr(c.V0 + 4 * pro, 4), OPN["hoff%d" % k], S_X[slot], S_X[slot] + 1), "G",
+                      dict(region=("H", slot), tag=("G",) + key, piece=k, ring=("pro", pro), dst=c.V0 + 4 * pro))
         r = nring[0] % c.NRING
         nring[0] += 1
         ring[key] = r
+        assert ring_pre.get(key, r) == r, (key, r, ring_pre[key])
         return Op("global_load_dwordx4 %s, %s, s[%d:%d]" % (vr(c.VST + 4 * r, 4), OPN["hoff%d" % k], S_X[slot], S_X[slot] + 1), "G",
                   dict(region=("H", slot), tag=("G",) + key, piece=k, ring=r, dst=c.VST + 4 * r))
 
-    def xform(slot, keys):
-        """GN form: the pieces `keys` (one or two, interleaved instruction by instruction: a transcendental's result is never read
-        by the next instruction) -> list of Op: 18 VALU per dword pair, then the ds_write_b128 of each piece.
+    def xform(slot, key, r, d=None):
+        """GN form: the piece in ring quad r -> list of Op: 72 VALU (two dwords at a time, interleaved instruction by instruction:
+        a transcendental's result is never read by the next instruction -- the gfx940 forwarding hazard), then its ds_write_b128.
         y = bf16(x a + d); out = bf16(y / (1 + 2^(-y log2 e)))  (csrc/groupnorm.hip::gn_apply_kernel, osk_common.h::silu)"""
         out = []
-        P = [(c.VST + 4 * ring[key], c.VT + 4 * n, key) for n, key in enumerate(keys)]
+        d = c.VST + 4 * r if d is None else d
+        mode = GN_EXP.get("valu")          # experiments: "none" = loads and writes only, "notrans" = v_mov for v_exp / v_rcp
 
-        def each(fmt, kind="V", **meta):
-            for d, t, key in P:
-                out.append(Op(fmt(d, t), kind, dict(meta, key=key, quad=(d - c.VST) // 4)))
+        def each(P, fmt, **flags):
+            for w, t in P:
+                text = fmt(w, t)
+                if mode == "notrans" and text.startswith(("v_exp", "v_rcp")):
+                    text = "v_mov_b32_e32 " + text.split(" ", 1)[1]
+                meta = dict(key=key, quad=r)
+                if flags.get("src"):
+                    meta["src"] = w
+                if flags.get("tab"):
+                    meta["tab"] = True
+                if flags.get("dst"):
+                    meta["dstw"] = w
+                out.append(Op(text, "V", meta))
 
-        for w in range(4):
-            each(lambda d, t: "v_lshlrev_b32_e32 %s, 16, %s" % (vr(t), vr(d + w)), src=w)
-            each(lambda d, t: "v_and_b32_e32 %s, s%d, %s" % (vr(t + 1), S_MASK, vr(d + w)), src=w)
-            each(lambda d, t: "v_fma_f32 %s, %s, %s, %s" % (vr(t), vr(t), vr(c.VSC + 2 * w), vr(c.VSH + 2 * w)), tab=True)
-            each(lambda d, t: "v_fma_f32 %s, %s, %s, %s" % (vr(t + 1), vr(t + 1), vr(c.VSC + 2 * w + 1), vr(c.VSH + 2 * w + 1)), tab=True)
-            each(lambda d, t: "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(t), vr(t), vr(t + 1)))
-            each(lambda d, t: "v_and_b32_e32 %s, s%d, %s" % (vr(t + 1), S_MASK, vr(t)))
-            each(lambda d, t: "v_lshlrev_b32_e32 %s, 16, %s" % (vr(t), vr(t)))
-            each(lambda d, t: "v_mul_f32_e32 %s, s%d, %s" % (vr(t + 2), S_NL2E, vr(t)))
-            each(lambda d, t: "v_mul_f32_e32 %s, s%d, %s" % (vr(t + 3), S_NL2E, vr(t + 1)))
-            each(lambda d, t: "v_exp_f32_e32 %s, %s" % (vr(t + 2), vr(t + 2)))
-            each(lambda d, t: "v_exp_f32_e32 %s, %s" % (vr(t + 3), vr(t + 3)))
-            each(lambda d, t: "v_add_f32_e32 %s, 1.0, %s" % (vr(t + 2), vr(t + 2)))
-            each(lambda d, t: "v_add_f32_e32 %s, 1.0, %s" % (vr(t + 3), vr(t + 3)))
-            each(lambda d, t: "v_rcp_f32_e32 %s, %s" % (vr(t + 2), vr(t + 2)))
-            each(lambda d, t: "v_rcp_f32_e32 %s, %s" % (vr(t + 3), vr(t + 3)))
-            each(lambda d, t: "v_mul_f32_e32 %s, %s, %s" % (vr(t), vr(t), vr(t + 2)))
-            each(lambda d, t: "v_mul_f32_e32 %s, %s, %s" % (vr(t + 1), vr(t + 1), vr(t + 3)))
-            each(lambda d, t: "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(d + w), vr(t), vr(t + 1)), dstw=w)
-        for d, t, key in P:
-            k = key[-1]
-            out.append(Op("ds_write_b128 %s, %s offset:%d" % (OPN["hdw%d" % k], vr(d, 4), slot * c.SLOT), "Wd",
-                          dict(region=("H", slot), tag=("HW",) + key, piece=k, src=d, key=key)))
+        for w0 in (0, 2):
+            P = [(w0, c.VT), (w0 + 1, c.VT + 4)]
+            each(P, lambda w, t: "v_lshlrev_b32_e32 %s, 16, %s" % (vr(t), vr(d + w)), src=1)
+            each(P, lambda w, t: "v_and_b32_e32 %s, s%d, %s" % (vr(t + 1), S_MASK, vr(d + w)), src=1)
+            each(P, lambda w, t: "v_fma_f32 %s, %s, %s, %s" % (vr(t), vr(t), vr(c.VSC + 2 * w), vr(c.VSH + 2 * w)), tab=1)
+            each(P, lambda w, t: "v_fma_f32 %s, %s, %s, %s" % (vr(t + 1), vr(t + 1), vr(c.VSC + 2 * w + 1), vr(c.VSH + 2 * w + 1)), tab=1)
+            each(P, lambda w, t: "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(t), vr(t), vr(t + 1)))
+            each(P, lambda w, t: "v_and_b32_e32 %s, s%d, %s" % (vr(t + 1), S_MASK, vr(t)))
+            each(P, lambda w, t: "v_lshlrev_b32_e32 %s, 16, %s" % (vr(t), vr(t)))
+            each(P, lambda w, t: "v_mul_f32_e32 %s, s%d, %s" % (vr(t + 2), S_NL2E, vr(t)))
+            each(P, lambda w, t: "v_mul_f32_e32 %s, s%d, %s" % (vr(t + 3), S_NL2E, vr(t + 1)))
+            each(P, lambda w, t: "v_exp_f32_e32 %s, %s" % (vr(t + 2), vr(t + 2)))
+            each(P, lambda w, t: "v_exp_f32_e32 %s, %s" % (vr(t + 3), vr(t + 3)))
+            each(P, lambda w, t: "v_add_f32_e32 %s, 1.0, %s" % (vr(t + 2), vr(t + 2)))
+            each(P, lambda w, t: "v_add_f32_e32 %s, 1.0, %s" % (vr(t + 3), vr(t + 3)))
+            each(P, lambda w, t: "v_rcp_f32_e32 %s, %s" % (vr(t + 2), vr(t + 2)))
+            each(P, lambda w, t: "v_rcp_f32_e32 %s, %s" % (vr(t + 3), vr(t + 3)))
+            each(P, lambda w, t: "v_mul_f32_e32 %s, %s, %s" % (vr(t), vr(t), vr(t + 2)))
+            each(P, lambda w, t: "v_mul_f32_e32 %s, %s, %s" % (vr(t + 1), vr(t + 1), vr(t + 3)))
+            each(P, lambda w, t: "v_cvt_pk_bf16_f32 %s, %s, %s" % (vr(d + w), vr(t), vr(t + 1)), dst=1)
+        if mode == "none":
+            out = []
+        k = key[-1]
+        out.append(Op("ds_write_b128 %s, %s offset:%d" % (OPN["hdw%d" % k], vr(d, 4), slot * c.SLOT), "Wd",
+                      dict(region=("H", slot), tag=("HW",) + key, piece=k, src=d, key=key, quad=r)))
         return out
 
     def table_load(cond):
@@ -345,27 +381,22 @@ def generate(c):
             dma_issue(p)
         for o in w_advance(0):
             ops.append(o)
-        # halo frames 0, 1 of channel block 0 through the register ring, two pieces at a time: slot 1's pair p is fetched into
-        # the quads slot 0's pair p has just left
-        pairs = [(slot, pr) for slot in (0, 1) for pr in range(3)]
-        def pro_load(slot, pr):
-            for k in (2 * pr, 2 * pr + 1):
-                o = g_load(slot, k, ("pro", slot, k))
-                ops.append(o)
-                vm.append(o.meta["tag"])
-            if pr == 2:
+        # halo frames 0, 1 of channel block 0: all 12 pieces of this wave are fetched at once (ONE memory latency per tile) into
+        # the fragment registers, then transformed and written in order
+        pro = [(slot, k) for slot in (0, 1) for k in range(6)]
+        assert 4 * len(pro) <= 64
+        for n, (slot, k) in enumerate(pro):
+            o = g_load(slot, k, ("pro", slot, k), pro=n)
+            ops.append(o)
+            vm.append(o.meta["tag"])
+            if k == 5:
                 ops.extend(add64(S_X[slot], "64"))
-        for slot, pr in pairs[:3]:
-            pro_load(slot, pr)
-        for n, (slot, pr) in enumerate(pairs):
-            vm_need(("G", "pro", slot, 2 * pr + 1))
-            for o in xform(slot, [("pro", slot, 2 * pr), ("pro", slot, 2 * pr + 1)]):
+        for n, (slot, k) in enumerate(pro):
+            vm_need(("G", "pro", slot, k))
+            for o in xform(slot, ("pro", slot, k), ("pro", n), c.V0 + 4 * n):
                 ops.append(o)
                 if o.kind == "Wd":
                     pend.append(o.meta["tag"])
-            if n + 3 < len(pairs):
-                pro_load(*pairs[n + 3])
-        nring[0] = 0                                                       # every quad is free again: the body starts at ring position 0
         emit("s_waitcnt vmcnt(0) lgkmcnt(0)", "W", dict(vm=0, lgkm=0))
         del vm[:]
         del pend[:]
@@ -400,6 +431,32 @@ def generate(c):
     del pend[:]
     vm_top = list(vm)
     publish = {}                           # GN form: step -> halo write tags that must have retired before its barrier
+    gn_fill = {}                           # GN form: step -> MFMA index -> fillers (transform, LDS write, table load)
+    if c.GN:
+        at = lambda time: (int(time), 2 + int((time - int(time)) * 60))
+        put = lambda time, item: gn_fill.setdefault(at(time)[0], {}).setdefault(at(time)[1], []).append(item)
+        nr = 0
+        for start, slot, t0, t1, _ in c.GN_GROUPS:
+            for i in range(6):                                   # piece i = the i-th load of the group (step start + i // 2)
+                key = (start + i // 2, slot, i)
+                r, nr = nr % c.NRING, nr + 1
+                ring_pre[key] = r
+                xo = xform(slot, key, r)
+                a, b = t0 + (t1 - t0) * i / 6.0, t0 + (t1 - t0) * (i + 1) / 6.0
+                assert a >= start + i // 2 + 1, "a piece is transformed less than a step behind its load"
+                put(a, ("vmwait", [("T", 3), ("G",) + key]))
+                for n, o in enumerate(xo):
+                    if o.kind == "Wd":
+                        put(a + (b - a) * (n + 0.5) / len(xo), ("dswrite", o))
+                        if at(a + (b - a) * (n + 0.5) / len(xo))[0] + 1 < BODY:      # (the body's last step: lgkmcnt(0) at the loop top / exit)
+                            publish.setdefault(at(a + (b - a) * (n + 0.5) / len(xo))[0] + 1, []).append(o.meta["tag"])
+                    else:
+                        put(a + (b - a) * (n + 0.5) / len(xo), ("valu", o))
+        for time, cond in c.TAB_TIMES.items():
+            tl = table_load(cond)
+            put(time, ("salu", [o for o in tl if o.kind != "G"]))
+            for q, o in enumerate(o for o in tl if o.kind == "G"):
+                put(time + (q + 1) / 60.0, ("vmem", o))
     for s in range(BODY):
         if s % c.BAR == 0:
             vm_need(("W", s + c.BAR))      # every step whose fragment reads are issued before the next barrier
@@ -431,24 +488,8 @@ def generate(c):
                 fill[4 + n * gap].append(("salu", w_advance(s + LEAD)))
             if kind in "hg" and n == len(pieces) - 1 and HALO_STEPS[s][1] == c.NT - 1:
                 fill[4 + n * gap].append(("salu", h_advance(s)))
-        if c.GN:
-            if s in c.TAB_STEPS:           # behind the last fma of the old rows (step s - 1), ahead of the next group's first wait
-                tl = table_load(c.TAB_STEPS[s])
-                fill[20].append(("salu", [o for o in tl if o.kind != "G"]))
-                for q, o in enumerate(o for o in tl if o.kind == "G"):
-                    fill[21 + q].append(("vmem", o))
-            s0 = s - c.LAT
-            if s0 in HALO_STEPS:           # transform + LDS write of the two pieces fetched at step s0
-                slot, third = HALO_STEPS[s0][:2]
-                keys = [(s0, slot, 2 * third), (s0, slot, 2 * third + 1)]
-                xo = xform(slot, keys)
-                fill[1].append(("vmwait", [("T", 3), ("G",) + keys[1]]))
-                nv = len(xo) - 2
-                for n, o in enumerate(xo[:nv]):
-                    fill[2 + (n * 60) // nv].append(("valu", o))
-                for o in xo[nv:]:
-                    fill[62].append(("dswrite", o))
-                    publish.setdefault(s + 2, []).append(o.meta["tag"])
+        for key_, items in gn_fill.get(s, {}).items():
+            fill[key_].extend(items)
         m = 0
         for j in range(c.NBJ):
             for i in range(NB):
@@ -506,7 +547,14 @@ def clobbers(c):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc"))
+    ap.add_argument("--gn-exp", default="", help='experiments (tools/make_conv_gn_variants.sh): JSON for GN_EXP, e.g. {"valu": "notrans"}')
     args = ap.parse_args()
+    if args.gn_exp:
+        import json
+        exp = json.loads(args.gn_exp)
+        if "windows" in exp:       # {"f2" | "plain": {start: [slot, T0, T1]}}
+            exp["windows"] = {k == "f2": {int(st): tuple(v) for st, v in d.items()} for k, d in exp["windows"].items()}
+        GN_EXP.update(exp)
     c = Cfg(8, f2=True)
     with open(os.path.join(args.out, "convswf_body_n128.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_conv_sw_asm.py -- do not edit.  Sliding-window CausalConv3d K loop, two-frame form: 16 x 16 voxel "
