@@ -7,8 +7,12 @@ run() {  # name, counters, command...
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/$name -o $name -- "$@" > $O/$name.log 2>&1
   tail -1 $O/$name.log | cut -c1-160
 }
+export OSK_BENCH_NO_GN_FOLD=1
 run vae_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
 run vae_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
+# the same step with the opt-in GroupNorm fold (hunyuan_vae.FOLD_GN)
+OSK_VAE_FOLD_GN=1 run vaefold_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
+OSK_VAE_FOLD_GN=1 run vaefold_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
 if [ -n "$PMC_LINEAR_CONV" ]; then   # the round-1 tile mapping of conv256t for comparison
   run vaelin_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
   run vaelin_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
@@ -30,6 +34,11 @@ for f in sorted(glob.glob(sys.argv[1] + "/*/*counter_collection.csv")):
             agg[(key, r["Counter_Name"])][0] += float(r["Counter_Value"])
             agg[(key, r["Counter_Name"])][1] += 1
     run = f.split("/")[-2]
+    tot = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        tot[r["Counter_Name"]] += float(r["Counter_Value"])
+    for c, v in sorted(tot.items()):
+        print(f"{run:10s} {'ALL KERNELS':20s} {c:12s} total {v:.6g} KB")
     for (k, c), (v, n) in sorted(agg.items()):
         print(f"{run:10s} {k:20s} {c:12s} total {v:.6g} KB over {n} launches")
 PY
