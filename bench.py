@@ -245,7 +245,7 @@ def vae_line(dev, T, S, steps, warmup, cpu_budget_s):
         "step_tflops": round((enc_f + dec_f) / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round((enc_f + dec_f) / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
         "gn_fold": None if fold_ms is None else {"ms_per_step": round(fold_ms, 3), "what": "same model and input with hunyuan_vae.FOLD_GN = True (opt-in: GroupNorm + SiLU applied "
-                    "inside the consuming sliding-window conv; 12 GB less HBM traffic per step)"},
+                    "inside the consuming sliding-window conv; 16 GB less fabric traffic per step)"},
         # all conv launches of one encode + decode: conv3d_256.hip where Cin % 128 == 0 -- the LDS sliding-window kernels
         # (convsw_kernel / convsw2_kernel) for the stride-1 3 x 3 x 3 layers incl. the fused-upsample ones, the implicit-GEMM
         # conv256x_kernel for strided / 1 x 1 x 1 layers --, conv3d_kernel (conv3d.hip) for conv_in / conv_out / the narrow layers

@@ -48,6 +48,13 @@ struct GemmPack {
   GemmParams p[NP];
 };
 
+#ifdef OSK_GEMM_TILE_TIMING   // tools/make_gemm_timing_lib.sh: where a tile's time goes (s_memtime sums of wave 0 of every workgroup)
+__device__ unsigned long long osk_gemm_tile_ticks[4];   // address set-up, asm statement (cold start + K loop), epilogue, tiles
+#define OSK_TT(i, t0) if (threadIdx.x == 0) atomicAdd(&osk_gemm_tile_ticks[i], __builtin_amdgcn_s_memtime() - (t0))
+#else
+#define OSK_TT(i, t0)
+#endif
+
 template <bool OUT_F32, int NP>
 __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk) {
   constexpr int WT = OSKX_NB * 16, BN = 256;   // wave tile side
@@ -111,6 +118,9 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
   unsigned prefetched = 0;
   for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
     const int itn = it + (int)gridDim.x;
+#ifdef OSK_GEMM_TILE_TIMING
+    const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
+#endif
     int sel, m0, n0, seln = 0, m0n = 0, n0n = 0;
     tile_of(it, sel, m0, n0);
     const GemmParams& p = pk.p[NP == 1 ? 0 : sel];                 // wave-uniform: kernel-argument loads at a scalar offset
@@ -150,13 +160,25 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
       "v"(aoff[6]), "v"(aoff[7]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]), "v"(woff[5]),  \
       "v"(woff[6]), "v"(woff[7]), "v"(boff), "s"(abase), "s"(wbase), "s"(bbase), "s"(nk), "s"(adst), "s"(wdst),        \
       "s"(flags), "s"(dAs), "s"(dWs), "v"(aoffp), "v"(woffp)
+    OSK_TT(0, tt0);
+#ifdef OSK_GEMM_TILE_TIMING
+    const unsigned long long tt1 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile(
 #include "gemm256x_body.inc"
         OSKW_OPERANDS : OSKX_CLOBBERS);
+    OSK_TT(1, tt1);
+#ifdef OSK_GEMM_TILE_TIMING
+    const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
+#endif
 
     const int b_first = m0w / p.crpb, b_last = (m0w + WT - 1) / p.crpb;
     const bool interior = m0w + WT <= p.M && n0w + WT <= p.N && b_first == b_last;  // wave-uniform
     epi16::epilogue_all<GeoX, OUT_F32>(p, m0w, n0w, l15, q4, interior, folded);
+    OSK_TT(2, tt2);
+#ifdef OSK_GEMM_TILE_TIMING
+    if (threadIdx.x == 0) atomicAdd(&osk_gemm_tile_ticks[3], 1ull);
+#endif
     prefetched = has_next ? 1u : 0u;
   }
 }
@@ -180,6 +202,15 @@ int launch_one(const GemmParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef OSK_GEMM_TILE_TIMING
+// read and clear the tick sums (tools/gemm_tile_timing.py)
+extern "C" int osk_gemm_tile_timing_read(unsigned long long* out4) {
+  unsigned long long zero[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(osk_gemm_tile_ticks), sizeof(zero)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(osk_gemm_tile_ticks), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int launch_gemm256x(const GemmParams& p, int out_f32, hipStream_t st) {
   return out_f32 ? launch_one<true>(p, st) : launch_one<false>(p, st);

@@ -334,7 +334,7 @@ def _gn(mod: nn.GroupNorm, x: Tensor, silu: bool) -> Tensor:
 
 # norm -> SiLU -> conv of the resnet blocks as ONE conv launch that reads the un-normalised tensor (_gn_silu_conv).  Opt-in: on the
 # 1.4 kW MI355X the encode + decode takes the same time either way (the transform's VALU work beside the MFMAs costs the convs what
-# the apply pass cost the HBM: profiles/r04m_vae_gn_fold_ab.jsonl); what it buys is 12 GB less HBM traffic per encode + decode and
+# the apply pass cost the HBM: profiles/r04m_vae_gn_fold_ab.jsonl); what it buys is 16 GB less fabric traffic per encode + decode (90.7 -> 74.2 GB by PMC) and
 # one full-resolution activation buffer less.  (OSK_VAE_FOLD_GN=1 in the environment turns it on at import.)
 FOLD_GN = bool(os.environ.get("OSK_VAE_FOLD_GN"))
 

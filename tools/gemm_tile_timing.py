@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Where a gemm256x_kernel tile's time goes, per shape: OSK_ALT_LIB=tools/lib/libosk_gemm_timing.so python tools/gemm_tile_timing.py
+(tools/make_gemm_timing_lib.sh).  s_memtime ticks of wave 0 of every workgroup, summed over the launch: address set-up before the
+asm statement, the asm statement (cold start + K loop), the epilogue.  One JSON line per shape: microseconds per tile at the
+100 MHz constant the counter runs at (s_memtime is REFCLK on gfx9-family parts) -- and as shares, which need no clock."""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import _altlib
+
+lib_path = _altlib.install()
+assert lib_path, "run with OSK_ALT_LIB=tools/lib/libosk_gemm_timing.so"
+import torch
+from open_sora_amd import _C
+
+rd = _C.lib.osk_gemm_tile_timing_read          # (the same loaded module that owns the device-side counters)
+rd.restype = ctypes.c_int
+rd.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+dev = torch.device("cuda")
+M = 3 * 16896
+SHAPES = [(M, 3456, 1152, "XL qkv"), (M, 1152, 1152, "XL proj"), (M, 4608, 1152, "XL mlp up"), (M, 1152, 4608, "XL mlp down"),
+          (M, 9216, 3072, "11B qkv"), (8192, 8192, 8192, "8192^3")]
+buf = (ctypes.c_ulonglong * 4)()
+for m, n, k, name in SHAPES:
+    a = torch.randn(1, m, k, device=dev).to(torch.bfloat16)
+    w = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
+    b = torch.zeros(n, device=dev)
+    out = torch.empty(1, m, n, dtype=torch.bfloat16, device=dev)
+    for _ in range(2):
+        _C.gemm(a, w, b, out)
+    torch.cuda.synchronize()
+    rd(buf)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        _C.gemm(a, w, b, out)
+    e1.record()
+    torch.cuda.synchronize()
+    rd(buf)
+    setup, loop, epi, tiles = (int(x) for x in buf)
+    tot = setup + loop + epi
+    ms = e0.elapsed_time(e1) / 4
+    print(json.dumps({"shape": [m, n, k], "what": name, "ms_per_launch": round(ms, 4), "tflops": round(2 * m * n * k / ms / 1e9, 1),
+                      "tiles_per_launch": tiles // 4, "rounds": round(tiles / 4 / 256, 2),
+                      "ticks_per_tile": {"setup": round(setup / tiles, 1), "asm_statement": round(loop / tiles, 1), "epilogue": round(epi / tiles, 1)},
+                      "share": {"setup": round(setup / tot, 4), "asm_statement": round(loop / tot, 4), "epilogue": round(epi / tot, 4)},
+                      "launch_ms_over_rounds_x_tile": round(ms / (-(-tiles // 4 // 256)), 4)}), flush=True)

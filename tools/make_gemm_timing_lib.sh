@@ -1,0 +1,10 @@
+#!/bin/bash
+# gemm256x_kernel with s_memtime stamps around the address set-up, the asm statement and the epilogue of every tile
+# -> tools/lib/libosk_gemm_timing.so (tools/gemm_tile_timing.py reads the sums)
+set -e
+cd "$(dirname "$0")/.."
+python -c "import open_sora_amd.build as b; b.build_lib()"
+OBJ=open_sora_amd/lib/obj; mkdir -p tools/lib
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -DOSK_GEMM_TILE_TIMING -c open_sora_amd/csrc/gemm256x.hip -o /tmp/gemm256x_timing.o 2>/dev/null
+hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lib/libosk_gemm_timing.so $(ls $OBJ/*.o | grep -v "/gemm256x.o") /tmp/gemm256x_timing.o
+echo "built tools/lib/libosk_gemm_timing.so"
