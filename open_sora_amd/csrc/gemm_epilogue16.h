@@ -61,6 +61,60 @@ OSK_DEV void pair_interior(const GemmParams& p, const int64_t* rowoff, const int
   }
 }
 
+// ---- bf16 interior, round 4: stores that cover whole 128-byte row pieces.  After pair_interior's lane-row exchange a store
+// instruction of column block J writes 32 rows x 32 bytes: 32 half-line accesses per KiB, and a workgroup tile's 128 KiB took
+// ~11.4 k cycles (19-20 % of a K = 1152 tile; tools/gemm_tile_timing.py) at ~2.8 cycles per (instruction, line) -- the store path
+// is issue-bound per touched line, not per byte.  Here the 16-byte chunks of four column blocks are transposed across the four
+// lanes of a quad (rows l15 = 4 a .. 4 a + 3: two DPP butterfly steps) so that register r of lane j holds row 4 a + r's chunk of
+// column block 4 b + j: one store instruction then writes 8 rows x 128 contiguous bytes (the two halves q4 >> 1 complete a block).
+// (quad_transpose: osk_common.h)
+
+// the 16-byte chunk pair_interior stores for (J, I): columns 16 J + 8 (q4 >> 1) .. + 7 of output row 16 (I + (q4 & 1)) + l15
+template <class Geo, bool GATE, int GELU, int J, int I>
+OSK_DEV uint4 chunk_interior(const GemmParams& p, const int64_t* rowoff, int n0w, int q4, const float4& gq) {
+  constexpr int NB = Geo::NB;
+  const int n = n0w + J * 16 + q4 * 4;
+  float a0[4], a1[4];
+  tile_values<Geo, J * NB + I, GATE, GELU>(p, rowoff[I], n, gq, a0);
+  tile_values<Geo, J * NB + I + 1, GATE, GELU>(p, rowoff[I + 1], n, gq, a1);
+  auto sx = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a1[0], a1[1]), false, false);
+  auto sy = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[2], a1[3]), false, false);
+  return make_uint4(sx[0], sy[0], sx[1], sy[1]);
+}
+
+// one pair of row blocks (I, I + 1), all NB column blocks: NB chunks per lane, transposed in groups of four, NB stores of
+// 8 rows x 128 bytes.  own = element offset of this lane's own store row (storeoff[I / 2]: + its 8-column half), crs = row stride:
+// the rows of an interior wave tile lie in one batch item, so row 4 a + r is (r - j) rows from the lane's own row 4 a + j.
+template <class Geo, bool GATE, int GELU, int I, int... Js>
+OSK_DEV void row_pair_wide(const GemmParams& p, const int64_t* rowoff, int64_t own, int n0w, int q4, int lane, const float4* gq,
+                           std::integer_sequence<int, Js...>) {
+  constexpr int NB = Geo::NB;
+  static_assert(NB % 4 == 0, "column blocks are transposed in groups of four");
+  uint4 d[NB];
+  ((d[Js] = chunk_interior<Geo, GATE, GELU, Js, I>(p, rowoff, n0w, q4, gq[Js])), ...);
+  const int j = lane & 3;
+  const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+  for (int b = 0; b < NB / 4; ++b) {
+    quad_transpose(d[4 * b].x, d[4 * b + 1].x, d[4 * b + 2].x, d[4 * b + 3].x, odd, hi);
+    quad_transpose(d[4 * b].y, d[4 * b + 1].y, d[4 * b + 2].y, d[4 * b + 3].y, odd, hi);
+    quad_transpose(d[4 * b].z, d[4 * b + 1].z, d[4 * b + 2].z, d[4 * b + 3].z, odd, hi);
+    quad_transpose(d[4 * b].w, d[4 * b + 1].w, d[4 * b + 2].w, d[4 * b + 3].w, odd, hi);
+  }
+  unsigned short* base = reinterpret_cast<unsigned short*>(p.C) + own + n0w + 16 * j - (int64_t)j * p.crs;
+#pragma unroll
+  for (int b = 0; b < NB / 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<uint4*>(base + (int64_t)r * p.crs + 64 * b) = d[4 * b + r];
+}
+
+template <class Geo, bool GATE, int GELU, int... Is>
+OSK_DEV void tile_interior_wide(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, int lane,
+                                const float4* gq, std::integer_sequence<int, Is...>) {
+  (row_pair_wide<Geo, GATE, GELU, 2 * Is>(p, rowoff, storeoff[Is], n0w, q4, lane, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
+}
+
 // edge tiles: per-element bounds checks (rows >= M were computed on clamped copies of row M-1 and are dropped)
 template <class Geo, bool OUT_F32, int T>
 OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded) {
@@ -109,6 +163,15 @@ OSK_DEV void cols_interior(const GemmParams& p, const int64_t* rowoff, const int
     if constexpr (GATE) gq[j] = *reinterpret_cast<const float4*>(p.gate + (m0w / p.crpb) * p.gbs + n0w + j * 16 + q4 * 4);
   }
   // GELU class of the whole wave tile (wave-uniform): none / all / per element where the boundary cuts through it
+  if constexpr (!OUT_F32) {
+#ifndef OSK_GEMM_NARROW_STORES   // (A/B builds of tools/: the 32-byte row pieces of round 3)
+    const int lane = q4 * 16 + (int)(threadIdx.x & 15);
+    if (n0w + NB * 16 <= p.gelu_from) tile_interior_wide<Geo, GATE, GELU_NONE>(p, rowoff, storeoff, n0w, q4, lane, gq, seq);
+    else if (n0w >= p.gelu_from) tile_interior_wide<Geo, GATE, GELU_ALL>(p, rowoff, storeoff, n0w, q4, lane, gq, seq);
+    else tile_interior_wide<Geo, GATE, GELU_MIXED>(p, rowoff, storeoff, n0w, q4, lane, gq, seq);
+    return;
+#endif
+  }
   if (n0w + NB * 16 <= p.gelu_from) tile_interior<Geo, OUT_F32, GATE, GELU_NONE>(p, rowoff, storeoff, n0w, q4, gq, seq);
   else if (n0w >= p.gelu_from) tile_interior<Geo, OUT_F32, GATE, GELU_ALL>(p, rowoff, storeoff, n0w, q4, gq, seq);
   else tile_interior<Geo, OUT_F32, GATE, GELU_MIXED>(p, rowoff, storeoff, n0w, q4, gq, seq);

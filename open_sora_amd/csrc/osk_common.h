@@ -70,6 +70,22 @@ OSK_DEV float gelu_tanh(float x) {
 }
 OSK_DEV float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 
+// 4 x 4 transpose of (register, lane-of-a-quad): X[r] of lane j -> X[j] of lane r, within every quad of lanes; two DPP butterfly
+// steps (lane bit 0 against register bit 0, then bit 1 against bit 1).  The 16 x 16 MFMA epilogues (gemm_epilogue16.h,
+// conv3d_256.hip) use it to turn "a lane owns 16 bytes of ITS row in each of four column blocks" into "a quad owns 64 contiguous
+// bytes of each of its four rows": stores that cover whole 128-byte row pieces.
+OSK_DEV unsigned dpp_swap1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }   // quad_perm [1,0,3,2]
+OSK_DEV unsigned dpp_swap2(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); }   // quad_perm [2,3,0,1]
+OSK_DEV void quad_transpose(unsigned& x0, unsigned& x1, unsigned& x2, unsigned& x3, bool odd, bool hi) {
+  const unsigned s0 = dpp_swap1(x0), s1 = dpp_swap1(x1), s2 = dpp_swap1(x2), s3 = dpp_swap1(x3);
+  const unsigned y0 = odd ? s1 : x0, y1 = odd ? x1 : s0, y2 = odd ? s3 : x2, y3 = odd ? x3 : s2;
+  const unsigned t0 = dpp_swap2(y0), t1 = dpp_swap2(y1), t2 = dpp_swap2(y2), t3 = dpp_swap2(y3);
+  x0 = hi ? t2 : y0;
+  x1 = hi ? t3 : y1;
+  x2 = hi ? y2 : t0;
+  x3 = hi ? y3 : t1;
+}
+
 // Bijective XCD-aware remap of a 1-D block id (block b is observed on XCD b % 8): give every XCD a
 // contiguous range of logical tiles so neighbouring tiles share that XCD's private 4 MiB L2.
 OSK_DEV int xcd_remap(int bid, int nblk) {

@@ -188,3 +188,51 @@ def test_attention_schedule_invariants():
         assert L.V_END <= 256 and L.V_END + L.A_END <= 512   # unified register file of one wave per SIMD
         for m in re.finditer(r"ds_read_b128 [^\n]* offset:(\d+)", text):
             assert int(m.group(1)) < 65536   # 16-bit LDS immediate
+
+
+def test_compiler_code_never_writes_an_agpr_beside_the_asm_accumulators():
+    """The hand-scheduled K loops leave their accumulators in AGPRs and the C++ epilogues read them back with one-instruction asm
+    statements (`v_accvgpr_read_b32`); to the compiler the asm statement merely CLOBBERS a0..a255, so nothing tells it that they are
+    live afterwards -- on gfx90a+ the register allocator may park a VGPR value in an AGPR (`v_accvgpr_write_b32 aN, vM`) when an
+    epilogue's pressure gets high enough, silently corrupting an accumulator tile (seen in round 4: a wider conv epilogue made it
+    use a0..a4 in `convsw_kernel<8, UP>`; first row pair of every wave tile wrong).  Invariant, checked on the compiler's own
+    assembly of every file with such an epilogue: OUTSIDE the inline-asm regions there is no AGPR write at all."""
+    import concurrent.futures
+    import shutil
+    import tempfile
+
+    import pytest
+
+    from open_sora_amd import build
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    files = ["gemm256x.hip", "gemm256p.hip", "gemm256.hip", "conv3d_256.hip", "attention_asm72.hip", "attention_asm72w.hip",
+             "attention_asm72p8.hip", "attention_asm128.hip", "attention_asm128p8.hip"]
+    with tempfile.TemporaryDirectory() as d:
+        def compile_one(name):
+            out = os.path.join(d, name + ".s")
+            r = subprocess.run([hipcc, *build.FLAGS, "-S", "--cuda-device-only", "-x", "hip", os.path.join(CSRC, name), "-o", out],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-400:]
+            bad, kernel, in_asm, n_asm_reads = [], None, False, 0
+            for ln in open(out):
+                m = re.match(r"^(_Z\S+):", ln)
+                if m:
+                    kernel = m.group(1)
+                if "#ASMSTART" in ln:
+                    in_asm = True
+                elif "#ASMEND" in ln:
+                    in_asm = False
+                elif in_asm and "v_accvgpr_read_b32" in ln:
+                    n_asm_reads += 1
+                elif not in_asm and re.search(r"\sv_accvgpr_(write_b32|mov_b32) a\d+|\sv_mfma\w* a\[", ln):
+                    bad.append((kernel, ln.strip()))
+            return name, bad, n_asm_reads
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(9, os.cpu_count() or 4)) as ex:
+            results = list(ex.map(compile_one, files))
+    assert sum(n for _, _, n in results) > 500          # the scan sees the asm-side accumulator reads it is about
+    for name, bad, _ in results:
+        assert not bad, (name, len(bad), bad[:4])
