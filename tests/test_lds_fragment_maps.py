@@ -68,3 +68,40 @@ def test_lds_dma_piece_writes_whole_swizzled_rows():
             assert image_addr(r, c) == r * 128 + ((l & 7) << 4)   # lands at the lane's linear LDS position
             seen.add((r, c))
         assert len(seen) == 64
+
+
+def test_epilogue_quad_transpose_store_map():
+    """gemm_epilogue16.h::row_pair_wide / osk_common.h::quad_transpose, restated: after the lane-row exchange lane (q4, l15) holds,
+    for the row-block pair (I, I + 1) and column block J, the 16-byte chunk (row 16 (I + (q4 & 1)) + l15, columns 16 J + 8 (q4 >> 1));
+    two DPP butterfly steps (quad_perm [1,0,3,2] against register bit 0, [2,3,0,1] against bit 1) transpose (register, lane-of-quad);
+    the store of register r of group b then goes to (own row - j + r, columns 64 b + 16 j + 8 (q4 >> 1)), j = lane % 4.  Checked: the
+    label that arrives in every register IS the address it is stored to, the 128 x 128 wave tile is covered exactly once, and one
+    store instruction touches 8 rows x 128 contiguous bytes (round 3: 32 rows x 32 bytes)."""
+    import numpy as np
+
+    lanes = np.arange(64)
+    q4, l15, j = lanes >> 4, lanes & 15, lanes & 3
+    odd, hi = (lanes & 1).astype(bool), (lanes & 2).astype(bool)
+    swap1, swap2 = (lambda v: v[lanes ^ 1]), (lambda v: v[lanes ^ 2])
+    seen = set()
+    for I in (0, 2, 4, 6):
+        own = 16 * (I + (q4 & 1)) + l15
+        d = [own * 1000 + 16 * J + 8 * (q4 >> 1) for J in range(8)]            # label = row * 1000 + first column
+        for b in range(2):
+            x0, x1, x2, x3 = d[4 * b: 4 * b + 4]
+            s0, s1, s2, s3 = swap1(x0), swap1(x1), swap1(x2), swap1(x3)
+            y0, y1, y2, y3 = np.where(odd, s1, x0), np.where(odd, x1, s0), np.where(odd, s3, x2), np.where(odd, x3, s2)
+            t0, t1, t2, t3 = swap2(y0), swap2(y1), swap2(y2), swap2(y3)
+            d[4 * b: 4 * b + 4] = [np.where(hi, t2, y0), np.where(hi, t3, y1), np.where(hi, y2, t0), np.where(hi, y3, t1)]
+        for b in range(2):
+            for r in range(4):
+                row, col = own - j + r, 64 * b + 16 * j + 8 * (q4 >> 1)
+                assert (d[4 * b + r] == row * 1000 + col).all(), (I, b, r)
+                pieces = {}
+                for ln in lanes:
+                    key = (int(row[ln]), int(col[ln]))
+                    assert key not in seen
+                    seen.add(key)
+                    pieces.setdefault(key[0], []).append(key[1])
+                assert len(pieces) == 8 and all(sorted(c) == list(range(64 * b, 64 * b + 64, 8)) for c in pieces.values())
+    assert len(seen) == 128 * 16
