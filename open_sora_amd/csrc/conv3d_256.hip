@@ -22,6 +22,15 @@ namespace {
 OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v); }
 
+#ifdef OSK_CONV_TILE_TIMING   // tools/make_conv_timing_lib.sh: where a sliding-window tile's time goes (s_memtime sums of wave 0 of every workgroup)
+__device__ unsigned long long osk_conv_tile_ticks[4];   // address set-up, asm statement (prologue + K loop), epilogue, tiles
+#define OSK_CT(i, t0) if (threadIdx.x == 0) atomicAdd(&osk_conv_tile_ticks[i], __builtin_amdgcn_s_memtime() - (t0))
+#define OSK_CT_STAMP(name) const unsigned long long name = __builtin_amdgcn_s_memtime()
+#else
+#define OSK_CT(i, t0)
+#define OSK_CT_STAMP(name)
+#endif
+
 // Tile row -> output voxel (linear index over [B, To, Ho, Wo]).
 //   linear (brick = 0): row r of M-tile bm is voxel 256 bm + r: a tile is a run of 256 voxels along W.
 //   brick  (brick = 1, Ho % 16 == 0 and Wo % 16 == 0): M-tile bm = (spatial brick, frame) with the FRAME index fastest;
@@ -388,6 +397,7 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   const int sub = lane >> 2, pos = lane & 3;                     // an LDS-DMA piece = 16 rows of 64 bytes: lane -> (row, position)
 
   for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
+  OSK_CT_STAMP(ct0);
   const int tile = xcd_remap(it, ntiles);
   const int bm = tile / nbn, bn = tile - bm * nbn;
   const int n0 = bn * BN;
@@ -452,6 +462,8 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
   ::"v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(yb), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(hoff[0]),       \
       "v"(hoff[1]), "v"(hoff[2]), "v"(hoff[3]), "v"(hoff[4]), "v"(hoff[5]), "s"(wbase), "s"(xb[0]), "s"(xb[1]), "s"(xb[2]),  \
       "s"(xb[3]), "s"(cin2), "s"(nbody), "s"(dst), "s"(dst), "s"(dst5)
+  OSK_CT(0, ct0);
+  OSK_CT_STAMP(ct1);
   // GN form: + the LDS write address of each halo piece, this lane's 64 bytes inside a channel block's table rows, the table of batch b
 #define OSKSWG_OPERANDS                                                                                                      \
   ::"v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(yb), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(hoff[0]),       \
@@ -481,7 +493,13 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
 #include "convswu_body_n128.inc"
         OSKSW_OPERANDS : OSKSW128_CLOBBERS);
   }
+  OSK_CT(1, ct1);
+  OSK_CT_STAMP(ct2);
   epilogue_all_x<NBJ>(p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
+  OSK_CT(2, ct2);
+#ifdef OSK_CONV_TILE_TIMING
+  if (threadIdx.x == 0) atomicAdd(&osk_conv_tile_ticks[3], 1ull);
+#endif
   }   // tile loop
 }
 
@@ -512,6 +530,7 @@ __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
   const int sub = lane >> 2, pos = lane & 3;
 
   for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
+  OSK_CT_STAMP(ct0);
   const int bm = xcd_remap(it, ntiles);
   const int tp = bm % ntp, sb = bm / ntp;                          // tile_row_to_voxel()'s brick = 2 order
   const int wb = sb % nwb, qq = sb / nwb;
@@ -547,6 +566,8 @@ __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
     xb[d] = rfl64((uint64_t)(uintptr_t)(p.x + ((int64_t)b * p.T + fs) * p.H * p.W * p.Cin));
   }
   const uint64_t wbase = rfl64((uint64_t)(uintptr_t)p.w);
+  OSK_CT(0, ct0);
+  OSK_CT_STAMP(ct1);
   if constexpr (GN) {
     const unsigned goff = (unsigned)pos * 64;
     const uint64_t gbase = rfl64((uint64_t)(uintptr_t)(p.gn_in + (int64_t)b * p.Cin * 2));
@@ -558,7 +579,13 @@ __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
 #include "convswf_body_n128.inc"
         OSKSW_OPERANDS : OSKSW256_CLOBBERS);
   }
+  OSK_CT(1, ct1);
+  OSK_CT_STAMP(ct2);
   epilogue_all_x<NBJ>(p, bm, wave * 128, 0, 0, l15, q4, smem);
+  OSK_CT(2, ct2);
+#ifdef OSK_CONV_TILE_TIMING
+  if (threadIdx.x == 0) atomicAdd(&osk_conv_tile_ticks[3], 1ull);
+#endif
   }   // tile loop
 }
 
@@ -619,6 +646,15 @@ bool conv256_gn_in_supported(const ConvParams& p) {
   return convsw_supported(p) && !p.up_hw && (p.Cout >= 256 || (p.Cout == 128 && p.To >= 2));
 #endif
 }
+
+#ifdef OSK_CONV_TILE_TIMING
+// read and clear the tick sums (tools/conv_tile_timing.py)
+extern "C" int osk_conv_tile_timing_read(unsigned long long* out4) {
+  unsigned long long zero[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(osk_conv_tile_ticks), sizeof(zero)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(osk_conv_tile_ticks), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // 32-bit per-lane byte offsets: both tensors must span < 4 GiB; whole K steps per tap in pairs: Cin % 128 == 0
 bool conv256_supported(const ConvParams& p, int64_t x_bytes, int64_t w_bytes) {
