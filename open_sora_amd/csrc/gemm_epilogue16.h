@@ -83,7 +83,9 @@ OSK_DEV uint4 chunk_interior(const GemmParams& p, const int64_t* rowoff, int n0w
 }
 
 // one pair of row blocks (I, I + 1), all NB column blocks: NB chunks per lane, transposed in groups of four, NB stores of
-// 8 rows x 128 bytes.  own = element offset of this lane's own store row (storeoff[I / 2]: + its 8-column half), crs = row stride:
+// 8 rows x 128 bytes.  In-place residual (res == C, the blocks' x = x + gate * proj(..)): the stores of this call cover exactly the 32
+// rows x 16 NB columns whose residual pieces this call's tile_values() read, and every one of those loads is issued before the
+// first store (the transposes need all NB chunks), as in pair_interior.  own = element offset of this lane's own store row (storeoff[I / 2]: + its 8-column half), crs = row stride:
 // the rows of an interior wave tile lie in one batch item, so row 4 a + r is (r - j) rows from the lane's own row 4 a + j.
 template <class Geo, bool GATE, int GELU, int I, int... Js>
 OSK_DEV void row_pair_wide(const GemmParams& p, const int64_t* rowoff, int64_t own, int n0w, int q4, int lane, const float4* gq,
