@@ -8,6 +8,7 @@
 //  * V^T tile = 128 dim rows + the ones row 128 (softmax denominator = accumulator row 128, a fifth O^T row tile).
 // Numerics are those of the head_dim-72 kernel: P = exp2(S') with S' = q.k - M straight out of the MFMA, M moves only
 // when a row max exceeds it by more than 8 (log2 units).
+#include "acc_quads.h"
 #include "attention_params.h"
 #include "attention_asm_regs.inc"
 
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
 
   // ---- Q fragments (pre-scaled by scale*log2(e)) -> AGPRs; k-step 8 = padding (zero; dim 128 receives -M in the asm)
   int qi[NU];
+  osk_v4f qv[NU * 9];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     qi[u] = qb * 256 + wave * 64 + u * 32 + l31;
@@ -82,20 +84,12 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
     // FAST: with a score bound B <= 56 no softmax reference is needed for range control: the body skips the padding k-step
     // (whose only job is to carry the reference through the MFMA) and exponentiates the raw scores, P = exp2(s) in
     // [2^-56, 2^56]; O and the row sum carry the same factor (attention_asm128_n2_f0.inc, tools/gen_attn_asm.py "nom")
-#define OSK_QIN_A                                                                                            \
-  "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),    \
-      "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]), "v"(w[16]), "v"(w[17]), "v"(w[18]), \
-      "v"(w[19])
-#define OSK_QIN_B                                                                                            \
-  "v"(w[20]), "v"(w[21]), "v"(w[22]), "v"(w[23]), "v"(w[24]), "v"(w[25]), "v"(w[26]), "v"(w[27]), "v"(w[28]),     \
-      "v"(w[29]), "v"(w[30]), "v"(w[31]), "v"(w[32]), "v"(w[33]), "v"(w[34]), "v"(w[35])
-    if (u == 0) {
-      asm volatile(OSK128N2_QW0_0 ::OSK_QIN_A : OSK128N2_A_CLOBBERS);
-      asm volatile(OSK128N2_QW0_1 ::OSK_QIN_B : OSK128N2_A_CLOBBERS);
-    } else {
-      asm volatile(OSK128N2_QW1_0 ::OSK_QIN_A : OSK128N2_A_CLOBBERS);
-      asm volatile(OSK128N2_QW1_1 ::OSK_QIN_B : OSK128N2_A_CLOBBERS);
-    }
+    // Q fragments as VALUES: quad ks of block u; the loop statement takes them as inputs in their fixed AGPRs (acc_quads.h), so the
+    // compiler writes them there itself and knows they are live until the loop has read them
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qv[u * 9 + ks][i] = __uint_as_float(w[ks * 4 + i]);
   }
 
   // ---- per-lane LDS-DMA source offsets: K instruction j = wave + 4 i -> image j / 8, key rows 8 (j % 8) + lane / 8;
@@ -136,7 +130,8 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
   : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(koff[3]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), \
     "v"(fo[0]), "v"(fo[1]), "v"(fo[2]), "v"(fo[3]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(koffL[3]),      \
     "v"(maskval), "v"(onesaddr), "s"(kbase), "s"(vbase),                                                             \
-    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nvw)
+    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nvw), \
+    OSK_AQ_IN_40_5(qv), OSK_AQ_IN_45_4(qv + 5), OSK_AQ_IN_49_5(qv + 9), OSK_AQ_IN_54_4(qv + 14)
   if constexpr (FAST) {
     asm volatile(
 #include "attention_asm128_n2_f0.inc"
@@ -148,28 +143,21 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
         OSK128_OPERANDS : OSK128N2_CLOBBERS);
   }
 
+  // the O^T accumulators as values the compiler knows (acc_quads.h): outputs of an empty statement right behind the loop
+  static_assert(OSK128N2_AQ0 == 160 && OSK128N2_AQ1 == 196 && OSK128N2_AO_REGS == 160,
+                "the generated loops' register map: the operand lists above and below bind exactly these AGPRs");
+  osk_v4f ov[40];
+  asm volatile("" : OSK_AQ_OUT_0_40(ov));
+
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 128 (sum of P), store
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     float o[NDT][16];
 #pragma unroll
     for (int d = 0; d < NDT; ++d) {
-#define OSK_OOUT                                                                                             \
-  "=v"(o[d][0]), "=v"(o[d][1]), "=v"(o[d][2]), "=v"(o[d][3]), "=v"(o[d][4]), "=v"(o[d][5]), "=v"(o[d][6]),          \
-      "=v"(o[d][7]), "=v"(o[d][8]), "=v"(o[d][9]), "=v"(o[d][10]), "=v"(o[d][11]), "=v"(o[d][12]), "=v"(o[d][13]), \
-      "=v"(o[d][14]), "=v"(o[d][15])
-      switch (u * NDT + d) {
-        case 0: asm volatile(OSK128N2_OR0 : OSK_OOUT); break;
-        case 1: asm volatile(OSK128N2_OR1 : OSK_OOUT); break;
-        case 2: asm volatile(OSK128N2_OR2 : OSK_OOUT); break;
-        case 3: asm volatile(OSK128N2_OR3 : OSK_OOUT); break;
-        case 4: asm volatile(OSK128N2_OR4 : OSK_OOUT); break;
-        case 5: asm volatile(OSK128N2_OR5 : OSK_OOUT); break;
-        case 6: asm volatile(OSK128N2_OR6 : OSK_OOUT); break;
-        case 7: asm volatile(OSK128N2_OR7 : OSK_OOUT); break;
-        case 8: asm volatile(OSK128N2_OR8 : OSK_OOUT); break;
-        default: asm volatile(OSK128N2_OR9 : OSK_OOUT); break;
-      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)   // row tile (u, d) = registers 16 (u NDT + d) ..: in place, in program order
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(o[d][i]) : "a"(ov[(u * NDT + d) * 4 + i / 4][i % 4]));
     }
     // row 128 of O^T = sum_k P: row 0 of row tile 4 = lanes hi == 0, register 0
     const unsigned lu = __float_as_uint(o[4][0]);

@@ -2,6 +2,7 @@
 // head_dim-72 twin of attention_asm128p8.hip (see there): 4 waves x 64 query rows, QK^T and the softmax bookkeeping of
 // attention_asm72.hip, P and V^T as e4m3, one v_mfma_f32_32x32x64_f8f6f4 per O^T row tile (3 x 64 cycles instead of
 // 12 x 32), V^T with RP = 80 rows per head from osk_v_transpose_fp8 (72 dims, the ones / key-validity row 72, zero rows).
+#include "acc_quads.h"
 #include "attention_params.h"
 #include "attention_asm_regs.inc"
 
@@ -46,6 +47,7 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
 
   // ---- Q fragments, pre-scaled by scale*log2(e), -> AGPRs (u-major, k-step, 4 words)
   int qi[NU];
+  osk_v4f qv[NU * 5];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     qi[u] = qb * 256 + wave * (32 * NU) + u * 32 + l31;
@@ -67,15 +69,12 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
       }
       w[ks * 4 + 0] = s.x; w[ks * 4 + 1] = s.y; w[ks * 4 + 2] = s.z; w[ks * 4 + 3] = s.w;
     }
-#define OSK_QIN                                                                                              \
-  "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),    \
-      "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]), "v"(w[16]), "v"(w[17]), "v"(w[18]), \
-      "v"(w[19])
-    if (u == 0) {
-      asm volatile(OSK72P8N2_QW0_0 ::OSK_QIN : OSK72P8N2_A_CLOBBERS);
-    } else {
-      asm volatile(OSK72P8N2_QW1_0 ::OSK_QIN : OSK72P8N2_A_CLOBBERS);
-    }
+    // Q fragments as VALUES: quad ks of block u; the loop statement takes them as inputs in their fixed AGPRs (acc_quads.h), so the
+    // compiler writes them there itself and knows they are live until the loop has read them
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qv[u * 5 + ks][i] = __uint_as_float(w[ks * 4 + i]);
   }
 
   // ---- per-lane LDS-DMA source offsets (bytes from the loader's tile base) of this wave's instruction slots:
@@ -141,10 +140,17 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
   : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff8[0]), "v"(voff8[1]), "v"(fo[0]), "v"(fo[1]),                 \
     "v"(fo[2]), "v"(fo[3]), "v"(kc[0]), "v"(kc[1]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(vf0), "v"(vf1), \
     "s"(kbase), "s"(vbase),                                                                                          \
-    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw)
+    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tps), "s"(nt), "s"(kdst), "s"(vdst), "s"(nkw), "s"(nvw), \
+    OSK_AQ_IN_24_5(qv), OSK_AQ_IN_29_5(qv + 5)
   asm volatile(
 #include "attention_asm72p8_n2_v0.inc"
       OSK72P8_OPERANDS : OSK72P8N2_CLOBBERS);
+
+  // the O^T accumulators as values the compiler knows (acc_quads.h): outputs of an empty statement right behind the loop
+  static_assert(OSK72P8N2_AQ0 == 96 && OSK72P8N2_AQ1 == 116 && OSK72P8N2_AO_REGS == 96,
+                "the generated loop's register map: the operand lists above and below bind exactly these AGPRs");
+  osk_v4f ov[24];
+  asm volatile("" : OSK_AQ_OUT_0_24(ov));
 
   // ---- epilogue: O^T out of the AGPRs, normalise by accumulator row 72 (sum of P), store
 #pragma unroll
@@ -152,25 +158,9 @@ __global__ void __launch_bounds__(NU == 2 ? 256 : 512, NU == 2 ? 1 : 2) attn_asm
     float o[NDT][16];
 #pragma unroll
     for (int d = 0; d < NDT; ++d) {
-#define OSK_OOUT                                                                                             \
-  "=v"(o[d][0]), "=v"(o[d][1]), "=v"(o[d][2]), "=v"(o[d][3]), "=v"(o[d][4]), "=v"(o[d][5]), "=v"(o[d][6]),          \
-      "=v"(o[d][7]), "=v"(o[d][8]), "=v"(o[d][9]), "=v"(o[d][10]), "=v"(o[d][11]), "=v"(o[d][12]), "=v"(o[d][13]), \
-      "=v"(o[d][14]), "=v"(o[d][15])
-      if constexpr (NU == 2) {
-        if (u == 0 && d == 0) {
-          asm volatile(OSK72P8N2_OR0 : OSK_OOUT);
-        } else if (u == 0 && d == 1) {
-          asm volatile(OSK72P8N2_OR1 : OSK_OOUT);
-        } else if (u == 0 && d == 2) {
-          asm volatile(OSK72P8N2_OR2 : OSK_OOUT);
-        } else if (u == 1 && d == 0) {
-          asm volatile(OSK72P8N2_OR3 : OSK_OOUT);
-        } else if (u == 1 && d == 1) {
-          asm volatile(OSK72P8N2_OR4 : OSK_OOUT);
-        } else {
-          asm volatile(OSK72P8N2_OR5 : OSK_OOUT);
-        }
-      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)   // row tile (u, d) = registers 16 (u NDT + d) ..: in place, in program order
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(o[d][i]) : "a"(ov[(u * NDT + d) * 4 + i / 4][i % 4]));
     }
     // row 72 of O^T = sum_k P: lanes hi == 0, register (8 & 3) + 4 (8 >> 3) = 4 of row tile 2
     const unsigned lu = __float_as_uint(o[2][4]);

@@ -9,6 +9,7 @@
 //     instead of 188, half the LDS fragment traffic and half the LDS-DMA issue per flop.  O^T: 160 AGPRs, Q: 80, 252 VGPRs.
 // Only the bounded body exists in this layout (the general running-reference body needs its max-chain temporaries where the fifth
 // V^T fragment slot lives); the entry point takes it for bounded calls with Lq >= 1024 (attention_fwd.hip).
+#include "acc_quads.h"
 #include "attention_params.h"
 #include "attention_asm_regs.inc"
 
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
 
   // ---- Q fragments, pre-scaled by scale*log2(e), -> AGPRs (u-major, k-step, 4 words)
   int qi[NU];
+  osk_v4f qv[NU * 5];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     qi[u] = qb * ROWS + wave * (32 * NU) + u * 32 + l31;
@@ -98,14 +100,12 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
     if constexpr (FAST) {
       if (hi) w[16] = (__float_as_uint(-p.bound) >> 16) & 0xFFFFu;
     }
-#define OSK_QIN                                                                                              \
-  "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),    \
-      "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]), "v"(w[16]), "v"(w[17]), "v"(w[18]), \
-      "v"(w[19])
-    if (u == 0) asm volatile(OSK72W_QW0 ::OSK_QIN : OSK72W_A_CLOBBERS);
-    else if (u == 1) asm volatile(OSK72W_QW1 ::OSK_QIN : OSK72W_A_CLOBBERS);
-    else if (u == 2) asm volatile(OSK72W_QW2 ::OSK_QIN : OSK72W_A_CLOBBERS);
-    else asm volatile(OSK72W_QW3 ::OSK_QIN : OSK72W_A_CLOBBERS);
+    // Q fragments as VALUES: quad ks of block u; the loop statement takes them as inputs in their fixed AGPRs (acc_quads.h), so the
+    // compiler writes them there itself and knows they are live until the loop has read them
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qv[u * 5 + ks][i] = __uint_as_float(w[ks * 4 + i]);
   }
 
   // ---- per-lane LDS-DMA source offsets (bytes from the loader's tile base) of this wave's instruction slots:
@@ -173,34 +173,30 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
   : "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(fo[0]), "v"(fo[1]),     \
     "v"(fo[2]), "v"(fo[3]), "v"(kc[0]), "v"(kc[1]), "v"(koffL[0]), "v"(koffL[1]), "v"(koffL[2]), "v"(maskval),      \
     "v"(onesaddr), "v"(vo[0]), "v"(vo[1]), "s"(kbase), "s"(vbase),                                                   \
-    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tpsnt), "s"(kdst), "s"(vdst), "s"(nkvw)
+    "s"(kstep), "s"(kjump), "s"(vjump), "s"(tpsnt), "s"(kdst), "s"(vdst), "s"(nkvw), \
+    OSK_AQ_IN_40_5(qv), OSK_AQ_IN_45_5(qv + 5), OSK_AQ_IN_50_5(qv + 10), OSK_AQ_IN_55_5(qv + 15)
   asm volatile(
 #include "attention_asm72w_f0.inc"
       OSK72_OPERANDS : OSK72W_CLOBBERS);
   m_ref[0] = m_ref[1] = p.bound;
 
+  // the O^T accumulators as values the compiler knows (acc_quads.h): outputs of an empty statement right behind the loop
+  static_assert(OSK72W_AQ0 == 160 && OSK72W_AQ1 == 180 && OSK72W_AQ2 == 200 && OSK72W_AQ3 == 220 && OSK72W_AO_REGS == 160,
+                "the generated loop's register map: the operand lists above and below bind exactly these AGPRs");
+  osk_v4f ov[40];
+  asm volatile("" : OSK_AQ_OUT_0_40(ov));
+
   // ---- epilogue: O^T out of the AGPRs -- per 16-query block (u, half): lane = query l15, dims 16 db + 4 r4 + i in register
   //      4 db + i -- normalise by accumulator row 72 (sum of P: block 4, lane row 2, register 0), store
   static_assert(OSK72_NDB == 5, "epilogue written for 5 row blocks of 16");
-#define OSK_OOUT20                                                                                                   \
-  "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]), "=v"(o[4]), "=v"(o[5]), "=v"(o[6]), "=v"(o[7]), "=v"(o[8]), "=v"(o[9]), \
-      "=v"(o[10]), "=v"(o[11]), "=v"(o[12]), "=v"(o[13]), "=v"(o[14]), "=v"(o[15]), "=v"(o[16]), "=v"(o[17]), "=v"(o[18]),  \
-      "=v"(o[19])
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float o[20];
-      switch (u * 2 + half) {
-        case 0: asm volatile(OSK72W_OR0 : OSK_OOUT20); break;
-        case 1: asm volatile(OSK72W_OR1 : OSK_OOUT20); break;
-        case 2: asm volatile(OSK72W_OR2 : OSK_OOUT20); break;
-        case 3: asm volatile(OSK72W_OR3 : OSK_OOUT20); break;
-        case 4: asm volatile(OSK72W_OR4 : OSK_OOUT20); break;
-        case 5: asm volatile(OSK72W_OR5 : OSK_OOUT20); break;
-        case 6: asm volatile(OSK72W_OR6 : OSK_OOUT20); break;
-        default: asm volatile(OSK72W_OR7 : OSK_OOUT20); break;
-      }
+#pragma unroll
+      for (int i = 0; i < 20; ++i)   // block (u, half) = registers 20 (2 u + half) ..: in place, in program order
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(o[i]) : "a"(ov[(u * 2 + half) * 5 + i / 4][i % 4]));
       const float l_tot = __shfl(o[16], 32 + l15, 64);
       const float inv = 1.0f / l_tot;
       // the reference max lives in the SCORE layout (lane = query lane % 32 of block u): fetch this lane's query's

@@ -11,6 +11,7 @@
 // profiles/r02_* -- and are generator options / git history now.)
 //
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 2 * Cin * Cout * k^3 * B*To*Ho*Wo.
+#include "acc_quads.h"
 #include "conv_params.h"
 #include "gemm256x_regs.inc"
 #include "convsw_regs.inc"
@@ -101,21 +102,18 @@ typedef __bf16 gn_bf16x2_t __attribute__((ext_vector_type(2)));
 // cheaper one per flop, profiles/r02_gemm_experiments.md): 8 x 8 accumulator tiles of 16 x 16 per wave, the same LDS image read
 // through a 16-row x 32-k lane map, K loop conv256x_body.inc (tools/gen_gemm_asm.py::gen_conv_x4).  Of every 16 x 16 tile
 // (J = channel block, I = voxel block) a lane owns voxel row 16 I + l15 and channels 16 J + 4 q4 .. + 3.
-#define OSKCX_OUT4 "=v"(v4[0]), "=v"(v4[1]), "=v"(v4[2]), "=v"(v4[3])
+// tile T's 4 accumulators = quad T of aq: the wave's accumulators as compiler-visible values (acc_quads.h: outputs of an empty asm
+// statement behind the K-loop statement), read in place and in program order
 template <int T>
-OSK_DEV void read_x(float* v4) {
-#define OSKCX_CASE(t) else if constexpr (T == t) asm volatile(OSKX_AR##t : OSKCX_OUT4)
-  if constexpr (T < 0) {}
-  OSKCX_CASE(0); OSKCX_CASE(1); OSKCX_CASE(2); OSKCX_CASE(3); OSKCX_CASE(4); OSKCX_CASE(5); OSKCX_CASE(6); OSKCX_CASE(7);
-  OSKCX_CASE(8); OSKCX_CASE(9); OSKCX_CASE(10); OSKCX_CASE(11); OSKCX_CASE(12); OSKCX_CASE(13); OSKCX_CASE(14); OSKCX_CASE(15);
-  OSKCX_CASE(16); OSKCX_CASE(17); OSKCX_CASE(18); OSKCX_CASE(19); OSKCX_CASE(20); OSKCX_CASE(21); OSKCX_CASE(22); OSKCX_CASE(23);
-  OSKCX_CASE(24); OSKCX_CASE(25); OSKCX_CASE(26); OSKCX_CASE(27); OSKCX_CASE(28); OSKCX_CASE(29); OSKCX_CASE(30); OSKCX_CASE(31);
-  OSKCX_CASE(32); OSKCX_CASE(33); OSKCX_CASE(34); OSKCX_CASE(35); OSKCX_CASE(36); OSKCX_CASE(37); OSKCX_CASE(38); OSKCX_CASE(39);
-  OSKCX_CASE(40); OSKCX_CASE(41); OSKCX_CASE(42); OSKCX_CASE(43); OSKCX_CASE(44); OSKCX_CASE(45); OSKCX_CASE(46); OSKCX_CASE(47);
-  OSKCX_CASE(48); OSKCX_CASE(49); OSKCX_CASE(50); OSKCX_CASE(51); OSKCX_CASE(52); OSKCX_CASE(53); OSKCX_CASE(54); OSKCX_CASE(55);
-  OSKCX_CASE(56); OSKCX_CASE(57); OSKCX_CASE(58); OSKCX_CASE(59); OSKCX_CASE(60); OSKCX_CASE(61); OSKCX_CASE(62); OSKCX_CASE(63);
-#undef OSKCX_CASE
+OSK_DEV void read_x(const osk_v4f* aq, float* v4) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v4[i]) : "a"(aq[T][i]));
 }
+static_assert(OSKX_ACC_QUADS == 64 && OSKX128_ACC_QUADS == 32, "the generated loops' accumulator map: quad T = tile T");
+#define OSKCX_ACC(NBJ_, aq)                                     \
+  osk_v4f aq[(NBJ_) * 8];                                       \
+  if constexpr ((NBJ_) == 8) asm volatile("" : OSK_AQ_OUT_0_64(aq)); \
+  else asm volatile("" : OSK_AQ_OUT_0_32(aq))
 
 // sum over the 16 lanes of a lane row, in every lane (the DPP half of half_wave_sum)
 OSK_DEV float row16_sum(float v) {
@@ -131,7 +129,7 @@ OSK_DEV float row16_sum(float v) {
 // fast path of one pair of voxel blocks (I, I + 1) of channel block J: whole 16-channel block inside Cout, rows 16-byte
 // addressable.  RES / GN are compile-time, bias arrives as a register quad: 64 tiles per wave make per-tile branches count.
 template <bool RES, bool GN, int J, int I>
-OSK_DEV void pair_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid,
+OSK_DEV void pair_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid,
                     int n, int ncol, const float4& bq, float& gs, float& gq) {
   float a0[4], a1[4];
   uint2 r0 = make_uint2(0, 0), r1 = r0;
@@ -139,8 +137,8 @@ OSK_DEV void pair_x(const ConvParams& p, const int64_t* rowoff, const bool* vali
     r0 = *reinterpret_cast<const uint2*>(p.res + rowoff[I] + n);        // rows beyond M read row 0 (clamped offsets)
     r1 = *reinterpret_cast<const uint2*>(p.res + rowoff[I + 1] + n);
   }
-  read_x<J * OSKX_NB + I>(a0);
-  read_x<J * OSKX_NB + I + 1>(a1);
+  read_x<J * OSKX_NB + I>(aq, a0);
+  read_x<J * OSKX_NB + I + 1>(aq, a1);
   a0[0] += bq.x; a0[1] += bq.y; a0[2] += bq.z; a0[3] += bq.w;
   a1[0] += bq.x; a1[1] += bq.y; a1[2] += bq.z; a1[3] += bq.w;
   if constexpr (RES) {
@@ -172,15 +170,15 @@ OSK_DEV void pair_x(const ConvParams& p, const int64_t* rowoff, const bool* vali
 // right (with the channel block outermost the pieces of one 64-byte sector left four stores apart: +30 % fabric-side writes).
 // FULL: every channel block of the wave tile lies inside Cout (no per-block test)
 template <bool RES, bool GN, bool FULL, int I, int... Js>
-OSK_DEV void rowpair_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid,
+OSK_DEV void rowpair_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid,
                        int n0w, int q4, const float4* bq, float* gs, float* gq, std::integer_sequence<int, Js...>) {
   ((FULL || n0w + Js * 16 < p.Cout
-        ? pair_x<RES, GN, Js, I>(p, rowoff, valid, storeoff, svalid, n0w + Js * 16 + q4 * 4, n0w + Js * 16, bq[Js], gs[Js], gq[Js])
+        ? pair_x<RES, GN, Js, I>(aq, p, rowoff, valid, storeoff, svalid, n0w + Js * 16 + q4 * 4, n0w + Js * 16, bq[Js], gs[Js], gq[Js])
         : (void)0), ...);
 }
 
 template <bool RES, bool GN, bool FULL, int NBJ, int... Is>
-OSK_DEV void tile_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid, int n0,
+OSK_DEV void tile_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid, int n0,
                     int n0w, int l15, int q4, float* ls, std::integer_sequence<int, Is...>) {
   float4 bq[NBJ];
   float gs[NBJ], gq[NBJ];
@@ -191,7 +189,7 @@ OSK_DEV void tile_x(const ConvParams& p, const int64_t* rowoff, const bool* vali
     const int n = n0w + j * 16 + q4 * 4;
     if (p.bias && (FULL || n < p.Cout)) bq[j] = *reinterpret_cast<const float4*>(p.bias + n);
   }
-  (rowpair_x<RES, GN, FULL, 2 * Is>(p, rowoff, valid, storeoff, svalid, n0w, q4, bq, gs, gq, std::make_integer_sequence<int, NBJ>{}), ...);
+  (rowpair_x<RES, GN, FULL, 2 * Is>(aq, p, rowoff, valid, storeoff, svalid, n0w, q4, bq, gs, gq, std::make_integer_sequence<int, NBJ>{}), ...);
   if constexpr (GN) {
     const int cpg = p.Cout / p.gn_G;
 #pragma unroll
@@ -208,19 +206,19 @@ OSK_DEV void tile_x(const ConvParams& p, const int64_t* rowoff, const bool* vali
 }
 
 template <bool RES, bool GN, int NBJ>
-OSK_DEV void cols_x(const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid, int n0,
+OSK_DEV void cols_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid, int n0,
                     int n0w, int l15, int q4, float* ls) {
   constexpr auto seq = std::make_integer_sequence<int, OSKX_NB / 2>{};
-  if (n0w + NBJ * 16 <= p.Cout) tile_x<RES, GN, true, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, seq);
-  else tile_x<RES, GN, false, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, seq);   // ragged last tile column
+  if (n0w + NBJ * 16 <= p.Cout) tile_x<RES, GN, true, NBJ>(aq, p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, seq);
+  else tile_x<RES, GN, false, NBJ>(aq, p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls, seq);   // ragged last tile column
 }
 
 // generic path of one tile (any Cout, any alignment): per-element bounds checks, no statistics
 template <int T>
-OSK_DEV void tile_x_generic(const ConvParams& p, int bm, int r0w, int n0w, int l15, int q4) {
+OSK_DEV void tile_x_generic(const osk_v4f* aq, const ConvParams& p, int bm, int r0w, int n0w, int l15, int q4) {
   constexpr int J = T / OSKX_NB, I = T % OSKX_NB;
   float acc[4];
-  read_x<T>(acc);
+  read_x<T>(aq, acc);
   const int m = tile_row_to_voxel(p, bm, r0w + I * 16 + l15);
   if (m >= p.M) return;
   const int64_t roff = (int64_t)m * p.Cout;
@@ -232,14 +230,14 @@ OSK_DEV void tile_x_generic(const ConvParams& p, int bm, int r0w, int n0w, int l
   }
 }
 template <int... Ts>
-OSK_DEV void tiles_x_generic(const ConvParams& p, int bm, int r0w, int n0w, int l15, int q4, std::integer_sequence<int, Ts...>) {
-  (tile_x_generic<Ts>(p, bm, r0w, n0w, l15, q4), ...);
+OSK_DEV void tiles_x_generic(const osk_v4f* aq, const ConvParams& p, int bm, int r0w, int n0w, int l15, int q4, std::integer_sequence<int, Ts...>) {
+  (tile_x_generic<Ts>(aq, p, bm, r0w, n0w, l15, q4), ...);
 }
 
 // the whole workgroup calls this after its K loop (see epilogue_all): NBJ = 16-channel blocks per wave (8: 256 channels per
 // workgroup tile from n0, 4: 128)
 template <int NBJ>
-OSK_DEV void epilogue_all_x(const ConvParams& p, int bm, int r0w, int n0, int n0w, int l15, int q4, unsigned char* smem) {
+OSK_DEV void epilogue_all_x(const osk_v4f* aq, const ConvParams& p, int bm, int r0w, int n0, int n0w, int l15, int q4, unsigned char* smem) {
   constexpr int NB = OSKX_NB, BN = 32 * NBJ;
   const bool fast = (p.Cout & 15) == 0 && ((((uintptr_t)p.out) & 15) == 0) && (!p.res || (((uintptr_t)p.res) & 7) == 0) &&
                     (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
@@ -256,7 +254,7 @@ OSK_DEV void epilogue_all_x(const ConvParams& p, int bm, int r0w, int n0, int n0
   }
   if (n0w < p.Cout) {                      // wave tiles entirely beyond Cout have nothing to store
     if (!fast) {
-      tiles_x_generic(p, bm, r0w, n0w, l15, q4, std::make_integer_sequence<int, NB * NBJ>{});
+      tiles_x_generic(aq, p, bm, r0w, n0w, l15, q4, std::make_integer_sequence<int, NB * NBJ>{});
     } else {
       // element offsets of this lane's NB voxel rows (rows beyond M: clamped to row 0 for loads, masked for stores and
       // statistics) and of the NB / 2 rows it STORES after the lane-row exchange (+ its 8-channel half)
@@ -274,11 +272,11 @@ OSK_DEV void epilogue_all_x(const ConvParams& p, int bm, int r0w, int n0, int n0
         svalid[i] = (q4 & 1) ? valid[2 * i + 1] : valid[2 * i];
       }
       if (p.gn_sums) {
-        if (p.res) cols_x<true, true, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
-        else cols_x<false, true, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
+        if (p.res) cols_x<true, true, NBJ>(aq, p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
+        else cols_x<false, true, NBJ>(aq, p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
       } else {
-        if (p.res) cols_x<true, false, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
-        else cols_x<false, false, NBJ>(p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
+        if (p.res) cols_x<true, false, NBJ>(aq, p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
+        else cols_x<false, false, NBJ>(aq, p, rowoff, valid, storeoff, svalid, n0, n0w, l15, q4, ls);
       }
     }
   }
@@ -346,7 +344,8 @@ __global__ void __launch_bounds__(256, 1) conv256x_kernel(const ConvParams p) {
 #include "conv256x_body_n128.inc"
         OSKCX_OPERANDS : OSKX128_CONV_CLOBBERS);
   }
-  epilogue_all_x<NBJ>(p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
+  OSKCX_ACC(NBJ, aq);
+  epilogue_all_x<NBJ>(aq, p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
   }   // tile loop
 }
 
@@ -493,9 +492,10 @@ __global__ void __launch_bounds__(256, 1) convsw_kernel(const ConvParams p) {
 #include "convswu_body_n128.inc"
         OSKSW_OPERANDS : OSKSW128_CLOBBERS);
   }
+  OSKCX_ACC(NBJ, aq);
   OSK_CT(1, ct1);
   OSK_CT_STAMP(ct2);
-  epilogue_all_x<NBJ>(p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
+  epilogue_all_x<NBJ>(aq, p, bm, wm * WT, n0, n0 + wn * WTN, l15, q4, smem);
   OSK_CT(2, ct2);
 #ifdef OSK_CONV_TILE_TIMING
   if (threadIdx.x == 0) atomicAdd(&osk_conv_tile_ticks[3], 1ull);
@@ -579,9 +579,10 @@ __global__ void __launch_bounds__(256, 1) convsw2_kernel(const ConvParams p) {
 #include "convswf_body_n128.inc"
         OSKSW_OPERANDS : OSKSW256_CLOBBERS);
   }
+  OSKCX_ACC(NBJ, aq);
   OSK_CT(1, ct1);
   OSK_CT_STAMP(ct2);
-  epilogue_all_x<NBJ>(p, bm, wave * 128, 0, 0, l15, q4, smem);
+  epilogue_all_x<NBJ>(aq, p, bm, wave * 128, 0, 0, l15, q4, smem);
   OSK_CT(2, ct2);
 #ifdef OSK_CONV_TILE_TIMING
   if (threadIdx.x == 0) atomicAdd(&osk_conv_tile_ticks[3], 1ull);

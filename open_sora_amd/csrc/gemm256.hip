@@ -15,6 +15,7 @@
 // gemm256_fp8_body_n*.inc on v_mfma_f32_32x32x64_f8f6f4 (2x the bf16 MAC rate), epilogue v = acc * sa[m] * sw[n] first.
 //
 // Roofline: MFMA bf16 (fp8 instantiation: MFMA fp8).  Algorithmic FLOPs = 2*M*N*K.
+#include "acc_quads.h"
 #include "gemm_params.h"
 #include "gemm256_regs_n256.inc"
 #include "gemm256_regs_n128.inc"
@@ -27,34 +28,18 @@ namespace {
 OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v); }
 
-#define OSKG_OUT16                                                                                               \
-  "=v"(v16[0]), "=v"(v16[1]), "=v"(v16[2]), "=v"(v16[3]), "=v"(v16[4]), "=v"(v16[5]), "=v"(v16[6]), "=v"(v16[7]),    \
-      "=v"(v16[8]), "=v"(v16[9]), "=v"(v16[10]), "=v"(v16[11]), "=v"(v16[12]), "=v"(v16[13]), "=v"(v16[14]),          \
-      "=v"(v16[15])
-
-template <int BN, int T>
-OSK_DEV void read_acc(float* v16) {
-  if constexpr (BN == 256) {
-    if constexpr (T == 0) asm volatile(OSKG256_AR0 : OSKG_OUT16);
-    else if constexpr (T == 1) asm volatile(OSKG256_AR1 : OSKG_OUT16);
-    else if constexpr (T == 2) asm volatile(OSKG256_AR2 : OSKG_OUT16);
-    else if constexpr (T == 3) asm volatile(OSKG256_AR3 : OSKG_OUT16);
-    else if constexpr (T == 4) asm volatile(OSKG256_AR4 : OSKG_OUT16);
-    else if constexpr (T == 5) asm volatile(OSKG256_AR5 : OSKG_OUT16);
-    else if constexpr (T == 6) asm volatile(OSKG256_AR6 : OSKG_OUT16);
-    else asm volatile(OSKG256_AR7 : OSKG_OUT16);
-  } else {
-    if constexpr (T == 0) asm volatile(OSKG128_AR0 : OSKG_OUT16);
-    else if constexpr (T == 1) asm volatile(OSKG128_AR1 : OSKG_OUT16);
-    else if constexpr (T == 2) asm volatile(OSKG128_AR2 : OSKG_OUT16);
-    else asm volatile(OSKG128_AR3 : OSKG_OUT16);
-  }
+// tile T's 16 accumulators = quads 4 T .. 4 T + 3 of aq (acc_quads.h: compiler-visible values, outputs of an empty asm statement
+// behind the K loop): read in place and in program order
+template <int T>
+OSK_DEV void read_acc(const osk_v4f* aq, float* v16) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v16[i]) : "a"(aq[4 * T + i / 4][i % 4]));
 }
 
 // one 32 x 32 accumulator tile T = tn * TM + tm.  INTERIOR: the wave's whole tile lies inside C (wave-uniform), so
 // there is no per-element bounds check and the column vectors (bias, gate) were loaded once per tn by the caller.
 template <int BN, bool OUT_F32, bool FP8, bool INTERIOR, int T>
-OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int hi, const float4* bq, const float4* gq,
+OSK_DEV void epilogue_tile(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l31, int hi, const float4* bq, const float4* gq,
                            const float4* sq) {
   constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   constexpr int tn = T / TM, tm = T % TM;
@@ -70,7 +55,7 @@ OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int h
         rv[qd] = *reinterpret_cast<const uint2*>(p.res + roff + n0w + tn * 32 + qd * 8 + hi * 4);
     }
     float acc[16];
-    read_acc<BN, T>(acc);
+    read_acc<T>(aq, acc);
     float sa = 1.f;
     if constexpr (FP8) sa = p.sa[mc];
     uint2 packed[4];
@@ -120,7 +105,7 @@ OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int h
     }
   } else {
     float acc[16];
-    read_acc<BN, T>(acc);
+    read_acc<T>(aq, acc);
     if (m >= p.M) return;
     const float* grow = p.gate ? p.gate + b * p.gbs : nullptr;
 #pragma unroll
@@ -140,7 +125,7 @@ OSK_DEV void epilogue_tile(const GemmParams& p, int m0w, int n0w, int l31, int h
 }
 
 template <int BN, bool OUT_F32, bool FP8, bool INTERIOR, int... Ts>
-OSK_DEV void epilogue_tn(const GemmParams& p, int m0w, int n0w, int l31, int hi, std::integer_sequence<int, Ts...>) {
+OSK_DEV void epilogue_tn(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l31, int hi, std::integer_sequence<int, Ts...>) {
   // Ts = the TM tiles of one tn: column vectors once, then the row tiles
   constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   constexpr int tn = ((Ts, ...)) / TM;  // all Ts share tn
@@ -157,18 +142,18 @@ OSK_DEV void epilogue_tn(const GemmParams& p, int m0w, int n0w, int l31, int hi,
       if constexpr (FP8) sq[qd] = *reinterpret_cast<const float4*>(p.sw + n);
     }
   }
-  (epilogue_tile<BN, OUT_F32, FP8, INTERIOR, Ts>(p, m0w, n0w, l31, hi, bq, gq, sq), ...);
+  (epilogue_tile<BN, OUT_F32, FP8, INTERIOR, Ts>(aq, p, m0w, n0w, l31, hi, bq, gq, sq), ...);
 }
 
 template <int BN, bool OUT_F32, bool FP8, bool INTERIOR>
-OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l31, int hi) {
+OSK_DEV void epilogue_all(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l31, int hi) {
   constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   if constexpr (TM == 4) {
-    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1, 2, 3>{});
-    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 4, 5, 6, 7>{});
+    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(aq, p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1, 2, 3>{});
+    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(aq, p, m0w, n0w, l31, hi, std::integer_sequence<int, 4, 5, 6, 7>{});
   } else {
-    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1>{});
-    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(p, m0w, n0w, l31, hi, std::integer_sequence<int, 2, 3>{});
+    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(aq, p, m0w, n0w, l31, hi, std::integer_sequence<int, 0, 1>{});
+    epilogue_tn<BN, OUT_F32, FP8, INTERIOR>(aq, p, m0w, n0w, l31, hi, std::integer_sequence<int, 2, 3>{});
   }
 }
 
@@ -242,13 +227,17 @@ __global__ void __launch_bounds__(512, 2) gemm256_kernel(const GemmParams p) {
         OSKG_OPERANDS : OSKQ128_CLOBBERS);
   }
   (void)NWD;
+  static_assert(OSKG256_ACC_QUADS == 32 && OSKG128_ACC_QUADS == 16, "the generated loops' accumulator map: tile t = quads 4 t .. 4 t + 3");
+  osk_v4f aq[TM * TN * 4];
+  if constexpr (BN == 256) asm volatile("" : OSK_AQ_OUT_0_32(aq));
+  else asm volatile("" : OSK_AQ_OUT_0_16(aq));
 
   // ---- epilogue: lane owns row m = ... + l31, columns n = quad*8 + hi*4 + {0..3} of every 32 x 32 tile
   const int m0w = m0 + wm * TM * 32, n0w = n0 + wn * TN * 32;
   const int b_first = m0w / p.crpb, b_last = (m0w + TM * 32 - 1) / p.crpb;
   const bool interior = m0w + TM * 32 <= p.M && n0w + TN * 32 <= p.N && b_first == b_last;  // wave-uniform
-  if (interior) epilogue_all<BN, OUT_F32, FP8, true>(p, m0w, n0w, l31, hi);
-  else epilogue_all<BN, OUT_F32, FP8, false>(p, m0w, n0w, l31, hi);
+  if (interior) epilogue_all<BN, OUT_F32, FP8, true>(aq, p, m0w, n0w, l31, hi);
+  else epilogue_all<BN, OUT_F32, FP8, false>(aq, p, m0w, n0w, l31, hi);
 }
 
 template <int BN, bool OUT_F32, bool FP8>

@@ -27,28 +27,11 @@ namespace {
 OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v); }
 
-#define OSKP_OUT16                                                                                               \
-  "=v"(v16[0]), "=v"(v16[1]), "=v"(v16[2]), "=v"(v16[3]), "=v"(v16[4]), "=v"(v16[5]), "=v"(v16[6]), "=v"(v16[7]),    \
-      "=v"(v16[8]), "=v"(v16[9]), "=v"(v16[10]), "=v"(v16[11]), "=v"(v16[12]), "=v"(v16[13]), "=v"(v16[14]),          \
-      "=v"(v16[15])
-
-template <int BN, int T>
-OSK_DEV void read_acc(float* v16) {
-  if constexpr (BN == 256) {
-    if constexpr (T == 0) asm volatile(OSKG256_AR0 : OSKP_OUT16);
-    else if constexpr (T == 1) asm volatile(OSKG256_AR1 : OSKP_OUT16);
-    else if constexpr (T == 2) asm volatile(OSKG256_AR2 : OSKP_OUT16);
-    else if constexpr (T == 3) asm volatile(OSKG256_AR3 : OSKP_OUT16);
-    else if constexpr (T == 4) asm volatile(OSKG256_AR4 : OSKP_OUT16);
-    else if constexpr (T == 5) asm volatile(OSKG256_AR5 : OSKP_OUT16);
-    else if constexpr (T == 6) asm volatile(OSKG256_AR6 : OSKP_OUT16);
-    else asm volatile(OSKG256_AR7 : OSKP_OUT16);
-  } else {
-    if constexpr (T == 0) asm volatile(OSKG128_AR0 : OSKP_OUT16);
-    else if constexpr (T == 1) asm volatile(OSKG128_AR1 : OSKP_OUT16);
-    else if constexpr (T == 2) asm volatile(OSKG128_AR2 : OSKP_OUT16);
-    else asm volatile(OSKG128_AR3 : OSKP_OUT16);
-  }
+// tile T's 16 accumulators = quads 4 T .. 4 T + 3 of aq (acc_quads.h): read in place and in program order
+template <int T>
+OSK_DEV void read_acc(const osk_v4f* aq, float* v16) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v16[i]) : "a"(aq[4 * T + i / 4][i % 4]));
 }
 
 template <int BN>
@@ -56,7 +39,7 @@ struct Geo {
   static constexpr int TM = BN == 256 ? OSKG256_TM : OSKG128_TM;
   static constexpr int TN = BN == 256 ? OSKG256_TN : OSKG128_TN;
   template <int T>
-  OSK_DEV void read(float* v16) { read_acc<BN, T>(v16); }
+  OSK_DEV void read(const osk_v4f* aq, float* v16) { read_acc<T>(aq, v16); }
 };
 
 // SCHED: K-step schedule of the generated body (tools/gen_gemm_asm.py::gen_pers): 0 = the round-1 order (fragment reads
@@ -142,10 +125,14 @@ __global__ void __launch_bounds__(512, 2) gemm256p_kernel(const GemmParams p) {
     asm volatile(
 #include "gemm256p_body_n128_s0.inc"
         OSKP_OPERANDS : OSKP128_CLOBBERS);
+    static_assert(BN == 128, "accumulator quads below: 64 registers");
+    static_assert(OSKG128_ACC_QUADS == 16, "the generated loop's accumulator map: tile t = quads 4 t .. 4 t + 3");
+    osk_v4f aq[16];
+    asm volatile("" : OSK_AQ_OUT_0_16(aq));
 
     const int b_first = m0w / p.crpb, b_last = (m0w + TM * 32 - 1) / p.crpb;
     const bool interior = m0w + TM * 32 <= p.M && n0w + TN * 32 <= p.N && b_first == b_last;  // wave-uniform
-    epi::epilogue_all<Geo<BN>, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded);
+    epi::epilogue_all<Geo<BN>, OUT_F32>(aq, p, m0w, n0w, l31, hi, interior, folded);
     prefetched = 1;
   }
 }

@@ -11,6 +11,7 @@
 // K loop: tools/gen_gemm_asm.py::gen_x4; epilogue: gemm_epilogue16.h.
 //
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 2*M*N*K.
+#include "acc_quads.h"
 #include "gemm_epilogue16.h"
 #include "gemm256x_regs.inc"
 
@@ -20,23 +21,14 @@ namespace {
 OSK_DEV unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 OSK_DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((unsigned)(v >> 32)) << 32) | rfl((unsigned)v); }
 
-#define OSKX_OUT4 "=v"(v4[0]), "=v"(v4[1]), "=v"(v4[2]), "=v"(v4[3])
-
+// The wave's 256 accumulators as 64 quads (tile T = J * NB + I is quad T): made compiler-visible values by an empty asm
+// statement behind the K-loop statement (acc_quads.h) -- the epilogue reads aq[T][i], the compiler emits the v_accvgpr_read.
 struct GeoX {
   static constexpr int NB = OSKX_NB;
   template <int T>
-  OSK_DEV void read(float* v4) {
-#define OSKX_CASE(t) else if constexpr (T == t) asm volatile(OSKX_AR##t : OSKX_OUT4)
-    if constexpr (T < 0) {}
-    OSKX_CASE(0); OSKX_CASE(1); OSKX_CASE(2); OSKX_CASE(3); OSKX_CASE(4); OSKX_CASE(5); OSKX_CASE(6); OSKX_CASE(7);
-    OSKX_CASE(8); OSKX_CASE(9); OSKX_CASE(10); OSKX_CASE(11); OSKX_CASE(12); OSKX_CASE(13); OSKX_CASE(14); OSKX_CASE(15);
-    OSKX_CASE(16); OSKX_CASE(17); OSKX_CASE(18); OSKX_CASE(19); OSKX_CASE(20); OSKX_CASE(21); OSKX_CASE(22); OSKX_CASE(23);
-    OSKX_CASE(24); OSKX_CASE(25); OSKX_CASE(26); OSKX_CASE(27); OSKX_CASE(28); OSKX_CASE(29); OSKX_CASE(30); OSKX_CASE(31);
-    OSKX_CASE(32); OSKX_CASE(33); OSKX_CASE(34); OSKX_CASE(35); OSKX_CASE(36); OSKX_CASE(37); OSKX_CASE(38); OSKX_CASE(39);
-    OSKX_CASE(40); OSKX_CASE(41); OSKX_CASE(42); OSKX_CASE(43); OSKX_CASE(44); OSKX_CASE(45); OSKX_CASE(46); OSKX_CASE(47);
-    OSKX_CASE(48); OSKX_CASE(49); OSKX_CASE(50); OSKX_CASE(51); OSKX_CASE(52); OSKX_CASE(53); OSKX_CASE(54); OSKX_CASE(55);
-    OSKX_CASE(56); OSKX_CASE(57); OSKX_CASE(58); OSKX_CASE(59); OSKX_CASE(60); OSKX_CASE(61); OSKX_CASE(62); OSKX_CASE(63);
-#undef OSKX_CASE
+  OSK_DEV void read(const osk_v4f* aq, float* v4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v4[i]) : "a"(aq[T][i]));   // (in place, in program order)
   }
 };
 
@@ -167,6 +159,9 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
     asm volatile(
 #include "gemm256x_body.inc"
         OSKW_OPERANDS : OSKX_CLOBBERS);
+    static_assert(OSKX_ACC_QUADS == 64, "the generated loop's accumulator map: quad T = tile T, a0 .. a255");
+    osk_v4f aq[64];
+    asm volatile("" : OSK_AQ_OUT_0_64(aq));
     OSK_TT(1, tt1);
 #ifdef OSK_GEMM_TILE_TIMING
     const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
@@ -174,7 +169,7 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
 
     const int b_first = m0w / p.crpb, b_last = (m0w + WT - 1) / p.crpb;
     const bool interior = m0w + WT <= p.M && n0w + WT <= p.N && b_first == b_last;  // wave-uniform
-    epi16::epilogue_all<GeoX, OUT_F32>(p, m0w, n0w, l15, q4, interior, folded);
+    epi16::epilogue_all<GeoX, OUT_F32>(aq, p, m0w, n0w, l15, q4, interior, folded);
     OSK_TT(2, tt2);
 #ifdef OSK_GEMM_TILE_TIMING
     if (threadIdx.x == 0) atomicAdd(&osk_gemm_tile_ticks[3], 1ull);

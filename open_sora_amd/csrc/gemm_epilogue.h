@@ -1,8 +1,10 @@
 // Fused epilogue of the large-tile GEMM kernels (gemm256.hip [fp8], gemm256p.hip; the 16 x 16 accumulator layout of gemm256x.hip has its own: gemm_epilogue16.h): bias / GELU-tanh / gate * x + residual /
 // bf16 or f32 store, on the accumulator layout of v_mfma_f32_32x32x16_bf16 with swapped operands (a lane owns ONE output
 // row and 4 consecutive columns per 8-column block).  Geo supplies the wave tile: TM x TN MFMA tiles and
-// read<T>(float[16]) = the 16 accumulator registers of tile T = tn * TM + tm.
+// read<T>(aq, float[16]) = the 16 accumulator registers of tile T = tn * TM + tm out of aq = the wave's accumulator quads as
+// compiler-visible values (acc_quads.h: outputs of an empty asm statement behind the K loop; tile T = quads 4 T .. 4 T + 3).
 #pragma once
+#include "acc_quads.h"
 #include "gemm_params.h"
 
 namespace osk_gemm {
@@ -14,7 +16,7 @@ enum { GELU_NONE = 0, GELU_ALL = 1, GELU_MIXED = 2 };
 // no bounds checks.  FOLDED: the bias is already in the accumulator.  A lane owns row m0w + tm*32 + l31 and columns
 // tn*32 + qd*8 + hi*4 + {0..3}, qd = 0..3.
 template <class Geo, bool OUT_F32, int T>
-OSK_DEV void tile_interior(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool folded, int gelu, const float4* bq,
+OSK_DEV void tile_interior(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l31, int hi, bool folded, int gelu, const float4* bq,
                            const float4* gq) {
   constexpr int TM = Geo::TM;
   constexpr int tn = T / TM, tm = T % TM;
@@ -28,7 +30,7 @@ OSK_DEV void tile_interior(const GemmParams& p, int m0w, int n0w, int l31, int h
       rv[qd] = *reinterpret_cast<const uint2*>(p.res + roff + n0w + tn * 32 + qd * 8 + hi * 4);
   }
   float acc[16];
-  Geo::template read<T>(acc);
+  Geo::template read<T>(aq, acc);
   if (!folded && p.bias) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -87,11 +89,11 @@ OSK_DEV void tile_interior(const GemmParams& p, int m0w, int n0w, int l31, int h
 
 // edge tiles: per-element bounds checks (rows >= M were computed on clamped copies of row M-1 and are dropped)
 template <class Geo, bool OUT_F32, int T>
-OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool folded) {
+OSK_DEV void tile_edge(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l31, int hi, bool folded) {
   constexpr int TM = Geo::TM;
   constexpr int tn = T / TM, tm = T % TM;
   float acc[16];
-  Geo::template read<T>(acc);
+  Geo::template read<T>(aq, acc);
   const int m = m0w + tm * 32 + l31;
   if (m >= p.M) return;
   const int b = m / p.crpb, l = m - b * p.crpb;
@@ -112,7 +114,7 @@ OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l31, int hi, b
 }
 
 template <class Geo, bool OUT_F32, int... Ts>
-OSK_DEV void epilogue_tn(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded,
+OSK_DEV void epilogue_tn(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded,
                          std::integer_sequence<int, Ts...>) {
   constexpr int TM = Geo::TM;
   constexpr int tn = ((Ts, ...)) / TM;   // all Ts share tn
@@ -127,30 +129,30 @@ OSK_DEV void epilogue_tn(const GemmParams& p, int m0w, int n0w, int l31, int hi,
       if (!folded && p.bias) bq[qd] = *reinterpret_cast<const float4*>(p.bias + n);
       if (p.gate) gq[qd] = *reinterpret_cast<const float4*>(p.gate + b * p.gbs + n);
     }
-    (tile_interior<Geo, OUT_F32, Ts>(p, m0w, n0w, l31, hi, folded, gelu, bq, gq), ...);
+    (tile_interior<Geo, OUT_F32, Ts>(aq, p, m0w, n0w, l31, hi, folded, gelu, bq, gq), ...);
   } else {
-    (tile_edge<Geo, OUT_F32, Ts>(p, m0w, n0w, l31, hi, folded), ...);
+    (tile_edge<Geo, OUT_F32, Ts>(aq, p, m0w, n0w, l31, hi, folded), ...);
   }
 }
 
 template <class Geo, bool OUT_F32, int TN_, int... Is>
-OSK_DEV void epilogue_rows(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded,
+OSK_DEV void epilogue_rows(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded,
                            std::integer_sequence<int, Is...>) {
   // Is = 0 .. TM-1: the tiles of column block TN_
-  epilogue_tn<Geo, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, (TN_ * Geo::TM + Is)...>{});
+  epilogue_tn<Geo, OUT_F32>(aq, p, m0w, n0w, l31, hi, interior, folded, std::integer_sequence<int, (TN_ * Geo::TM + Is)...>{});
 }
 
 template <class Geo, bool OUT_F32, int... TNs>
-OSK_DEV void epilogue_cols(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded,
+OSK_DEV void epilogue_cols(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded,
                            std::integer_sequence<int, TNs...>) {
-  (epilogue_rows<Geo, OUT_F32, TNs>(p, m0w, n0w, l31, hi, interior, folded, std::make_integer_sequence<int, Geo::TM>{}), ...);
+  (epilogue_rows<Geo, OUT_F32, TNs>(aq, p, m0w, n0w, l31, hi, interior, folded, std::make_integer_sequence<int, Geo::TM>{}), ...);
 }
 
 // the whole wave tile: column block by column block (column vectors -- bias, gate -- are loaded once per block)
 template <class Geo, bool OUT_F32>
-OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded) {
+OSK_DEV void epilogue_all(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l31, int hi, bool interior, bool folded) {
   if (m0w >= p.M || n0w >= p.N) return;   // the whole wave tile lies outside C (ragged last tile row / column): wave-uniform
-  epilogue_cols<Geo, OUT_F32>(p, m0w, n0w, l31, hi, interior, folded, std::make_integer_sequence<int, Geo::TN>{});
+  epilogue_cols<Geo, OUT_F32>(aq, p, m0w, n0w, l31, hi, interior, folded, std::make_integer_sequence<int, Geo::TN>{});
 }
 
 }  // namespace epi

@@ -1,7 +1,8 @@
 // Fused epilogue of gemm256x.hip: gemm_epilogue.h's bias / GELU-tanh / gate * x + residual / bf16 or f32 store on the
 // accumulator layout of v_mfma_f32_16x16x32_bf16 with swapped operands: of every 16 x 16 tile (J = column block, I = row
 // block) a lane owns output row 16 I + l15 (l15 = lane % 16) and the 4 consecutive columns 16 J + 4 q4 .. + 3 (q4 = lane / 16).
-// Geo supplies NB (16-blocks per wave tile side) and read<T>(float[4]) = the 4 accumulator registers of tile T = J * NB + I.
+// Geo supplies NB (16-blocks per wave tile side) and read<T>(acc, float[4]) = the 4 accumulator registers of tile T = J * NB + I out of
+// acc = the wave's accumulator quads as compiler-visible values (acc_quads.h: outputs of an empty asm statement behind the K loop).
 #pragma once
 #include "gemm_epilogue.h"
 
@@ -16,10 +17,10 @@ using epi::GELU_NONE;
 // accumulators started from it (an interior wave tile has all its columns inside N, which is the kernel's "folded" condition).
 // GATE and the tile's GELU class are compile-time / hoisted: 64 tiles per wave make every per-tile branch count.
 template <class Geo, int T, bool GATE, int GELU>
-OSK_DEV void tile_values(const GemmParams& p, int64_t roff, int n, const float4& gq, float* acc) {
+OSK_DEV void tile_values(const osk_v4f* aq, const GemmParams& p, int64_t roff, int n, const float4& gq, float* acc) {
   uint2 rv = make_uint2(0, 0);
   if constexpr (GATE) rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
-  Geo::template read<T>(acc);
+  Geo::template read<T>(aq, acc);
   if constexpr (GELU == GELU_ALL) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = gelu_tanh(acc[i]);
@@ -43,12 +44,12 @@ OSK_DEV void tile_values(const GemmParams& p, int64_t roff, int n, const float4&
 // odd rows take tile I + 1: lane (q4, l15) stores 8 columns (16 J + 8 (q4 / 2) ..) of output row 16 (I + (q4 & 1)) + l15.
 // (The caller routes outputs that are not 16-byte addressable to the edge path.)
 template <class Geo, bool OUT_F32, bool GATE, int GELU, int J, int I>
-OSK_DEV void pair_interior(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4& gq) {
+OSK_DEV void pair_interior(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4& gq) {
   constexpr int NB = Geo::NB;
   const int n = n0w + J * 16 + q4 * 4;
   float a0[4], a1[4];
-  tile_values<Geo, J * NB + I, GATE, GELU>(p, rowoff[I], n, gq, a0);
-  tile_values<Geo, J * NB + I + 1, GATE, GELU>(p, rowoff[I + 1], n, gq, a1);
+  tile_values<Geo, J * NB + I, GATE, GELU>(aq, p, rowoff[I], n, gq, a0);
+  tile_values<Geo, J * NB + I + 1, GATE, GELU>(aq, p, rowoff[I + 1], n, gq, a1);
   if constexpr (OUT_F32) {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + rowoff[I] + n) = make_float4(a0[0], a0[1], a0[2], a0[3]);
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + rowoff[I + 1] + n) = make_float4(a1[0], a1[1], a1[2], a1[3]);
@@ -71,12 +72,12 @@ OSK_DEV void pair_interior(const GemmParams& p, const int64_t* rowoff, const int
 
 // the 16-byte chunk pair_interior stores for (J, I): columns 16 J + 8 (q4 >> 1) .. + 7 of output row 16 (I + (q4 & 1)) + l15
 template <class Geo, bool GATE, int GELU, int J, int I>
-OSK_DEV uint4 chunk_interior(const GemmParams& p, const int64_t* rowoff, int n0w, int q4, const float4& gq) {
+OSK_DEV uint4 chunk_interior(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, int n0w, int q4, const float4& gq) {
   constexpr int NB = Geo::NB;
   const int n = n0w + J * 16 + q4 * 4;
   float a0[4], a1[4];
-  tile_values<Geo, J * NB + I, GATE, GELU>(p, rowoff[I], n, gq, a0);
-  tile_values<Geo, J * NB + I + 1, GATE, GELU>(p, rowoff[I + 1], n, gq, a1);
+  tile_values<Geo, J * NB + I, GATE, GELU>(aq, p, rowoff[I], n, gq, a0);
+  tile_values<Geo, J * NB + I + 1, GATE, GELU>(aq, p, rowoff[I + 1], n, gq, a1);
   auto sx = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a1[0], a1[1]), false, false);
   auto sy = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[2], a1[3]), false, false);
   return make_uint4(sx[0], sy[0], sx[1], sy[1]);
@@ -88,12 +89,12 @@ OSK_DEV uint4 chunk_interior(const GemmParams& p, const int64_t* rowoff, int n0w
 // first store (the transposes need all NB chunks), as in pair_interior.  own = element offset of this lane's own store row (storeoff[I / 2]: + its 8-column half), crs = row stride:
 // the rows of an interior wave tile lie in one batch item, so row 4 a + r is (r - j) rows from the lane's own row 4 a + j.
 template <class Geo, bool GATE, int GELU, int I, int... Js>
-OSK_DEV void row_pair_wide(const GemmParams& p, const int64_t* rowoff, int64_t own, int n0w, int q4, int lane, const float4* gq,
+OSK_DEV void row_pair_wide(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, int64_t own, int n0w, int q4, int lane, const float4* gq,
                            std::integer_sequence<int, Js...>) {
   constexpr int NB = Geo::NB;
   static_assert(NB % 4 == 0, "column blocks are transposed in groups of four");
   uint4 d[NB];
-  ((d[Js] = chunk_interior<Geo, GATE, GELU, Js, I>(p, rowoff, n0w, q4, gq[Js])), ...);
+  ((d[Js] = chunk_interior<Geo, GATE, GELU, Js, I>(aq, p, rowoff, n0w, q4, gq[Js])), ...);
   const int j = lane & 3;
   const bool odd = lane & 1, hi = lane & 2;
 #pragma unroll
@@ -112,18 +113,18 @@ OSK_DEV void row_pair_wide(const GemmParams& p, const int64_t* rowoff, int64_t o
 }
 
 template <class Geo, bool GATE, int GELU, int... Is>
-OSK_DEV void tile_interior_wide(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, int lane,
+OSK_DEV void tile_interior_wide(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, int lane,
                                 const float4* gq, std::integer_sequence<int, Is...>) {
-  (row_pair_wide<Geo, GATE, GELU, 2 * Is>(p, rowoff, storeoff[Is], n0w, q4, lane, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
+  (row_pair_wide<Geo, GATE, GELU, 2 * Is>(aq, p, rowoff, storeoff[Is], n0w, q4, lane, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
 }
 
 // edge tiles: per-element bounds checks (rows >= M were computed on clamped copies of row M-1 and are dropped)
 template <class Geo, bool OUT_F32, int T>
-OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded) {
+OSK_DEV void tile_edge(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded) {
   constexpr int NB = Geo::NB;
   constexpr int J = T / NB, I = T % NB;
   float acc[4];
-  Geo::template read<T>(acc);
+  Geo::template read<T>(aq, acc);
   const int m = m0w + I * 16 + l15;
   if (m >= p.M) return;
   const int b = m / p.crpb, l = m - b * p.crpb;
@@ -143,19 +144,19 @@ OSK_DEV void tile_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, b
 // all column blocks J of one pair of row blocks, back to back: consecutive stores fill a row's 32-byte pieces left to right
 // (with the column block outermost, the pieces of one 64-byte sector left four stores apart: +20 % fabric-side write traffic)
 template <class Geo, bool OUT_F32, bool GATE, int GELU, int I, int... Js>
-OSK_DEV void row_pair(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4* gq,
+OSK_DEV void row_pair(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4* gq,
                       std::integer_sequence<int, Js...>) {
-  (pair_interior<Geo, OUT_F32, GATE, GELU, Js, I>(p, rowoff, storeoff, n0w, q4, gq[Js]), ...);
+  (pair_interior<Geo, OUT_F32, GATE, GELU, Js, I>(aq, p, rowoff, storeoff, n0w, q4, gq[Js]), ...);
 }
 
 template <class Geo, bool OUT_F32, bool GATE, int GELU, int... Is>
-OSK_DEV void tile_interior(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4* gq,
+OSK_DEV void tile_interior(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, const float4* gq,
                            std::integer_sequence<int, Is...>) {
-  (row_pair<Geo, OUT_F32, GATE, GELU, 2 * Is>(p, rowoff, storeoff, n0w, q4, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
+  (row_pair<Geo, OUT_F32, GATE, GELU, 2 * Is>(aq, p, rowoff, storeoff, n0w, q4, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
 }
 
 template <class Geo, bool OUT_F32, bool GATE>
-OSK_DEV void cols_interior(const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int m0w, int n0w, int q4) {
+OSK_DEV void cols_interior(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int m0w, int n0w, int q4) {
   constexpr int NB = Geo::NB;
   constexpr auto seq = std::make_integer_sequence<int, NB / 2>{};
   float4 gq[NB];                          // gate of this lane's 4 channels of every column block (one batch per interior wave tile)
@@ -168,33 +169,33 @@ OSK_DEV void cols_interior(const GemmParams& p, const int64_t* rowoff, const int
   if constexpr (!OUT_F32) {
 #ifndef OSK_GEMM_NARROW_STORES   // (A/B builds of tools/: the 32-byte row pieces of round 3)
     const int lane = q4 * 16 + (int)(threadIdx.x & 15);
-    if (n0w + NB * 16 <= p.gelu_from) tile_interior_wide<Geo, GATE, GELU_NONE>(p, rowoff, storeoff, n0w, q4, lane, gq, seq);
-    else if (n0w >= p.gelu_from) tile_interior_wide<Geo, GATE, GELU_ALL>(p, rowoff, storeoff, n0w, q4, lane, gq, seq);
-    else tile_interior_wide<Geo, GATE, GELU_MIXED>(p, rowoff, storeoff, n0w, q4, lane, gq, seq);
+    if (n0w + NB * 16 <= p.gelu_from) tile_interior_wide<Geo, GATE, GELU_NONE>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, seq);
+    else if (n0w >= p.gelu_from) tile_interior_wide<Geo, GATE, GELU_ALL>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, seq);
+    else tile_interior_wide<Geo, GATE, GELU_MIXED>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, seq);
     return;
 #endif
   }
-  if (n0w + NB * 16 <= p.gelu_from) tile_interior<Geo, OUT_F32, GATE, GELU_NONE>(p, rowoff, storeoff, n0w, q4, gq, seq);
-  else if (n0w >= p.gelu_from) tile_interior<Geo, OUT_F32, GATE, GELU_ALL>(p, rowoff, storeoff, n0w, q4, gq, seq);
-  else tile_interior<Geo, OUT_F32, GATE, GELU_MIXED>(p, rowoff, storeoff, n0w, q4, gq, seq);
+  if (n0w + NB * 16 <= p.gelu_from) tile_interior<Geo, OUT_F32, GATE, GELU_NONE>(aq, p, rowoff, storeoff, n0w, q4, gq, seq);
+  else if (n0w >= p.gelu_from) tile_interior<Geo, OUT_F32, GATE, GELU_ALL>(aq, p, rowoff, storeoff, n0w, q4, gq, seq);
+  else tile_interior<Geo, OUT_F32, GATE, GELU_MIXED>(aq, p, rowoff, storeoff, n0w, q4, gq, seq);
 }
 
 template <class Geo, bool OUT_F32, int... Ts>
-OSK_DEV void tiles_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded, std::integer_sequence<int, Ts...>) {
-  (tile_edge<Geo, OUT_F32, Ts>(p, m0w, n0w, l15, q4, folded), ...);
+OSK_DEV void tiles_edge(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded, std::integer_sequence<int, Ts...>) {
+  (tile_edge<Geo, OUT_F32, Ts>(aq, p, m0w, n0w, l15, q4, folded), ...);
 }
 
 // ---- GEGLU class (f4; north_star's "GEGLU MLP"): column blocks come in (value, gate) pairs 2 J2, 2 J2 + 1 -- the same lane holds
 // the same output row and the same 4 relative channels of both -- and the wave tile's 128 GEMM columns become 64 output columns at
 // n0w / 2.  bf16 output only; bias folded into the accumulators (interior) or added here (edge), in the packed column order.
 template <class Geo, int J2, int I>
-OSK_DEV void geglu_pair_interior(const GemmParams& p, const int64_t* storeoff, int n0o) {
+OSK_DEV void geglu_pair_interior(const osk_v4f* aq, const GemmParams& p, const int64_t* storeoff, int n0o) {
   constexpr int NB = Geo::NB;
   float v0[4], g0[4], v1[4], g1[4];
-  Geo::template read<(2 * J2) * NB + I>(v0);
-  Geo::template read<(2 * J2 + 1) * NB + I>(g0);
-  Geo::template read<(2 * J2) * NB + I + 1>(v1);
-  Geo::template read<(2 * J2 + 1) * NB + I + 1>(g1);
+  Geo::template read<(2 * J2) * NB + I>(aq, v0);
+  Geo::template read<(2 * J2 + 1) * NB + I>(aq, g0);
+  Geo::template read<(2 * J2) * NB + I + 1>(aq, v1);
+  Geo::template read<(2 * J2 + 1) * NB + I + 1>(aq, g1);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     v0[i] *= gelu_tanh(g0[i]);
@@ -206,22 +207,22 @@ OSK_DEV void geglu_pair_interior(const GemmParams& p, const int64_t* storeoff, i
 }
 
 template <class Geo, int I, int... J2s>
-OSK_DEV void geglu_row_pair(const GemmParams& p, const int64_t* storeoff, int n0o, std::integer_sequence<int, J2s...>) {
-  (geglu_pair_interior<Geo, J2s, I>(p, storeoff, n0o), ...);
+OSK_DEV void geglu_row_pair(const osk_v4f* aq, const GemmParams& p, const int64_t* storeoff, int n0o, std::integer_sequence<int, J2s...>) {
+  (geglu_pair_interior<Geo, J2s, I>(aq, p, storeoff, n0o), ...);
 }
 
 template <class Geo, int... Is>
-OSK_DEV void geglu_interior(const GemmParams& p, const int64_t* storeoff, int n0o, std::integer_sequence<int, Is...>) {
-  (geglu_row_pair<Geo, 2 * Is>(p, storeoff, n0o, std::make_integer_sequence<int, Geo::NB / 2>{}), ...);
+OSK_DEV void geglu_interior(const osk_v4f* aq, const GemmParams& p, const int64_t* storeoff, int n0o, std::integer_sequence<int, Is...>) {
+  (geglu_row_pair<Geo, 2 * Is>(aq, p, storeoff, n0o, std::make_integer_sequence<int, Geo::NB / 2>{}), ...);
 }
 
 template <class Geo, int T2>   // T2 = J2 * NB + I
-OSK_DEV void geglu_tile_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded) {
+OSK_DEV void geglu_tile_edge(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded) {
   constexpr int NB = Geo::NB;
   constexpr int J2 = T2 / NB, I = T2 % NB;
   float v[4], g[4];
-  Geo::template read<(2 * J2) * NB + I>(v);
-  Geo::template read<(2 * J2 + 1) * NB + I>(g);
+  Geo::template read<(2 * J2) * NB + I>(aq, v);
+  Geo::template read<(2 * J2 + 1) * NB + I>(aq, g);
   const int m = m0w + I * 16 + l15;
   if (m >= p.M) return;
   const int b = m / p.crpb, l = m - b * p.crpb;
@@ -236,33 +237,33 @@ OSK_DEV void geglu_tile_edge(const GemmParams& p, int m0w, int n0w, int l15, int
 }
 
 template <class Geo, int... Ts>
-OSK_DEV void geglu_tiles_edge(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded, std::integer_sequence<int, Ts...>) {
-  (geglu_tile_edge<Geo, Ts>(p, m0w, n0w, l15, q4, folded), ...);
+OSK_DEV void geglu_tiles_edge(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4, bool folded, std::integer_sequence<int, Ts...>) {
+  (geglu_tile_edge<Geo, Ts>(aq, p, m0w, n0w, l15, q4, folded), ...);
 }
 
 template <class Geo>
-OSK_DEV void geglu_all(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool interior, bool folded) {
+OSK_DEV void geglu_all(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4, bool interior, bool folded) {
   constexpr int NB = Geo::NB;
   if (m0w >= p.M || n0w >= p.N) return;
   const bool wide = ((((uintptr_t)p.C) & 15) == 0) && ((p.crs & 7) == 0) && ((p.cbs & 7) == 0);
   if (!interior || !wide || (p.bias && !folded)) {
-    geglu_tiles_edge<Geo>(p, m0w, n0w, l15, q4, folded, std::make_integer_sequence<int, (NB / 2) * NB>{});
+    geglu_tiles_edge<Geo>(aq, p, m0w, n0w, l15, q4, folded, std::make_integer_sequence<int, (NB / 2) * NB>{});
     return;
   }
   int64_t storeoff[NB / 2];
   const int b = m0w / p.crpb, l0 = m0w - b * p.crpb + l15;
 #pragma unroll
   for (int i = 0; i < NB / 2; ++i) storeoff[i] = b * p.cbs + (int64_t)(l0 + 16 * (2 * i + (q4 & 1))) * p.crs + (q4 >> 1) * 8;
-  geglu_interior<Geo>(p, storeoff, n0w / 2, std::make_integer_sequence<int, NB / 2>{});
+  geglu_interior<Geo>(aq, p, storeoff, n0w / 2, std::make_integer_sequence<int, NB / 2>{});
 }
 
 // the whole 128 x 128 wave tile
 template <class Geo, bool OUT_F32>
-OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l15, int q4, bool interior, bool folded) {
+OSK_DEV void epilogue_all(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4, bool interior, bool folded) {
   constexpr int NB = Geo::NB;
   if constexpr (!OUT_F32) {
     if (p.geglu) {   // (kernel-argument uniform)
-      geglu_all<Geo>(p, m0w, n0w, l15, q4, interior, folded);
+      geglu_all<Geo>(aq, p, m0w, n0w, l15, q4, interior, folded);
       return;
     }
   }
@@ -270,7 +271,7 @@ OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l15, int q4
   // the fast path stores 16 bytes per lane (bf16) / reads 8-byte residual pieces: C, its strides and the tile origin must allow it
   const bool wide = OUT_F32 || (((((uintptr_t)p.C) & 15) == 0) && ((p.crs & 7) == 0) && ((p.cbs & 7) == 0));
   if (!interior || !wide || (p.bias && !folded)) {
-    tiles_edge<Geo, OUT_F32>(p, m0w, n0w, l15, q4, folded, std::make_integer_sequence<int, NB * NB>{});
+    tiles_edge<Geo, OUT_F32>(aq, p, m0w, n0w, l15, q4, folded, std::make_integer_sequence<int, NB * NB>{});
     return;
   }
   // element offsets of this lane's NB output rows (an interior wave tile lies inside one batch: one division for all of them),
@@ -281,8 +282,8 @@ OSK_DEV void epilogue_all(const GemmParams& p, int m0w, int n0w, int l15, int q4
   for (int i = 0; i < NB; ++i) rowoff[i] = b * p.cbs + (int64_t)(l0 + 16 * i) * p.crs;
 #pragma unroll
   for (int i = 0; i < NB / 2; ++i) storeoff[i] = ((q4 & 1) ? rowoff[2 * i + 1] : rowoff[2 * i]) + (q4 >> 1) * 8;
-  if (p.gate) cols_interior<Geo, OUT_F32, true>(p, rowoff, storeoff, m0w, n0w, q4);
-  else cols_interior<Geo, OUT_F32, false>(p, rowoff, storeoff, m0w, n0w, q4);
+  if (p.gate) cols_interior<Geo, OUT_F32, true>(aq, p, rowoff, storeoff, m0w, n0w, q4);
+  else cols_interior<Geo, OUT_F32, false>(aq, p, rowoff, storeoff, m0w, n0w, q4);
 }
 
 }  // namespace epi16

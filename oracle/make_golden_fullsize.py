@@ -9,6 +9,10 @@ oracle/synth.py, never stored):
   z        the whole latent mean [1, 16, 9, 32, 32] (147 k values)
   dec_s8   the decoded video sampled at every 8th row and column (offset 3), all 33 frames: [1, 3, 33, 32, 32]
   dec_mean / dec_sq   per (channel, frame) mean and mean of squares of the whole decoded video (f64 accumulation): [3, 33]
+  e_ref_z / e_ref_dec   relL2 of the reference's own eager-bf16 run (bf16 parameters and activations) against the fp32 run, over the
+                        whole latent / the whole decoded video; a_ref_z / a_ref_dec the max-abs differences; z_absmax / dec_absmax
+                        (round 5: SURVEY 8(d)'s reference-precision comparator, committed with the fixture so that the GPU test's
+                        bound is max(1.5 e_ref, 2^-8) instead of a hand-set number)
 tests/test_gpu_vae.py::test_full_size_encode_decode_vs_reference_fixture compares the HIP path with these.
 """
 from __future__ import annotations
@@ -53,6 +57,17 @@ def main():
         dec = model.decode(zin)
         print(f"decode: {time.time() - t0:.0f} s  dec {tuple(dec.shape)}", flush=True)
         out.update(summarize_dec(dec))
+        # the reference-precision comparator: the same module with bf16 parameters on bf16 inputs
+        m16 = model.to(torch.bfloat16)
+        z16 = m16.encode(x.bfloat16(), sample_posterior=False).float()
+        print(f"bf16 encode: {time.time() - t0:.0f} s  finite {bool(torch.isfinite(z16).all())}", flush=True)
+        d16 = m16.decode(zin.bfloat16()).float()
+        print(f"bf16 decode: {time.time() - t0:.0f} s  finite {bool(torch.isfinite(d16).all())}", flush=True)
+        for tag, a, b in (("z", z16, z.float()), ("dec", d16, dec.float())):
+            out["e_ref_" + tag] = np.float64((a.double() - b.double()).norm() / b.double().norm())
+            out["a_ref_" + tag] = np.float64((a.double() - b.double()).abs().max())
+            out[tag + "_absmax"] = np.float64(b.abs().max())
+        print({k: float(v) for k, v in out.items() if np.ndim(v) == 0}, flush=True)
     path = os.path.join(OUT_DIR, "vae_fullsize_cfg3.npz")
     np.savez_compressed(path, **out)
     print(f"{path}: {os.path.getsize(path)} B")

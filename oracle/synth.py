@@ -112,11 +112,14 @@ def mmdit_param_shapes(cfg: dict) -> dict:
     return s
 
 
-def make_params(shapes: dict, seed: int = 0, round_bf16: bool = True) -> dict:
+def make_params(shapes: dict, seed: int = 0, round_bf16: bool = True, workers: int = 1) -> dict:
     """name -> fp32 numpy array.  Weights ~ N(0, 1/fan_in), biases ~ N(0, 0.02^2),
-    RMSNorm scales ~ 1 + 0.1 N(0,1), GroupNorm weight ~ 1 + 0.1 N, all bf16-representable."""
-    out = {}
-    for name, shape in shapes.items():
+    RMSNorm scales ~ 1 + 0.1 N(0,1), GroupNorm weight ~ 1 + 0.1 N, all bf16-representable.
+    Every tensor is a pure function of (name, seed, shape), so `workers` > 1 only spreads the tensors over threads
+    (numpy releases the GIL inside its ufuncs): same bits, the 0.8 G parameters of the XL denoiser in seconds on a many-core host."""
+
+    def one(item):
+        name, shape = item
         if name.endswith(".scale") or (name.endswith(".weight") and len(shape) == 1):
             a = normal(name, seed, shape, std=0.1, mean=1.0)
         elif name.endswith(".bias"):
@@ -124,8 +127,14 @@ def make_params(shapes: dict, seed: int = 0, round_bf16: bool = True) -> dict:
         else:
             fan_in = int(np.prod(shape[1:]))
             a = normal(name, seed, shape, std=fan_in ** -0.5)
-        out[name] = bf16_round(a) if round_bf16 else a
-    return out
+        return name, (bf16_round(a) if round_bf16 else a)
+
+    if workers and workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=int(workers)) as pool:
+            return dict(pool.map(one, shapes.items()))
+    return dict(map(one, shapes.items()))
 
 
 def mmdit_inputs(cfg: dict, B: int, T: int, h: int, w: int, L_txt: int, seed: int = 42, t: float = 0.7) -> dict:

@@ -404,8 +404,10 @@ def test_full_size_encode_decode_vs_reference_fixture(hip_lib, fold):
     reference's own AutoencoderKLCausal3D (fp32, CPU, run once offline by oracle/make_golden_fullsize.py) returns for
     synth.vae_video(1, 33, 256, 256) / synth.vae_latent(1, 9, 32, 32) with the synthetic shipped-width weights: the whole latent
     mean, the decoded video on an 8 x 8 pixel lattice, and per (channel, frame) first and second moments of the whole video.
-    No bf16 comparator is run here (a full-size bf16 oracle pass is tens of minutes of CPU): fixed bounds with head-room over
-    the measured values (MI355X, round 4: latent 1.10e-2, decoded lattice 1.15e-2, per-frame mean 3.5e-4, mean square 7.5e-4)."""
+    Tolerance (round 5): SURVEY 8(d)'s rule against the COMMITTED reference-precision error -- the fixture also holds e_ref_z /
+    e_ref_dec = relL2 of the reference's own eager-bf16 run (bf16 parameters and activations) against its fp32 run, made by the same
+    script: e_ours <= max(1.5 e_ref, 2^-8), max-abs <= 4 a_ref (measured on MI355X, round 4: latent 1.10e-2 against e_ref 1.15e-2,
+    decoded lattice 1.15e-2 against 1.21e-2); the per-frame moments of the whole video within the same error scale."""
     from oracle import make_golden_fullsize as FS
     from open_sora_amd import hunyuan_vae
 
@@ -429,8 +431,16 @@ def test_full_size_encode_decode_vs_reference_fixture(hip_lib, fold):
     em = float(np.abs(got["dec_mean"] - g["dec_mean"]).max())
     es = float(np.abs(got["dec_sq"] - g["dec_sq"]).max() / np.abs(g["dec_sq"]).max())
     print(f"full-size cfg 3 vs the reference fixture: latent relL2 {ez:.3e}, decoded lattice relL2 {ed:.3e}, per-frame mean |d| {em:.3e}, mean-square rel {es:.3e}")
-    assert ez <= 1.6e-2 and ed <= 2.0e-2, (ez, ed)
-    assert em <= 4e-3 * max(1.0, float(np.abs(g["dec_mean"]).max())) and es <= 2e-2, (em, es)
+    e_ref_z, e_ref_dec, floor = float(g["e_ref_z"]), float(g["e_ref_dec"]), 2.0 ** -8
+    az = float((z.double() - zt.double()).abs().max())
+    ad = float(np.abs(got["dec_s8"].astype(np.float64) - g["dec_s8"]).max())
+    print(f"   reference bf16 vs fp32: latent relL2 {e_ref_z:.3e} max-abs {float(g['a_ref_z']):.3e}; decoded relL2 {e_ref_dec:.3e} max-abs {float(g['a_ref_dec']):.3e};"
+          f" ours max-abs latent {az:.3e} decoded lattice {ad:.3e}")
+    assert ez <= max(1.5 * e_ref_z, floor) and ed <= max(1.5 * e_ref_dec, floor), (ez, ed)
+    assert az <= 4.0 * float(g["a_ref_z"]) and ad <= 4.0 * float(g["a_ref_dec"]), (az, ad)
+    # moments of the WHOLE video: a frame mean off by more than the reference-precision error of an rms pixel would be a bias
+    rms = float(np.sqrt(np.abs(g["dec_sq"]).max()))
+    assert em <= 0.5 * e_ref_dec * rms and es <= 3.0 * e_ref_dec, (em, es)
 
 
 def test_large_tile_conv_is_deterministic_under_load(hip_lib):

@@ -1392,11 +1392,13 @@ def main():
         f.write("#define OSK72W_CLOBBERS %s\n" % ", ".join(clobw))
         f.write("#define OSK72W_A_CLOBBERS %s\n" % ", ".join('"a%d"' % i for i in range(0, LW.A_END)))
         f.write("#define OSK72W_NSLOT %d\n" % LW.NSLOT)
+        # register map the wrapper binds as asm operands (acc_quads.h): Q fragment words of block u = AGPRs AQ(u) .. + 4 NKS,
+        # O^T of (u, 16-query block qb) = AGPRs 4 NDB (2 u + qb) .. (row block db, register i at + 4 db + i)
         for u in range(LW.NUW):
-            f.write("#define OSK72W_QW%d %s\n" % (u, " ".join('"v_accvgpr_write_b32 a%d, %%%d\\n"' % (LW.AQW(u, 0) + i, i) for i in range(4 * LW.G.NKS))))
+            f.write("#define OSK72W_AQ%d %d\n" % (u, LW.AQW(u, 0)))
             for qb in range(2):
-                f.write("#define OSK72W_OR%d %s\n" % (u * 2 + qb, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (db * 4 + i, LW.AO16W(u, qb, db) + i)
-                                                                           for db in range(LW.G.NDB) for i in range(4))))
+                assert all(LW.AO16W(u, qb, db) == 4 * LW.G.NDB * (2 * u + qb) + 4 * db for db in range(LW.G.NDB))
+        f.write("#define OSK72W_AO_REGS %d\n" % (4 * LW.G.NDB * 2 * LW.NUW))
         for hd, pv8 in sorted({(h, p8) for h, _, p8 in layouts}):
             G = mk(2, hd, pv8).G
             P = "OSK%s_" % tagof(hd, pv8).upper()
@@ -1418,20 +1420,15 @@ def main():
             f.write("#define %sNSLOT %d\n" % (P, L.NSLOT))
             if pv8:
                 f.write("#define %sNSLOT_V %d\n" % (P, L.NSLOT_V))
-            for u in range(nu):   # Q fragment words of query block u -> AGPRs, at most 20 operands per statement
-                words = G.NKS * 4
-                for part, w0 in enumerate(range(0, words, 20)):
-                    n = min(20, words - w0)
-                    f.write("#define %sQW%d_%d %s\n" % (P, u, part, " ".join('"v_accvgpr_write_b32 a%d, %%%d\\n"' % (L.AQ(u, 0) + w0 + i, i) for i in range(n))))
-            if L.PV16:   # O^T of (u, 16-query block qb): 4 NDB registers (row block db, register i) -> operands %0..%19
-                for u in range(nu):
-                    for qb in range(2):
-                        f.write("#define %sOR%d %s\n" % (P, u * 2 + qb, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (db * 4 + i, L.AO16(u, qb, db) + i)
-                                                                                  for db in range(G.NDB) for i in range(4))))
+            # register map the wrapper binds as asm operands (acc_quads.h): Q fragment words of block u = AGPRs AQ(u) .. + 4 NKS
+            for u in range(nu):
+                f.write("#define %sAQ%d %d\n" % (P, u, L.AQ(u, 0)))
+            if L.PV16:   # O^T of (u, 16-query block qb) = AGPRs 4 NDB (2 u + qb) .. (row block db, register i at + 4 db + i)
+                assert all(L.AO16(u, qb, db) == 4 * G.NDB * (2 * u + qb) + 4 * db for u in range(nu) for qb in range(2) for db in range(G.NDB))
+                f.write("#define %sAO_REGS %d\n" % (P, 4 * G.NDB * 2 * nu))
                 continue
-            for u in range(nu):   # O^T row tile (u, d) -> operands %0..%15
-                for d in range(G.NDT):
-                    f.write("#define %sOR%d %s\n" % (P, u * G.NDT + d, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, L.AO(u, d) + i) for i in range(16))))
+            assert all(L.AO(u, d) == 16 * (u * G.NDT + d) for u in range(nu) for d in range(G.NDT))   # O^T row tile (u, d): 16 registers
+            f.write("#define %sAO_REGS %d\n" % (P, 16 * G.NDT * nu))
 
 
 if __name__ == "__main__":

@@ -1786,8 +1786,8 @@ def main():
             clob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN)] + ['"a%d"' % i for i in range(c.NACC)] + \
                    ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
             f.write("#define %sCLOBBERS %s\n" % (P, ", ".join(clob)))
-            for t in range(c.TM * c.TN):
-                f.write("#define %sAR%d %s\n" % (P, t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
+            # accumulator tile t = AGPRs 16 t .. 16 t + 15 = quads 4 t .. 4 t + 3 (the wrappers bind them as asm outputs: acc_quads.h)
+            f.write("#define %sACC_QUADS %d\n" % (P, c.NACC // 4))
             if args.experiments:
                 sclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 4)] + ['"a%d"' % i for i in range(c.NACC)] + \
                         ['"s%d"' % i for i in range(S_FIRST, SEG_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
@@ -1826,8 +1826,6 @@ def main():
             cclob = ['"v%d"' % i for i in range(c.V0, c.V0 + c.VN + 6 + 1 + 2 * c.NA)] + ['"a%d"' % i for i in range(c.NACC)] + \
                     ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
             f.write("#define OSKW_CONV_CLOBBERS %s\n" % ", ".join(cclob))
-            for t in range(c.TM * c.TN):
-                f.write("#define OSKW_AR%d %s\n" % (t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 16 + i) for i in range(16))))
     cx = Cfg4x()
     write_body("gemm256x_body.inc", "256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, persistent workgroup.", lambda: gen_x4(cx))
     write_body("conv256x_body.inc", "256 x 256 x 64 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32_bf16, whole K axis (all filter taps).",
@@ -1847,8 +1845,8 @@ def main():
         cclob = ['"v%d"' % i for i in range(cx.V0, cx.V0 + cx.VN + 2 + 1 + 2 * cx.NA)] + ['"a%d"' % i for i in range(cx.NACC)] + \
                 ['"s%d"' % i for i in range(S_FIRST, CONV_S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
         f.write("#define OSKX_CONV_CLOBBERS %s\n" % ", ".join(cclob))
-        for t in range(cx.NB * cx.NB):
-            f.write("#define OSKX_AR%d %s\n" % (t, " ".join('"v_accvgpr_read_b32 %%%d, a%d\\n"' % (i, t * 4 + i) for i in range(4))))
+        # accumulator tile T = J * NB + I = AGPR quad T (the wrappers bind the quads as asm outputs: acc_quads.h)
+        f.write("#define OSKX_ACC_QUADS %d\n#define OSKX128_ACC_QUADS %d\n" % (cx.NACC // 4, cx128.NACC // 4))
     for bn in (256, 128):
         c = Cfg(bn, fp8=True)
         with open(os.path.join(args.out, "gemm256_fp8_body_n%d.inc" % bn), "w") as f:
