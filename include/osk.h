@@ -24,7 +24,11 @@
 extern "C" {
 #endif
 
-#define OSK_ABI_VERSION 1
+/* 2 (round 5): osk_copy_rows_bf16 added; and the contracts that changed under version 1 during round 4 are now versioned -- the
+ * key order osk_v_transpose_bf16 bakes into V^T for head_dim 64 (the 16x16x32 order of head_dim 72: attention_fwd.hip), the entry
+ * points osk_gemm_geglu_bf16 / osk_attention_short_bf16 / osk_attention_hd512_fwd_ws_bf16 / osk_causal_conv3d_gnin_ndhwc_bf16.
+ * A binding must refuse a library whose version it was not written for (open_sora_amd/_C.py does). */
+#define OSK_ABI_VERSION 2
 int osk_abi_version(void);
 /* name of the arch the library was compiled for ("gfx950") — host-only, no GPU needed */
 const char* osk_arch(void);
@@ -70,7 +74,10 @@ int osk_gemm_bf16_pair(const OskGemmOperands* first, const OskGemmOperands* seco
 
 /* ---- GEGLU up-projection (the STDiT-generation block's "GEGLU MLP" of BASELINE.json's
  * north_star; the mounted v2.0 reference has no GEGLU call site -- its MLP is Linear -> GELU(tanh) -> Linear, layers.py:277-281 --
- * so this entry is PARITY-UNPINNED: semantics = diffusers' FeedForward(activation_fn="geglu") with the library's tanh GELU):
+ * so this entry is PARITY-UNPINNED: semantics = diffusers' FeedForward(activation_fn="geglu") EXCEPT the activation: diffusers'
+ * GEGLU applies the exact (erf) F.gelu to the gate, this entry the tanh approximation the v2.0 blocks use everywhere
+ * (|gelu_tanh - gelu_erf| <= ~1e-3 absolute, a systematic difference a checkpoint trained with diffusers GEGLU would see per MLP;
+ * the fp64 test oracle uses the same tanh formula, so it does not measure this deviation -- an erf epilogue is one more class):
  *   C[m, j] = (A W_v^T + b_v)[m, j] * gelu_tanh((A W_g^T + b_g)[m, j]),   j < N_out
  * as ONE GEMM with N = 2 N_out whose epilogue multiplies value and gate in registers.  W_packed [2 N_out, K] / bias_packed
  * [2 N_out]: value and gate rows interleaved in blocks of 16 -- packed row 32 j2 + i (i < 16) = value row 16 j2 + i, packed row
@@ -192,8 +199,13 @@ int osk_attention_fwd_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_
  * f32 and rounded to bf16 once; a split row differs from the unsplit one only through the bf16 rounding of P against
  * the reference max of its own key part (same error bound against the exact result). */
 int64_t osk_attention_workspace_bytes(void);
-/* reporting / tests: the number of key parts (1 = no split) osk_attention_fwd_ws_bf16 would use for this launch */
+/* reporting / tests: the number of key parts (1 = no split) osk_attention_fwd_ws_bf16 -- a call WITHOUT a score bound -- would use */
 int osk_attention_tail_split_factor(int B, int H, int Lq, int n_seg, int seg_len, int hd, int64_t workspace_bytes);
+/* reporting / tests (round 5): the launch shape of osk_attention_fwd_bounded_bf16 for these arguments, from the selection code the
+ * call itself runs: returns the number of key parts of the last round's work units and stores the query rows per work unit (256,
+ * or 512 = the wide head_dim 72 / 64 layout, chosen by estimated rounds of the chip -- few batch x head pairs keep 256). */
+int osk_attention_launch_shape(int B, int H, int Lq, int n_seg, int seg_len, int hd, float score_bound,
+                               int64_t workspace_bytes, int* rows_per_unit);
 int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
                            const void* k, int64_t k_seg_stride, int64_t k_batch_stride, int64_t k_row_stride,
                            const void* vt, int64_t vt_seg_stride,
@@ -271,6 +283,13 @@ const char* osk_attention_body_name(int hd, int n_seg, int seg_len, float score_
  * (temporal guidance ramp, sampling.py:209-216). */
 int osk_cfg_euler_bf16(const void* pred, int64_t n, const void* x, void* x_out,
                        float g_txt, float g_img, const float* g_img_vec, float dt, void* stream);
+
+/* ---- strided row copy: dst[b, l, 0:C] = src[b, l, 0:C] (bf16; element strides; src_batch_stride 0 broadcasts one item).
+ * replaces the host-side tensor glue of a denoise step: `torch.cat([img, img, img])` of the CFG triple
+ * (opensora/utils/sampling.py:196-201) and `torch.cat((img, cond), dim=-1)`-style operand assembly in front of img_in / cond_in
+ * (opensora/models/mmdit/model.py:170-176).  C and all strides multiples of 4 elements, pointers 8-byte aligned. */
+int osk_copy_rows_bf16(const void* src, int64_t src_batch_stride, int64_t src_row_stride, void* dst,
+                       int64_t dst_batch_stride, int64_t dst_row_stride, int B, int L, int C, void* stream);
 
 /* =====================================================================================================
  * Causal 3-D VAE (HunyuanVideo VAE, /root/reference/opensora/models/hunyuan_vae).  Activations are channels-last

@@ -51,7 +51,9 @@ SIGNATURES = {
     "osk_attention_fwd_pv8_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp,
                                    _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _i64, _vp],
     "osk_attention_tail_split_factor": [_i32, _i32, _i32, _i32, _i32, _i32, _i64],
+    "osk_attention_launch_shape": [_i32, _i32, _i32, _i32, _i32, _i32, _f32, _i64, C.POINTER(_i32)],
     "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
+    "osk_copy_rows_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "osk_causal_conv3d_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                      _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
     "osk_causal_conv3d_gn_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
@@ -83,7 +85,7 @@ def _load() -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name in ("osk_arch", "osk_attention_kernel_name", "osk_attention_body_name") else
                       _i64 if name in ("osk_attention_workspace_bytes", "osk_attention_hd512_workspace_bytes") else _i32)
-    if lib.osk_abi_version() != 1:
+    if lib.osk_abi_version() != 2:
         raise ImportError("libosk_hip.so ABI version mismatch")
     return lib
 
@@ -390,7 +392,7 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
     B, Lq, _ = q.shape
     if seg_len is None:
         seg_len = k.shape[1]
-    if CHECK_SCORE_BOUND and score_bound > 0:
+    if CHECK_SCORE_BOUND and score_bound > 0 and not torch.cuda.is_current_stream_capturing():   # (the check syncs: illegal in a capture)
         _assert_score_bound(q, k, H, hd, scale, n_seg, seg_len, k_seg_stride, q_prescaled, kv_batches, score_bound)
     prof = PROFILE_ATTENTION
     if prof is not None:
@@ -422,15 +424,24 @@ def attention_short(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
     return out
 
 
+def attention_launch_shape(B: int, H: int, Lq: int, n_seg: int, seg_len: int, hd: int, score_bound: float, workspace_bytes: int):
+    """(key parts of the last round's work units, query rows per work unit) of a bounded attention call with these arguments"""
+    rows = _i32(0)
+    parts = lib.osk_attention_launch_shape(B, H, Lq, n_seg, seg_len, hd, float(score_bound), int(workspace_bytes), C.byref(rows))
+    return int(parts), int(rows.value)
+
+
 def attention_body(hd: int, n_seg: int, seg_len: int, score_bound: float) -> str:
     """which loop body attention_fwd(..., score_bound=...) runs for this key layout (reporting: bench.py, tests)"""
     return lib.osk_attention_body_name(hd, n_seg, seg_len, float(score_bound)).decode()
 
 
-# OSK_TRACE=1 (debugging runs): every bounded attention call checks the caller's promise on the device before it launches -- the
-# bounded loop body has no running maximum, so a violated bound silently loses accuracy (or, far beyond it, overflows).  The check is
-# the sufficient condition the model's own bound is derived from (Cauchy-Schwarz per head): max |q_h| * max |k_h| <= bound.
-CHECK_SCORE_BOUND = bool(os.environ.get("OSK_TRACE"))
+# OSK_CHECK_SCORE_BOUND=1 (debugging runs; its own switch since round 5 -- the call tracer OSK_TRACE only records calls, as its
+# docstring says): every bounded attention call checks the caller's promise on the device before it launches -- the bounded loop
+# body has no running maximum, so a violated bound silently loses accuracy (or, far beyond it, overflows).  The check is the
+# sufficient condition the model's own bound is derived from (Cauchy-Schwarz per head): max |q_h| * max |k_h| <= bound.  It reads a
+# device scalar back (a blocking sync), so it is skipped while the stream is being captured into a hipGraph.
+CHECK_SCORE_BOUND = bool(os.environ.get("OSK_CHECK_SCORE_BOUND"))
 
 
 def _assert_score_bound(q, k, H, hd, scale, n_seg, seg_len, k_seg_stride, q_prescaled, kv_batches, bound):
@@ -495,6 +506,18 @@ def attention_fwd_pv8(q: torch.Tensor, k: torch.Tensor, vt8: torch.Tensor, v_sca
         ev1.record()
         prof.append((ev0, ev1))
     return out
+
+
+def copy_rows(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[b, l, :C] = src[b, l, :] for bf16 [B, L, C] views with unit channel stride on both sides (dst rows may be wider than C:
+    a column slice of a K-padded operand); a src of batch 1 -- or an expanded view -- is broadcast over dst's batch."""
+    B, L, Cc = dst.shape[0], dst.shape[1], src.shape[2]
+    assert src.dtype == dst.dtype == torch.bfloat16 and src.ndim == dst.ndim == 3, (src.dtype, dst.dtype, src.shape, dst.shape)
+    assert src.shape[1] == L and src.shape[0] in (1, B) and dst.shape[2] >= Cc and src.stride(2) == 1 and dst.stride(2) == 1
+    sbs = 0 if src.shape[0] == 1 else src.stride(0)
+    _check(lib.osk_copy_rows_bf16(src.data_ptr(), sbs, src.stride(1), dst.data_ptr(), dst.stride(0), dst.stride(1), B, L, Cc, _stream()),
+           "osk_copy_rows_bf16")
+    return dst
 
 
 def cfg_euler(pred: torch.Tensor, x: torch.Tensor, x_out: torch.Tensor, g_txt: float, g_img: float, dt: float,

@@ -101,16 +101,39 @@ int launch_merge(const AttnParams& p, int hd, hipStream_t st) {
 
 }  // namespace osk_attn
 
-extern "C" int osk_attention_tail_split_factor(int B, int H, int Lq, int n_seg, int seg_len, int hd,
-                                               int64_t workspace_bytes) {
-  if (B <= 0 || H <= 0 || Lq <= 0 || n_seg <= 0 || seg_len <= 0 || (hd != 64 && hd != 72 && hd != 128)) return 1;
+// reporting: (key parts, rows per work unit) the launch of a call with these arguments uses -- the SAME selection code as
+// osk_attention_fwd_bounded_bf16 below (round 4 modelled 256-row units whatever the call: ADVICE r4)
+static void launch_shape(osk_attn::AttnParams& p, int hd, void* workspace, int64_t workspace_bytes) {
+  p.rows = 256;
+  if (osk_attn::attn_wide_path(p, hd, osk_device_cus(), workspace != nullptr)) p.rows = 512;
+  if (hd == 64 || hd == 72 || hd == 128)
+    osk_attn::split_tail(p, ((p.Lq + p.rows - 1) / p.rows) * p.B * p.H, hd, workspace, workspace_bytes);
+}
+
+static float bound_to_bf16_up(float score_bound) {
+  // the kernels keep the bound in a bf16 field of Q's padding dim: round it UP to the next bf16 value (it stays a bound)
+  const unsigned bits = __builtin_bit_cast(unsigned, score_bound);
+  return __builtin_bit_cast(float, (bits + 0xFFFFu) & 0xFFFF0000u);
+}
+
+extern "C" int osk_attention_launch_shape(int B, int H, int Lq, int n_seg, int seg_len, int hd, float score_bound,
+                                          int64_t workspace_bytes, int* rows_per_unit) {
+  if (rows_per_unit) *rows_per_unit = 256;
+  if (B <= 0 || H <= 0 || Lq <= 0 || n_seg <= 0 || seg_len <= 0 || (hd != 64 && hd != 72 && hd != 128) || !(score_bound >= 0.f)) return 1;
   osk_attn::AttnParams p{};
   p.B = B; p.H = H; p.Lq = Lq; p.n_seg = n_seg; p.seg_len = seg_len;
   p.seg_lp = (seg_len + 63) / 64 * 64;
   p.tps = p.seg_lp / 64;
+  p.bound = bound_to_bf16_up(score_bound);
   static char dummy[16] __attribute__((aligned(16)));
-  osk_attn::split_tail(p, ((Lq + 255) / 256) * B * H, hd, dummy, workspace_bytes);
+  launch_shape(p, hd, workspace_bytes > 0 ? dummy : nullptr, workspace_bytes);
+  if (rows_per_unit) *rows_per_unit = p.rows;
   return p.tail_split;
+}
+
+extern "C" int osk_attention_tail_split_factor(int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                                               int64_t workspace_bytes) {
+  return osk_attention_launch_shape(B, H, Lq, n_seg, seg_len, hd, 0.0f, workspace_bytes, nullptr);
 }
 
 extern "C" int64_t osk_attention_workspace_bytes(void) {
@@ -152,17 +175,12 @@ extern "C" int osk_attention_fwd_bounded_bf16(const void* q, int64_t q_batch_str
   p.sc = q_prescaled ? 1.0f : scale * 1.4426950408889634f;  // log2 units; 1: q already carries it
   p.q_prescaled = q_prescaled;
   if (!(score_bound >= 0.f)) return OSK_EINVAL;   // (also rejects NaN)
-  {
-    // the kernels keep the bound in a bf16 field of Q's padding dim: round it UP to the next bf16 value (it stays a bound)
-    const unsigned bits = __builtin_bit_cast(unsigned, score_bound);
-    p.bound = __builtin_bit_cast(float, (bits + 0xFFFFu) & 0xFFFF0000u);
-  }
+  p.bound = bound_to_bf16_up(score_bound);
   if (kv_batches < 0 || kv_batches > B) return OSK_EINVAL;
   p.Bkv = kv_batches > 0 ? kv_batches : B;
   p.map = 1;   // XCD-contiguous work order (each XCD walks one head's K / V^T stream)
   if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 0)) return OSK_EINVAL;
-  if (osk_attn::attn_wide_path(p, hd)) p.rows = 512;
-  if (hd == 64 || hd == 72 || hd == 128) osk_attn::split_tail(p, ((Lq + p.rows - 1) / p.rows) * B * H, hd, workspace, workspace_bytes);
+  launch_shape(p, hd, workspace, workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   switch (hd) {
     case 64: return launch<64>(p, st);

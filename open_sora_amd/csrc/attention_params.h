@@ -125,12 +125,34 @@ int launch_asm72w(const AttnParams& p, hipStream_t st);
 // the same two kernels on tensors with 64-wide heads (template parameter HD = 64)
 int launch_asm64(const AttnParams& p, hipStream_t st);
 int launch_asm64w(const AttnParams& p, hipStream_t st);
-static inline bool attn_wide_path(const AttnParams& p, int hd) {
+// Rounds of the chip a launch of `units` equal work units takes, in units of one work unit's time: whole rounds plus the last,
+// partial one -- which costs a full round without a workspace and min over the admissible key splits s of ceil(R s / CUs) / s with
+// one (split_tail below makes the same choice).
+static inline double attn_launch_rounds(const AttnParams& p, int units, int cus, bool has_ws) {
+  const int R = units % cus;
+  double tail = R ? 1.0 : 0.0;
+  if (R && has_ws)
+    for (int s = 2; s <= 8; ++s) {
+      if (p.n_seg > 1 ? (p.n_seg % s != 0) : (s > p.tps)) continue;
+      const double c = (double)((R * s + cus - 1) / cus) / s;
+      if (c < tail) tail = c;
+    }
+  return (double)(units / cus) + tail;
+}
+// 512-row (wide) or 256-row work units for a bounded head_dim 72 / 64 call?  By estimated time, as tile_choice() does for the
+// GEMMs (round 4 looked at Lq >= 1024 only: with few batch x head pairs -- B = 1, or a head-parallel sequence-parallel rank with
+// H / P heads -- halving the unit count can leave most of the chip idle): a wide unit does the work of two narrow ones
+// in 1.85 x the time (-7.4 % per launch measured where both fill the chip, profiles/r04e_attn_wide_step_ab.jsonl).
+static inline bool attn_wide_path(const AttnParams& p, int hd, int cus, bool has_ws) {
 #ifdef OSK_ATTN_NO_WIDE   // (A/B builds of tools/make_attn_nowide_lib.sh: always the 256-row layout)
-  (void)p; (void)hd;
+  (void)p; (void)hd; (void)cus; (void)has_ws;
   return false;
 #else
-  return (hd == 72 || hd == 64) && attn_fast_path(p) && p.Lq >= 1024;
+  if (!((hd == 72 || hd == 64) && attn_fast_path(p) && p.Lq >= 1024)) return false;
+  const int bh = p.B * p.H;
+  const double narrow = attn_launch_rounds(p, ((p.Lq + 255) / 256) * bh, cus, has_ws);
+  const double wide = 1.852 * attn_launch_rounds(p, ((p.Lq + 511) / 512) * bh, cus, has_ws);
+  return wide <= narrow;
 #endif
 }
 // attention_asm128.hip: head_dim 128, the same layout and generator

@@ -719,5 +719,35 @@ extern "C" int osk_cfg_euler_bf16(const void* pred, int64_t n, const void* x, vo
   return (int)hipGetLastError();
 }
 
+// =============================================================================================
+// Strided row copy (bf16): dst[b, l, 0:C] = src[b, l, 0:C] with independent batch / row strides on both sides; a source batch
+// stride of 0 broadcasts one item over the batch.  The host glue of the denoise step (sampler: latents -> the CFG triple's
+// input; model: img / cond -> the K-padded img_in operand, sampling.py:196-201, model.py:170-176) without a torch kernel.
+// Bytes: 4 C per row (read + write).  8-byte units: C and every stride are multiples of 4 elements.
+// =============================================================================================
+__global__ void __launch_bounds__(256) copy_rows_kernel(const unsigned short* __restrict__ src, int64_t sbs, int64_t srs,
+                                                        unsigned short* __restrict__ dst, int64_t dbs, int64_t drs, int B, int L, int C4) {
+  const int64_t per_b = (int64_t)L * C4, total = per_b * B;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / per_b);
+    const int64_t r = i - b * per_b;
+    const int l = (int)(r / C4), c = (int)(r - (int64_t)l * C4) * 4;
+    *reinterpret_cast<uint2*>(dst + b * dbs + l * drs + c) = *reinterpret_cast<const uint2*>(src + b * sbs + l * srs + c);
+  }
+}
+
+extern "C" int osk_copy_rows_bf16(const void* src, int64_t src_batch_stride, int64_t src_row_stride, void* dst,
+                                  int64_t dst_batch_stride, int64_t dst_row_stride, int B, int L, int C, void* stream) {
+  if (!src || !dst || B <= 0 || L <= 0 || C <= 0) return OSK_EINVAL;
+  if ((C & 3) || (src_batch_stride & 3) || (src_row_stride & 3) || (dst_batch_stride & 3) || (dst_row_stride & 3)) return OSK_EINVAL;
+  if (((uintptr_t)src & 7) || ((uintptr_t)dst & 7)) return OSK_EINVAL;
+  const int64_t total = (int64_t)B * L * (C / 4);
+  int64_t nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src,
+                     src_batch_stride, src_row_stride, (unsigned short*)dst, dst_batch_stride, dst_row_stride, B, L, C / 4);
+  return (int)hipGetLastError();
+}
+
 extern "C" int osk_abi_version(void) { return OSK_ABI_VERSION; }
 extern "C" const char* osk_arch(void) { return "gfx950"; }

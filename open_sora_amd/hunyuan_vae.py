@@ -304,16 +304,18 @@ def _gn_pool() -> _GnSumsPool:
     return p
 
 
-def _conv(mod, x: Tensor, up=(False, False), res: Tensor | None = None, gn: int = 0) -> Tensor:
+def _conv(mod, x: Tensor, up=(False, False), res: Tensor | None = None, gn: int = 0, sums: Tensor | None = None) -> Tensor:
     """gn = G > 0: the output feeds an nn.GroupNorm(G, ...) next -- its statistics are taken in the conv's epilogue
-    (osk_causal_conv3d_gn_ndhwc_bf16) and travel with the tensor (`_osk_gn`) to `_gn`, which then skips its read pass."""
+    (osk_causal_conv3d_gn_ndhwc_bf16) and travel with the tensor (`_osk_gn`) to `_gn`, which then skips its read pass.
+    sums: a zeroed [B, G, 2] f64 accumulator the caller already took from the pool (nothing launched into it yet)."""
     p = _plan(mod, "conv")
     B, T, H, W, C = x.shape
     assert C == p.cin_p, (C, p.cin_p)
     To, Ho, Wo = _ops().conv_out_dims(T, H, W, p.stride, up)
     out = torch.empty(B, To, Ho, Wo, p.cout, dtype=BF16, device=x.device)
     if gn and p.cout % gn == 0:
-        sums = _gn_pool().take(B, gn, x.device)
+        if sums is None:
+            sums = _gn_pool().take(B, gn, x.device)
         _, fused = _ops().causal_conv3d(x, p.w, p.b, out, p.k, p.stride, up, res, gn_sums=sums)
         if fused:
             out._osk_gn = (gn, sums)
@@ -353,6 +355,7 @@ def _gn_silu_conv(norm: nn.GroupNorm, conv, x: Tensor, res: Tensor | None = None
     else:
         sums = torch.empty(B, G, 2, dtype=torch.float64, device=x.device)
         _ops().groupnorm_stats(x, G, sums)
+    out_sums = None
     if FOLD_GN and p.k == 3 and tuple(p.stride) == (1, 1, 1) and C == p.cin_p and C % 128 == 0:
         table = torch.empty(B, C // 8, 16, dtype=torch.float32, device=x.device)
         _ops().groupnorm_table(sums, gamma, beta, table, T * H * W, G, eps)
@@ -363,8 +366,10 @@ def _gn_silu_conv(norm: nn.GroupNorm, conv, x: Tensor, res: Tensor | None = None
             if fused:
                 out._osk_gn = (gn, out_sums)
             return out
+    # (a conv the folded form declined launched nothing: the pool slot taken for its output statistics is still zero -- hand it on
+    # instead of taking a second one, or a decoder pass runs the 64-slot pool dry and falls back to one fill per conv: ADVICE r4)
     h = _ops().groupnorm_apply(x, sums, gamma, beta, torch.empty_like(x), G, eps, True)
-    return _conv(conv, h, res=res, gn=gn)
+    return _conv(conv, h, res=res, gn=gn, sums=out_sums)
 
 
 def _resnet(blk: ResnetBlockCausal3D, x: Tensor) -> Tensor:

@@ -522,18 +522,34 @@ def _workspace(owner, B, L_txt, L_img, D, R, H, hd, device) -> _Workspace:
 # =============================================================================================
 # RoPE table handling
 # =============================================================================================
+_PE_MEMO: list = [None]   # (pe object(s) held alive, versions, hd, result): the conversion of the LAST pe seen
+
+
 def _pe_to_cos_sin(pe, hd: int):
     """Reference positional-embedding formats -> (cos, sin) f32 [B, L, hd/2], rope_mode.
     EmbedND tensor [B,1,L,hd/2,2,2] (layers.py:38-44; entries cos,-sin,sin,cos) -> mode 0 (interleaved);
-    LigerEmbedND tuple of [B,L,hd] (layers.py:55-65; halves repeated)           -> mode 1 (half-split)."""
+    LigerEmbedND tuple of [B,L,hd] (layers.py:55-65; halves repeated)           -> mode 1 (half-split).
+    A reference model hands the SAME pe object to each of its blocks (model.py:218-229): the conversion (two strided
+    gathers) is done once per object and remembered while that object is alive and unmodified -- 57 processor calls of a
+    forward pay for one."""
     if isinstance(pe, _RopeTable):
         return pe.cos, pe.sin, pe.mode
+    parts = (pe,) if isinstance(pe, torch.Tensor) else tuple(pe)
+
+    def version(t):   # (tensors made under inference_mode keep no version counter -- and cannot be modified in place: 0)
+        return 0 if t.is_inference() else t._version
+
+    vers = tuple(version(t) for t in parts)
+    m = _PE_MEMO[0]
+    if m is not None and m[2] == hd and len(m[0]) == len(parts) and all(a is b for a, b in zip(m[0], parts)) and m[1] == vers:
+        return m[3]
     if isinstance(pe, torch.Tensor):
-        cos = pe[:, 0, :, :, 0, 0].float().contiguous()
-        sin = pe[:, 0, :, :, 1, 0].float().contiguous()
-        return cos, sin, 0
-    cos, sin = pe
-    return cos[..., : hd // 2].float().contiguous(), sin[..., : hd // 2].float().contiguous(), 1
+        res = (pe[:, 0, :, :, 0, 0].float().contiguous(), pe[:, 0, :, :, 1, 0].float().contiguous(), 0)
+    else:
+        cos, sin = pe
+        res = (cos[..., : hd // 2].float().contiguous(), sin[..., : hd // 2].float().contiguous(), 1)
+    _PE_MEMO[0] = (parts, vers, hd, res)
+    return res
 
 
 @dataclass
@@ -598,14 +614,21 @@ def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd
 
 
 def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: int, col_txt: int, rope: _RopeTable,
-                     H: int, hd: int, sp=None):
+                     H: int, hd: int, sp=None, x_in=None, x_out=None):
     """DoubleStreamBlockProcessor.__call__ (layers.py:195-253) on the workspace's joint buffers.
     Residual streams live in ws.x ([:, :L_txt] txt, [:, L_txt:] img) and are updated in place.
     sp: a seqpar.SeqPar when the token axis is sharded (ws then holds this rank's rows; either stream may be
-    empty on a rank) — K/V are projected first and all-gathered while the Q projection runs."""
+    empty on a rank) — K/V are projected first and all-gathered while the Q projection runs.
+    x_in / x_out = (img, txt) pairs (stand-alone processor calls, both streams present, sp None): the block READS its input
+    streams from x_in (first LayerNorm, residual of the attention projection) and continues the residual streams in x_out, so a
+    caller's tensors are neither copied in nor modified."""
     D = H * hd
     Lt, Li = ws.L_txt, ws.L_img
     x_txt, x_img = ws.x[:, :Lt], ws.x[:, Lt:]
+    r_img, r_txt = x_img, x_txt            # where the block's input streams are read from
+    if x_in is not None:
+        assert sp is None and Li and Lt and x_out is not None
+        (r_img, r_txt), (x_img, x_txt) = x_in, x_out
     xm_txt, xm_img = ws.xm[:, :Lt], ws.xm[:, Lt:]
     y = ws.y_double(D)
     (i_sh1, i_sc1, i_g1, i_sh2, i_sc2, i_g2), mbs = _mod_views(mod, col_img, 6, D)
@@ -613,9 +636,9 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
     csb = rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0
     streams = []
     if Li:
-        streams.append((plan.img, x_img, xm_img, y[:, Lt:], i_sh1, i_sc1))
+        streams.append((plan.img, r_img, xm_img, y[:, Lt:], i_sh1, i_sc1))
     if Lt:
-        streams.append((plan.txt, x_txt, xm_txt, y[:, :Lt], t_sh1, t_sc1))
+        streams.append((plan.txt, r_txt, xm_txt, y[:, :Lt], t_sh1, t_sc1))
 
     acts = [_ln_modulate_for(aw.qkv_w, x_s, sh1, sc1, xm_s, mbs) for aw, x_s, xm_s, y_s, sh1, sc1 in streams]
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D:]
@@ -639,8 +662,8 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
         _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         sp.attention(ws, pending, q, v, H, hd, plan.score_bound)
     if paired:   # layers.py:247-252 for both streams, Linear by Linear
-        _linear_pair(dict(a=v[:, Lt:], w=plan.img.proj_w, bias=plan.img.proj_b, out=x_img, res=x_img, gate=i_g1, gate_batch_stride=mbs),
-                     dict(a=v[:, :Lt], w=plan.txt.proj_w, bias=plan.txt.proj_b, out=x_txt, res=x_txt, gate=t_g1, gate_batch_stride=mbs))
+        _linear_pair(dict(a=v[:, Lt:], w=plan.img.proj_w, bias=plan.img.proj_b, out=x_img, res=r_img, gate=i_g1, gate_batch_stride=mbs),
+                     dict(a=v[:, :Lt], w=plan.txt.proj_w, bias=plan.txt.proj_b, out=x_txt, res=r_txt, gate=t_g1, gate_batch_stride=mbs))
         (iw0, ib0, iw2, ib2), (tw0, tb0, tw2, tb2) = plan.img_mlp, plan.txt_mlp
         a_img = _ln_modulate_for(iw0, x_img, i_sh2, i_sc2, xm_img, mbs)
         a_txt = _ln_modulate_for(tw0, x_txt, t_sh2, t_sc2, xm_txt, mbs)
@@ -661,15 +684,18 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
 
 
 def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, rope: _RopeTable, H: int, hd: int,
-                     R: int, sp=None):
+                     R: int, sp=None, x_in=None, x_out=None):
     """SingleStreamBlockProcessor.__call__ (layers.py:309-334).  linear1's output row is [q|k|v|mlp]; attention
     writes into the v slot so linear2 reads the contiguous [attn | gelu(mlp)] columns: no torch.cat.
-    sp: see run_double_block — the K/V all-gather overlaps the Q and MLP-up projections."""
+    sp: see run_double_block — the K/V all-gather overlaps the Q and MLP-up projections.
+    x_in / x_out (stand-alone processor calls): read the stream from x_in, write the block's result into x_out."""
     D = H * hd
+    x_src = ws.x if x_in is None else x_in
+    x_dst = ws.x if x_out is None else x_out
     y = ws.y_single(D, R)
     (shift, scale, gate), mbs = _mod_views(mod, col, 3, D)
     csb = rope.cos.stride(0) if rope.cos.shape[0] > 1 else 0
-    act = _ln_modulate_for(plan.w1, ws.x, shift, scale, ws.xm, mbs)
+    act = _ln_modulate_for(plan.w1, x_src, shift, scale, ws.xm, mbs)
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D: 3 * D]
     scales = (plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale)
     if sp is None:
@@ -685,18 +711,24 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
         _linear(act, plan.w1[:D], None if b1 is None else b1[:D], q)
         _OPS.qknorm_rope(q, None, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         sp.attention(ws, pending, q, v, H, hd, plan.score_bound)
-    _linear(y[:, :, 2 * D:], plan.w2, plan.b2, ws.x, res=ws.x, gate=gate, gate_batch_stride=mbs)
+    _linear(y[:, :, 2 * D:], plan.w2, plan.b2, x_dst, res=x_src, gate=gate, gate_batch_stride=mbs)
 
 
-def _run_modulation(vec32: Tensor, layers, D: int) -> Tensor:
-    """Modulation.forward (layers.py:186-191) for a list of layers sharing vec: one GEMV launch."""
-    cols, col, task_layers = [], 0, []
-    for w, b in layers:
-        task_layers.append((w, b, col))
-        cols.append(col)
-        col += w.shape[0]
-    tasks = _OPS.GemvTasks(task_layers, vec32.device)
-    mod = torch.empty(vec32.shape[0], col, dtype=torch.float32, device=vec32.device)
+def _run_modulation(vec32: Tensor, plan, D: int) -> Tensor:
+    """Modulation.forward (layers.py:186-191) for the layers of one block plan sharing vec: one GEMV launch.  The task table
+    (four small device tensors) is part of the plan: built once per (plan, device), not per call -- a reference model with 57
+    processors installed used to pay 228 synchronous host-to-device copies per forward for it (VERDICT r4 weak #7)."""
+    cached = getattr(plan, "_mod_tasks", None)
+    if cached is None or cached[0] != str(vec32.device) or cached[1] is not _OPS:
+        cols, col, task_layers = [], 0, []
+        for w, b in plan.mod_layers:
+            task_layers.append((w, b, col))
+            cols.append(col)
+            col += w.shape[0]
+        cached = (str(vec32.device), _OPS, _OPS.GemvTasks(task_layers, vec32.device), cols, col)
+        plan._mod_tasks = cached
+    _, _, tasks, cols, ncol = cached
+    mod = torch.empty(vec32.shape[0], ncol, dtype=torch.float32, device=vec32.device)
     _OPS.gemv_tasks(vec32, tasks, mod, act_in=1)
     return mod, cols
 
@@ -710,8 +742,16 @@ class _ProcessorPool:
 _PROC_POOL = _ProcessorPool()
 
 
+def _direct_ok(*ts) -> bool:
+    """can the block kernels read these caller tensors in place (LayerNorm input, residual operand of a GEMM epilogue)?"""
+    return all(t.dtype == BF16 and t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 for t in ts)
+
+
 class HipDoubleStreamBlockProcessor:
-    """Drop-in for DoubleStreamBlockProcessor (layers.py:195-253): `(block, img, txt, vec, pe) -> (img, txt)`."""
+    """Drop-in for DoubleStreamBlockProcessor (layers.py:195-253): `(block, img, txt, vec, pe) -> (img, txt)`.
+    bf16 callers (the reference's inference dtype): the kernels read the caller's img / txt in place (LayerNorm input, residual of
+    the attention-projection GEMM) and the residual stream continues in two fresh output tensors that are returned as they are
+    -- no copy in, no clone out; other dtypes are staged through the workspace."""
 
     def __call__(self, attn: nn.Module, img: Tensor, txt: Tensor, vec: Tensor, pe) -> tuple[Tensor, Tensor]:
         H, hd = attn.num_heads, attn.head_dim
@@ -722,15 +762,21 @@ class HipDoubleStreamBlockProcessor:
         R = plan.img_mlp[0].shape[0]
         ws = _workspace(_PROC_POOL, B, Lt, Li, D, R, H, hd, img.device)
         cos, sin, mode = _pe_to_cos_sin(pe, hd)
-        mod, cols = _run_modulation(vec.float().contiguous(), plan.mod_layers, D)
+        mod, cols = _run_modulation(vec.float().contiguous(), plan, D)
+        rope = _RopeTable(cos, sin, mode)
+        if Li and Lt and _direct_ok(img, txt):
+            o_img, o_txt = torch.empty(B, Li, D, dtype=BF16, device=img.device), torch.empty(B, Lt, D, dtype=BF16, device=img.device)
+            run_double_block(plan, ws, mod, cols[0], cols[1], rope, H, hd, x_in=(img, txt), x_out=(o_img, o_txt))
+            return o_img, o_txt
         ws.x[:, Lt:].copy_(img)
         ws.x[:, :Lt].copy_(txt)
-        run_double_block(plan, ws, mod, cols[0], cols[1], _RopeTable(cos, sin, mode), H, hd)
+        run_double_block(plan, ws, mod, cols[0], cols[1], rope, H, hd)
         return ws.x[:, Lt:].clone().to(img.dtype), ws.x[:, :Lt].clone().to(txt.dtype)
 
 
 class HipSingleStreamBlockProcessor:
-    """Drop-in for SingleStreamBlockProcessor (layers.py:309-334): `(block, x, vec, pe) -> x`."""
+    """Drop-in for SingleStreamBlockProcessor (layers.py:309-334): `(block, x, vec, pe) -> x` (bf16 callers: x is read in place,
+    the result is written straight into the returned tensor)."""
 
     def __call__(self, attn: nn.Module, x: Tensor, vec: Tensor, pe) -> Tensor:
         H, hd = attn.num_heads, attn.head_dim
@@ -740,9 +786,14 @@ class HipSingleStreamBlockProcessor:
         R = plan.w1.shape[0] - 3 * D
         ws = _workspace(_PROC_POOL, B, 0, L, D, R, H, hd, x.device)
         cos, sin, mode = _pe_to_cos_sin(pe, hd)
-        mod, cols = _run_modulation(vec.float().contiguous(), plan.mod_layers, D)
+        mod, cols = _run_modulation(vec.float().contiguous(), plan, D)
+        rope = _RopeTable(cos, sin, mode)
+        if _direct_ok(x):
+            out = torch.empty(B, L, D, dtype=BF16, device=x.device)
+            run_single_block(plan, ws, mod, cols[0], rope, H, hd, R, x_in=x, x_out=out)
+            return out
         ws.x.copy_(x)
-        run_single_block(plan, ws, mod, cols[0], _RopeTable(cos, sin, mode), H, hd, R)
+        run_single_block(plan, ws, mod, cols[0], rope, H, hd, R)
         return ws.x.clone().to(x.dtype)
 
 
@@ -933,9 +984,16 @@ class MMDiTModel(_OskState, nn.Module):
             if a_in is None or a_in.shape[2] != Kp:
                 a_in = ws.a_in = torch.zeros(B, Li, Kp, dtype=BF16, device=dev)
             C_in = img.shape[2]
-            a_in[:, :, :C_in].copy_(img)
+
+            def put(src, col):   # src -> columns [col, col + C) of the K-padded operand: one osk_copy_rows_bf16 launch, no torch kernel
+                if src.dtype == BF16 and src.stride(2) == 1 and src.shape[2] % 4 == 0 and col % 4 == 0:
+                    _OPS.copy_rows(src, a_in[:, :, col:])
+                else:
+                    a_in[:, :, col: col + src.shape[2]].copy_(src)
+
+            put(img, 0)
             if cfg.cond_embed:
-                a_in[:, :, C_in: C_in + cond.shape[2]].copy_(cond)
+                put(cond, C_in)
             _OPS.gemm(a_in, p["in_w"], p["in_b"], ws.x[:, Lt:])
         # --- txt_in
         if Lt:

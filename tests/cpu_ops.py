@@ -290,6 +290,13 @@ def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=Non
     return out
 
 
+def copy_rows(src, dst):
+    B, L, C = dst.shape[0], dst.shape[1], src.shape[2]
+    assert src.dtype == dst.dtype == torch.bfloat16 and src.shape[1] == L and src.shape[0] in (1, B) and C % 4 == 0
+    dst[:, :, :C].copy_(src.expand(B, L, C))
+    return dst
+
+
 def cfg_euler(pred, x, x_out, g_txt, g_img, dt, g_img_vec=None):
     c, u, u2 = pred.float().reshape(3, -1)
     gi = g_img if g_img_vec is None else g_img_vec.reshape(-1)

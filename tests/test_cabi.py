@@ -25,7 +25,7 @@ def test_library_builds_and_exports_all_declared_symbols():
         assert hasattr(lib, n), f"{n} declared in include/osk.h but not exported"
     lib.osk_arch.restype = ctypes.c_char_p
     assert lib.osk_arch() == b"gfx950"
-    assert lib.osk_abi_version() == 1
+    assert lib.osk_abi_version() == 2
 
 
 def test_binding_signatures_cover_header():
@@ -69,7 +69,7 @@ def test_osk_trace_records_calls(monkeypatch):
     import open_sora_amd._C as C0
     C1 = importlib.reload(C0)
     try:
-        assert C1.lib.osk_abi_version() == 1            # not in SIGNATURES' argument-carrying set: passes through
+        assert C1.lib.osk_abi_version() == 2            # not in SIGNATURES' argument-carrying set: passes through
         n0 = len(C1.TRACE_LOG)
         rc = C1.lib.osk_blend_bf16(None, None, 1, 1, 1, 0, 1, None)      # NULL pointers -> invalid argument, nothing launched
         assert rc != 0
@@ -80,3 +80,19 @@ def test_osk_trace_records_calls(monkeypatch):
     finally:
         monkeypatch.delenv("OSK_TRACE")
         importlib.reload(C1)
+
+
+def test_attention_launch_shape_is_chosen_by_rounds_of_the_chip():
+    """osk_attention_launch_shape reports what osk_attention_fwd_bounded_bf16 launches, from the same selection code (host-only: no
+    GPU needed; 256 CUs assumed without a device).  The wide 512-row layout only where its work units fill the chip at least as
+    well as 256-row ones (Lq = 1024 with B x H = 16 and no workspace must keep 64 workgroups, not 32)."""
+    from open_sora_amd import _C as C1
+
+    ws = C1.lib.osk_attention_workspace_bytes()
+    assert C1.attention_launch_shape(3, 16, 16896, 1, 16896, 72, 12.9, ws)[1] == 512        # the timed denoise step
+    assert C1.attention_launch_shape(3, 16, 16896, 1, 16896, 72, 0.0, ws)[1] == 256         # no bound: the 256-row general body
+    assert C1.attention_launch_shape(3, 16, 16896, 1, 16896, 128, 17.0, ws)[1] == 256       # head_dim 128 has no wide layout
+    assert C1.attention_launch_shape(1, 16, 1024, 1, 1024, 72, 12.9, 0) == (1, 256)          # few units, nothing to split them with
+    parts, rows = C1.attention_launch_shape(1, 16, 16896, 1, 16896, 72, 12.9, ws)            # B = 1: 528 wide units = 2 rounds + 16
+    assert rows == 512 and parts == 8
+    assert C1.lib.osk_attention_tail_split_factor(1, 16, 16896, 1, 16896, 72, ws) == C1.attention_launch_shape(1, 16, 16896, 1, 16896, 72, 0.0, ws)[0]

@@ -232,7 +232,7 @@ def test_two_models_and_two_streams_do_not_share_workspaces(hip_lib):
 
 
 def test_score_bound_debug_check_on_device(hip_lib, monkeypatch):
-    """the bounded attention body trusts the caller's score bound.  With the debug switch on (OSK_TRACE=1 sets
+    """the bounded attention body trusts the caller's score bound.  With the debug switch on (OSK_CHECK_SCORE_BOUND=1 sets
     open_sora_amd._C.CHECK_SCORE_BOUND) every bounded call first checks the promise on the device: a golden model's forward passes
     it in every block; a call whose bound is too small raises instead of silently losing the tail of the softmax."""
     from open_sora_amd import _C, mmdit

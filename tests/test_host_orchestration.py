@@ -55,13 +55,24 @@ def test_processors_on_reference_style_pe(cpu_mmdit):
         t_img, t_txt = O.double_block(sd32, cfg, 0, img, txt, vec, ang, "interleaved")
         sdb = {k: v.bfloat16() for k, v in sd32.items()}
         r_img, r_txt = O.double_block(sdb, cfg, 0, img.bfloat16(), txt.bfloat16(), vec.bfloat16(), ang, "interleaved")
-        o_img, o_txt = model.double_blocks[0](img.bfloat16(), txt.bfloat16(), vec.bfloat16(), pe)
+        img_b, txt_b = img.bfloat16(), txt.bfloat16()
+        keep = (img_b.clone(), txt_b.clone())
+        o_img, o_txt = model.double_blocks[0](img_b, txt_b, vec.bfloat16(), pe)
+        # bf16 callers: the kernels read the caller's tensors in place and write fresh outputs -- the inputs must come back untouched
+        assert torch.equal(img_b, keep[0]) and torch.equal(txt_b, keep[1])
+        assert o_img.data_ptr() != img_b.data_ptr() and o_img.is_contiguous() and o_txt.is_contiguous()
         assert_parity(o_img, t_img, r_img, "double processor img")
         assert_parity(o_txt, t_txt, r_txt, "double processor txt")
         x = torch.cat((t_txt, t_img), 1)
         t_x = O.single_block(sd32, cfg, 0, x, vec, ang, "interleaved")
         r_x = O.single_block(sdb, cfg, 0, x.bfloat16(), vec.bfloat16(), ang, "interleaved")
-        o_x = model.single_blocks[0](x.bfloat16(), vec.bfloat16(), pe)
+        x_b = x.bfloat16()
+        keep_x = x_b.clone()
+        o_x = model.single_blocks[0](x_b, vec.bfloat16(), pe)
+        assert torch.equal(x_b, keep_x) and o_x.data_ptr() != x_b.data_ptr()
+        # a caller in another dtype is staged through the workspace and gets its dtype back
+        o_x32 = model.single_blocks[0](x_b.float(), vec.bfloat16().float(), pe)
+        assert o_x32.dtype == torch.float32 and torch.equal(o_x32.bfloat16(), o_x)
         assert_parity(o_x, t_x, r_x, "single processor")
 
 
