@@ -475,6 +475,16 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
             elapsed = time.perf_counter() - t0
             prof, _C.PROFILE_ATTENTION = _C.PROFILE_ATTENTION, None
             x = st["x"]
+        # sequence parallelism: how long the compute stream STALLED on each kind of exchange (q / k / v / o all-to-alls or the K / V^T
+        # all-gathers, the final gather), from event pairs around every wait() in 2 extra steps outside the timed region
+        exposed = None
+        if world > 1 and nb == 3:
+            sp.exposed = []
+            barrier()
+            run_denoise(x, 0, 2)
+            barrier()
+            exposed = {k_: round(v_ / 2, 3) for k_, v_ in sp.exposed_summary().items()}
+            sp.exposed = None
         # the attention body the timed steps ran (before any side measurement touches the QK-norm scales)
         rep = model.attention_report(world if sp_mode and "all-gather" in sp_mode else 1, L // world if world > 1 else L)
         # SURVEY.md section 8(d) cfg 2 asks for B = 1 (the pure step) next to the reference's CFG triple: a second, separately
@@ -675,7 +685,9 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
     if rel8 is not None:
         out["rel_l2_vs_bf16"] = round(rel8, 5)
     if world > 1:
-        out["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "exchange": sp_mode}
+        out["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "exchange": sp_mode,
+                       "exposed_comm_ms_per_step_rank0": exposed,
+                       "exposed_comm_what": "time the compute stream stalled in wait() per exchange kind (event pairs, 2 steps outside the timed region)"}
     del model
     torch.cuda.empty_cache()
     return out

@@ -284,12 +284,15 @@ const char* osk_attention_body_name(int hd, int n_seg, int seg_len, float score_
 int osk_cfg_euler_bf16(const void* pred, int64_t n, const void* x, void* x_out,
                        float g_txt, float g_img, const float* g_img_vec, float dt, void* stream);
 
-/* ---- strided row copy: dst[b, l, 0:C] = src[b, l, 0:C] (bf16; element strides; src_batch_stride 0 broadcasts one item).
+/* ---- strided row copy: dst[j, b, l, 0:C] = src[j, b, l, 0:C] (bf16; element strides; src_batch_stride 0 broadcasts one item).
  * replaces the host-side tensor glue of a denoise step: `torch.cat([img, img, img])` of the CFG triple
- * (opensora/utils/sampling.py:196-201) and `torch.cat((img, cond), dim=-1)`-style operand assembly in front of img_in / cond_in
- * (opensora/models/mmdit/model.py:170-176).  C and all strides multiples of 4 elements, pointers 8-byte aligned. */
-int osk_copy_rows_bf16(const void* src, int64_t src_batch_stride, int64_t src_row_stride, void* dst,
-                       int64_t dst_batch_stride, int64_t dst_row_stride, int B, int L, int C, void* stream);
+ * (opensora/utils/sampling.py:196-201), the operand assembly in front of img_in / cond_in (opensora/models/mmdit/model.py:170-176),
+ * and -- with n_chunks = P -- the two rearranges around the head all-to-all of the sequence-parallel attention
+ * (opensora/models/mmdit/distributed.py:473-495: [B, L/P, P x Dg] <-> [P, B, L/P, Dg]; the token-major side has chunk stride Dg).
+ * C and all strides multiples of 4 elements, pointers 8-byte aligned. */
+int osk_copy_rows_bf16(const void* src, int64_t src_chunk_stride, int64_t src_batch_stride, int64_t src_row_stride, void* dst,
+                       int64_t dst_chunk_stride, int64_t dst_batch_stride, int64_t dst_row_stride, int n_chunks, int B, int L, int C,
+                       void* stream);
 
 /* =====================================================================================================
  * Causal 3-D VAE (HunyuanVideo VAE, /root/reference/opensora/models/hunyuan_vae).  Activations are channels-last

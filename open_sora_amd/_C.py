@@ -53,7 +53,7 @@ SIGNATURES = {
     "osk_attention_tail_split_factor": [_i32, _i32, _i32, _i32, _i32, _i32, _i64],
     "osk_attention_launch_shape": [_i32, _i32, _i32, _i32, _i32, _i32, _f32, _i64, C.POINTER(_i32)],
     "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
-    "osk_copy_rows_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "osk_copy_rows_bf16": [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp],
     "osk_causal_conv3d_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
                                      _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
     "osk_causal_conv3d_gn_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,
@@ -509,14 +509,17 @@ def attention_fwd_pv8(q: torch.Tensor, k: torch.Tensor, vt8: torch.Tensor, v_sca
 
 
 def copy_rows(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
-    """dst[b, l, :C] = src[b, l, :] for bf16 [B, L, C] views with unit channel stride on both sides (dst rows may be wider than C:
-    a column slice of a K-padded operand); a src of batch 1 -- or an expanded view -- is broadcast over dst's batch."""
-    B, L, Cc = dst.shape[0], dst.shape[1], src.shape[2]
-    assert src.dtype == dst.dtype == torch.bfloat16 and src.ndim == dst.ndim == 3, (src.dtype, dst.dtype, src.shape, dst.shape)
-    assert src.shape[1] == L and src.shape[0] in (1, B) and dst.shape[2] >= Cc and src.stride(2) == 1 and dst.stride(2) == 1
-    sbs = 0 if src.shape[0] == 1 else src.stride(0)
-    _check(lib.osk_copy_rows_bf16(src.data_ptr(), sbs, src.stride(1), dst.data_ptr(), dst.stride(0), dst.stride(1), B, L, Cc, _stream()),
-           "osk_copy_rows_bf16")
+    """dst[..., :C] = src for bf16 [B, L, C] -- or [P, B, L, C], P chunks -- views with unit channel stride on both sides (dst rows
+    may be wider than C: a column slice of a K-padded operand; either side's chunk axis may be a column group of a token-major
+    tensor: `x.view(B, L, P, C).permute(2, 0, 1, 3)`); a 3-D src of batch 1 -- or an expanded view -- is broadcast over dst's batch."""
+    assert src.dtype == dst.dtype == torch.bfloat16 and src.ndim == dst.ndim and src.ndim in (3, 4), (src.dtype, dst.dtype, src.shape, dst.shape)
+    if src.ndim == 3:
+        src, dst = src.unsqueeze(0), dst.unsqueeze(0)
+    NC, B, L, Cc = dst.shape[0], dst.shape[1], dst.shape[2], src.shape[3]
+    assert src.shape[0] == NC and src.shape[2] == L and src.shape[1] in (1, B) and dst.shape[3] >= Cc and src.stride(3) == 1 and dst.stride(3) == 1
+    sbs = 0 if src.shape[1] == 1 else src.stride(1)
+    _check(lib.osk_copy_rows_bf16(src.data_ptr(), src.stride(0), sbs, src.stride(2), dst.data_ptr(), dst.stride(0), dst.stride(1), dst.stride(2),
+                                  NC, B, L, Cc, _stream()), "osk_copy_rows_bf16")
     return dst
 
 

@@ -720,32 +720,41 @@ extern "C" int osk_cfg_euler_bf16(const void* pred, int64_t n, const void* x, vo
 }
 
 // =============================================================================================
-// Strided row copy (bf16): dst[b, l, 0:C] = src[b, l, 0:C] with independent batch / row strides on both sides; a source batch
-// stride of 0 broadcasts one item over the batch.  The host glue of the denoise step (sampler: latents -> the CFG triple's
-// input; model: img / cond -> the K-padded img_in operand, sampling.py:196-201, model.py:170-176) without a torch kernel.
+// Strided row copy (bf16): dst[j, b, l, 0:C] = src[j, b, l, 0:C] with independent chunk / batch / row strides on both sides; a
+// source batch stride of 0 broadcasts one item over the batch.  The host glue of the denoise step without a torch kernel:
+// sampler: latents -> the CFG triple's input; model: img / cond -> the K-padded img_in operand (sampling.py:196-201,
+// model.py:170-176); sequence parallelism: "all heads of my tokens" [B, L/P, P x Dg] <-> "P head groups" [P, B, L/P, Dg] around
+// the head all-to-all (the rearranges of distributed.py:473-495; chunk j = columns j Dg .. of the token-major side).
 // Bytes: 4 C per row (read + write).  8-byte units: C and every stride are multiples of 4 elements.
 // =============================================================================================
-__global__ void __launch_bounds__(256) copy_rows_kernel(const unsigned short* __restrict__ src, int64_t sbs, int64_t srs,
-                                                        unsigned short* __restrict__ dst, int64_t dbs, int64_t drs, int B, int L, int C4) {
-  const int64_t per_b = (int64_t)L * C4, total = per_b * B;
+__global__ void __launch_bounds__(256) copy_rows_kernel(const unsigned short* __restrict__ src, int64_t scs, int64_t sbs, int64_t srs,
+                                                        unsigned short* __restrict__ dst, int64_t dcs, int64_t dbs, int64_t drs,
+                                                        int NC, int B, int L, int C4) {
+  const int64_t per_b = (int64_t)L * C4, per_c = per_b * B, total = per_c * NC;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int b = (int)(i / per_b);
-    const int64_t r = i - b * per_b;
+    const int j = (int)(i / per_c);
+    const int64_t rj = i - j * per_c;
+    const int b = (int)(rj / per_b);
+    const int64_t r = rj - b * per_b;
     const int l = (int)(r / C4), c = (int)(r - (int64_t)l * C4) * 4;
-    *reinterpret_cast<uint2*>(dst + b * dbs + l * drs + c) = *reinterpret_cast<const uint2*>(src + b * sbs + l * srs + c);
+    *reinterpret_cast<uint2*>(dst + j * dcs + b * dbs + l * drs + c) = *reinterpret_cast<const uint2*>(src + j * scs + b * sbs + l * srs + c);
   }
 }
 
-extern "C" int osk_copy_rows_bf16(const void* src, int64_t src_batch_stride, int64_t src_row_stride, void* dst,
-                                  int64_t dst_batch_stride, int64_t dst_row_stride, int B, int L, int C, void* stream) {
-  if (!src || !dst || B <= 0 || L <= 0 || C <= 0) return OSK_EINVAL;
-  if ((C & 3) || (src_batch_stride & 3) || (src_row_stride & 3) || (dst_batch_stride & 3) || (dst_row_stride & 3)) return OSK_EINVAL;
+extern "C" int osk_copy_rows_bf16(const void* src, int64_t src_chunk_stride, int64_t src_batch_stride, int64_t src_row_stride, void* dst,
+                                  int64_t dst_chunk_stride, int64_t dst_batch_stride, int64_t dst_row_stride, int n_chunks, int B, int L,
+                                  int C, void* stream) {
+  if (!src || !dst || n_chunks <= 0 || B <= 0 || L <= 0 || C <= 0) return OSK_EINVAL;
+  if ((C & 3) || (src_chunk_stride & 3) || (src_batch_stride & 3) || (src_row_stride & 3) || (dst_chunk_stride & 3) ||
+      (dst_batch_stride & 3) || (dst_row_stride & 3))
+    return OSK_EINVAL;
   if (((uintptr_t)src & 7) || ((uintptr_t)dst & 7)) return OSK_EINVAL;
-  const int64_t total = (int64_t)B * L * (C / 4);
+  const int64_t total = (int64_t)n_chunks * B * L * (C / 4);
   int64_t nb = (total + 255) / 256;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src,
-                     src_batch_stride, src_row_stride, (unsigned short*)dst, dst_batch_stride, dst_row_stride, B, L, C / 4);
+                     src_chunk_stride, src_batch_stride, src_row_stride, (unsigned short*)dst, dst_chunk_stride, dst_batch_stride,
+                     dst_row_stride, n_chunks, B, L, C / 4);
   return (int)hipGetLastError();
 }
 

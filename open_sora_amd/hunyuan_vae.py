@@ -251,7 +251,9 @@ def _plan(mod, kind):
     or one rewritten in place through the parameter itself, rebuilds it.  A load_state_dict at ANY level (the layer itself, a
     block, the whole VAE -- also under torch.inference_mode(), where the version key cannot see the copy) drops it through a
     post hook on the layer.  Writes through `p.data` are not visible: call AutoencoderKLCausal3D.invalidate_plan() after them."""
-    leaf = mod.conv if isinstance(mod, CausalConv3d) else mod
+    # the parameter-owning layer: a CausalConv3d (this package's holder or the REFERENCE's own class -- vae_plugin.py runs this
+    # engine on the reference's modules) wraps its nn.Conv3d as `.conv`
+    leaf = mod.conv if not isinstance(mod, nn.Conv3d) and isinstance(getattr(mod, "conv", None), nn.Conv3d) else mod
     key = tuple((q.data_ptr(), 0 if q.is_inference() else q._version) for q in leaf.parameters())
     c = _PLANS.get(leaf)
     p = c[1] if c is not None and c[0] == key else None

@@ -707,9 +707,15 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
         _linear(act, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])
         _OPS.qknorm_rope(None, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
         pending = sp.gather_kv_start(ws, k, v, H, hd, plan.pv8)
-        _linear(act, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
+        mlp_up = lambda: _linear(act, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
+        head_mode = sp.head_parallel(H)
+        if not head_mode:    # K / V^T all-gather: the MLP-up and Q projections both overlap it
+            mlp_up()
         _linear(act, plan.w1[:D], None if b1 is None else b1[:D], q)
         _OPS.qknorm_rope(q, None, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
+        if head_mode:        # head exchange: q has to travel too -- project it first, the MLP-up GEMM (the block's largest) hides its all-to-all
+            pending = sp.q_exchange_start(pending, q, H, hd)
+            mlp_up()
         sp.attention(ws, pending, q, v, H, hd, plan.score_bound)
     _linear(y[:, :, 2 * D:], plan.w2, plan.b2, x_dst, res=x_src, gate=gate, gate_batch_stride=mbs)
 

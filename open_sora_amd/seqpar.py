@@ -115,9 +115,32 @@ class SeqPar:
         self.tp = transport if transport is not None else DistTransport(group)
         self.P, self.rank = self.tp.P, self.tp.rank
         self._bufs = {}
+        self.exposed = None   # a list while bench.py measures exposed communication (see _timed_wait)
         self.mode = mode or os.environ.get("OSK_SP_MODE", "auto")   # "allgather" | "ulysses" | "auto"
         if self.mode not in ("allgather", "ulysses", "auto"):
             raise ValueError(f"unknown sequence-parallel mode {self.mode!r}")
+
+    # ------------------------------------------------------------------ exposed-communication accounting (bench.py --gpus N)
+    def _timed_wait(self, work, what: str):
+        """wait() on an exchange; with `self.exposed` set to a list, bracket the wait with two events on the compute stream: the
+        time between them is what the compute stream STALLED for this exchange -- its exposed part (0 when the exchange finished
+        behind the kernels queued in front of the wait).  Events only; the host does not block."""
+        rec = self.exposed
+        if rec is None or not torch.cuda.is_available():
+            work.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        work.wait()
+        e1.record()
+        rec.append((what, e0, e1))
+
+    def exposed_summary(self) -> dict:
+        """ms the compute stream stalled per exchange kind since `exposed` was set (call after a synchronize)"""
+        out: dict = {}
+        for what, e0, e1 in self.exposed or []:
+            out[what] = out.get(what, 0.0) + e0.elapsed_time(e1)
+        return {k: round(v, 3) for k, v in out.items()}
 
     def head_parallel(self, H: int) -> bool:
         """exchange heads (all-to-all) instead of gathering K / V^T?"""
@@ -178,13 +201,13 @@ class SeqPar:
             sv = mmdit.v_scale_fp8(v, H, hd)
             self.tp.all_reduce_max(sv)
             k_all, vt8_all = self._buffers8(B, Lloc, H, hd, k.device)
-            k_all[self.rank].copy_(k)
+            mmdit.ops().copy_rows(k, k_all[self.rank])
             mmdit.ops().v_transpose_fp8(v, sv, vt8_all[self.rank], H, hd)
             wk = self.tp.all_gather(k_all.view(-1), k_all[self.rank].view(-1))
             wv = self.tp.all_gather(vt8_all.view(-1), vt8_all[self.rank].view(-1))
             return "pv8", k_all, vt8_all, sv, wk, wv
         k_all, vt_all = self._buffers(B, Lloc, H, hd, k.device)
-        k_all[self.rank].copy_(k)
+        mmdit.ops().copy_rows(k, k_all[self.rank])
         mmdit.ops().v_transpose(v, vt_all[self.rank], H, hd)
         wk = self.tp.all_gather(k_all.view(-1), k_all[self.rank].view(-1))
         wv = self.tp.all_gather(vt_all.view(-1), vt_all[self.rank].view(-1))
@@ -200,15 +223,15 @@ class SeqPar:
         ops = mmdit.ops()
         if isinstance(pending[0], str):   # "pv8"
             _, k_all, vt8_all, sv, wk, wv = pending
-            wk.wait()
-            wv.wait()
+            self._timed_wait(wk, "k")
+            self._timed_wait(wv, "v")
             ops.attention_fwd_pv8(q, k_all[0], vt8_all, sv, out, H, hd, hd ** -0.5, n_seg=self.P, seg_len=Lloc,
                                   k_seg_stride=k_all.stride(0), vt_seg_stride=vt8_all.stride(0), q_prescaled=True,
                                   workspace=ops.attention_workspace(q.device))
             return
         k_all, vt_all, wk, wv = pending
-        wk.wait()
-        wv.wait()
+        self._timed_wait(wk, "k")
+        self._timed_wait(wv, "v")
         ops.attention_fwd(q, k_all[0], vt_all, out, H, hd, hd ** -0.5, n_seg=self.P, seg_len=Lloc,
                           k_seg_stride=k_all.stride(0), vt_seg_stride=vt_all.stride(0), q_prescaled=True,
                           workspace=ops.attention_workspace(q.device), score_bound=score_bound)
@@ -229,9 +252,15 @@ class SeqPar:
         return b
 
     def _to_head_chunks(self, dst: Tensor, x: Tensor):
-        """[B, L/P, H*hd] (all heads of my tokens) -> dst [P, B, L/P, (H/P)*hd]: chunk j = head group j, for rank j"""
+        """[B, L/P, H*hd] (all heads of my tokens) -> dst [P, B, L/P, (H/P)*hd]: chunk j = head group j, for rank j.
+        ONE osk_copy_rows_bf16 launch (chunk j of the source = columns j Dg ..): round 4 ran a torch permute-copy here, four per block."""
         B, Lloc, D = x.shape
-        dst.copy_(x.view(B, Lloc, self.P, D // self.P).permute(2, 0, 1, 3))
+        mmdit.ops().copy_rows(x.view(B, Lloc, self.P, D // self.P).permute(2, 0, 1, 3), dst)
+
+    def _from_head_chunks(self, out: Tensor, src: Tensor):
+        """the way back: src [P, B, L/P, Dg] (head group j of my tokens, from rank j) -> out [B, L/P, P x Dg], head groups side by side"""
+        B, Lloc, D = out.shape
+        mmdit.ops().copy_rows(src, out.view(B, Lloc, self.P, D // self.P).permute(2, 0, 1, 3))
 
     def _heads_kv_start(self, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False):
         B, Lloc, _ = k.shape
@@ -242,14 +271,25 @@ class SeqPar:
         wv = self.tp.all_to_all(bufs["vr"].view(-1), bufs["vs"].view(-1))
         return "heads", bufs, wk, wv, pv8
 
+    def q_exchange_start(self, pending, q: Tensor, H: int, hd: int):
+        """Head-parallel mode: start the all-to-all of the (normed, rotated, pre-scaled) queries and return the extended handle
+        tuple -- whatever the caller queues before attention() overlaps it (single blocks: the MLP-up projection, the largest GEMM of
+        the block; round 4 started this exchange inside attention() and waited on the spot).  All-gather mode: nothing to do."""
+        if not (isinstance(pending[0], str) and pending[0] == "heads") or len(pending) > 5:
+            return pending
+        bufs = pending[1]
+        self._to_head_chunks(bufs["qs"], q)
+        wq = self.tp.all_to_all(bufs["qr"].view(-1), bufs["qs"].view(-1))
+        return (*pending, wq)
+
     def _heads_attention(self, pending, q: Tensor, out: Tensor, H: int, hd: int, score_bound: float = 0.0):
-        _, bufs, wk, wv, pv8 = pending
+        pending = self.q_exchange_start(pending, q, H, hd)     # (a caller that did not start it earlier)
+        _, bufs, wk, wv, pv8, wq = pending
         B, Lloc, D = q.shape
         P, Hg = self.P, H // self.P
-        self._to_head_chunks(bufs["qs"], q)
-        self.tp.all_to_all(bufs["qr"].view(-1), bufs["qs"].view(-1)).wait()
-        wk.wait()
-        wv.wait()
+        self._timed_wait(wq, "q")
+        self._timed_wait(wk, "k")
+        self._timed_wait(wv, "v")
         # received chunk s = source rank s's tokens = key segment s; [P, B] is also the query "batch" axis
         ops = mmdit.ops()
         qr, kr, os_ = bufs["qr"].view(P * B, Lloc, Hg * hd), bufs["kr"], bufs["os"].view(P * B, Lloc, Hg * hd)
@@ -269,8 +309,8 @@ class SeqPar:
                               vt_seg_stride=vt.stride(0), q_prescaled=True, kv_batches=B,
                               workspace=ops.attention_workspace(q.device), score_bound=score_bound)
         # chunk s of the output belongs to rank s's tokens: straight back, then head groups side by side
-        self.tp.all_to_all(bufs["orr"].view(-1), bufs["os"].view(-1)).wait()
-        out.view(B, Lloc, P, D // P).permute(2, 0, 1, 3).copy_(bufs["orr"])
+        self._timed_wait(self.tp.all_to_all(bufs["orr"].view(-1), bufs["os"].view(-1)), "o")
+        self._from_head_chunks(out, bufs["orr"])
 
     # ------------------------------------------------------------------ output
     def gather_output(self, ws, project, C_out: int, L_txt: int) -> Tensor:
@@ -279,7 +319,7 @@ class SeqPar:
         B, Lloc = ws.B, ws.L
         full = torch.empty(self.P, B, Lloc, C_out, dtype=BF16, device=ws.x.device)
         project(full[self.rank])
-        self.tp.all_gather(full.view(-1), full[self.rank].view(-1)).wait()
+        self._timed_wait(self.tp.all_gather(full.view(-1), full[self.rank].view(-1)), "out")
         return full.permute(1, 0, 2, 3).reshape(B, self.P * Lloc, C_out)[:, L_txt:].contiguous()
 
 

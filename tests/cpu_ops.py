@@ -291,9 +291,9 @@ def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=Non
 
 
 def copy_rows(src, dst):
-    B, L, C = dst.shape[0], dst.shape[1], src.shape[2]
-    assert src.dtype == dst.dtype == torch.bfloat16 and src.shape[1] == L and src.shape[0] in (1, B) and C % 4 == 0
-    dst[:, :, :C].copy_(src.expand(B, L, C))
+    assert src.dtype == dst.dtype == torch.bfloat16 and src.ndim == dst.ndim and src.ndim in (3, 4) and src.shape[-1] % 4 == 0
+    C = src.shape[-1]
+    dst[..., :C].copy_(src.expand(*dst.shape[:-1], C))
     return dst
 
 

@@ -146,7 +146,10 @@ def test_xl_timed_configuration_vs_reference_fixture(hip_lib):
     with torch.inference_mode():
         out = model(**_to(inp3, BF, DEV)).float().cpu()
     assert list(out.shape) == [3, G["T"] * G["h"] * G["w"], cfg["in_channels"]] and torch.isfinite(out).all()
-    assert model.attention_report(3, 16896)["bodies"] == ["attn_asm72w_kernel<FAST>"], "not the loop body the bench times"
+    rep = model.attention_report(1, 16896)
+    assert rep["bodies"] == ["attn_asm72_kernel<FAST>"], "not the loop body the bench times"
+    assert hip_lib.attention_launch_shape(3, cfg["num_heads"], 16896, 1, 16896, 72, rep["score_bound_max"],
+                                          hip_lib.lib.osk_attention_workspace_bytes())[1] == 512, "not the wide layout the bench times"
     e_ref, a_ref = float(g["e_ref"]), float(g["a_ref"])
     truth = torch.from_numpy(g["out_s8"])
     tnorm = float(np.sqrt(g["ch_sq"].sum()))          # rms over tokens of the whole truth, per channel -> Frobenius scale

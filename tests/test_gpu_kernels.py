@@ -804,6 +804,27 @@ def test_cfg_euler(hip_lib):
     bf16_ulp_close(xo.float().cpu(), ref.bfloat16().float(), abs_=1e-3)
 
 
+def test_copy_rows(hip_lib):
+    """osk_copy_rows_bf16: strided row copies of the step's host glue -- a column slice of a wider operand as destination, a
+    batch-broadcast source, odd row counts; bit-exact, nothing outside the destination columns touched."""
+    B, L, C, Kp = 3, 1031, 68, 192
+    src = rnd("s", (B, L, C))
+    dst = torch.full((B, L, Kp), 7.0, dtype=BF, device=DEV)
+    hip_lib.copy_rows(src, dst[:, :, 64:])
+    assert torch.equal(dst[:, :, 64:64 + C], src) and bool((dst[:, :, :64] == 7).all()) and bool((dst[:, :, 64 + C:] == 7).all())
+    one = rnd("o", (1, L, 64))
+    out = torch.empty(B, L, 64, dtype=BF, device=DEV)
+    hip_lib.copy_rows(one, out)
+    assert torch.equal(out, one.expand(B, L, 64))
+    wide = rnd("w", (2, 40, 256))
+    view = wide[:, 3:36, 128:192]                       # strided source: row stride 256, column offset
+    out2 = torch.empty(2, 33, 64, dtype=BF, device=DEV)
+    hip_lib.copy_rows(view, out2)
+    assert torch.equal(out2, view)
+    with pytest.raises(RuntimeError):
+        hip_lib.copy_rows(rnd("b", (1, 8, 6)), torch.empty(1, 8, 6, dtype=BF, device=DEV))   # C % 4 != 0
+
+
 def test_errors_raise(hip_lib):
     a = torch.zeros(1, 8, 100, dtype=BF, device=DEV)
     w = torch.zeros(16, 100, dtype=BF, device=DEV)

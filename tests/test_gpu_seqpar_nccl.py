@@ -49,10 +49,22 @@ def _worker(rank, world, port, name, geom, q, mode, fp8):
             single = model(**inp).float().cpu()
             sp = seqpar.enable(model, mode=mode)
             assert model._sp is not None and sp.P == world and dist.get_backend() == "nccl"
-            outs = [model(**inp).float().cpu() for _ in range(3)]   # repeated calls reuse the gathered-K/V buffers
+            # 12 forwards back to back, no host sync in between: repeated calls reuse the exchange buffers while RCCL's kernels share
+            # the CUs with the hand-scheduled MFMA loops -- the screen that caught the packed-FP32 cross-kernel interference on one GPU
+            # (profiles/r03_cross_kernel_interference.md) applied to the first real multi-GPU run
+            outs_dev = [model(**inp) for _ in range(12)]
+            torch.cuda.synchronize()
+            outs = [o.float().cpu() for o in outs_dev]
+            sp.exposed = []                                           # exposed-communication accounting (bench.py --gpus N)
+            model(**inp)
+            torch.cuda.synchronize()
+            summary = sp.exposed_summary()
+            assert summary and all(v >= 0.0 for v in summary.values()) and "out" in summary, summary
+            sp.exposed = None
             seqpar.disable(model)
         torch.cuda.synchronize()
-        assert all(torch.equal(outs[0], o) for o in outs[1:]), "sequence-parallel forward is not repeatable"
+        bad = [i for i, o in enumerate(outs[1:], 1) if not torch.equal(outs[0], o)]
+        assert not bad, f"sequence-parallel forward is not repeatable: forwards {bad} of 12 differ from forward 0"
         q.put((rank, single.numpy(), outs[0].numpy()))
     except BaseException:
         import traceback

@@ -165,3 +165,45 @@ def test_groupnorm_fold_is_opt_in_and_equivalent(cpu_vae):
         vae.FOLD_GN = False
     d = (fold.float() - plain.float()).abs().max()
     assert d <= 2.0 ** -6 * plain.float().abs().max(), d
+
+
+def test_plugin_targets_run_on_the_reference_modules(cpu_vae):
+    """SURVEY 8(b) "VAE plugin point" (VERDICT r4 missing #3): the reference's OWN AutoencoderKLCausal3D (oracle/ref_loader.py) with
+    open_sora_amd.vae_plugin's from_native_module targets installed on its encoder / decoder -- the ShardFormer replacement
+    convention of hunyuan_vae/policy.py:13-48 -- against the same module un-patched (fp32 truth, bf16 comparator).  The state dict
+    is untouched, the reference's own encode / decode / tiling Python drives the kernels, uninstall restores the native modules;
+    and the per-layer target (one CausalConv3d) equals the native layer."""
+    from oracle import make_golden, ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("/root/reference not mounted")
+    from open_sora_amd import vae_plugin
+
+    cfg, B, T, H, W = configs.VAE_GOLDEN["c32_single_frame"] if "c32_single_frame" in configs.VAE_GOLDEN else next(iter(configs.VAE_GOLDEN.values()))
+    name = next(n for n, v in configs.VAE_GOLDEN.items() if v[0] is cfg)
+    g = np.load(os.path.join(GOLDEN_DIR, f"vae_{name}.npz"))
+    ref = make_golden.reference_vae(cfg)
+    x = torch.from_numpy(synth.vae_video(B, T, H, W))
+    zin = torch.from_numpy(synth.vae_latent(B, *g["z"].shape[2:]))
+    with torch.inference_mode():
+        z_t = ref.encode(x, sample_posterior=False)
+        d_t = ref.decode(zin)
+        refb = ref.to(BF)
+        keys = list(refb.state_dict().keys())
+        z_r = finite_retry(lambda: refb.encode(x.to(BF), sample_posterior=False))
+        d_r = finite_retry(lambda: refb.decode(zin.to(BF)))
+        vae_plugin.install(refb)
+        assert isinstance(refb.encoder, vae_plugin.HipEncoderCausal3D) and isinstance(refb.decoder, vae_plugin.HipDecoderCausal3D)
+        assert list(refb.state_dict().keys()) == keys, "the plug-in changed the state dict"
+        z = refb.encode(x.to(BF), sample_posterior=False)
+        dec = refb.decode(zin.to(BF))
+        assert z.dtype == BF and dec.dtype == BF
+        assert_parity(z, z_t, z_r, f"reference VAE + HIP encoder target [{name}]")
+        assert_parity(dec, d_t, d_r, f"reference VAE + HIP decoder target [{name}]")
+        # per-layer granularity: one CausalConv3d of the (native) decoder
+        vae_plugin.uninstall(refb)
+        assert not isinstance(refb.encoder, vae_plugin.HipEncoderCausal3D)
+        conv = refb.decoder.conv_in
+        h_nat = conv(zin.to(BF))
+        h_hip = vae_plugin.HipCausalConv3d.from_native_module(conv)(zin.to(BF))
+        assert h_hip.shape == h_nat.shape and (h_hip.float() - h_nat.float()).abs().max() <= 2.0 ** -6 * h_nat.float().abs().max() + 1e-3
