@@ -64,8 +64,10 @@ OSK_DEV float gelu_tanh(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2 u) == x / (1 + 2^(-2 log2(e) u)):
   // two multiplies, one fma, v_exp_f32, one add, v_rcp_f32, one multiply (1-ulp transcendentals: the result is
   // rounded to bf16 by the caller).  x -> -inf: 2^(+inf) = inf, rcp = 0, result -0; x -> +inf: x.
-  const float t = x * __builtin_fmaf(0.044715f, x * x, 1.0f);
-  const float e = __builtin_amdgcn_exp2f(t * (-2.0f * 0.7978845608028654f * 1.4426950408889634f));
+  // (round 5: the exponent's constant factor folded into the cubic's coefficients -- one multiply less per element; the GELU class
+  // costs the GEMM epilogue 11.5 k cycles per 256 x 256 tile, profiles/r05a_gemm_tile_timing_by_epilogue_class.jsonl)
+  constexpr float K0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(0.044715f * K0, x * x, K0));
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 OSK_DEV float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }

@@ -29,8 +29,11 @@ SHAPES = [(M, 3456, 1152, "XL qkv", "plain"), (M, 1152, 1152, "XL proj", "gate")
           (M, 4608, 1152, "XL mlp up (no GELU)", "plain"), (16896, 8064, 1152, "XL linear1, B=1", "gelu_from_3456"),
           (16896, 1152, 5760, "XL linear2, B=1", "gate"),
           (M, 9216, 3072, "11B qkv", "plain"), (8192, 8192, 8192, "8192^3", "plain")]
+only = os.environ.get("OSK_TT_ONLY")          # e.g. OSK_TT_ONLY=gate: only the shapes of that epilogue class
 buf = (ctypes.c_ulonglong * 4)()
 for m, n, k, name, cls in SHAPES:
+    if only and only not in cls:
+        continue
     a = torch.randn(1, m, k, device=dev).to(torch.bfloat16)
     w = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
     b = torch.zeros(n, device=dev)
