@@ -128,15 +128,14 @@ OSK_DEV float row16_sum(float v) {
 
 // fast path of one pair of voxel blocks (I, I + 1) of channel block J: whole 16-channel block inside Cout, rows 16-byte
 // addressable.  RES / GN are compile-time, bias arrives as a register quad: 64 tiles per wave make per-tile branches count.
-// rv: this lane's residual pieces of tiles (J, I) and (J, I + 1), loaded ahead by tile_x's software pipeline (RES only)
 template <bool RES, bool GN, int J, int I>
-OSK_DEV void pair_x(const osk_v4f* aq, const ConvParams& p, const bool* valid, const int64_t* storeoff, const bool* svalid,
-                    int ncol, const float4& bq, float& gs, float& gq, const uint2* rv) {
+OSK_DEV void pair_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid,
+                    int n, int ncol, const float4& bq, float& gs, float& gq) {
   float a0[4], a1[4];
   uint2 r0 = make_uint2(0, 0), r1 = r0;
   if constexpr (RES) {
-    r0 = rv[0];
-    r1 = rv[1];
+    r0 = *reinterpret_cast<const uint2*>(p.res + rowoff[I] + n);        // rows beyond M read row 0 (clamped offsets)
+    r1 = *reinterpret_cast<const uint2*>(p.res + rowoff[I + 1] + n);
   }
   read_x<J * OSKX_NB + I>(aq, a0);
   read_x<J * OSKX_NB + I + 1>(aq, a1);
@@ -167,35 +166,15 @@ OSK_DEV void pair_x(const osk_v4f* aq, const ConvParams& p, const bool* valid, c
   if (svalid[I / 2]) *reinterpret_cast<uint4*>(p.out + storeoff[I / 2] + ncol) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
 }
 
-// the residual pieces of one pair of voxel blocks (I, I + 1), all channel blocks: 2 NBJ loads of 8 bytes per lane, issued back to back
-// (rows beyond M read row 0: clamped offsets)
-template <bool FULL, int I, int... Js>
-OSK_DEV void load_res_x(const ConvParams& p, const int64_t* rowoff, int n0w, int q4, uint2 (*rv)[2], std::integer_sequence<int, Js...>) {
-  ((FULL || n0w + Js * 16 < p.Cout
-        ? (void)(rv[Js][0] = *reinterpret_cast<const uint2*>(p.res + rowoff[I] + n0w + Js * 16 + q4 * 4),
-                 rv[Js][1] = *reinterpret_cast<const uint2*>(p.res + rowoff[I + 1] + n0w + Js * 16 + q4 * 4))
-        : (void)0), ...);
-}
-
 // all channel blocks J of one pair of voxel blocks, back to back: consecutive stores fill a voxel row's 32-byte pieces left to
 // right (with the channel block outermost the pieces of one 64-byte sector left four stores apart: +30 % fabric-side writes).
 // FULL: every channel block of the wave tile lies inside Cout (no per-block test)
 template <bool RES, bool GN, bool FULL, int I, int... Js>
-OSK_DEV void rowpair_x(const osk_v4f* aq, const ConvParams& p, const bool* valid, const int64_t* storeoff, const bool* svalid,
-                       int n0w, const float4* bq, float* gs, float* gq, const uint2 (*rv)[2], std::integer_sequence<int, Js...>) {
+OSK_DEV void rowpair_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid,
+                       int n0w, int q4, const float4* bq, float* gs, float* gq, std::integer_sequence<int, Js...>) {
   ((FULL || n0w + Js * 16 < p.Cout
-        ? pair_x<RES, GN, Js, I>(aq, p, valid, storeoff, svalid, n0w + Js * 16, bq[Js], gs[Js], gq[Js], rv[Js])
+        ? pair_x<RES, GN, Js, I>(aq, p, rowoff, valid, storeoff, svalid, n0w + Js * 16 + q4 * 4, n0w + Js * 16, bq[Js], gs[Js], gq[Js])
         : (void)0), ...);
-}
-
-// RES (the resnet blocks' conv2 / shortcut sum): the residual pieces are a software pipeline over the voxel-block pairs, as in
-// gemm_epilogue16.h::wide_step -- a pair's memory latency is paid once per wave tile, not once per pair
-template <bool RES, bool GN, bool FULL, int NBJ, int IP>
-OSK_DEV void step_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowoff, const bool* valid, const int64_t* storeoff, const bool* svalid,
-                    int n0w, int q4, const float4* bq, float* gs, float* gq, uint2 (*rv)[NBJ][2]) {
-  constexpr auto js = std::make_integer_sequence<int, NBJ>{};
-  if constexpr (RES && IP + 1 < OSKX_NB / 2) load_res_x<FULL, 2 * (IP + 1)>(p, rowoff, n0w, q4, rv[(IP + 1) & 1], js);
-  rowpair_x<RES, GN, FULL, 2 * IP>(aq, p, valid, storeoff, svalid, n0w, bq, gs, gq, rv[IP & 1], js);
 }
 
 template <bool RES, bool GN, bool FULL, int NBJ, int... Is>
@@ -203,8 +182,6 @@ OSK_DEV void tile_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowof
                     int n0w, int l15, int q4, float* ls, std::integer_sequence<int, Is...>) {
   float4 bq[NBJ];
   float gs[NBJ], gq[NBJ];
-  uint2 rv[2][NBJ][2];
-  if constexpr (RES) load_res_x<FULL, 0>(p, rowoff, n0w, q4, rv[0], std::make_integer_sequence<int, NBJ>{});
 #pragma unroll
   for (int j = 0; j < NBJ; ++j) {
     bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -212,7 +189,7 @@ OSK_DEV void tile_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowof
     const int n = n0w + j * 16 + q4 * 4;
     if (p.bias && (FULL || n < p.Cout)) bq[j] = *reinterpret_cast<const float4*>(p.bias + n);
   }
-  (step_x<RES, GN, FULL, NBJ, Is>(aq, p, rowoff, valid, storeoff, svalid, n0w, q4, bq, gs, gq, rv), ...);
+  (rowpair_x<RES, GN, FULL, 2 * Is>(aq, p, rowoff, valid, storeoff, svalid, n0w, q4, bq, gs, gq, std::make_integer_sequence<int, NBJ>{}), ...);
   if constexpr (GN) {
     const int cpg = p.Cout / p.gn_G;
 #pragma unroll

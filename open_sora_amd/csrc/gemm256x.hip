@@ -152,24 +152,6 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
       "v"(aoff[6]), "v"(aoff[7]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]), "v"(woff[5]),  \
       "v"(woff[6]), "v"(woff[7]), "v"(boff), "s"(abase), "s"(wbase), "s"(bbase), "s"(nk), "s"(adst), "s"(wdst),        \
       "s"(flags), "s"(dAs), "s"(dWs), "v"(aoffp), "v"(woffp)
-    // gate * x + residual epilogues: touch the residual lines of this wave tile (128 rows x 256 bytes: one dword per 128-byte line,
-    // 4 loads per lane) BEFORE the K loop, so that the epilogue's residual loads -- which sit behind the next tile's 32 LDS-DMA
-    // pieces in the in-order vmcnt queue anyway -- find them in L2 instead of paying a fabric round trip.  The values are dummies:
-    // kept alive until behind the epilogue (the compiler's own wait for them must not land between the K loop and the epilogue).
-    unsigned res_touch[4] = {0u, 0u, 0u, 0u};
-#ifndef OSK_GEMM_NO_RES_TOUCH
-    if (p.gate != nullptr && m0w < p.M && n0w + 64 < p.N) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int m = m0w + h * 64 + lane;
-        m = m < p.M ? m : p.M - 1;
-        const int b = m / p.crpb, l = m - b * p.crpb;
-        const unsigned short* r = p.res + b * p.cbs + (int64_t)l * p.crs + n0w;
-        res_touch[2 * h] = *reinterpret_cast<const unsigned*>(r);
-        res_touch[2 * h + 1] = *reinterpret_cast<const unsigned*>(r + 64);
-      }
-    }
-#endif
     OSK_TT(0, tt0);
 #ifdef OSK_GEMM_TILE_TIMING
     const unsigned long long tt1 = __builtin_amdgcn_s_memtime();
@@ -188,7 +170,6 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
     const int b_first = m0w / p.crpb, b_last = (m0w + WT - 1) / p.crpb;
     const bool interior = m0w + WT <= p.M && n0w + WT <= p.N && b_first == b_last;  // wave-uniform
     epi16::epilogue_all<GeoX, OUT_F32>(aq, p, m0w, n0w, l15, q4, interior, folded);
-    asm volatile("" ::"v"(res_touch[0]), "v"(res_touch[1]), "v"(res_touch[2]), "v"(res_touch[3]));
     OSK_TT(2, tt2);
 #ifdef OSK_GEMM_TILE_TIMING
     if (threadIdx.x == 0) atomicAdd(&osk_gemm_tile_ticks[3], 1ull);

@@ -16,13 +16,10 @@ using epi::GELU_NONE;
 // one interior tile up to (not including) the store: acc[4] -> final values.  Interior tiles never add the bias here: the
 // accumulators started from it (an interior wave tile has all its columns inside N, which is the kernel's "folded" condition).
 // GATE and the tile's GELU class are compile-time / hoisted: 64 tiles per wave make every per-tile branch count.
-// PRE: the residual piece arrives in rvp (loaded by the caller ahead of time: row_pair_wide's software pipeline) instead of being
-// loaded here
-template <class Geo, int T, bool GATE, int GELU, bool PRE = false>
-OSK_DEV void tile_values(const osk_v4f* aq, const GemmParams& p, int64_t roff, int n, const float4& gq, float* acc,
-                         uint2 rvp = make_uint2(0, 0)) {
-  uint2 rv = rvp;
-  if constexpr (GATE && !PRE) rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+template <class Geo, int T, bool GATE, int GELU>
+OSK_DEV void tile_values(const osk_v4f* aq, const GemmParams& p, int64_t roff, int n, const float4& gq, float* acc) {
+  uint2 rv = make_uint2(0, 0);
+  if constexpr (GATE) rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
   Geo::template read<T>(aq, acc);
   if constexpr (GELU == GELU_ALL) {
 #pragma unroll
@@ -73,40 +70,31 @@ OSK_DEV void pair_interior(const osk_v4f* aq, const GemmParams& p, const int64_t
 // column block 4 b + j: one store instruction then writes 8 rows x 128 contiguous bytes (the two halves q4 >> 1 complete a block).
 // (quad_transpose: osk_common.h)
 
-// the 16-byte chunk pair_interior stores for (J, I): columns 16 J + 8 (q4 >> 1) .. + 7 of output row 16 (I + (q4 & 1)) + l15.
-// rv: this lane's residual pieces of tiles (J, I) and (J, I + 1), loaded ahead by the caller (GATE only)
+// the 16-byte chunk pair_interior stores for (J, I): columns 16 J + 8 (q4 >> 1) .. + 7 of output row 16 (I + (q4 & 1)) + l15
 template <class Geo, bool GATE, int GELU, int J, int I>
-OSK_DEV uint4 chunk_interior(const osk_v4f* aq, const GemmParams& p, int n0w, int q4, const float4& gq, const uint2* rv) {
+OSK_DEV uint4 chunk_interior(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, int n0w, int q4, const float4& gq) {
   constexpr int NB = Geo::NB;
   const int n = n0w + J * 16 + q4 * 4;
   float a0[4], a1[4];
-  tile_values<Geo, J * NB + I, GATE, GELU, true>(aq, p, 0, n, gq, a0, rv[0]);
-  tile_values<Geo, J * NB + I + 1, GATE, GELU, true>(aq, p, 0, n, gq, a1, rv[1]);
+  tile_values<Geo, J * NB + I, GATE, GELU>(aq, p, rowoff[I], n, gq, a0);
+  tile_values<Geo, J * NB + I + 1, GATE, GELU>(aq, p, rowoff[I + 1], n, gq, a1);
   auto sx = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a1[0], a1[1]), false, false);
   auto sy = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[2], a1[3]), false, false);
   return make_uint4(sx[0], sy[0], sx[1], sy[1]);
 }
 
-// the residual pieces of one pair of row blocks (I, I + 1), all NB column blocks: 2 NB loads of 8 bytes per lane, issued back to back
-template <class Geo, int I, int... Js>
-OSK_DEV void load_row_pair_res(const GemmParams& p, const int64_t* rowoff, int n0w, int q4, uint2 (*rv)[2], std::integer_sequence<int, Js...>) {
-  ((rv[Js][0] = *reinterpret_cast<const uint2*>(p.res + rowoff[I] + n0w + Js * 16 + q4 * 4),
-    rv[Js][1] = *reinterpret_cast<const uint2*>(p.res + rowoff[I + 1] + n0w + Js * 16 + q4 * 4)), ...);
-}
-
 // one pair of row blocks (I, I + 1), all NB column blocks: NB chunks per lane, transposed in groups of four, NB stores of
 // 8 rows x 128 bytes.  In-place residual (res == C, the blocks' x = x + gate * proj(..)): the stores of this call cover exactly the 32
-// rows x 16 NB columns whose residual pieces rv holds -- loaded by the caller BEFORE any store to those rows (tile_interior_wide
-// issues the loads of pair I + 2 in front of this call: other rows).  own = element offset of this lane's own store row
-// (storeoff[I / 2]: + its 8-column half), crs = row stride: the rows of an interior wave tile lie in one batch item, so row 4 a + r
-// is (r - j) rows from the lane's own row 4 a + j.
+// rows x 16 NB columns whose residual pieces this call's tile_values() read, and every one of those loads is issued before the
+// first store (the transposes need all NB chunks), as in pair_interior.  own = element offset of this lane's own store row (storeoff[I / 2]: + its 8-column half), crs = row stride:
+// the rows of an interior wave tile lie in one batch item, so row 4 a + r is (r - j) rows from the lane's own row 4 a + j.
 template <class Geo, bool GATE, int GELU, int I, int... Js>
-OSK_DEV void row_pair_wide(const osk_v4f* aq, const GemmParams& p, int64_t own, int n0w, int q4, int lane, const float4* gq,
-                           const uint2 (*rv)[2], std::integer_sequence<int, Js...>) {
+OSK_DEV void row_pair_wide(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, int64_t own, int n0w, int q4, int lane, const float4* gq,
+                           std::integer_sequence<int, Js...>) {
   constexpr int NB = Geo::NB;
   static_assert(NB % 4 == 0, "column blocks are transposed in groups of four");
   uint4 d[NB];
-  ((d[Js] = chunk_interior<Geo, GATE, GELU, Js, I>(aq, p, n0w, q4, gq[Js], rv[Js])), ...);
+  ((d[Js] = chunk_interior<Geo, GATE, GELU, Js, I>(aq, p, rowoff, n0w, q4, gq[Js])), ...);
   const int j = lane & 3;
   const bool odd = lane & 1, hi = lane & 2;
 #pragma unroll
@@ -124,31 +112,10 @@ OSK_DEV void row_pair_wide(const osk_v4f* aq, const GemmParams& p, int64_t own, 
       *reinterpret_cast<uint4*>(base + (int64_t)r * p.crs + 64 * b) = d[4 * b + r];
 }
 
-// GATE: the residual pieces are a SOFTWARE PIPELINE over the row-block pairs -- pair 0's loads are issued first, and before a pair is
-// processed the next pair's loads go out, so a pair's memory latency (and the in-order wait behind the next tile's 32 LDS-DMA pieces
-// the K loop left in flight) is paid once per wave tile instead of once per pair.  Round 4 loaded inside tile_values(): 4 x
-// (16 loads, full latency, convert, store) in series = 32-45 k cycles per tile against 8.5 k for the plain epilogue
-// (profiles/r05a_gemm_tile_timing_by_epilogue_class.jsonl).
-template <class Geo, bool GATE, int GELU, int IP>
-OSK_DEV void wide_step(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, int lane,
-                       const float4* gq, uint2 (*rv)[Geo::NB][2]) {
-  constexpr int NB = Geo::NB;
-  constexpr auto js = std::make_integer_sequence<int, NB>{};
-#ifdef OSK_GEMM_GATE_SERIAL   // (A/B builds of tools/: round 4's order -- a pair's loads right in front of its own conversion)
-  if constexpr (GATE && IP > 0) load_row_pair_res<Geo, 2 * IP>(p, rowoff, n0w, q4, rv[IP & 1], js);
-#else
-  if constexpr (GATE && IP + 1 < NB / 2) load_row_pair_res<Geo, 2 * (IP + 1)>(p, rowoff, n0w, q4, rv[(IP + 1) & 1], js);
-#endif
-  row_pair_wide<Geo, GATE, GELU, 2 * IP>(aq, p, storeoff[IP], n0w, q4, lane, gq, rv[IP & 1], js);
-}
-
 template <class Geo, bool GATE, int GELU, int... Is>
 OSK_DEV void tile_interior_wide(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, int lane,
                                 const float4* gq, std::integer_sequence<int, Is...>) {
-  constexpr int NB = Geo::NB;
-  uint2 rv[2][NB][2];   // residual pieces of two row-block pairs: the one being processed and the next one, already in flight
-  if constexpr (GATE) load_row_pair_res<Geo, 0>(p, rowoff, n0w, q4, rv[0], std::make_integer_sequence<int, NB>{});
-  (wide_step<Geo, GATE, GELU, Is>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, rv), ...);
+  (row_pair_wide<Geo, GATE, GELU, 2 * Is>(aq, p, rowoff, storeoff[Is], n0w, q4, lane, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
 }
 
 // edge tiles: per-element bounds checks (rows >= M were computed on clamped copies of row M-1 and are dropped)
@@ -202,15 +169,10 @@ OSK_DEV void cols_interior(const osk_v4f* aq, const GemmParams& p, const int64_t
   if constexpr (!OUT_F32) {
 #ifndef OSK_GEMM_NARROW_STORES   // (A/B builds of tools/: the 32-byte row pieces of round 3)
     const int lane = q4 * 16 + (int)(threadIdx.x & 15);
-    if (n0w + NB * 16 <= p.gelu_from) {
-      tile_interior_wide<Geo, GATE, GELU_NONE>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, seq);
-      return;
-    }
-    if constexpr (!GATE) {   // (GELU together with gate * x + residual: no Linear of the path has it -- the narrow-store path below serves it)
-      if (n0w >= p.gelu_from) tile_interior_wide<Geo, GATE, GELU_ALL>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, seq);
-      else tile_interior_wide<Geo, GATE, GELU_MIXED>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, seq);
-      return;
-    }
+    if (n0w + NB * 16 <= p.gelu_from) tile_interior_wide<Geo, GATE, GELU_NONE>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, seq);
+    else if (n0w >= p.gelu_from) tile_interior_wide<Geo, GATE, GELU_ALL>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, seq);
+    else tile_interior_wide<Geo, GATE, GELU_MIXED>(aq, p, rowoff, storeoff, n0w, q4, lane, gq, seq);
+    return;
 #endif
   }
   if (n0w + NB * 16 <= p.gelu_from) tile_interior<Geo, OUT_F32, GATE, GELU_NONE>(aq, p, rowoff, storeoff, n0w, q4, gq, seq);
