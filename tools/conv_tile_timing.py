@@ -21,6 +21,8 @@ rd = _C.lib.osk_conv_tile_timing_read
 rd.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 rd.restype = ctypes.c_int
 gn = len(sys.argv) > 1 and sys.argv[1] == "gn"
+cls = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("res", "res_stats", "stats") else "plain"   # epilogue class of the plain conv:
+# res = + residual add (the resnet blocks' conv2), stats = + the consumer GroupNorm's statistics (osk_causal_conv3d_gn_ndhwc_bf16)
 dev = torch.device("cuda")
 BF = torch.bfloat16
 SHAPES = [(128, 128, 33, 256, 256), (256, 128, 33, 256, 256), (256, 256, 33, 128, 128), (512, 256, 33, 128, 128), (512, 512, 17, 64, 64)]
@@ -33,11 +35,16 @@ for ci, co, T, H, W in SHAPES:
     out = torch.empty(1, T, H, W, co, dtype=BF, device=dev)
     table = torch.ones(1, ci // 8, 16, device=dev)
 
+    res = torch.randn(1, T, H, W, co, device=dev, generator=g).to(BF) if "res" in cls else None
+    sums = torch.zeros(1, 32, 2, dtype=torch.float64, device=dev) if "stats" in cls else None
+
     def run():
         if gn:
             assert _C.causal_conv3d_gn_in(x, table, w, b, out, 3)[0]
+        elif sums is not None:
+            _C.causal_conv3d(x, w, b, out, 3, (1, 1, 1), (False, False), res, gn_sums=sums)
         else:
-            _C.causal_conv3d(x, w, b, out, 3)
+            _C.causal_conv3d(x, w, b, out, 3, (1, 1, 1), (False, False), res)
 
     run()
     run()
@@ -53,7 +60,7 @@ for ci, co, T, H, W in SHAPES:
     setup, loop, epi, tiles = (int(v) for v in buf)
     tot = setup + loop + epi
     ms = e0.elapsed_time(e1) / 4
-    print(json.dumps({"shape": [ci, co, T, H, W], "gn_form": gn, "ms_per_launch": round(ms, 4),
+    print(json.dumps({"shape": [ci, co, T, H, W], "gn_form": gn, "epilogue": cls, "ms_per_launch": round(ms, 4),
                       "tflops": round(2.0 * ci * co * 27 * T * H * W / ms / 1e9, 1), "tiles_per_launch": tiles // 4,
                       "ticks_per_tile": {"setup": round(setup / tiles, 1), "asm_statement": round(loop / tiles, 1), "epilogue": round(epi / tiles, 1)},
                       "share": {"setup": round(setup / tot, 4), "asm_statement": round(loop / tot, 4), "epilogue": round(epi / tot, 4)}}), flush=True)
