@@ -165,7 +165,12 @@ def test_xl_timed_configuration_vs_reference_fixture(hip_lib):
         assert a <= 4.0 * a_ref, (b, a)
         # whole-output moments: a mean off by more than the reference-precision error scale of an rms entry would be a bias
         assert em <= 1.5 * e_ref * tnorm / np.sqrt(len(g["ch_mean"])) and es <= 3.0 * e_ref, (b, em, es)
-    assert rel_l2(out[1], out[0]) <= 1e-3 and rel_l2(out[2], out[0]) <= 1e-3, "batch entries with equal inputs differ"
+    # equal inputs in the three batch entries: the arithmetic per element is the same except where the launch geometry differs by
+    # entry (the attention work units of the last, partial round are split over the key axis and merged -- another summation order
+    # for those rows), so the entries agree to bf16 rounding noise carried through 28 blocks, well inside the parity bound itself
+    d1, d2 = rel_l2(out[1], out[0]), rel_l2(out[2], out[0])
+    print(f"   batch entries with equal inputs: relL2 entry 1 vs 0 {d1:.3e}, entry 2 vs 0 {d2:.3e}")
+    assert max(d1, d2) <= 1.5 * e_ref, "batch entries with equal inputs differ beyond the reference-precision error"
 
 
 # ------------------------------------------------------------------------------------------------ 11B geometry (the shipped config)
