@@ -108,43 +108,14 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
   const unsigned adst = rfl(lds_base + wave * 1024), wdst = rfl(lds_base + OSKX_W_BASE + wave * 1024);
 
   unsigned prefetched = 0;
-  // carried from one tile to the next when both are affine tiles of the same problem (= when the next tile was prefetched): its
-  // position and the wave-uniform deltas of its per-lane source offsets -- the 9 divisions and the 64-bit address arithmetic of
-  // offsets() / the prefetch lanes then run once per RUN of tiles, not once per tile (set-up: 1.7 k of a 57 k-cycle K = 1152 tile)
-  int sel_c = 0, m0_c = 0, n0_c = 0;
-  unsigned dA_c = 0, dW_c = 0;
-  unsigned aoff[8], woff[8], aoffp = 0, woffp = 0;
   for (int it = blockIdx.x; it < ntiles; it += (int)gridDim.x) {
     const int itn = it + (int)gridDim.x;
 #ifdef OSK_GEMM_TILE_TIMING
     const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
 #endif
     int sel, m0, n0, seln = 0, m0n = 0, n0n = 0;
-    if (prefetched) {
-      sel = sel_c; m0 = m0_c; n0 = n0_c;
-    } else {
-      tile_of(it, sel, m0, n0);
-    }
-    const GemmParams& p = (NP == 1 || sel == 0) ? pk.p[0] : pk.p[NP - 1];   // wave-uniform: kernel-argument loads at a scalar offset
-    if (prefetched) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        aoff[i] += dA_c;
-        woff[i] += dW_c;
-      }
-      aoffp += dA_c;
-      woffp += dW_c;
-    } else {
-      offsets(p, m0, n0, aoff, woff);
-      // prefetch lanes: lane l of wave w touches row 64 w + l of the A tile and of the W tile (one dword per 128-byte line)
-      int m = m0 + wave * 64 + lane;
-      m = m < p.M ? m : p.M - 1;
-      const int b = m / p.arpb, l = m - b * p.arpb;
-      aoffp = (unsigned)((b * p.abs_ + (int64_t)l * p.ars) * 2);
-      int n = n0 + wave * 64 + lane;
-      n = n < p.N ? n : p.N - 1;
-      woffp = (unsigned)((int64_t)n * p.wrs * 2);
-    }
+    tile_of(it, sel, m0, n0);
+    const GemmParams& p = pk.p[NP == 1 ? 0 : sel];                 // wave-uniform: kernel-argument loads at a scalar offset
     bool has_next = itn < ntiles;
     unsigned dA = 0, dW = 0;
     if (has_next) {
@@ -155,16 +126,27 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
       dA = (unsigned)(a_origin(p, m0n) - a_origin(p, m0));
       dW = (unsigned)(((int64_t)n0n - n0) * p.wrs * 2);
     }
-    sel_c = seln; m0_c = m0n; n0_c = n0n;
-    dA_c = dA; dW_c = dW;
     const uint64_t abase = rfl64((uint64_t)(uintptr_t)p.A), wbase = rfl64((uint64_t)(uintptr_t)p.W);
     const uint64_t bbase = rfl64((uint64_t)(uintptr_t)p.bias);
+    unsigned aoff[8], woff[8];
+    offsets(p, m0, n0, aoff, woff);
     const int m0w = m0 + wm * WT, n0w = n0 + wn * WT;
     const bool folded = p.bias != nullptr && n0w + WT <= p.N;                 // wave-uniform
     const unsigned boff = (unsigned)((n0w + q4 * 4) * 4);
     const unsigned flags = rfl(prefetched | (has_next ? 2u : 0u) | (folded ? 4u : 0u));
     const unsigned dAs = rfl(dA), dWs = rfl(dW);
 
+    // prefetch lanes: lane l of wave w touches row 64 w + l of the A tile and of the W tile (one dword per 128-byte line)
+    unsigned aoffp, woffp;
+    {
+      int m = m0 + wave * 64 + lane;
+      m = m < p.M ? m : p.M - 1;
+      const int b = m / p.arpb, l = m - b * p.arpb;
+      aoffp = (unsigned)((b * p.abs_ + (int64_t)l * p.ars) * 2);
+      int n = n0 + wave * 64 + lane;
+      n = n < p.N ? n : p.N - 1;
+      woffp = (unsigned)((int64_t)n * p.wrs * 2);
+    }
 #define OSKW_OPERANDS                                                                                               \
   ::"v"(faA0), "v"(faW0), "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(aoff[4]), "v"(aoff[5]),          \
       "v"(aoff[6]), "v"(aoff[7]), "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[3]), "v"(woff[4]), "v"(woff[5]),  \
