@@ -638,7 +638,7 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
         elif hd == 72 and L // world >= 1024 and all("FAST" in b_ for b_ in rep["bodies"]):
             kname = "attn_asm72w_kernel"       # bounded calls with >= 1024 query rows: the wide layout of the FAST body
         # HBM bytes per launch: RECORDED, not measured in this run -- PMC passes (FETCH_SIZE doubled per the gfx950 correction,
-        # + WRITE_SIZE) of the same kernel at the same shape, collected by tools/gpu_final_r4.sh (its PMC passes over tools/attn_only.py) and committed under profiles/
+        # + WRITE_SIZE) of the same kernel at the same shape, collected by tools/gpu_final_r5.sh / tools/gpu_pmc_attn_p8.sh (PMC passes over tools/attn_only.py) and committed under profiles/
         traffic, traffic_src = None, None
         rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "attn_traffic.json")
         if os.path.exists(rec_path):
@@ -657,7 +657,7 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
                     "score_bound": round(rep["score_bound_max"], 3), "score_bound_limit": rep["bound_limit"],
                     "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_kind": "recorded (PMC passes of this kernel at this shape, see traffic_source)",
+                    "traffic": traffic, "traffic_kind": "recorded (PMC passes of this kernel at this shape, see traffic_source)" if traffic else "no record for this kernel / shape",
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": 4 * nb * Lq * H * hd * 2 if world == 1 else None,
                     "launches": len(durs), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": fl}
