@@ -1,0 +1,128 @@
+// Issue rate of the VALU instructions the attention / GEMM epilogues are made of, ONE wave per SIMD (the layout of every asm kernel here):
+// N independent instructions back to back, timed with s_memtime (shader clock) by every wave; prints cycles per instruction.
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_rate_probe.hip -o /tmp/valu_rate_probe && /tmp/valu_rate_probe
+// (the issue-stream model of the attention loop body charges v_exp_f32 16 cycles, full-rate VALU 4.)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cstdint>
+#include <cstdlib>
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+template <int KIND>
+__global__ void __launch_bounds__(256, 1) probe(unsigned long long* out, float seed, const unsigned char* gbuf) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const unsigned ldsbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (threadIdx.x >> 6) * 8192);
+  const unsigned ldsaddr = ldsbase + (threadIdx.x & 63) * 16;
+  const unsigned goff = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 8192;
+  const unsigned long long gbase = (unsigned long long)(uintptr_t)(gbuf + (size_t)blockIdx.x * 65536);
+  float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+  unsigned b0 = threadIdx.x, b1 = b0 + 1;
+  typedef float v4f_t __attribute__((ext_vector_type(4)));
+  const v4f_t fa = {a0, a1, a2, a3}, fb = {a4, a5, a6, a7};   // (bit patterns only: operands of the bf16 MFMAs)
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < 16; ++it) {
+    // 64 x 8 = 512 instructions per iteration, 8 independent chains
+    if (KIND == 0) { REP64(asm volatile("v_mul_f32 %0, %0, %0\n v_mul_f32 %1, %1, %1\n v_mul_f32 %2, %2, %2\n v_mul_f32 %3, %3, %3\n v_mul_f32 %4, %4, %4\n v_mul_f32 %5, %5, %5\n v_mul_f32 %6, %6, %6\n v_mul_f32 %7, %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+    if (KIND == 1) { REP64(asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+    if (KIND == 2) { REP64(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+    if (KIND == 3) { REP64(asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1\n v_cvt_pk_bf16_f32 %2, %2, %3\n v_cvt_pk_bf16_f32 %4, %4, %5\n v_cvt_pk_bf16_f32 %6, %6, %7\n v_cvt_pk_bf16_f32 %1, %1, %0\n v_cvt_pk_bf16_f32 %3, %3, %2\n v_cvt_pk_bf16_f32 %5, %5, %4\n v_cvt_pk_bf16_f32 %7, %7, %6" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+    if (KIND == 4) { REP64(asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+    if (KIND == 5) { REP64(asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %3, %4\n v_fma_f32 %3, %3, %4, %5\n v_fma_f32 %4, %4, %5, %6\n v_fma_f32 %5, %5, %6, %7\n v_fma_f32 %6, %6, %7, %0\n v_fma_f32 %7, %7, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+    if (KIND == 6) { REP64(asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_write_b32 a1, %1\n v_accvgpr_write_b32 a2, %2\n v_accvgpr_write_b32 a3, %3\n v_accvgpr_read_b32 %4, a0\n v_accvgpr_read_b32 %5, a1\n v_accvgpr_read_b32 %6, a2\n v_accvgpr_read_b32 %7, a3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "a0", "a1", "a2", "a3");) }
+    if (KIND == 7) { REP64(asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+    // ---- the matrix pipe beside the VALU: 8 independent 16x16x32 MFMAs (4-register accumulators a0..a31), alone and with VALU fillers
+#define MF(i) "v_mfma_f32_16x16x32_bf16 a[" #i ":" #i "+3], %0, %1, a[" #i ":" #i "+3]\n"
+#define MFOPS : : "v"(fa), "v"(fb) : "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31"
+    if (KIND == 8) { REP64(asm volatile(MF(0) MF(4) MF(8) MF(12) MF(16) MF(20) MF(24) MF(28) MFOPS);) }
+    if (KIND == 9) {   // one v_exp_f32 behind every MFMA
+      REP64(asm volatile(MF(0) "v_exp_f32 %2, %2\n" MF(4) "v_exp_f32 %3, %3\n" MF(8) "v_exp_f32 %4, %4\n" MF(12) "v_exp_f32 %5, %5\n" MF(16) "v_exp_f32 %2, %2\n" MF(20) "v_exp_f32 %3, %3\n" MF(24) "v_exp_f32 %4, %4\n" MF(28) "v_exp_f32 %5, %5\n"
+                         : : "v"(fa), "v"(fb), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31");) }
+    if (KIND == 10) {  // three v_mul_f32 behind every MFMA
+#define M3 "v_mul_f32 %2, %2, %2\n v_mul_f32 %3, %3, %3\n v_mul_f32 %4, %4, %4\n"
+      REP64(asm volatile(MF(0) M3 MF(4) M3 MF(8) M3 MF(12) M3 MF(16) M3 MF(20) M3 MF(24) M3 MF(28) M3
+                         : : "v"(fa), "v"(fb), "v"(a0), "v"(a1), "v"(a2) : "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31");) }
+    if (KIND == 11) {  // one v_exp_f32 + one v_mul_f32 behind every MFMA (the attention body's mix: 64 exp + 48 others per 60 MFMAs)
+      REP64(asm volatile(MF(0) "v_exp_f32 %2, %2\n v_mul_f32 %3, %3, %3\n" MF(4) "v_exp_f32 %4, %4\n v_mul_f32 %5, %5, %5\n" MF(8) "v_exp_f32 %2, %2\n v_mul_f32 %3, %3, %3\n" MF(12) "v_exp_f32 %4, %4\n v_mul_f32 %5, %5, %5\n" MF(16) "v_exp_f32 %2, %2\n v_mul_f32 %3, %3, %3\n" MF(20) "v_exp_f32 %4, %4\n v_mul_f32 %5, %5, %5\n" MF(24) "v_exp_f32 %2, %2\n v_mul_f32 %3, %3, %3\n" MF(28) "v_exp_f32 %4, %4\n v_mul_f32 %5, %5, %5\n"
+                         : : "v"(fa), "v"(fb), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31");) }
+    // ---- LDS fragment reads, LDS-DMA, scalar code: alone and in MFMA shadows
+#define ACC32 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31"
+#define DSR(r) "ds_read_b128 v[" #r ":" #r "+3], %2 offset:" #r "*64\n"
+    if (KIND == 12) { REP64(asm volatile(DSR(100) DSR(104) DSR(108) DSR(112) DSR(116) DSR(120) DSR(124) DSR(128) "s_waitcnt lgkmcnt(0)\n"
+                         : : "v"(fa), "v"(fb), "v"(ldsaddr) : "v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131");) }
+    if (KIND == 13) {  // one ds_read_b128 behind every MFMA (the GEMM / conv loops: 16-32 reads per 64-128 MFMAs)
+      REP64(asm volatile(MF(0) DSR(100) MF(4) DSR(104) MF(8) DSR(108) MF(12) DSR(112) MF(16) DSR(116) MF(20) DSR(120) MF(24) DSR(124) MF(28) DSR(128) "s_waitcnt lgkmcnt(0)\n"
+                         : : "v"(fa), "v"(fb), "v"(ldsaddr) : ACC32, "v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131");) }
+#define DMA(off) "s_add_u32 m0, %3, " #off "\n s_nop 0\n global_load_lds_dwordx4 %2, %4\n"
+    if (KIND == 14) { REP64(asm volatile(DMA(0) DMA(1024) DMA(2048) DMA(3072) DMA(4096) DMA(5120) DMA(6144) DMA(7168) "s_waitcnt vmcnt(0)\n"
+                         : : "v"(fa), "v"(fb), "v"(goff), "s"(ldsbase), "s"(gbase) : "m0", "memory");) }
+    if (KIND == 15) {  // one LDS-DMA piece per 4 MFMAs (the GEMM K loop's spacing), 2 pieces per 8 MFMAs
+      REP64(asm volatile(MF(0) DMA(0) MF(4) MF(8) MF(12) MF(16) DMA(1024) MF(20) MF(24) MF(28) "s_waitcnt vmcnt(0)\n"
+                         : : "v"(fa), "v"(fb), "v"(goff), "s"(ldsbase), "s"(gbase) : ACC32, "m0", "memory");) }
+    if (KIND == 16) { REP64(asm volatile("s_add_u32 s40, s40, 1\n s_add_u32 s41, s41, 1\n s_add_u32 s42, s42, 1\n s_add_u32 s43, s43, 1\n s_add_u32 s40, s40, 1\n s_add_u32 s41, s41, 1\n s_add_u32 s42, s42, 1\n s_add_u32 s43, s43, 1\n" : : : "s40", "s41", "s42", "s43", "scc");) }
+#define MF32(i) "v_mfma_f32_32x32x16_bf16 a[" #i ":" #i "+15], %0, %1, a[" #i ":" #i "+15]\n"
+#define ACC128 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
+    if (KIND == 17) { REP64(asm volatile(MF32(0) MF32(16) MF32(32) MF32(48) MF32(64) MF32(80) MF32(96) MF32(112) : : "v"(fa), "v"(fb) : ACC128);) }
+    if (KIND == 18) {  // 32x32x16 + 2 v_exp_f32 + 2 v_cvt_pk (the attention QK^T phase's fillers)
+#define F4 "v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_cvt_pk_bf16_f32 %4, %4, %5\n v_cvt_pk_bf16_f32 %5, %5, %4\n"
+      REP64(asm volatile(MF32(0) F4 MF32(16) F4 MF32(32) F4 MF32(48) F4 MF32(64) F4 MF32(80) F4 MF32(96) F4 MF32(112) F4
+                         : : "v"(fa), "v"(fb), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : ACC128);) }
+    if (KIND == 19) {  // 32x32x16 + 4 v_exp_f32 + 2 v_cvt_pk + 1 swap (a denser mix: 34 + 9.6 + 8.5 cycles of VALU per 32-cycle MFMA)
+#define F7 "v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_cvt_pk_bf16_f32 %4, %4, %5\n v_cvt_pk_bf16_f32 %5, %5, %4\n v_permlane16_swap_b32 %4, %5\n"
+      REP64(asm volatile(MF32(0) F7 MF32(16) F7 MF32(32) F7 MF32(48) F7 MF32(64) F7 MF32(80) F7 MF32(96) F7 MF32(112) F7
+                         : : "v"(fa), "v"(fb), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : ACC128);) }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+  if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678f && b0 == b1) out[0] = 0;   // keep the chains alive
+}
+
+template <int KIND>
+double run(const char* name, unsigned long long* d, int blocks) {
+  static void* gb = nullptr;
+  if (!gb) { hipMalloc(&gb, (size_t)blocks * 65536 + 65536); hipMemset(gb, 0, (size_t)blocks * 65536 + 65536); }
+  hipFuncSetAttribute(reinterpret_cast<const void*>(probe<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(256), 65536, 0, d, 1.0f, (const unsigned char*)gb);
+  hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(256), 65536, 0, d, 1.0f, (const unsigned char*)gb);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(blocks * 4);
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  double s = 0;
+  for (auto v : h) s += (double)v;
+  const double per = s / h.size() / (16.0 * 512.0);
+  printf("{\"instruction\": \"%s\", \"cycles_per_instruction_one_wave_per_simd\": %.2f}\n", name, per);
+  fflush(stdout);
+  return per;
+}
+
+int main(int argc, char** argv) {
+  const int only = argc > 1 ? atoi(argv[1]) : -1;
+#define RUN(K, NAME) if (only < 0 || only == K) run<K>(NAME, d, blocks)
+  unsigned long long* d;
+  const int blocks = 256;
+  hipMalloc(&d, blocks * 4 * 8);
+  RUN(0, "v_mul_f32");
+  RUN(5, "v_fma_f32");
+  RUN(1, "v_exp_f32");
+  RUN(2, "v_rcp_f32");
+  RUN(3, "v_cvt_pk_bf16_f32");
+  RUN(4, "v_permlane16_swap_b32");
+  RUN(7, "v_mov_b32_dpp quad_perm");
+  RUN(6, "v_accvgpr_write_b32 / v_accvgpr_read_b32 (4 + 4)");
+  // the next four count 8 MFMAs (+ fillers) as "8 instructions": cycles per MFMA GROUP = printed value x 1  (512 groups of ... per iteration)
+  RUN(8, "v_mfma_f32_16x16x32_bf16 alone (per MFMA)");
+  RUN(9, "v_mfma_f32_16x16x32_bf16 + 1 v_exp_f32 (per MFMA)");
+  RUN(10, "v_mfma_f32_16x16x32_bf16 + 3 v_mul_f32 (per MFMA)");
+  RUN(11, "v_mfma_f32_16x16x32_bf16 + 1 v_exp_f32 + 1 v_mul_f32 (per MFMA)");
+  RUN(12, "ds_read_b128 x 8 + lgkmcnt(0) (per read)");
+  RUN(13, "v_mfma_f32_16x16x32_bf16 + 1 ds_read_b128 (per MFMA; lgkmcnt(0) per 8)");
+  RUN(14, "global_load_lds_dwordx4 x 8 (+ m0 write, s_nop) + vmcnt(0) (per piece, 4 waves per CU issuing)");
+  RUN(15, "8 x v_mfma_f32_16x16x32_bf16 + 2 LDS-DMA pieces + vmcnt(0) (per MFMA)");
+  RUN(16, "s_add_u32");
+  RUN(17, "v_mfma_f32_32x32x16_bf16 alone (per MFMA)");
+  RUN(18, "v_mfma_f32_32x32x16_bf16 + 2 v_exp_f32 + 2 v_cvt_pk_bf16_f32 (per MFMA)");
+  RUN(19, "v_mfma_f32_32x32x16_bf16 + 4 v_exp_f32 + 2 v_cvt_pk_bf16_f32 + 1 v_permlane16_swap (per MFMA)");
+  return 0;
+}
