@@ -118,8 +118,10 @@ int main(int argc, char** argv) {
   RUN(11, "v_mfma_f32_16x16x32_bf16 + 1 v_exp_f32 + 1 v_mul_f32 (per MFMA)");
   RUN(12, "ds_read_b128 x 8 + lgkmcnt(0) (per read)");
   RUN(13, "v_mfma_f32_16x16x32_bf16 + 1 ds_read_b128 (per MFMA; lgkmcnt(0) per 8)");
-  RUN(14, "global_load_lds_dwordx4 x 8 (+ m0 write, s_nop) + vmcnt(0) (per piece, 4 waves per CU issuing)");
-  RUN(15, "8 x v_mfma_f32_16x16x32_bf16 + 2 LDS-DMA pieces + vmcnt(0) (per MFMA)");
+  // kinds 14 / 15 (LDS-DMA pieces alone / in MFMA shadows) did NOT complete within 15 s on the MI355X box in round 5 (cause not found: the
+  // same instruction form runs in every generated loop); they only run when asked for by number -- under a timeout
+  if (only == 14) run<14>("global_load_lds_dwordx4 x 8 (+ m0 write, s_nop) + vmcnt(0) (per piece, 4 waves per CU issuing)", d, blocks);
+  if (only == 15) run<15>("8 x v_mfma_f32_16x16x32_bf16 + 2 LDS-DMA pieces + vmcnt(0) (per MFMA)", d, blocks);
   RUN(16, "s_add_u32");
   RUN(17, "v_mfma_f32_32x32x16_bf16 alone (per MFMA)");
   RUN(18, "v_mfma_f32_32x32x16_bf16 + 2 v_exp_f32 + 2 v_cvt_pk_bf16_f32 (per MFMA)");
