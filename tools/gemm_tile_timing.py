@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Where a gemm256x_kernel tile's time goes, per shape: OSK_ALT_LIB=tools/lib/libosk_gemm_timing.so python tools/gemm_tile_timing.py
 (tools/make_gemm_timing_lib.sh).  s_memtime ticks of wave 0 of every workgroup, summed over the launch: address set-up before the
-asm statement, the asm statement (cold start + K loop), the epilogue.  One JSON line per shape: microseconds per tile at the
-100 MHz constant the counter runs at (s_memtime is REFCLK on gfx9-family parts) -- and as shares, which need no clock."""
+asm statement, the asm statement (cold start + K loop), the epilogue.  One JSON line per shape: ticks per tile (on MI355X s_memtime advances at about the
+shader clock -- a v_mul_f32 stream measures 4.5 ticks per instruction, tools/valu_rate_probe.hip -- so ticks read as cycles) and shares."""
 import ctypes
 import json
 import os
