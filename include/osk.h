@@ -57,6 +57,13 @@ int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_row_stride, i
                   const void* res, const float* gate, int64_t gate_batch_stride,
                   int M, int N, int K, int gelu_from, int out_f32, void* stream);
 
+/* reporting / tools: the tile kernel osk_gemm_bf16 picks for an [M, N, K] problem whose operands the large tiles support -- 2 = 256 x 256
+ * (gemm256x_kernel), 1 = 256 x 128 (gemm256p_kernel), 0 = 128 x 128 (gemm_bf16_kernel) -- by estimated rounds of the chip x per-tile rate;
+ * osk_gemm_tile_override(kind) forces one of them process-wide for same-process A/B timing (tools/gemm_tile_ab.py; -1 = back to the estimate;
+ * never set in production code). */
+int osk_gemm_tile_choice(int M, int N, int K);
+int osk_gemm_tile_override(int tile_kind);
+
 /* ---- TWO Linear layers that differ only in their operands and row count in ONE launch.
  * replaces the img-stream / txt-stream pairs of DoubleStreamBlockProcessor (layers.py:209-215 img_attn.qkv | txt_attn.qkv,
  * 247 img_attn.proj | 251 txt_attn.proj, 248 img_mlp | 252 txt_mlp): same N, K and epilogue kind, separate weights, inputs and

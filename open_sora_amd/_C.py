@@ -29,6 +29,8 @@ SIGNATURES = {
     "osk_gemm_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
                       _i32, _i32, _i32, _i32, _i32, _vp],
     "osk_gemm_bf16_pair": [_vp, _vp, _i32, _i32, _i32, _vp],     # two OskGemmOperands structs by pointer
+    "osk_gemm_tile_choice": [_i32, _i32, _i32],
+    "osk_gemm_tile_override": [_i32],
     "osk_ln_modulate_fp8": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
     "osk_quantize_rows_fp8": [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _i32, _vp],
     "osk_gemm_fp8": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,

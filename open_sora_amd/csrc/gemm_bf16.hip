@@ -12,6 +12,7 @@
 // 32-row x 16-B fragment reads of the 32x32x16 MFMA (see DESIGN.md "LDS layouts").
 //
 // Roofline: MFMA bf16 (2.5 PFLOP/s dense).  Algorithmic FLOPs = 2*M*N*K.
+#include <atomic>
 #include "gemm_params.h"
 #include "../../include/osk.h"
 
@@ -197,15 +198,21 @@ static int fill_params(GemmParams& p, const void* A, int64_t a_batch_stride, int
   return OSK_OK;
 }
 
-// tile choice by estimated time = rounds of the grid over the chip x time of one tile.  Per-tile throughput measured at the XL
-// shapes (MI355X, random data): 256x256 ~1.0, 256x128 ~0.78, 128x128 (this file) ~0.72 of the large tile's rate; one workgroup
-// per CU for the large tiles, two 256-thread ones for this file's kernel.  -> 2: 256 x 256, 1: 256 x 128, 0: 128 x 128
-static int tile_choice(int M, int N, double* cost = nullptr) {
+// tile choice by estimated time = rounds of the grid over the chip x time of one tile.  Per-tile throughput relative to the 256 x 256
+// kernel, measured on MI355X with random data at whole rounds (round 5, tools/gemm_tile_ab.py, profiles/r05i_gemm_tile_ab.jsonl):
+// 256 x 128 (gemm256p) 0.74 at K = 1152 and 0.60 at K >= 4608 (round 2 assumed 0.78 whatever K: at CFG batch 1 that sent the three
+// N = 1152 Linears of every block to the 256 x 128 kernel, 9-13 % slower there than two rounds of 256 x 256 tiles); 128 x 128 (this file)
+// ~0.55 with two co-resident 256-thread workgroups per CU (round 2: 0.72).  -> 2: 256 x 256, 1: 256 x 128, 0: 128 x 128
+static std::atomic<int> g_tile_override{-1};   // tools / tests only (osk_gemm_tile_override): -1 = by estimate
+static int tile_choice(int M, int N, int K, double* cost = nullptr) {
   auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
+  const int forced = g_tile_override.load(std::memory_order_relaxed);
+  if (forced >= 0 && !cost) return forced;
   const int64_t m256 = (M + 255) / 256, m128 = (M + 127) / 128;
+  const double r128 = K >= 2304 ? 0.60 : 0.74;
   const double c256 = rounds(m256 * ((N + 255) / 256), 256) * 4.0 / 1.00;
-  const double c128 = rounds(m256 * ((N + 127) / 128), 256) * 2.0 / 0.78;
-  const double cold = rounds(m128 * ((N + 127) / 128), 512) * 1.0 / (0.5 * 0.72);  // 2 co-resident tiles share a CU
+  const double c128 = rounds(m256 * ((N + 127) / 128), 256) * 2.0 / r128;
+  const double cold = rounds(m128 * ((N + 127) / 128), 512) * 1.0 / (0.5 * 0.55);  // 2 co-resident tiles share a CU
   const bool wide = N >= 256 && c256 <= c128;
   const double best = wide ? c256 : c128;
   if (cost) *cost = cold < best ? cold : best;
@@ -253,7 +260,7 @@ extern "C" int osk_gemm_geglu_bf16(const void* A, int64_t a_batch_stride, int64_
   if (rc != OSK_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   p.geglu = 1;
-  if (large_tiles_ok(p) && tile_choice(M, N) == 2) return osk_gemm::launch_gemm256x(p, 0, st);
+  if (large_tiles_ok(p) && tile_choice(M, N, K) == 2) return osk_gemm::launch_gemm256x(p, 0, st);
   // small / odd shapes: plain GEMM (bias added, no activation) into the workspace, then the row kernel
   if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < (int64_t)M * N * 2) return OSK_EUNSUPPORTED;
   const int rc2 = osk_gemm_bf16(A, a_batch_stride, a_row_stride, a_rows_per_batch, W_packed, w_row_stride, bias_packed, workspace,
@@ -264,6 +271,16 @@ extern "C" int osk_gemm_geglu_bf16(const void* A, int64_t a_batch_stride, int64_
   hipLaunchKernelGGL(geglu_rows_kernel, dim3(blocks), dim3(256), 0, st, (const unsigned short*)workspace, (unsigned short*)C,
                      c_batch_stride, c_row_stride, c_rows_per_batch, M, N_out);
   return (int)hipGetLastError();
+}
+
+// reporting / tools: which tile kernel osk_gemm_bf16 launches for an [M, N] problem the large tiles support (2: 256 x 256
+// gemm256x_kernel, 1: 256 x 128 gemm256p_kernel, 0: 128 x 128 gemm_bf16_kernel), and an override for same-process A/B timing of the
+// three (tile_kind -1 restores the estimate; process-wide, not for production use)
+extern "C" int osk_gemm_tile_choice(int M, int N, int K) { return tile_choice(M, N, K); }
+extern "C" int osk_gemm_tile_override(int tile_kind) {
+  if (tile_kind < -1 || tile_kind > 2) return OSK_EINVAL;
+  g_tile_override.store(tile_kind, std::memory_order_relaxed);
+  return OSK_OK;
 }
 
 extern "C" int osk_gemm_bf16_pair(const OskGemmOperands* a, const OskGemmOperands* b, int N, int K, int gelu_from, void* stream) {
@@ -283,8 +300,8 @@ extern "C" int osk_gemm_bf16_pair(const OskGemmOperands* a, const OskGemmOperand
   // tiles ride in the larger one's last round (XL: 2688 + 84 tiles = 11 rounds either way) -- but not when they would open a new,
   // nearly empty round (11B geometry: 2304 tiles are exactly 9 rounds; + 72 tiles would make it 10)
   double c_big = 0.0, c_small = 0.0;
-  if (large_tiles_ok(p[0]) && large_tiles_ok(p[1]) && tile_choice(p[big].M, N, &c_big) == 2) {
-    tile_choice(p[big ^ 1].M, N, &c_small);
+  if (large_tiles_ok(p[0]) && large_tiles_ok(p[1]) && tile_choice(p[big].M, N, K, &c_big) == 2) {
+    tile_choice(p[big ^ 1].M, N, K, &c_small);
     const int64_t nbn = (N + 255) / 256, tiles = ((p[0].M + 255) / 256 + (p[1].M + 255) / 256) * nbn;
     const double c_pair = (double)((tiles + 255) / 256) * 4.0;
     if (c_pair < c_big + c_small) return osk_gemm::launch_gemm256x_pair(p[big], p[big ^ 1], (hipStream_t)stream);
@@ -315,7 +332,7 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
     const int64_t a_span = (int64_t)(nb - 1) * a_batch_stride + (int64_t)(a_rows_per_batch - 1) * a_row_stride + K;
     const int64_t w_span = (int64_t)(N - 1) * w_row_stride + K;
     if (osk_gemm::gemm256_supported(p, a_span, w_span)) {
-      const int kind = tile_choice(M, N);
+      const int kind = tile_choice(M, N, K);
       if (kind == 2) return osk_gemm::launch_gemm256x(p, out_f32, st);    // 256 x 256 tiles, 4 waves, v_mfma_f32_16x16x32_bf16
       if (kind == 1) return osk_gemm::launch_gemm256p(p, out_f32, st);    // 256 x 128 tiles, 8 waves, v_mfma_f32_32x32x16_bf16
     }
