@@ -213,6 +213,9 @@ int osk_attention_tail_split_factor(int B, int H, int Lq, int n_seg, int seg_len
  * or 512 = the wide head_dim 72 / 64 layout, chosen by estimated rounds of the chip -- few batch x head pairs keep 256). */
 int osk_attention_launch_shape(int B, int H, int Lq, int n_seg, int seg_len, int hd, float score_bound,
                                int64_t workspace_bytes, int* rows_per_unit);
+/* tools only: force the work-unit rows of bounded head_dim 72 / 64 calls process-wide (256, or 512 where the wide layout is legal) for
+ * same-process A/B timing (tools/attn_layout_ab.py); 0 = back to the estimate.  Never set in production code. */
+int osk_attention_rows_override(int rows_per_unit);
 int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
                            const void* k, int64_t k_seg_stride, int64_t k_batch_stride, int64_t k_row_stride,
                            const void* vt, int64_t vt_seg_stride,

@@ -54,6 +54,7 @@ SIGNATURES = {
                                    _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _i64, _vp],
     "osk_attention_tail_split_factor": [_i32, _i32, _i32, _i32, _i32, _i32, _i64],
     "osk_attention_launch_shape": [_i32, _i32, _i32, _i32, _i32, _i32, _f32, _i64, C.POINTER(_i32)],
+    "osk_attention_rows_override": [_i32],
     "osk_cfg_euler_bf16": [_vp, _i64, _vp, _vp, _f32, _f32, _vp, _f32, _vp],
     "osk_copy_rows_bf16": [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp],
     "osk_causal_conv3d_ndhwc_bf16": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32,

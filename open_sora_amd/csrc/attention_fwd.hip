@@ -5,6 +5,7 @@
 // (attn_fwd_kernel<64>, 400 lines: 8 waves x 32 rows, register-staged tiles) -- head_dim 64 now runs the head_dim-72 loop.
 //
 // Roofline: MFMA bf16.  Algorithmic FLOPs = 4 * B * H * Lq * Lk * hd (QK^T + PV, not halved).
+#include <atomic>
 #include "attention_params.h"
 #include "../../include/osk.h"
 
@@ -103,9 +104,12 @@ int launch_merge(const AttnParams& p, int hd, hipStream_t st) {
 
 // reporting: (key parts, rows per work unit) the launch of a call with these arguments uses -- the SAME selection code as
 // osk_attention_fwd_bounded_bf16 below (round 4 modelled 256-row units whatever the call: ADVICE r4)
+static std::atomic<int> g_rows_override{0};   // tools only (osk_attention_rows_override): 0 = by estimate, 256 / 512 = forced where legal
 static void launch_shape(osk_attn::AttnParams& p, int hd, void* workspace, int64_t workspace_bytes) {
   p.rows = 256;
-  if (osk_attn::attn_wide_path(p, hd, osk_device_cus(), workspace != nullptr)) p.rows = 512;
+  const int forced = g_rows_override.load(std::memory_order_relaxed);
+  const bool wide_legal = (hd == 72 || hd == 64) && osk_attn::attn_fast_path(p) && p.Lq >= 1024;
+  if (forced ? (forced == 512 && wide_legal) : osk_attn::attn_wide_path(p, hd, osk_device_cus(), workspace != nullptr)) p.rows = 512;
   if (hd == 64 || hd == 72 || hd == 128)
     osk_attn::split_tail(p, ((p.Lq + p.rows - 1) / p.rows) * p.B * p.H, hd, workspace, workspace_bytes);
 }
@@ -129,6 +133,12 @@ extern "C" int osk_attention_launch_shape(int B, int H, int Lq, int n_seg, int s
   launch_shape(p, hd, workspace_bytes > 0 ? dummy : nullptr, workspace_bytes);
   if (rows_per_unit) *rows_per_unit = p.rows;
   return p.tail_split;
+}
+
+extern "C" int osk_attention_rows_override(int rows_per_unit) {
+  if (rows_per_unit != 0 && rows_per_unit != 256 && rows_per_unit != 512) return OSK_EINVAL;
+  g_rows_override.store(rows_per_unit, std::memory_order_relaxed);
+  return OSK_OK;
 }
 
 extern "C" int osk_attention_tail_split_factor(int B, int H, int Lq, int n_seg, int seg_len, int hd,
