@@ -154,6 +154,8 @@ def ar(base, n=1):
     return "a%d" % base if n == 1 else "a[%d:%d]" % (base, base + n - 1)
 
 
+N2_BUDGET = {"m32": 24, "pv16": 9, "pv8": 60}   # filler cycles per MFMA shadow of the 256-row bodies (round 5: 24 / 9 instead of 30 / 13, as in
+# the wide body -- the MFMA's own issue takes 4.4 cycles of its shadow; --n2-budget: experiments)
 FAST_WINDOWS_OVERRIDE = {}   # (hd, nu) -> [a0, a1, b0, b1, c0, c1]; set by --fast-windows (experiments) or below (production)
 
 
@@ -879,7 +881,7 @@ def body(st, L, k, safe):
                     break
                 if totals[ci] * frac - c[4] <= 0 and i < last:
                     break
-                if used >= (60 if kind == "pv" and L.PV8 else (13 if kind == "pv" and L.PV16 else 30)) and i < last:
+                if used >= (N2_BUDGET["pv8"] if kind == "pv" and L.PV8 else (N2_BUDGET["pv16"] if kind == "pv" and L.PV16 else N2_BUDGET["m32"])) and i < last:
                     break
                 st.emit(text, kind_)
                 used += cost(kind_)
@@ -1076,7 +1078,7 @@ def pvw_mfma(st, L, b):
     st.emit("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (dst, vr(L.VR0 + db * 4, 4), vr(L.PB(u, 2 * ph + qb), 4), dst), "X")
 
 
-WIDE_EXP = {"gap": 1, "win": None, "vm": 0, "swapnop": False, "kwait2": True, "dmafill": True}   # production values; --wide-exp flips them   # --wide-exp (experiments): DMA piece spacing in the trailing shadows, filler windows, swap placement
+WIDE_EXP = {"gap": 1, "win": None, "vm": 0, "swapnop": False, "kwait2": True, "dmafill": True, "budget": (9, 24)}   # production values; --wide-exp flips them   # --wide-exp (experiments): DMA piece spacing in the trailing shadows, filler windows, swap placement
 
 
 def body_wide(st, L, k, h, safe=False):
@@ -1168,7 +1170,7 @@ def body_wide(st, L, k, h, safe=False):
                 kind_, text = items[c[3]]
                 if totals[ci] * frac - c[4] <= 0 and i < last:
                     break
-                if used >= (13 if kind == "pv" else 30) and i < last:
+                if used >= (WIDE_EXP["budget"][0] if kind == "pv" else WIDE_EXP["budget"][1]) and i < last:   # filler cycles per 16 / 32-cycle shadow (round 5: 9 / 24 -- an MFMA's own issue takes 4.4 cycles and v_exp_f32 8.5, not 8: with round 4's 13 / 30 the shadows were over-subscribed; in-step A/B -0.8 % per launch on two boxes, profiles/r05n_attn_filler_budget_ab.jsonl)
                     break
                 st.emit(text, kind_)
                 used += cost(kind_)
@@ -1304,9 +1306,12 @@ def main():
                     "rounds 1-2; changes the V^T key order the kernel expects, so only for timing runs with matching wrappers")
     ap.add_argument("--fast-windows", default="", help="experiment: hd:a0,a1,b0,b1 filler windows of the FAST body (layout NU = 2), e.g. 72:1,33,30,42")
     ap.add_argument("--fast-exp", default="", help="experiment: like --exp, applied to the FAST bodies only")
+    ap.add_argument("--n2-budget", default="", help="experiment: m32,pv16,pv8 filler-cycle budgets of the 256-row bodies' MFMA shadows (production 24,9,60)")
     ap.add_argument("--wide-exp", default="", help="experiment on the WIDE head_dim-72 body: gapN (LDS-DMA pieces every N trailing shadows) and / or "
                     "win:a0,a1,b0,b1 (filler windows), joined by +")
     args = ap.parse_args()
+    if args.n2_budget:
+        N2_BUDGET.update(zip(("m32", "pv16", "pv8"), (int(x) for x in args.n2_budget.split(","))))
     for tok in [t for t in args.wide_exp.split("+") if t]:
         if tok.startswith("gap"):
             WIDE_EXP["gap"] = int(tok[3:])
@@ -1316,6 +1321,8 @@ def main():
             WIDE_EXP[{"swapnop": "swapnop", "kwait1": "kwait2", "nodmafill": "dmafill"}[tok]] = tok == "swapnop"
         elif tok.startswith("vm"):
             WIDE_EXP["vm"] = int(tok[2:])
+        elif tok.startswith("budget:"):     # filler-cycle budget of a P.V / QK^T shadow (round 5: the MFMA's own issue takes 4.4 cycles)
+            WIDE_EXP["budget"] = tuple(int(x) for x in tok[7:].split(","))
         elif tok.startswith("win:"):
             w_ = [int(x) for x in tok[4:].split(",")]
             WIDE_EXP["win"] = w_ + [w_[3], w_[3]]
@@ -1333,7 +1340,7 @@ def main():
     safe = args.exp == "safe"
     gap = args.exp.startswith("dmagap")
     ablate = frozenset() if (safe or gap or not args.exp) else frozenset(args.exp.split("+"))
-    if (args.exp or args.fast_windows or args.fast_exp or args.no_pv16 or args.wide_exp) and os.path.realpath(args.out) == os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc")):
+    if (args.exp or args.fast_windows or args.fast_exp or args.no_pv16 or args.wide_exp or args.n2_budget) and os.path.realpath(args.out) == os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "open_sora_amd", "csrc")):
         raise SystemExit("--exp bodies are experiments: give --out a scratch directory, not the shipped csrc")
     if args.table:
         L = mk(args.table, args.hd, args.pv8) if args.table == 2 else Layout(args.table, args.hd, args.pv8)
