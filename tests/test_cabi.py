@@ -96,3 +96,21 @@ def test_attention_launch_shape_is_chosen_by_rounds_of_the_chip():
     parts, rows = C1.attention_launch_shape(1, 16, 16896, 1, 16896, 72, 12.9, ws)            # B = 1: 528 wide units = 2 rounds + 16
     assert rows == 512 and parts == 8
     assert C1.lib.osk_attention_tail_split_factor(1, 16, 16896, 1, 16896, 72, ws) == C1.attention_launch_shape(1, 16, 16896, 1, 16896, 72, 0.0, ws)[0]
+
+
+def test_gemm_tile_choice_follows_the_measured_rates():
+    """osk_gemm_tile_choice reports the tile kernel osk_gemm_bf16 launches (host-only; 256 CUs assumed without a device).  The
+    estimate was calibrated in round 5 against a same-process A/B of the three kernels (profiles/r05i_gemm_tile_ab.jsonl): the cases
+    below are the measured winners at the XL shapes -- CFG batch 3 and 1, and the rows sequence-parallel ranks hold."""
+    from open_sora_amd import _C as C1
+
+    L = 16896
+    pick = C1.lib.osk_gemm_tile_choice
+    for n, k in ((1152, 1152), (1152, 4608), (1152, 5760), (3456, 1152), (4608, 1152), (8064, 1152)):
+        assert pick(3 * L, n, k) == 2 and pick(L, n, k) == 2, (n, k)          # B = 3 and B = 1: 256 x 256 everywhere (B = 1, N = 1152:
+        assert pick(3 * L // 2, n, k) == 2 and pick(3 * L // 4, n, k) == 2     # two rounds of 256 x 256 beat three of 256 x 128)
+    for n, k in ((1152, 1152), (1152, 4608), (1152, 5760)):
+        assert pick(3 * L // 8, n, k) == 1 and pick(L // 4, n, k) == 1, (n, k)  # 25 / 17 row tiles x 5: half the chip idle with 256 x 256
+    assert pick(3 * L // 8, 8064, 1152) == 2
+    assert C1.lib.osk_gemm_tile_override(3) != 0 and C1.lib.osk_gemm_tile_override(-1) == 0   # invalid kind refused; estimate restored
+    assert C1.lib.osk_attention_rows_override(128) != 0 and C1.lib.osk_attention_rows_override(0) == 0
