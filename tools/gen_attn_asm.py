@@ -1078,7 +1078,7 @@ def pvw_mfma(st, L, b):
     st.emit("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (dst, vr(L.VR0 + db * 4, 4), vr(L.PB(u, 2 * ph + qb), 4), dst), "X")
 
 
-WIDE_EXP = {"gap": 1, "win": None, "vm": 0, "swapnop": False, "kwait2": True, "dmafill": True, "budget": (9, 24)}   # production values; --wide-exp flips them   # --wide-exp (experiments): DMA piece spacing in the trailing shadows, filler windows, swap placement
+WIDE_EXP = {"gap": 1, "win": None, "vm": 0, "swapnop": False, "kwait2": True, "dmafill": True, "budget": (9, 24), "pretrail": 0}   # production values; --wide-exp flips them   # --wide-exp (experiments): DMA piece spacing in the trailing shadows, filler windows, swap placement
 
 
 def body_wide(st, L, k, h, safe=False):
@@ -1096,6 +1096,19 @@ def body_wide(st, L, k, h, safe=False):
     dma = k_dma if which == "k" else v_dma
     gap = WIDE_EXP["gap"]
     pieces = list(range(nslot(L, which) - 1))[:(L.NTRAIL + gap - 1) // gap]
+    cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
+    clsA, clsB = [], []
+    for g in range(4):
+        for u in range(2):
+            (clsA if g < 2 else clsB).extend(exp_group(L, sc, u, g))
+        if g % 2 == 1:
+            for u in range(2):
+                (clsA if g < 2 else clsB).extend(swap_group(L, u, g // 2, guard=WIDE_EXP["swapnop"]))
+    # round 5: the trailing P.V shadows of the PREVIOUS half (8 x 16 cycles that carried only LDS-DMA M0 writes) take the first
+    # exponentials of THIS half's phase-0 scores -- complete since the previous body's QK^T, touched by nobody else: exp2 in place --
+    # one per shadow, out of the QK^T shadows that were the body's fullest.  A body entered at its entry label (the prologue's jump into
+    # body (0, 0)) has not run them: `pre` is returned and the prologue emits them itself.
+    pre = []
     for n in range(L.NTRAIL):
         pn = n // gap if n % gap == 0 else len(pieces)
         if pn < len(pieces):
@@ -1103,6 +1116,10 @@ def body_wide(st, L, k, h, safe=False):
         pvw_mfma(st, L, 32 + n)                    # pairs 8, 9 = (phase 1, row blocks 3, 4) of the previous body
         if pn < len(pieces):
             dma(st, L, dslot, pieces[pn], 2)
+        for _ in range(WIDE_EXP["pretrail"]):
+            if len(pre) < len(clsA) and clsA[len(pre)][0] == "e":
+                st.emit(clsA[len(pre)][1], "e")
+                pre.append(clsA[len(pre)])
     st.label(".L@@_entry%d%d" % (k, h))
     later = []
     deferred = []      # the LDS-DMA instruction of a piece whose M0 write was just emitted: goes behind the next filler instruction
@@ -1113,16 +1130,8 @@ def body_wide(st, L, k, h, safe=False):
             later.append((lambda i=i: dma(st, L, dslot, i), DMACOST))
     later.append((lambda: dma_last(st, L, which, dslot, uid), DMACOST))
     later.append((lambda: advance(st, which, uid, G.VSTEP, L, dslot), 20))
-    cost = lambda kind_: 8.0 if kind_ == "e" else (2.0 if kind_ == "n" else 4.0)
-    clsA, clsB = [], []
-    for g in range(4):
-        for u in range(2):
-            (clsA if g < 2 else clsB).extend(exp_group(L, sc, u, g))
-        if g % 2 == 1:
-            for u in range(2):
-                (clsA if g < 2 else clsB).extend(swap_group(L, u, g // 2, guard=WIDE_EXP["swapnop"]))
     W = WIDE_EXP["win"] or L.FAST_WINDOWS
-    classes = [[clsA, W[0], W[1], 0, 0.0], [clsB, W[2], W[3], 0, 0.0]]
+    classes = [[clsA, W[0], W[1], len(pre), sum(cost(o[0]) for o in pre)], [clsB, W[2], W[3], 0, 0.0]]
     totals = [sum(cost(o[0]) for o in c[0]) for c in classes]
     mf = [("qk", a) for a in range(20)] + [("pv", b) for b in range(32)]
     for n, (kind, idx) in enumerate(mf):
@@ -1196,7 +1205,7 @@ def body_wide(st, L, k, h, safe=False):
         st.emit("s_cbranch_scc0 .L@@_exit", "s")
         if k == 1:
             st.emit("s_branch .L@@_body00", "s")
-    return which, dslot, pieces
+    return which, dslot, pieces, pre
 
 
 def _check_p_ready_wide(st, k, h):
@@ -1267,9 +1276,11 @@ def _generate_wide(L, safe):
                 qkw_mfma(st, L, L.SA0, (ks * 2 + ph) * 2 + u)
     e("s_nop 15")
     e("s_nop 15")
-    which, dslot, pieces = body_wide(Stream(), L, 0, 0)
+    which, dslot, pieces, pre = body_wide(Stream(), L, 0, 0)
     for i in pieces:                            # what body (0, 0) does before its entry point
         (k_dma if which == "k" else v_dma)(st, L, dslot, i)
+    for kind_, text in pre:                     # (incl. the exponentials its trailing shadows carry: the two s_nop 15 above cover the QK^T latency)
+        e(text)
     for ks in range(4):
         kw_read(st, L, 0, 1, ks, ("k", ks))
     e("s_branch .L@@_entry00")
@@ -1321,6 +1332,8 @@ def main():
             WIDE_EXP[{"swapnop": "swapnop", "kwait1": "kwait2", "nodmafill": "dmafill"}[tok]] = tok == "swapnop"
         elif tok.startswith("vm"):
             WIDE_EXP["vm"] = int(tok[2:])
+        elif tok.startswith("pretrail"):    # exponentials of the body's own phase-0 scores per trailing P.V shadow (0: none)
+            WIDE_EXP["pretrail"] = int(tok[8:])
         elif tok.startswith("budget:"):     # filler-cycle budget of a P.V / QK^T shadow (round 5: the MFMA's own issue takes 4.4 cycles)
             WIDE_EXP["budget"] = tuple(int(x) for x in tok[7:].split(","))
         elif tok.startswith("win:"):
