@@ -243,12 +243,15 @@ __global__ void __launch_bounds__(256) qknorm_rope_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row-per-thread variant (default).  A block owns TPB = 256 / H consecutive tokens = TPB * H (token, head) rows.
+// Row-per-thread variant (default).  A block owns TPB = NT / H consecutive tokens = TPB * H (token, head) rows.
 // Global traffic is fully coalesced both ways: the TPB contiguous [H * hd] spans are copied to LDS with 16-byte loads
 // by all lanes, every thread then norms + rotates ONE row out of LDS entirely in registers (no cross-lane reduction,
 // both RoPE conventions lane-local), writes it back to LDS, and the spans leave with 16-byte stores.  cos / sin of
-// the block's tokens and the four scale vectors are staged in LDS once.  Same rounding points as above.
+// the block's tokens and this tensor's two scale vectors (as f32) are staged in LDS once.  Same rounding points as above.
 // LDS row stride hd*2 (+16 when hd % 32 == 0) bytes keeps the per-thread 16-byte row reads off each other's banks.
+// ONE global round trip per block (round 5): the scale, cos / sin and row loads are all issued into registers before the first
+// of them is waited for -- round 4's three dependent trips (scales -> barrier -> cos / sin -> barrier -> rows) left the
+// 7 resident blocks of a CU waiting on memory for most of their life (VALU ~35 % busy at 0.42 of the HBM roofline).
 // ---------------------------------------------------------------------------------------------
 template <int HD, int MODE, int NT>   // NT threads = NT (token, head) rows per block
 __global__ void __launch_bounds__(NT) qknorm_rope_rows_kernel(
@@ -259,17 +262,21 @@ __global__ void __launch_bounds__(NT) qknorm_rope_rows_kernel(
     float eps, float q_mult) {
   constexpr int RS = HD * 2 + ((HD % 32) == 0 ? 16 : 0);  // LDS row stride, bytes
   constexpr int CPR = HD / 8;                              // 16-byte chunks per row
+  constexpr int CSMAX = (HD / 4 + 3) / 4;                  // 16-byte cos / sin pieces per thread: (HD / 4) / TPT, TPT >= H >= 4
+  constexpr int SCMAX = (2 * HD + NT - 1) / NT;            // scale elements per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int tpb = NT / H, rows = tpb * H;
   unsigned char* s_rows = sm;                                            // [rows][RS]
   float* s_cs = reinterpret_cast<float*>(sm + NT * RS);                 // [tpb][2][HD/2]
-  unsigned short* s_sc = reinterpret_cast<unsigned short*>(s_cs + tpb * HD);  // [4][HD]
+  float* s_sc = s_cs + tpb * HD;                                         // [2][HD]: this tensor's scales, tokens < l_split | the rest
+  int* s_bl = reinterpret_cast<int*>(s_sc + 2 * HD);                     // [tpb][2]: (batch, position) of the block's tokens
   const int tid = threadIdx.x;
-  // token arithmetic in 32 bits (the entry point checks B * L < 2^31): a 64-bit division is ~10x the instructions of a 32-bit one,
-  // and round 3's version ran 2 of them per staged cos / sin element -- more integer work than the norm + rotation itself
+  // blockIdx.y picks the tensor: q and k are independent passes, two blocks instead of two serial phases
+  const int which = q && k ? (int)blockIdx.y : (k ? 1 : 0);
+  unsigned short* tb = which ? k : q;
+  // token arithmetic in 32 bits (the entry point checks B * L < 2^31): a 64-bit division is ~10x the instructions of a 32-bit one
   const int tok0 = (int)blockIdx.x * tpb;                                // first token (over B * L)
   const int ntok = B * L;
-  int* s_bl = reinterpret_cast<int*>(s_sc + 4 * HD);                     // [tpb][2]: (batch, position) of the block's tokens
   if (tid < tpb) {
     int tok = tok0 + tid;
     tok = tok < ntok ? tok : ntok - 1;
@@ -277,98 +284,123 @@ __global__ void __launch_bounds__(NT) qknorm_rope_rows_kernel(
     s_bl[2 * tid] = b;
     s_bl[2 * tid + 1] = tok - b * L;
   }
-  for (int i = tid; i < 4 * HD; i += NT) {
-    const unsigned short* src = i < HD ? qs0 : (i < 2 * HD ? ks0 : (i < 3 * HD ? qs1 : ks1));
-    s_sc[i] = src[i % HD];
+  unsigned short scv[SCMAX];               // (these loads do not need the token table: in flight across the barrier; index clamped,
+#pragma unroll                             //  not predicated: no branch, and the conversion waits until the LDS write)
+  for (int i = 0; i < SCMAX; ++i) {
+    int e = tid + i * NT;
+    e = e < 2 * HD ? e : 2 * HD - 1;
+    const unsigned short* src = e < HD ? (which ? ks0 : qs0) : (which ? ks1 : qs1);
+    scv[i] = src[e < HD ? e : e - HD];
   }
-  __syncthreads();
-  // ---- stage cos / sin rows of the block's tokens
-  const float stage_mult = (q && k ? (int)blockIdx.y : (k ? 1 : 0)) ? 1.0f : q_mult;
-  for (int i = tid; i < tpb * HD; i += NT) {
-    const int t = i / HD, j = i - t * HD;                                // (HD is a compile-time constant: multiply + shift)
-    const int64_t off = s_bl[2 * t] * csb + (int64_t)s_bl[2 * t + 1] * (HD / 2);
-    // (the q pass: softmax scale * log2(e) rides on the staged rotation, once per token instead of once per head; the two
-    //  orders of the products differ by f32 rounding only, far below the bf16 rounding that follows)
-    s_cs[i] = (j < HD / 2 ? cos_t[off + j] : sin_t[off + j - HD / 2]) * stage_mult;
+  __syncthreads();                         // token table visible (no global value has been used yet)
+  // ---- every remaining global read of the block: the token spans (TPT = NT / tpb consecutive threads walk ONE token's span,
+  //      TPT x 16 contiguous bytes per step) and the cos / sin rows of the block's tokens
+  const int tpt = NT / tpb;
+  const int ct = (int)((unsigned)tid / (unsigned)tpt), cj = tid - ct * tpt;
+  const bool cvalid = ct < tpb && tok0 + ct < ntok;
+  const int cti = ct < tpb ? ct : tpb - 1;
+  unsigned short* cspan = tb + s_bl[2 * cti] * bs + (int64_t)s_bl[2 * cti + 1] * rs;
+  const int span_chunks = H * CPR;         // 16-byte chunks of one token's [H * hd] span
+  // Loads AND LDS writes below are unconditional with clamped indices (a step past the end repeats the last piece: same bytes
+  // to the same LDS address): a predicated write lets the compiler sink its load into the branch, one round trip per piece.
+  uint4 pre[CPR];                          // span_chunks / TPT <= CPR steps (TPT >= H)
+#pragma unroll
+  for (int i = 0; i < CPR; ++i) {
+    int w = cj + i * tpt;
+    w = w < span_chunks ? w : span_chunks - 1;
+    pre[i] = *reinterpret_cast<const uint4*>(cspan + w * 8);
+  }
+  // cos | sin row of token ct: HD / 4 16-byte pieces (the entry point checked the alignment), walked by the same TPT threads
+  const int64_t csoff = s_bl[2 * cti] * csb + (int64_t)s_bl[2 * cti + 1] * (HD / 2);
+  float4 cs_pre[CSMAX];
+#pragma unroll
+  for (int i = 0; i < CSMAX; ++i) {
+    int c = cj + i * tpt;
+    c = c < HD / 4 ? c : HD / 4 - 1;
+    const float* src = c < HD / 8 ? cos_t + csoff + c * 4 : sin_t + csoff + (c - HD / 8) * 4;
+    cs_pre[i] = *reinterpret_cast<const float4*>(src);
+  }
+  // ---- into LDS
+  // (the q pass: softmax scale * log2(e) rides on the staged rotation, once per token instead of once per head; the two
+  //  orders of the products differ by f32 rounding only, far below the bf16 rounding that follows)
+  const float stage_mult = which ? 1.0f : q_mult;
+#pragma unroll
+  for (int i = 0; i < SCMAX; ++i) {
+    int e = tid + i * NT;
+    e = e < 2 * HD ? e : 2 * HD - 1;
+    s_sc[e] = bf16_bits_to_f32(scv[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < CSMAX; ++i) {
+    int c = cj + i * tpt;
+    c = c < HD / 4 ? c : HD / 4 - 1;
+    float4 u = cs_pre[i];
+    u.x *= stage_mult; u.y *= stage_mult; u.z *= stage_mult; u.w *= stage_mult;
+    reinterpret_cast<float4*>(s_cs)[cti * (HD / 4) + c] = u;
+  }
+#pragma unroll
+  for (int i = 0; i < CPR; ++i) {
+    int w = cj + i * tpt;
+    w = w < span_chunks ? w : span_chunks - 1;
+    *reinterpret_cast<uint4*>(s_rows + (cti * H + w / CPR) * RS + (w % CPR) * 16) = pre[i];
   }
   const int r = tid;                       // this thread's row
-  const int t_loc = (int)((unsigned)r / (unsigned)H), h = r - t_loc * H;
-  const bool rvalid = r < rows && tok0 + t_loc < ntok;
+  const int t_loc = (int)((unsigned)r / (unsigned)H);
   const int l_r = s_bl[2 * (t_loc < tpb ? t_loc : tpb - 1) + 1];
-  const int span_chunks = H * CPR;         // 16-byte chunks of one token's [H * hd] span
-  {
-    // blockIdx.y picks the tensor: q and k are independent passes, two blocks instead of two serial phases
-    const int which = q && k ? (int)blockIdx.y : (k ? 1 : 0);
-    unsigned short* tb = which ? k : q;
-    __syncthreads();                       // staging visible
-    // copy loops: TPT = 256 / tpb consecutive threads walk ONE token's span (TPT x 16 contiguous bytes per step), so the
-    // token -> (batch, position) division happens once per thread instead of once per 16-byte chunk
-    const int tpt = NT / tpb;
-    const int ct = (int)((unsigned)tid / (unsigned)tpt), cj = tid - ct * tpt;
-    const bool cvalid = ct < tpb && tok0 + ct < ntok;
-    const int cti = ct < tpb ? ct : tpb - 1;
-    unsigned short* cspan = tb + s_bl[2 * cti] * bs + (int64_t)s_bl[2 * cti + 1] * rs;
-    if (ct < tpb) {
-      for (int w = cj; w < span_chunks; w += tpt) {
-        const uint4 u = *reinterpret_cast<const uint4*>(cspan + w * 8);
-        *reinterpret_cast<uint4*>(s_rows + (ct * H + w / CPR) * RS + (w % CPR) * 16) = u;
+  __syncthreads();
+  if (r < rows) {
+    float v[HD];
+#pragma unroll
+    for (int c = 0; c < CPR; ++c) unpack8(*reinterpret_cast<const uint4*>(s_rows + r * RS + c * 16), v + c * 8);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < HD; ++j) ss += v[j] * v[j];
+    const float rrms = rsqrtf(ss / (float)HD + eps);
+    const float* sc = s_sc + (l_r < l_split ? 0 : HD);
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {       // 4 scales per 16-byte LDS read
+      const float4 w4 = *reinterpret_cast<const float4*>(sc + c * 4);
+      // reference rounding points: (x*rrms).to(bf16) * scale(bf16) -> bf16   (layers.py:107-111); two values per
+      // v_cvt_pk_bf16_f32, the halves widened back with one shift / one mask
+      const unsigned a1 = pack_bf16x2(v[c * 4 + 0] * rrms, v[c * 4 + 1] * rrms);
+      const unsigned b1 = pack_bf16x2(v[c * 4 + 2] * rrms, v[c * 4 + 3] * rrms);
+      const unsigned a2 = pack_bf16x2(bf16_lo(a1) * w4.x, bf16_hi(a1) * w4.y);
+      const unsigned b2 = pack_bf16x2(bf16_lo(b1) * w4.z, bf16_hi(b1) * w4.w);
+      v[c * 4 + 0] = bf16_lo(a2); v[c * 4 + 1] = bf16_hi(a2);
+      v[c * 4 + 2] = bf16_lo(b2); v[c * 4 + 3] = bf16_hi(b2);
+    }
+    const float* cr = s_cs + t_loc * HD;
+    const float* sr = cr + HD / 2;
+    float csv[HD / 2], snv[HD / 2];        // 4 angles per 16-byte LDS read (HD / 2 is a multiple of 4)
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      const float4 c4 = *reinterpret_cast<const float4*>(cr + c * 4);
+      const float4 s4 = *reinterpret_cast<const float4*>(sr + c * 4);
+      csv[c * 4 + 0] = c4.x; csv[c * 4 + 1] = c4.y; csv[c * 4 + 2] = c4.z; csv[c * 4 + 3] = c4.w;
+      snv[c * 4 + 0] = s4.x; snv[c * 4 + 1] = s4.y; snv[c * 4 + 2] = s4.z; snv[c * 4 + 3] = s4.w;
+    }
+#pragma unroll
+    for (int pj = 0; pj < HD / 2; ++pj) {
+      const float cs = csv[pj], sn = snv[pj];
+      if constexpr (MODE == 0) {           // pairs (2j, 2j+1)
+        const float a = v[2 * pj], b2 = v[2 * pj + 1];
+        v[2 * pj] = cs * a - sn * b2;
+        v[2 * pj + 1] = sn * a + cs * b2;
+      } else {                             // pairs (j, j + hd/2)
+        const float a = v[pj], b2 = v[pj + HD / 2];
+        v[pj] = a * cs - b2 * sn;
+        v[pj + HD / 2] = b2 * cs + a * sn;
       }
     }
-    __syncthreads();
-    if (r < rows) {
-      float v[HD];
 #pragma unroll
-      for (int c = 0; c < CPR; ++c) unpack8(*reinterpret_cast<const uint4*>(s_rows + r * RS + c * 16), v + c * 8);
-      float ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < HD; ++j) ss += v[j] * v[j];
-      const float rrms = rsqrtf(ss / (float)HD + eps);
-      const unsigned short* sc = s_sc + (which ? HD : 0) + (l_r < l_split ? 0 : 2 * HD);
-#pragma unroll
-      for (int c = 0; c < CPR; ++c) {        // 8 scales per 16-byte LDS read
-        float w8[8];
-        unpack8(*reinterpret_cast<const uint4*>(sc + c * 8), w8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          // reference rounding points: (x*rrms).to(bf16) * scale(bf16) -> bf16   (layers.py:107-111)
-          const float t1 = bf16_bits_to_f32(f32_to_bf16_bits(v[c * 8 + j] * rrms));
-          v[c * 8 + j] = bf16_bits_to_f32(f32_to_bf16_bits(t1 * w8[j]));
-        }
-      }
-      const float* cr = s_cs + t_loc * HD;
-      const float* sr = cr + HD / 2;
-      float csv[HD / 2], snv[HD / 2];        // 4 angles per 16-byte LDS read (HD / 2 is a multiple of 4)
-#pragma unroll
-      for (int c = 0; c < HD / 8; ++c) {
-        const float4 c4 = *reinterpret_cast<const float4*>(cr + c * 4);
-        const float4 s4 = *reinterpret_cast<const float4*>(sr + c * 4);
-        csv[c * 4 + 0] = c4.x; csv[c * 4 + 1] = c4.y; csv[c * 4 + 2] = c4.z; csv[c * 4 + 3] = c4.w;
-        snv[c * 4 + 0] = s4.x; snv[c * 4 + 1] = s4.y; snv[c * 4 + 2] = s4.z; snv[c * 4 + 3] = s4.w;
-      }
-#pragma unroll
-      for (int pj = 0; pj < HD / 2; ++pj) {
-        const float cs = csv[pj], sn = snv[pj];
-        if constexpr (MODE == 0) {           // pairs (2j, 2j+1)
-          const float a = v[2 * pj], b2 = v[2 * pj + 1];
-          v[2 * pj] = cs * a - sn * b2;
-          v[2 * pj + 1] = sn * a + cs * b2;
-        } else {                             // pairs (j, j + hd/2)
-          const float a = v[pj], b2 = v[pj + HD / 2];
-          v[pj] = a * cs - b2 * sn;
-          v[pj + HD / 2] = b2 * cs + a * sn;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < CPR; ++c) *reinterpret_cast<uint4*>(s_rows + r * RS + c * 16) = pack8(v + c * 8);
-    }
-    __syncthreads();
-    if (cvalid) {
-      for (int w = cj; w < span_chunks; w += tpt)
-        *reinterpret_cast<uint4*>(cspan + w * 8) =
-            *reinterpret_cast<const uint4*>(s_rows + (ct * H + w / CPR) * RS + (w % CPR) * 16);
-    }
+    for (int c = 0; c < CPR; ++c) *reinterpret_cast<uint4*>(s_rows + r * RS + c * 16) = pack8(v + c * 8);
   }
-  (void)rvalid;
+  __syncthreads();
+  if (cvalid) {
+    for (int w = cj; w < span_chunks; w += tpt)
+      *reinterpret_cast<uint4*>(cspan + w * 8) =
+          *reinterpret_cast<const uint4*>(s_rows + (ct * H + w / CPR) * RS + (w % CPR) * 16);
+  }
 }
 
 extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, const void* qs0,
@@ -381,8 +413,9 @@ extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, co
   const int64_t total = (int64_t)B * L * H;
   {
     // row-per-thread kernel (coalesced spans through LDS)
-    if (H <= 256 && (hd == 64 || hd == 72) && (rope_mode == 0 || rope_mode == 1) && (int64_t)B * L < (1ll << 31)) {  // hd 128: the lane-group
-      // kernel below already uses every lane (16 x 16 B per row) and a whole row per thread would need 256 VGPRs
+    if (H >= 4 && H <= 256 && (hd == 64 || hd == 72) && (rope_mode == 0 || rope_mode == 1) && (int64_t)B * L < (1ll << 31) &&
+        (((uintptr_t)cos_t | (uintptr_t)sin_t) & 15) == 0 && (csb & 3) == 0) {   // (16-byte cos / sin pieces; unaligned tables take the kernel below)
+      // hd 128: the lane-group kernel below already uses every lane (16 x 16 B per row) and a whole row per thread would need 256 VGPRs
       // 128-row blocks (round 4: 21 KB of LDS -> 7 blocks per CU instead of 3 x 42 KB: the copy-in / compute / copy-out phases of
       // more, smaller blocks interleave better) unless the head count needs the 256-row block to hold a whole token
       const int NT_ = H <= 128 ? 128 : 256;
@@ -392,7 +425,7 @@ extern "C" int osk_qknorm_rope_bf16(void* q, void* k, int64_t bs, int64_t rs, co
 #define LAUNCH_ROWS(HD, MODE)                                                                                   \
   {                                                                                                             \
     constexpr int RS_ = HD * 2 + ((HD % 32) == 0 ? 16 : 0);                                                     \
-    const size_t smem = (size_t)NT_ * RS_ + (size_t)tpb * HD * 4 + 4 * HD * 2 + (size_t)tpb * 8;                \
+    const size_t smem = (size_t)NT_ * RS_ + (size_t)tpb * HD * 4 + 2 * HD * 4 + (size_t)tpb * 8;                \
     if (NT_ == 128)                                                                                             \
       hipLaunchKernelGGL((qknorm_rope_rows_kernel<HD, MODE, 128>), grid, block, smem, st, (unsigned short*)q,   \
                          (unsigned short*)k, bs, rs, (const unsigned short*)qs0, (const unsigned short*)ks0,    \

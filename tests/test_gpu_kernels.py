@@ -270,8 +270,11 @@ def test_gemm_joint_buffer_rows(hip_lib):
 # ----------------------------------------------------------------------------- QK norm + RoPE
 @pytest.mark.parametrize("hd,axes", [(64, [16, 24, 24]), (72, [8, 32, 32]), (128, [16, 56, 56])])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_qknorm_rope(hip_lib, hd, axes, mode):
-    B, Lt, Li, H = 2, 9, 70, 3
+@pytest.mark.parametrize("H", [3, 6, 16])   # head_dim 64 / 72: H < 4 takes the lane-group kernel, H >= 4 the row-per-thread kernel (S: 6, XL: 16)
+def test_qknorm_rope(hip_lib, hd, axes, mode, H):
+    if hd == 128 and H != 3:
+        pytest.skip("head_dim 128 has one kernel")
+    B, Lt, Li = 2, 9, 70
     L, D = Lt + Li, H * hd
     y = rnd("qkv", (B, L, 3 * D), std=1.5)
     y0 = y.clone()
