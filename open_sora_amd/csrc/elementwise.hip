@@ -23,29 +23,33 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(
   const unsigned short* xr = x + b * xbs + l * xrs;
   unsigned short* orow = out + b * obs + l * ors;
   const int nchunk = D >> 3;
+  // Every load of the row is unconditional with a clamped chunk index (lanes past the row re-read its last chunk and are masked
+  // out of the sums and the stores): a load predicated together with its use waits inside the branch, so the row's 2-8 chunks
+  // and the modulation vectors became dependent round trips and a wave never had more than 1 KB in flight (round 5).
   float v[MAXC][8];
-  float s = 0.f;
+  uint4 u[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = lane + i * 64;
-    if (c < nchunk) {
-      uint4 u = *reinterpret_cast<const uint4*>(xr + c * 8);
-      unpack8(u, v[i]);
+    u[i] = *reinterpret_cast<const uint4*>(xr + (c < nchunk ? c : nchunk - 1) * 8);
+  }
+  float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[i][j];
-    }
+  for (int i = 0; i < MAXC; ++i) {
+    const bool in = lane + i * 64 < nchunk;
+    unpack8(u[i], v[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += in ? v[i][j] : 0.f;
   }
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + i * 64;
-    if (c < nchunk) {
+    const bool in = lane + i * 64 < nchunk;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = v[i][j] - mean;
-        q += d * d;
-      }
+    for (int j = 0; j < 8; ++j) {
+      const float d = v[i][j] - mean;
+      q += in ? d * d : 0.f;
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
@@ -54,22 +58,21 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = lane + i * 64;
-    if (c < nchunk) {
-      const float4 s0 = *reinterpret_cast<const float4*>(sc + c * 8);
-      const float4 s1 = *reinterpret_cast<const float4*>(sc + c * 8 + 4);
-      const float4 h0 = *reinterpret_cast<const float4*>(sh + c * 8);
-      const float4 h1 = *reinterpret_cast<const float4*>(sh + c * 8 + 4);
-      const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-      float o[8];
+    const int cc = c < nchunk ? c : nchunk - 1;
+    const float4 s0 = *reinterpret_cast<const float4*>(sc + cc * 8);
+    const float4 s1 = *reinterpret_cast<const float4*>(sc + cc * 8 + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(sh + cc * 8);
+    const float4 h1 = *reinterpret_cast<const float4*>(sh + cc * 8 + 4);
+    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (1.0f + scv[j]) * ((v[i][j] - mean) * rstd) + shv[j];
-      if constexpr (FP8) {
+    for (int j = 0; j < 8; ++j) o[j] = (1.0f + scv[j]) * ((v[i][j] - mean) * rstd) + shv[j];
+    if constexpr (FP8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[i][j] = bf16_bits_to_f32(f32_to_bf16_bits(o[j]));   // the bf16 value the GEMM would read
-      } else {
-        *reinterpret_cast<uint4*>(orow + c * 8) = pack8(o);
-      }
+      for (int j = 0; j < 8; ++j) v[i][j] = bf16_bits_to_f32(f32_to_bf16_bits(o[j]));   // the bf16 value the GEMM would read
+    } else {
+      if (c < nchunk) *reinterpret_cast<uint4*>(orow + c * 8) = pack8(o);
     }
   }
   if constexpr (FP8) {
@@ -553,14 +556,26 @@ __global__ void __launch_bounds__(256) gemv_tasks_kernel(
     const int* __restrict__ n_rows, float* __restrict__ out, int64_t obs, int act_in, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [MB][K]
   const int task = blockIdx.x;
-  for (int i = threadIdx.x; i < MB * K; i += 256) {
-    const int b = i / K, kk = i - b * K;
-    float t = 0.f;
-    if (b < Bv) {
-      t = x[b * xbs + kk];
-      if (act_in == 1) t = silu(t);
+  // 8 elements per thread and trip, loads first (clamped indices, unconditional LDS writes: a predicated write would pull its
+  // load into the branch and make every element a dependent round trip)
+  for (int i0 = threadIdx.x; i0 < MB * K; i0 += 256 * 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int i = i0 + u * 256;
+      i = i < MB * K ? i : MB * K - 1;
+      const int b = i / K, kk = i - b * K;
+      t[u] = x[(b < Bv ? b : Bv - 1) * xbs + kk];
     }
-    xs[i] = t;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int i = i0 + u * 256;
+      i = i < MB * K ? i : MB * K - 1;
+      const int b = i / K;
+      float v = t[u];
+      if (act_in == 1) v = silu(v);
+      xs[i] = b < Bv ? v : 0.f;
+    }
   }
   __syncthreads();
   const unsigned short* W = reinterpret_cast<const unsigned short*>(w_ptrs[task]);
@@ -569,33 +584,59 @@ __global__ void __launch_bounds__(256) gemv_tasks_kernel(
   const int col0 = out_cols[task];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nchunk = K >> 3;
-  for (int r = wave; r < nr; r += 4) {
-    const unsigned short* wr = W + (int64_t)r * K;
-    float acc[MB];
+  // RU rows per wave at a time: their 16-byte weight loads of one k position are all issued before the first is used (round 5;
+  // one row at a time made every row a dependent memory round trip: 0.9 TB/s over the 438 MB of adaLN weights of an XL step),
+  // and the x pieces read from LDS serve all RU rows.  Per row the per-lane summation order is unchanged.
+  constexpr int RU = MB == 8 ? 4 : 8;
+  for (int r0 = wave * RU; r0 < nr; r0 += 4 * RU) {
+    float acc[RU][MB];
+    const unsigned short* wr[RU];
 #pragma unroll
-    for (int b = 0; b < MB; ++b) acc[b] = 0.f;
+    for (int j = 0; j < RU; ++j) {
+      const int rr = r0 + j < nr ? r0 + j : nr - 1;   // (clamped: a row past the task repeats its last row, result dropped)
+      wr[j] = W + (int64_t)rr * K;
+#pragma unroll
+      for (int b = 0; b < MB; ++b) acc[j][b] = 0.f;
+    }
     for (int c = lane; c < nchunk; c += 64) {
-      uint4 u = *reinterpret_cast<const uint4*>(wr + c * 8);
-      float w[8];
-      unpack8(u, w);
+      uint4 u[RU];
+#pragma unroll
+      for (int j = 0; j < RU; ++j) u[j] = *reinterpret_cast<const uint4*>(wr[j] + c * 8);
+      float4 x0[MB], x1[MB];
 #pragma unroll
       for (int b = 0; b < MB; ++b) {
-        const float4 x0 = *reinterpret_cast<const float4*>(&xs[b * K + c * 8]);
-        const float4 x1 = *reinterpret_cast<const float4*>(&xs[b * K + c * 8 + 4]);
-        acc[b] += w[0] * x0.x + w[1] * x0.y + w[2] * x0.z + w[3] * x0.w + w[4] * x1.x + w[5] * x1.y +
-                  w[6] * x1.z + w[7] * x1.w;
+        x0[b] = *reinterpret_cast<const float4*>(&xs[b * K + c * 8]);
+        x1[b] = *reinterpret_cast<const float4*>(&xs[b * K + c * 8 + 4]);
+      }
+#pragma unroll
+      for (int j = 0; j < RU; ++j) {
+        float w[8];
+        unpack8(u[j], w);
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+          acc[j][b] += w[0] * x0[b].x + w[1] * x0[b].y + w[2] * x0[b].z + w[3] * x0[b].w + w[4] * x1[b].x + w[5] * x1[b].y +
+                       w[6] * x1[b].z + w[7] * x1[b].w;
       }
     }
 #pragma unroll
-    for (int b = 0; b < MB; ++b) acc[b] = wave_sum(acc[b]);
-    if (lane == 0) {
-      const float bv = bias ? bf16_bits_to_f32(bias[r]) : 0.f;
+    for (int j = 0; j < RU; ++j) {
 #pragma unroll
-      for (int b = 0; b < MB; ++b) {
-        if (b < Bv) {
-          float* o = out + b * obs + col0 + r;
-          const float val = acc[b] + bv;
-          *o = accumulate ? (*o + val) : val;
+      for (int b = 0; b < MB; ++b) acc[j][b] = wave_sum(acc[j][b]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < RU; ++j) {
+        const int r = r0 + j;
+        if (r < nr) {
+          const float bv = bias ? bf16_bits_to_f32(bias[r]) : 0.f;
+#pragma unroll
+          for (int b = 0; b < MB; ++b) {
+            if (b < Bv) {
+              float* o = out + b * obs + col0 + r;
+              const float val = acc[j][b] + bv;
+              *o = accumulate ? (*o + val) : val;
+            }
+          }
         }
       }
     }

@@ -33,3 +33,21 @@ for H, hd, R in ((16, 72, 4), (24, 128, 4)):
     vt = torch.empty(B, H, hd, L, device="cuda", dtype=torch.bfloat16)
     us = timeit(lambda: _C.v_transpose(v, vt, H, hd))
     print(json.dumps(dict(kernel=f"v_transpose hd{hd}", us=round(us, 1), gbps=round(2 * B * L * D * 2 / us / 1e3, 0))))
+
+# the adaLN modulation of one XL step: all 165 chunks of 1152 rows (9 double blocks x 2 streams x 6, 19 single blocks x 3) as ONE task list
+D, nl = 1152, 9 * 2 * 6 + 19 * 3
+ws = [torch.randn(D, D, device="cuda").mul(D ** -0.5).to(torch.bfloat16) for _ in range(nl)]
+bs_ = [torch.zeros(D, device="cuda", dtype=torch.bfloat16) for _ in range(nl)]
+tasks = _C.GemvTasks([(w, b, i * D) for i, (w, b) in enumerate(zip(ws, bs_))], "cuda")
+vec = torch.randn(3, D, device="cuda")
+mod = torch.empty(3, nl * D, device="cuda")
+us = timeit(lambda: _C.gemv_tasks(vec, tasks, mod, act_in=1))
+print(json.dumps(dict(kernel=f"gemv_tasks adaLN of an XL step ({nl} x {D} rows, K = {D}, 3 vectors)", us=round(us, 1), gbps=round(nl * D * D * 2 / us / 1e3, 0))))
+
+# LayerNorm + modulate at the XL and 11B widths (whole joint sequence, CFG batch 3)
+for Dm in (1152, 3072):
+    xx = torch.randn(B, L, Dm, device="cuda").to(torch.bfloat16)
+    oo = torch.empty_like(xx)
+    mv = torch.randn(B, 2 * Dm, device="cuda") * 0.1
+    us = timeit(lambda: _C.ln_modulate(xx, mv[:, :Dm], mv[:, Dm:], oo, mv.stride(0)))
+    print(json.dumps(dict(kernel=f"ln_modulate D{Dm}", us=round(us, 1), gbps=round(2 * B * L * Dm * 2 / us / 1e3, 0))))
