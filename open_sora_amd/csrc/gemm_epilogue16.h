@@ -17,9 +17,7 @@ using epi::GELU_NONE;
 // accumulators started from it (an interior wave tile has all its columns inside N, which is the kernel's "folded" condition).
 // GATE and the tile's GELU class are compile-time / hoisted: 64 tiles per wave make every per-tile branch count.
 template <class Geo, int T, bool GATE, int GELU>
-OSK_DEV void tile_values(const osk_v4f* aq, const GemmParams& p, int64_t roff, int n, const float4& gq, float* acc) {
-  uint2 rv = make_uint2(0, 0);
-  if constexpr (GATE) rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+OSK_DEV void tile_values_rv(const osk_v4f* aq, const GemmParams& p, int n, const float4& gq, const uint2& rv, float* acc) {
   Geo::template read<T>(aq, acc);
   if constexpr (GELU == GELU_ALL) {
 #pragma unroll
@@ -37,6 +35,13 @@ OSK_DEV void tile_values(const osk_v4f* aq, const GemmParams& p, int64_t roff, i
     acc[2] = bf16_lo(rv.y) + gq.z * acc[2];
     acc[3] = bf16_hi(rv.y) + gq.w * acc[3];
   }
+}
+// (the residual piece of the tile read in the accumulator layout: 8 bytes of the lane's row -- 16 rows x 32 bytes per instruction)
+template <class Geo, int T, bool GATE, int GELU>
+OSK_DEV void tile_values(const osk_v4f* aq, const GemmParams& p, int64_t roff, int n, const float4& gq, float* acc) {
+  uint2 rv = make_uint2(0, 0);
+  if constexpr (GATE) rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+  tile_values_rv<Geo, T, GATE, GELU>(aq, p, n, gq, rv, acc);
 }
 
 // Interior: the pair of row blocks (I, I + 1) of column block J.  bf16: v_permlane16_swap turns the two tiles' 8-byte pieces
@@ -83,20 +88,59 @@ OSK_DEV uint4 chunk_interior(const osk_v4f* aq, const GemmParams& p, const int64
   return make_uint4(sx[0], sy[0], sx[1], sy[1]);
 }
 
+// the same chunk with the residual handed in as the 16-byte chunk of the SAME (row, columns) in the store layout (row_pair_wide's
+// wide residual loads): v_permlane16_swap is an involution on its register pair, so swapping the chunk's (x, z) and (y, w) gives
+// back the two tiles' 8-byte pieces in the accumulator layout
+template <class Geo, int GELU, int J, int I>
+OSK_DEV uint4 chunk_interior_res(const osk_v4f* aq, const GemmParams& p, int n0w, int q4, const float4& gq, const uint4& rc) {
+  constexpr int NB = Geo::NB;
+  const int n = n0w + J * 16 + q4 * 4;
+  auto ux = __builtin_amdgcn_permlane16_swap(rc.x, rc.z, false, false);
+  auto uy = __builtin_amdgcn_permlane16_swap(rc.y, rc.w, false, false);
+  float a0[4], a1[4];
+  tile_values_rv<Geo, J * NB + I, true, GELU>(aq, p, n, gq, make_uint2(ux[0], uy[0]), a0);
+  tile_values_rv<Geo, J * NB + I + 1, true, GELU>(aq, p, n, gq, make_uint2(ux[1], uy[1]), a1);
+  auto sx = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a1[0], a1[1]), false, false);
+  auto sy = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[2], a1[3]), false, false);
+  return make_uint4(sx[0], sy[0], sx[1], sy[1]);
+}
+
 // one pair of row blocks (I, I + 1), all NB column blocks: NB chunks per lane, transposed in groups of four, NB stores of
 // 8 rows x 128 bytes.  In-place residual (res == C, the blocks' x = x + gate * proj(..)): the stores of this call cover exactly the 32
-// rows x 16 NB columns whose residual pieces this call's tile_values() read, and every one of those loads is issued before the
+// rows x 16 NB columns whose residual pieces this call read, and every one of those loads is issued before the
 // first store (the transposes need all NB chunks), as in pair_interior.  own = element offset of this lane's own store row (storeoff[I / 2]: + its 8-column half), crs = row stride:
 // the rows of an interior wave tile lie in one batch item, so row 4 a + r is (r - j) rows from the lane's own row 4 a + j.
-template <class Geo, bool GATE, int GELU, int I, int... Js>
+// RESW (round 5): the residual is read the way the result is stored -- NB loads of 8 rows x 128 bytes -- and brought back to the
+// accumulator layout by the inverse lane exchanges (quad_transpose and the swap are involutions): the 8-byte pieces of the
+// accumulator layout cost 2 NB loads of 16 rows x 32 bytes, ~2.8 cycles per (instruction, line) on the CU's one address path --
+// 13 k of the gate class's 21 k epilogue cycles per workgroup tile (profiles/r05b_gemm_gate_epilogue_ab.jsonl).
+template <class Geo, bool GATE, int GELU, bool RESW, int I, int... Js>
 OSK_DEV void row_pair_wide(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, int64_t own, int n0w, int q4, int lane, const float4* gq,
                            std::integer_sequence<int, Js...>) {
   constexpr int NB = Geo::NB;
   static_assert(NB % 4 == 0, "column blocks are transposed in groups of four");
   uint4 d[NB];
-  ((d[Js] = chunk_interior<Geo, GATE, GELU, Js, I>(aq, p, rowoff, n0w, q4, gq[Js])), ...);
   const int j = lane & 3;
   const bool odd = lane & 1, hi = lane & 2;
+  const int64_t base_off = own + n0w + 16 * j - (int64_t)j * p.crs;
+  if constexpr (GATE && RESW) {
+    uint4 rw[NB];
+    const unsigned short* rbase = p.res + base_off;
+#pragma unroll
+    for (int b = 0; b < NB / 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rw[4 * b + r] = *reinterpret_cast<const uint4*>(rbase + (int64_t)r * p.crs + 64 * b);
+#pragma unroll
+    for (int b = 0; b < NB / 4; ++b) {
+      quad_transpose(rw[4 * b].x, rw[4 * b + 1].x, rw[4 * b + 2].x, rw[4 * b + 3].x, odd, hi);
+      quad_transpose(rw[4 * b].y, rw[4 * b + 1].y, rw[4 * b + 2].y, rw[4 * b + 3].y, odd, hi);
+      quad_transpose(rw[4 * b].z, rw[4 * b + 1].z, rw[4 * b + 2].z, rw[4 * b + 3].z, odd, hi);
+      quad_transpose(rw[4 * b].w, rw[4 * b + 1].w, rw[4 * b + 2].w, rw[4 * b + 3].w, odd, hi);
+    }
+    ((d[Js] = chunk_interior_res<Geo, GELU, Js, I>(aq, p, n0w, q4, gq[Js], rw[Js])), ...);
+  } else {
+    ((d[Js] = chunk_interior<Geo, GATE, GELU, Js, I>(aq, p, rowoff, n0w, q4, gq[Js])), ...);
+  }
 #pragma unroll
   for (int b = 0; b < NB / 4; ++b) {
     quad_transpose(d[4 * b].x, d[4 * b + 1].x, d[4 * b + 2].x, d[4 * b + 3].x, odd, hi);
@@ -104,7 +148,7 @@ OSK_DEV void row_pair_wide(const osk_v4f* aq, const GemmParams& p, const int64_t
     quad_transpose(d[4 * b].z, d[4 * b + 1].z, d[4 * b + 2].z, d[4 * b + 3].z, odd, hi);
     quad_transpose(d[4 * b].w, d[4 * b + 1].w, d[4 * b + 2].w, d[4 * b + 3].w, odd, hi);
   }
-  unsigned short* base = reinterpret_cast<unsigned short*>(p.C) + own + n0w + 16 * j - (int64_t)j * p.crs;
+  unsigned short* base = reinterpret_cast<unsigned short*>(p.C) + base_off;
 #pragma unroll
   for (int b = 0; b < NB / 4; ++b)
 #pragma unroll
@@ -115,7 +159,15 @@ OSK_DEV void row_pair_wide(const osk_v4f* aq, const GemmParams& p, const int64_t
 template <class Geo, bool GATE, int GELU, int... Is>
 OSK_DEV void tile_interior_wide(const osk_v4f* aq, const GemmParams& p, const int64_t* rowoff, const int64_t* storeoff, int n0w, int q4, int lane,
                                 const float4* gq, std::integer_sequence<int, Is...>) {
-  (row_pair_wide<Geo, GATE, GELU, 2 * Is>(aq, p, rowoff, storeoff[Is], n0w, q4, lane, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
+  if constexpr (GATE) {
+#ifndef OSK_GEMM_NARROW_RES   // (A/B builds of tools/: the residual in 8-byte pieces)
+    if ((((uintptr_t)p.res) & 15) == 0) {   // (kernel-argument uniform; strides are C's, checked by the caller)
+      (row_pair_wide<Geo, GATE, GELU, true, 2 * Is>(aq, p, rowoff, storeoff[Is], n0w, q4, lane, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
+      return;
+    }
+#endif
+  }
+  (row_pair_wide<Geo, GATE, GELU, false, 2 * Is>(aq, p, rowoff, storeoff[Is], n0w, q4, lane, gq, std::make_integer_sequence<int, Geo::NB>{}), ...);
 }
 
 // edge tiles: per-element bounds checks (rows >= M were computed on clamped copies of row M-1 and are dropped)
