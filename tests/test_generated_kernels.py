@@ -130,6 +130,50 @@ def test_generated_loops_fit_the_instruction_cache():
             assert v <= 16 * 1024, (k, v)
 
 
+def test_hbm_kernels_issue_their_loads_before_the_first_wait():
+    """Round 5's rule for the HBM-bound kernels: all loads of a block are in flight before the first one is
+    waited for.  hipcc sinks a load whose only use sits behind a predicate into that branch and waits there -- one memory round trip
+    per piece (qknorm_rope_rows: 128 -> 84 us once the loads were unconditional with clamped indices).  Checked on the BUILT library:
+    the longest run of global loads without a vmcnt wait between them, per kernel."""
+    import shutil
+    import tempfile
+
+    import pytest
+
+    from open_sora_amd.build import build_lib
+
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("ROCm LLVM tools not found")
+    want = {r"qknorm_rope_rows_kernelILi72ELi0ELi128E": 8,      # 9 span pieces + 5 cos / sin pieces (the compiler keeps 8 in flight)
+            r"qknorm_rope_rows_kernelILi64ELi1ELi128E": 8,
+            r"gemv_tasks_kernelILi4E": 8,                        # 8 weight rows per wave; 8 x elements per staging trip
+            r"gemv_tasks_kernelILi8E": 4,
+            r"ln_modulate_kernelILi3ELb0E": 3,                   # the row's three 1 KB pieces (XL: D = 1152)
+            r"ln_modulate_kernelILi6ELb0E": 6}                   # 11B: D = 3072
+    runs = {}
+    with tempfile.TemporaryDirectory() as d:
+        lib = shutil.copy(build_lib(), os.path.join(d, "libosk_hip.so"))
+        subprocess.run([objdump, "--offloading", lib], capture_output=True, text=True, cwd=d)
+        for co in sorted(os.path.join(d, f) for f in os.listdir(d) if "gfx950" in f):
+            cur, run = None, 0
+            for ln in subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+                if m:
+                    cur, run = next((k for k in want if re.search(k, m.group(1))), None), 0
+                    continue
+                if cur is None:
+                    continue
+                if re.match(r"\s+global_load_", ln):
+                    run += 1
+                    runs[cur] = max(runs.get(cur, 0), run)
+                elif re.match(r"\s+s_waitcnt.*vmcnt", ln):
+                    run = 0
+    assert set(runs) == set(want), sorted(set(want) - set(runs))
+    for k, n in want.items():
+        assert runs[k] >= n, (k, runs[k], n)
+
+
 def test_no_orphan_generated_files():
     made = set()
     for p in glob.glob(os.path.join(CSRC, "*.inc")):
