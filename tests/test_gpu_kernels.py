@@ -178,6 +178,38 @@ def test_gemm_persistent_multi_tile(hip_lib, M_L, N, K, gelu_from, gated):
         assert (o32 - ref32).abs().max().item() <= 1e-3 * max(1.0, ref32.abs().max().item())
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])       # 128 x 128 (gemm_bf16_kernel), 256 x 128 (gemm256p_kernel), 256 x 256 (gemm256x_kernel)
+@pytest.mark.parametrize("gelu_from,gated", [(None, True), (640, False)])
+def test_gemm_every_tile_kernel_on_the_same_problem(hip_lib, kind, gelu_from, gated):
+    """Which tile kernel serves a shape is the dispatcher's estimate (osk_gemm_tile_choice; it moved in round 5), so coverage of a
+    kernel's epilogue classes by shape is coverage by luck.  Here every tile kernel is forced (osk_gemm_tile_override) over the same
+    problem -- the gate * x + residual class written in place (each kernel reads its residual in its own layout) and a GELU boundary
+    inside a tile -- against the f32 reference; ragged M (batch boundary inside a tile) and ragged N for the 256-wide tiles."""
+    B, L, N, K = 2, 3000, 1152, 256
+    a = rnd("a", (B, L, K), seed=51)
+    w = rnd("w", (N, K), std=K ** -0.5, seed=52)
+    bias = rnd("b", (N,), std=0.3, dtype=torch.float32, seed=53)
+    out = torch.empty(B, L, N, dtype=BF, device=DEV)
+    kw = {}
+    if gated:
+        res = rnd("r", (B, L, N), seed=54)
+        gate = rnd("g", (B, N), std=0.5, dtype=torch.float32, seed=55)
+        out.copy_(res)
+        kw = dict(res=out, gate=gate, gate_batch_stride=gate.stride(0))
+    assert hip_lib.lib.osk_gemm_tile_override(kind) == 0
+    try:
+        hip_lib.gemm(a, w, bias, out, gelu_from=gelu_from, **kw)
+        torch.cuda.synchronize()
+    finally:
+        hip_lib.lib.osk_gemm_tile_override(-1)
+    v = (a.float().reshape(B * L, K) @ w.float().T + bias).reshape(B, L, N)
+    if gelu_from is not None:
+        v = torch.cat([v[..., :gelu_from], torch.nn.functional.gelu(v[..., gelu_from:], approximate="tanh")], -1)
+    if gated:
+        v = res.float() + gate[:, None, :] * v
+    bf16_ulp_close(out.float().cpu(), v.bfloat16().float().cpu(), rel=2 ** -7, abs_=3e-3)
+
+
 @pytest.mark.parametrize("B,Li,Lt,N,K,gelu_from,gated", [
     (3, 4000, 512, 3456, 1152, None, False),     # double-block QKV at a reduced token count: both problems on the 256 x 256 tiles
     (3, 8000, 300, 1152, 1152, None, True),      # proj: gate * x + residual written in place, ragged N (4.5 column tiles), ragged M
