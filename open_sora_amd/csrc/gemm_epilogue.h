@@ -25,9 +25,28 @@ OSK_DEV void tile_interior(const osk_v4f* aq, const GemmParams& p, int m0w, int 
   const int64_t roff = b * p.cbs + (int64_t)l * p.crs;
   uint2 rv[4];
   if (p.gate) {
+    const unsigned short* rrow = p.res + roff + n0w + tn * 32;
+#ifndef OSK_GEMM_NARROW_RES   // (A/B builds of tools/: the residual in 8-byte pieces)
+    if ((((uintptr_t)rrow) & 15) == 0) {
+      // round 5: the residual read the way the bf16 result is stored below -- 16 bytes per lane, the whole 8-column block qd + hi of
+      // the lane's row -- and swapped back (v_permlane32_swap is an involution on its register pair) into the 8-byte pieces of blocks
+      // qd and qd + 1 in the accumulator layout: 2 loads of 32 rows x 32 bytes per tile instead of 4 of 32 rows x 16 bytes (the
+      // address path charges per (instruction, line), gemm_epilogue16.h).  In place (res == C): same bytes as this tile's stores,
+      // all read before the first of them.
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd)
-      rv[qd] = *reinterpret_cast<const uint2*>(p.res + roff + n0w + tn * 32 + qd * 8 + hi * 4);
+      for (int qd = 0; qd < 4; qd += 2) {
+        const uint4 rc = *reinterpret_cast<const uint4*>(rrow + (qd + hi) * 8);
+        auto ux = __builtin_amdgcn_permlane32_swap(rc.x, rc.z, false, false);
+        auto uy = __builtin_amdgcn_permlane32_swap(rc.y, rc.w, false, false);
+        rv[qd] = make_uint2(ux[0], uy[0]);
+        rv[qd + 1] = make_uint2(ux[1], uy[1]);
+      }
+    } else
+#endif
+    {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) rv[qd] = *reinterpret_cast<const uint2*>(rrow + qd * 8 + hi * 4);
+    }
   }
   float acc[16];
   Geo::template read<T>(aq, acc);

@@ -125,3 +125,38 @@ def test_residual_loaded_in_the_store_layout_comes_back_in_the_accumulator_layou
             uy0, uy1 = permlane16_swap(y, w)
             assert np.array_equal(np.concatenate([ux0, uy0], 1), acc_tile(R, J, I)), (J, I)
             assert np.array_equal(np.concatenate([ux1, uy1], 1), acc_tile(R, J, I + 1)), (J, I)
+
+
+# ---- the 32 x 32 accumulator layout of gemm256p / the fp8 kernel (open_sora_amd/csrc/gemm_epilogue.h): a lane owns ONE output row
+# (l31 = lane % 32) and, per 8-column block qd = 0..3, the 4 columns qd 8 + hi 4 .. + 3 (hi = lane / 32).  The bf16 store pairs the
+# blocks (qd, qd + 1) with v_permlane32_swap: the lower half-wave ends up with the whole block qd, the upper with block qd + 1.
+def permlane32_swap(x, y):
+    """v_permlane32_swap vdst = x, src = y: x' = [x.lo, y.lo], y' = [x.hi, y.hi] (halves of the wave)"""
+    x, y = x.reshape(2, 32, -1), y.reshape(2, 32, -1)
+    return np.stack([x[0], y[0]]).reshape(LANES, -1), np.stack([x[1], y[1]]).reshape(LANES, -1)
+
+
+def acc32_block(C, qd):
+    lane = np.arange(LANES)
+    l31, hi = lane & 31, lane >> 5
+    return np.stack([C[l31, qd * 8 + hi * 4 + i] for i in range(4)], 1)       # [lane, 4] = dwords (x | y) of packed[qd]
+
+
+def test_32x32_layout_store_chunk_and_its_inverse_for_the_residual():
+    C = np.arange(32 * 32, dtype=np.int64).reshape(32, 32)
+    lane = np.arange(LANES)
+    l31, hi = lane & 31, lane >> 5
+    for qd in (0, 2):
+        p0, p1 = acc32_block(C, qd), acc32_block(C, qd + 1)
+        sx0, sx1 = permlane32_swap(p0[:, 0:2], p1[:, 0:2])
+        sy0, sy1 = permlane32_swap(p0[:, 2:4], p1[:, 2:4])
+        chunk = np.concatenate([sx0, sy0, sx1, sy1], 1)
+        # stored at crow + (qd + hi) * 8: the 8 contiguous columns of block qd + hi of the lane's row
+        want = np.stack([C[l31, (qd + hi) * 8 + i] for i in range(8)], 1)
+        assert np.array_equal(chunk, want), qd
+        # residual: the 16 bytes at the same address, swapped back pairwise (x, z) and (y, w) = the 8-byte pieces of blocks qd, qd + 1
+        x, y, z, w = (want[:, 2 * c:2 * c + 2] for c in range(4))
+        ux0, ux1 = permlane32_swap(x, z)
+        uy0, uy1 = permlane32_swap(y, w)
+        assert np.array_equal(np.concatenate([ux0, uy0], 1), p0)
+        assert np.array_equal(np.concatenate([ux1, uy1], 1), p1)
