@@ -511,6 +511,18 @@ def attention_fwd_pv8(q: torch.Tensor, k: torch.Tensor, vt8: torch.Tensor, v_sca
     return out
 
 
+def copy_rows_ok(src: torch.Tensor, dst: torch.Tensor) -> bool:
+    """every precondition of osk_copy_rows_bf16 (csrc/elementwise.hip): bf16, unit channel stride, C % 4 == 0, all other strides
+    % 4 == 0, 8-byte aligned pointers, non-empty -- callers fall back to torch's copy otherwise"""
+    if not (src.dtype == dst.dtype == torch.bfloat16 and src.ndim == dst.ndim and src.ndim in (3, 4)):
+        return False
+    if src.numel() == 0 or src.shape[-1] % 4 or src.stride(-1) != 1 or dst.stride(-1) != 1 or dst.shape[-1] < src.shape[-1]:
+        return False
+    if any(st % 4 for st in src.stride()[:-1]) or any(st % 4 for st in dst.stride()[:-1]):
+        return False
+    return src.data_ptr() % 8 == 0 and dst.data_ptr() % 8 == 0
+
+
 def copy_rows(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """dst[..., :C] = src for bf16 [B, L, C] -- or [P, B, L, C], P chunks -- views with unit channel stride on both sides (dst rows
     may be wider than C: a column slice of a K-padded operand; either side's chunk axis may be a column group of a token-major

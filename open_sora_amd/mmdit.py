@@ -522,7 +522,7 @@ def _workspace(owner, B, L_txt, L_img, D, R, H, hd, device) -> _Workspace:
 # =============================================================================================
 # RoPE table handling
 # =============================================================================================
-_PE_MEMO: list = [None]   # (pe object(s) held alive, versions, hd, result): the conversion of the LAST pe seen
+_PE_MEMO: list = [None]   # (weakrefs of the pe tensor(s), versions, hd, device, stream key, result): the conversion of the LAST pe seen
 
 
 def _pe_to_cos_sin(pe, hd: int):
@@ -535,20 +535,26 @@ def _pe_to_cos_sin(pe, hd: int):
     if isinstance(pe, _RopeTable):
         return pe.cos, pe.sin, pe.mode
     parts = (pe,) if isinstance(pe, torch.Tensor) else tuple(pe)
-
-    def version(t):   # (tensors made under inference_mode keep no version counter -- and cannot be modified in place: 0)
-        return 0 if t.is_inference() else t._version
-
-    vers = tuple(version(t) for t in parts)
+    # The memo: keyed on the tensors' identity AND version counter, the device and the STREAM the conversion was
+    # enqueued on (a result produced on one stream is not ordered before work on another); held through weak references (it must
+    # not extend the life of a caller's pe); bypassed for inference tensors (they keep no version counter but CAN be refilled in
+    # place under torch.inference_mode()) and while the stream is being captured into a hipGraph (a result produced inside a
+    # capture only exists when the graph is replayed).
+    dev = parts[0].device
+    memo_ok = not any(t.is_inference() for t in parts) and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing())
+    vers = tuple(t._version for t in parts) if memo_ok else ()
+    skey = _stream_key(dev)
     m = _PE_MEMO[0]
-    if m is not None and m[2] == hd and len(m[0]) == len(parts) and all(a is b for a, b in zip(m[0], parts)) and m[1] == vers:
-        return m[3]
+    if (memo_ok and m is not None and m[2] == hd and m[3] == str(dev) and m[4] == skey and len(m[0]) == len(parts)
+            and all(r() is b for r, b in zip(m[0], parts)) and m[1] == vers):
+        return m[5]
     if isinstance(pe, torch.Tensor):
         res = (pe[:, 0, :, :, 0, 0].float().contiguous(), pe[:, 0, :, :, 1, 0].float().contiguous(), 0)
     else:
         cos, sin = pe
         res = (cos[..., : hd // 2].float().contiguous(), sin[..., : hd // 2].float().contiguous(), 1)
-    _PE_MEMO[0] = (parts, vers, hd, res)
+    if memo_ok:
+        _PE_MEMO[0] = (tuple(weakref.ref(t) for t in parts), vers, hd, str(dev), skey, res)
     return res
 
 
@@ -749,8 +755,12 @@ _PROC_POOL = _ProcessorPool()
 
 
 def _direct_ok(*ts) -> bool:
-    """can the block kernels read these caller tensors in place (LayerNorm input, residual operand of a GEMM epilogue)?"""
-    return all(t.dtype == BF16 and t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 for t in ts)
+    """can the block kernels read these caller tensors in place (LayerNorm input, residual operand of a GEMM epilogue)?  The GEMM
+    ABI carries ONE set of output strides that the residual shares (osk.h: `res` "shaped like C, same strides"), and the result goes
+    into a fresh contiguous [B, L, D] tensor: only a contiguous caller tensor qualifies (a strided view -- `joint[:, Lt:]`,
+    a column slice -- passed the old stride-multiple test and then failed the binding's stride assertion; it is staged through the
+    workspace instead, as before round 5)."""
+    return all(t.dtype == BF16 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts)
 
 
 class HipDoubleStreamBlockProcessor:
@@ -992,9 +1002,9 @@ class MMDiTModel(_OskState, nn.Module):
             C_in = img.shape[2]
 
             def put(src, col):   # src -> columns [col, col + C) of the K-padded operand: one osk_copy_rows_bf16 launch, no torch kernel
-                if src.dtype == BF16 and src.stride(2) == 1 and src.shape[2] % 4 == 0 and col % 4 == 0:
+                if col % 4 == 0 and _OPS.copy_rows_ok(src, a_in[:, :, col:]):
                     _OPS.copy_rows(src, a_in[:, :, col:])
-                else:
+                else:                # (layouts the kernel does not take -- odd strides / offsets, other dtypes: torch's copy handles any)
                     a_in[:, :, col: col + src.shape[2]].copy_(src)
 
             put(img, 0)

@@ -157,7 +157,7 @@ class I2VDenoiser:
         graph, pred = None, None
         for i, (t_curr, t_prev) in enumerate(zip(timesteps[:-1], timesteps[1:])):
             t_vec.fill_(t_curr)
-            if img3.dtype == torch.bfloat16 and x.shape[-1] % 4 == 0:
+            if _ops().copy_rows_ok(x, img3[:x.shape[0]]):
                 # the CFG triple's input = the latents three times over (sampling.py:196-201): one broadcast launch for one sample
                 for j in ([None] if x.shape[0] == 1 else range(3)):
                     _ops().copy_rows(x, img3 if j is None else img3[j * x.shape[0]:(j + 1) * x.shape[0]])

@@ -42,10 +42,42 @@ class _Adopted(nn.Module):
     @classmethod
     def from_native_module(cls, module: nn.Module, *args, **kwargs):
         """ShardFormer's constructor convention (policy.py: SubModuleReplacementDescription.target_module)"""
+        _assert_supported(module)
         return cls(module)
 
     def native_module(self) -> nn.Module:
         return self.__dict__["_osk_native"]
+
+
+def _assert_supported(native: nn.Module) -> None:
+    """The NDHWC engine hard-codes what the shipped Hunyuan VAE uses: swish, replicate causal padding, dilation 1, stride in {1, 2},
+    output_scale_factor 1, no dropout, GroupNorm(32, eps 1e-6), upsample factors in {1, 2}.  The reference's classes are
+    configurable beyond that (unet_causal_3d_blocks.py:63-96 `pad_mode`, :184-259 `output_scale_factor`, `dropout`, `non_linearity`):
+    adopting a module configured otherwise would change its numerics silently, so it is refused here."""
+    def bad(what, m):
+        raise ValueError(f"open_sora_amd VAE plug-in: unsupported configuration ({what}) on {type(m).__name__}; "
+                         "the HIP engine implements the shipped Hunyuan VAE settings only")
+
+    for m in native.modules():
+        if hasattr(m, "pad_mode") and getattr(m, "pad_mode") != "replicate":
+            bad(f"pad_mode={m.pad_mode!r}", m)
+        if isinstance(m, nn.Conv3d):
+            if tuple(m.dilation) != (1, 1, 1) or m.groups != 1:
+                bad(f"dilation={tuple(m.dilation)}, groups={m.groups}", m)
+            if any(s_ not in (1, 2) for s_ in m.stride) or any(k_ not in (1, 3) for k_ in m.kernel_size):
+                bad(f"stride={tuple(m.stride)}, kernel={tuple(m.kernel_size)}", m)
+        if hasattr(m, "output_scale_factor") and float(getattr(m, "output_scale_factor")) != 1.0:
+            bad(f"output_scale_factor={m.output_scale_factor}", m)
+        if isinstance(m, nn.Dropout) and m.p != 0.0 and native.training:
+            bad(f"dropout p={m.p} in training mode", m)
+        nl = getattr(m, "nonlinearity", None)
+        if isinstance(nl, nn.Module) and not isinstance(nl, nn.SiLU):
+            bad(f"nonlinearity={type(nl).__name__}", m)
+        if isinstance(m, nn.GroupNorm) and not m.affine:
+            bad("GroupNorm without affine parameters", m)
+        uf = getattr(m, "upsample_factor", None)
+        if uf is not None and any(int(f) not in (1, 2) for f in (uf if isinstance(uf, (tuple, list)) else (uf,))):
+            bad(f"upsample_factor={uf}", m)
 
 
 def _io_dtype(x: Tensor):

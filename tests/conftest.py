@@ -16,7 +16,7 @@ def pytest_configure(config):
 # GPU suite order under `pytest -x` (the driver's invocation): kernels first, then the VAE, the denoiser, the BASELINE
 # geometries, and the multi-process sequence-parallel cases LAST -- so that a failure in the most contention-sensitive
 # tests cannot keep the per-kernel tests from running (round 2: one seqpar case cut 71 collected tests short).
-_GPU_ORDER = ["test_gpu_kernels", "test_gpu_fp8", "test_gpu_stdit_shapes", "test_gpu_vae",
+_GPU_ORDER = ["test_gpu_kernels", "test_gpu_fp8", "test_gpu_rank_shapes", "test_gpu_stdit_shapes", "test_gpu_vae",
               "test_gpu_mmdit", "test_gpu_baseline_geometry", "test_gpu_overlap", "test_gpu_seqpar_1gpu", "test_gpu_seqpar_nccl"]
 
 

@@ -63,6 +63,7 @@ def gemm(a, w, bias, out, *, res=None, gate=None, gate_batch_stride=0, gelu_from
     _abi_check("osk_gemm_bf16", a.stride(2) == 1, a.stride(0) % 8 == 0, a.stride(1) % 8 == 0, w.stride(0) % 8 == 0,
                out.stride(0) % 4 == 0, out.stride(1) % 4 == 0, _al(a, 16), _al(w, 16), _al(out, 8), _al(bias, 16),
                gate is None or (res is not None and _al(gate, 16) and gate_batch_stride % 4 == 0 and _al(res, 8)))
+    assert res is None or res.stride() == out.stride(), "osk_gemm_bf16: the residual shares C's strides (the ABI carries no residual strides)"
     v = a.float() @ w.float().T
     if bias is not None:
         v = v + bias.float()
@@ -288,6 +289,16 @@ def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=Non
     if lse is not None:
         lse.copy_(torch.logsumexp(s_, -1))
     return out
+
+
+def copy_rows_ok(src, dst):
+    if not (src.dtype == dst.dtype == torch.bfloat16 and src.ndim == dst.ndim and src.ndim in (3, 4)):
+        return False
+    if src.numel() == 0 or src.shape[-1] % 4 or src.stride(-1) != 1 or dst.stride(-1) != 1 or dst.shape[-1] < src.shape[-1]:
+        return False
+    if any(st % 4 for st in src.stride()[:-1]) or any(st % 4 for st in dst.stride()[:-1]):
+        return False
+    return src.data_ptr() % 8 == 0 and dst.data_ptr() % 8 == 0
 
 
 def copy_rows(src, dst):

@@ -76,6 +76,53 @@ def test_processors_on_reference_style_pe(cpu_mmdit):
         assert_parity(o_x, t_x, r_x, "single processor")
 
 
+def test_processors_take_strided_caller_tensors(cpu_mmdit):
+    """a NON-contiguous bf16 caller tensor -- the img half of a joint [txt; img] buffer, a column slice of a
+    wider tensor -- must not be handed to the GEMM as its residual (the ABI carries one set of strides for C and res): it is
+    staged through the workspace and gives the contiguous call's result bit for bit."""
+    cfg, B, T, h, w, L_txt = configs.GOLDEN["hd64_eager_fused"]
+    model = _build(cpu_mmdit, cfg)
+    sd32 = torch_params(cfg)
+    with torch.inference_mode():
+        img, txt, vec, ang = O.prepare_block_inputs(sd32, cfg, **torch_inputs(cfg, B, T, h, w, L_txt))
+        c, s = torch.cos(ang), torch.sin(ang)
+        pe = torch.stack([c, -s, s, c], dim=-1).reshape(*ang.shape, 2, 2).float().unsqueeze(1)
+        img_b, txt_b, vec_b = img.bfloat16(), txt.bfloat16(), vec.bfloat16()
+        o_img, o_txt = model.double_blocks[0](img_b, txt_b, vec_b, pe)
+        joint = torch.cat((txt_b, img_b), 1)                                    # [B, Lt + Li, D]
+        Lt = txt_b.shape[1]
+        assert not joint[:, Lt:].is_contiguous() or B == 1
+        wide = torch.zeros(B, img_b.shape[1], img_b.shape[2] + 64, dtype=BF)
+        wide[:, :, :img_b.shape[2]] = img_b
+        for i_view in (joint[:, Lt:], wide[:, :, :img_b.shape[2]]):
+            s_img, s_txt = model.double_blocks[0](i_view, joint[:, :Lt], vec_b, pe)
+            assert torch.equal(s_img, o_img) and torch.equal(s_txt, o_txt)
+        x_b = torch.cat((o_txt, o_img), 1)
+        o_x = model.single_blocks[0](x_b, vec_b, pe)
+        wide_x = torch.zeros(B, x_b.shape[1], x_b.shape[2] + 64, dtype=BF)
+        wide_x[:, :, :x_b.shape[2]] = x_b
+        assert torch.equal(model.single_blocks[0](wide_x[:, :, :x_b.shape[2]], vec_b, pe), o_x)
+
+
+def test_pe_memo_is_not_fooled_by_refilled_inference_tensors(cpu_mmdit):
+    """a pe buffer created under inference_mode keeps no version counter and CAN be refilled in place there --
+    the conversion memo must not serve the old cos / sin for it."""
+    with torch.inference_mode():
+        pe = torch.zeros(1, 1, 8, 4, 2, 2)
+        pe[..., 0, 0] = 1.0
+        c0, _, _ = cpu_mmdit._pe_to_cos_sin(pe, 8)
+        assert float(c0.sum()) == 32.0
+        pe[..., 0, 0] = 0.5
+        c1, _, _ = cpu_mmdit._pe_to_cos_sin(pe, 8)
+        assert float(c1.sum()) == 16.0
+    pe2 = torch.zeros(1, 1, 8, 4, 2, 2)
+    pe2[..., 0, 0] = 1.0
+    a = cpu_mmdit._pe_to_cos_sin(pe2, 8)
+    assert cpu_mmdit._pe_to_cos_sin(pe2, 8)[0] is a[0]          # ordinary tensors: memoised ...
+    pe2[..., 0, 0] = 0.25
+    assert float(cpu_mmdit._pe_to_cos_sin(pe2, 8)[0].sum()) == 8.0   # ... until written in place
+
+
 def test_processors_install_on_reference_blocks(cpu_mmdit):
     """The plug-in point of the reference itself: block.set_processor(...) on the reference's own
     DoubleStreamBlock / SingleStreamBlock (only where /root/reference is mounted)."""

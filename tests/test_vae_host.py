@@ -207,3 +207,22 @@ def test_plugin_targets_run_on_the_reference_modules(cpu_vae):
         h_nat = conv(zin.to(BF))
         h_hip = vae_plugin.HipCausalConv3d.from_native_module(conv)(zin.to(BF))
         assert h_hip.shape == h_nat.shape and (h_hip.float() - h_nat.float()).abs().max() <= 2.0 ** -6 * h_nat.float().abs().max() + 1e-3
+
+
+def test_plugin_refuses_configurations_the_engine_does_not_implement(cpu_vae):
+    """the NDHWC engine hard-codes the shipped settings (replicate padding, output_scale_factor 1, SiLU, ...); adopting a
+    reference module configured otherwise would change its numerics silently -- from_native_module refuses it."""
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("/root/reference not mounted")
+    from open_sora_amd import vae_plugin
+
+    _, blocks = ref_loader.hunyuan_vae()
+    ok = blocks.CausalConv3d(8, 8, kernel_size=3)
+    vae_plugin.HipCausalConv3d.from_native_module(ok)
+    with pytest.raises(ValueError, match="pad_mode"):
+        vae_plugin.HipCausalConv3d.from_native_module(blocks.CausalConv3d(8, 8, kernel_size=3, pad_mode="constant"))
+    rb = blocks.ResnetBlockCausal3D(in_channels=32, out_channels=32, groups=32, output_scale_factor=2.0)
+    with pytest.raises(ValueError, match="output_scale_factor"):
+        vae_plugin._assert_supported(rb)
