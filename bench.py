@@ -188,18 +188,29 @@ def cfg1_line(dev, budget_s):
 
 
 def vae_cpu_baseline(budget_s):
-    """The oracle's CausalConv3d (fp32, all host cores) on a bounded sample: ONE 128->128 3x3x3 conv at
+    """The oracle's CausalConv3d (fp32, thread count by a sweep) on a bounded sample: ONE 128->128 3x3x3 conv at
     9 x 128 x 128 (a slice of the encoder's first ResNet stage), scaled to the whole encode+decode by FLOPs."""
     import torch.nn.functional as F
     from oracle import vae_oracle as V
 
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 128, 9, 128, 128, generator=g)
     sd = {"c.conv.weight": torch.randn(128, 128, 3, 3, 3, generator=g) * 0.02, "c.conv.bias": torch.zeros(128)}
     with torch.inference_mode():
-        V.causal_conv3d(sd, "c", x[:, :, :2])  # warm-up
+        # thread count by a sweep, as the DiT leg does (torch's CPU conv does not scale to every core of a many-core host either)
+        sweep, t_sweep = {}, time.perf_counter()
+        for n_ in sorted({n_ for n_ in (16, 32, 64, 128, ncpu) if n_ <= ncpu}):
+            torch.set_num_threads(n_)
+            V.causal_conv3d(sd, "c", x[:, :, :3])  # warm-up of this pool
+            t0 = time.perf_counter()
+            V.causal_conv3d(sd, "c", x[:, :, :3])
+            sweep[n_] = time.perf_counter() - t0
+            if time.perf_counter() - t_sweep > 0.25 * budget_s or sweep[n_] > 1.3 * min(sweep.values()):
+                break
+        ncores = min(sweep, key=sweep.get)
+        torch.set_num_threads(ncores)
+        vae_cpu_baseline.sweep = {str(k_): round(v_, 3) for k_, v_ in sweep.items()}
         t0 = time.perf_counter()
         n = 0
         while True:
@@ -208,6 +219,7 @@ def vae_cpu_baseline(budget_s):
             if time.perf_counter() - t0 > min(budget_s, 20.0) or n >= 8:
                 break
         dt = (time.perf_counter() - t0) / n
+    torch.set_num_threads(ncpu)
     fl = 2.0 * 128 * 128 * 27 * 9 * 128 * 128
     return fl / dt, ncores, dt
 
@@ -296,7 +308,8 @@ def vae_line(dev, T, S, steps, warmup, cpu_budget_s):
         fps, ncores, dt = vae_cpu_baseline(args.cpu_budget_s)
         cpu_s = (enc_f + dec_f) / fps
         res["cpu_baseline"] = {"value": round(T / cpu_s, 5), "unit": "video frames/s", "cores": ncores, "kind": "port",
-                               "sample": f"oracle CausalConv3d fp32 on {ncores} host threads: one 128->128 3x3x3 conv at 9x128x128 "
+                               "thread_sweep_s": getattr(vae_cpu_baseline, "sweep", None),
+                               "sample": f"oracle CausalConv3d fp32 on {ncores} host threads (best of the sweep in thread_sweep_s): one 128->128 3x3x3 conv at 9x128x128 "
                                          f"({dt:.2f} s, {fps / 1e12:.3f} TFLOP/s), encode+decode extrapolated by FLOPs = {cpu_s:.1f} s"}
     del model
     torch.cuda.empty_cache()
@@ -375,8 +388,18 @@ def main():
         out["vae"] = {k: v[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "step_tflops", "step_mfma_frac",
                                         "gn_fold", "roofline", "cpu_baseline") if k in v}
         b11 = dit_line(args, dev, None, 0, 1, "11B", 3, 1, with_b1=False)
-        keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "step_tflops", "step_mfma_frac", "roofline", "timed")
+        keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "step_tflops", "step_mfma_frac", "roofline", "roofline_gemm", "timed")
         out["11b"] = {k: b11[k] for k in keys}
+        # the only shape the reference publishes a wall time for (README.md:281-287: 256 px, 129 frames, 50 steps, 60 s on one H100
+        # with offload => <= 1.2 s per denoise step INCLUDING T5 / CLIP / VAE / offload traffic: an upper bound):
+        # the shipped 11B model at ITS shape -- latent 33 x 28 x 36 (224 x 288 px, configs/diffusion/inference/256px.py), L = 8,316 + 512,
+        # CFG triple.  Context only: other hardware, other software stack; `vs_baseline` of the headline stays null.
+        r256 = dit_line(args, dev, None, 0, 1, "11B", 5, 1, with_b1=False, geom=(33, 28, 36))
+        out["ref_256px_11b"] = {k: r256[k] for k in keys}
+        out["ref_256px_11b"]["reference_context"] = {
+            "h100_step_upper_bound_ms": 1200.0, "source": "/root/reference/README.md:281-287 (60 s / 50 steps, 1x H100, tensor parallel + offload; total includes text encoders, VAE, offload)",
+            "ratio_bound_over_ours": round(1200.0 / r256["ms_per_step"], 2),
+            "note": "NOT a like-for-like baseline (an upper bound on other hardware); the reference's achieved rate at this shape is >= 421 TFLOP/s (BASELINE.md section 1)"}
         # BASELINE configs[4]'s arithmetic (fp8 MFMA: block Linears + attention P.V; opt-in, outside the bf16 parity gate) on both
         # geometries, same process, same clock; roofline against the mixed bf16 / fp8 peak; rel_l2_vs_bf16 = one forward of the
         # same weights and inputs in both modes
@@ -389,12 +412,18 @@ def main():
             out["fp8"] = f8
         finally:
             args.fp8 = False
+        # BASELINE configs[3] / [4] and the reference's shipped 768 px SP = 8 workload: what ONE rank of such a run computes per block
+        # (attention launch with the body the model selects + the block Linears at the rank's rows), each with its roofline
+        from tools import rank_shapes
+
+        torch.cuda.empty_cache()
+        out["rank_shapes"] = rank_shapes.measure(dev)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
+def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1, geom=None):
     """One denoise-step measurement of the product's sampler: `sampling.I2VDenoiser.denoise` (the reference's Euler loop,
     opensora/utils/sampling.py:159-226) driving MMDiTModel.forward on the CFG triple, `warmup` untimed steps, then EXACTLY
     `steps` steps between barriers.  Returns the JSON object of the line (rank 0; other ranks: None)."""
@@ -402,7 +431,10 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
 
     cfg = dict(configs.MMDIT[model_name])
     T, hw = args.frames, args.latent_hw
-    L_img, L_txt = T * (hw // 2) * (hw // 2), 512
+    hh = hw                      # latent height / width (geom: a non-square side measurement, e.g. the reference's 256 px shape)
+    if geom is not None:
+        T, hh, hw = geom
+    L_img, L_txt = T * (hh // 2) * (hw // 2), 512
     L = L_img + L_txt
     nb = args.cfg_batch
     D, H = cfg["hidden_size"], cfg["num_heads"]
@@ -425,8 +457,8 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
 
     # synthetic inputs, resident in HBM before the timed region
     g = torch.Generator(device=dev).manual_seed(42)
-    z = torch.randn(1, 16, T, hw, hw, device=dev, dtype=torch.bfloat16, generator=g)
-    ts = sampling.get_schedule(SAMPLING_STEPS, (hw // 2) * (hw // 2), T)
+    z = torch.randn(1, 16, T, hh, hw, device=dev, dtype=torch.bfloat16, generator=g)
+    ts = sampling.get_schedule(SAMPLING_STEPS, (hh // 2) * (hw // 2), T)
     g2 = torch.Generator(device=dev).manual_seed(43)
 
     def sched(first, n):
@@ -450,9 +482,9 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
         if nb == 3:
             txt = (torch.randn(3, L_txt, cfg["context_in_dim"], device=dev, generator=g2) * 0.2).to(torch.bfloat16)
             y_vec = torch.randn(3, cfg["vec_in_dim"], device=dev, generator=g2).to(torch.bfloat16)
-            img_ids, txt_ids = sampling.prepare_ids(3, T, hw, hw, L_txt, dev, torch.bfloat16)
-            masks = torch.zeros(1, 1, T, hw, hw, device=dev, dtype=torch.bfloat16)
-            masked_ref = torch.zeros(1, 16, T, hw, hw, device=dev, dtype=torch.bfloat16)
+            img_ids, txt_ids = sampling.prepare_ids(3, T, hh, hw, L_txt, dev, torch.bfloat16)
+            masks = torch.zeros(1, 1, T, hh, hw, device=dev, dtype=torch.bfloat16)
+            masked_ref = torch.zeros(1, 16, T, hh, hw, device=dev, dtype=torch.bfloat16)
             x = sampling.pack(z).contiguous()
             if warmup:
                 x = run_denoise(x, 0, warmup)
@@ -465,7 +497,7 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
             prof, _C.PROFILE_ATTENTION = _C.PROFILE_ATTENTION, None
         else:
             timed_what = f"model forward + osk_cfg_euler_bf16 at CFG batch {nb} (a private loop: the sampler's loop is the triple)"
-            step, st = _plain_step(model, cfg, nb, z, ts, T, hw, L_img, L_txt, dev, g2)
+            step, st = _plain_step(model, cfg, nb, z, ts, T, hh, hw, L_img, L_txt, dev, g2)
             for i in range(warmup):
                 step(i)
             _C.PROFILE_ATTENTION = [] if rank == 0 else None
@@ -487,13 +519,23 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
             barrier()
             exposed = {k_: round(v_ / 2, 3) for k_, v_ in sp.exposed_summary().items()}
             sp.exposed = None
+        # roofline of the second MFMA kernel family (the Linear layers: 31 % of the XL step): HIP events around EVERY GEMM launch of
+        # 2 extra steps outside the timed region (the events of 170 launches per step would perturb `value`; they do not perturb
+        # a launch's own duration)
+        gemm_prof = None
+        if nb == 3 and world == 1:
+            _C.PROFILE_GEMM = []
+            torch.cuda.synchronize()
+            run_denoise(x, 0, 2)
+            torch.cuda.synchronize()
+            gemm_prof, _C.PROFILE_GEMM = _C.PROFILE_GEMM, None
         # the attention body the timed steps ran (before any side measurement touches the QK-norm scales)
         rep = model.attention_report(world if sp_mode and "all-gather" in sp_mode else 1, L // world if world > 1 else L)
         # SURVEY.md section 8(d) cfg 2 asks for B = 1 (the pure step) next to the reference's CFG triple: a second, separately
         # timed run at batch 1 (reported under "b1", never part of `value`)
         b1 = None
         if nb != 1 and world == 1 and with_b1:
-            step1, st1 = _plain_step(model, cfg, 1, z, ts, T, hw, L_img, L_txt, dev, g2)
+            step1, st1 = _plain_step(model, cfg, 1, z, ts, T, hh, hw, L_img, L_txt, dev, g2)
             n1 = max(3, min(steps, 10))
             step1(0)
             torch.cuda.synchronize()
@@ -661,6 +703,34 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": 4 * nb * Lq * H * hd * 2 if world == 1 else None,
                     "launches": len(durs), "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": fl}
+    roofline_gemm = None
+    if gemm_prof:
+        g_ms = sum(a_.elapsed_time(b_) for a_, b_, _ in gemm_prof) / 2
+        g_fl = sum(f_ for _, _, f_ in gemm_prof) / 2
+        # the block Linears only (>= 99.8 % of the GEMM FLOPs): launches of at least 1e11 FLOP -- the embedders / final layer are
+        # reported with everything in `all_launches`
+        blk = [(a_.elapsed_time(b_), f_) for a_, b_, f_ in gemm_prof if f_ >= 1e11]
+        b_ms, b_fl = sum(t_ for t_, _ in blk) / 2, sum(f_ for _, f_ in blk) / 2
+        peak_g = 2 * MFMA_BF16_PEAK_TFLOPS if args.fp8 else MFMA_BF16_PEAK_TFLOPS
+        ach_g = b_fl / (b_ms * 1e-3) / 1e12
+        traffic_g, traffic_g_src = None, None
+        rec_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "kernel_traffic.json")
+        if os.path.exists(rec_path) and model_name == "XL" and (T, hh, hw) == (16, 64, 64) and not args.fp8:
+            for rec in json.load(open(rec_path)):
+                if rec["kernel"].startswith("gemm256x"):   # the latest record wins
+                    traffic_g, traffic_g_src = rec["hbm_bytes_per_step"], rec["source"]
+        roofline_gemm = {"bound": "mfma", "kernel": "gemm256_kernel<fp8> (block Linears on the fp8 MFMA)" if args.fp8 else
+                         "gemm256x_kernel<.,1> + gemm256x_kernel<.,2> (img + txt pairs) (+ the Vt group launch: gemm256x_kernel<.,4>)",
+                         "achieved": round(ach_g, 1), "peak": peak_g, "unit": "TFLOP/s", "frac": round(ach_g / peak_g, 4),
+                         "traffic": traffic_g, "traffic_kind": "recorded per STEP (PMC passes, see traffic_source)" if traffic_g else "no record",
+                         "traffic_source": traffic_g_src,
+                         # per token and block, in units of D bf16 values: double = A reads 1 + 1 + 1 + 4, C writes 3 + 1 + 4 + 1, residual reads
+                         # 2 = 18; single = A 1 + 5, C 7 + 1, residual 1 = 15; + every weight once
+                         "algorithmic_bytes_per_step": int(nb * L * D * 2 * (cfg["depth"] * 18 + cfg["depth_single_blocks"] * 15)
+                                                           + 2 * D * D * (24 * cfg["depth"] + 12 * cfg["depth_single_blocks"])),
+                         "block_linear_launches_per_step": len(blk) // 2, "block_linear_ms_per_step": round(b_ms, 3), "flops_per_step": b_fl,
+                         "all_launches": {"per_step": len(gemm_prof) // 2, "ms_per_step": round(g_ms, 3), "flops_per_step": g_fl},
+                         "timing": "sum of HIP-event pairs around every GEMM launch, 2 steps outside the timed region"}
     step_flops = configs.flops_per_forward(cfg, nb, L_img, L_txt)
     out = {
         "metric": "latent_frames_per_sec (30-step rectified-flow sampling; denoise-step ms in ms_per_step)",
@@ -670,13 +740,16 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
         "dtype": "fp8-e4m3 block Linears (per-row scales) and attention P.V (per-head V scale); bf16 QK^T / norms / embedders" if args.fp8 else "bf16",
         "data": "synthetic",
         "config": {"workload": f"MMDiT-{model_name} (hidden {D}, {H}x{hd}, {cfg['depth']}+{cfg['depth_single_blocks']} blocks) "
-                               f"denoise step, latent {T}x{hw}x{hw} (16x512x512 px), L={L} tokens, CFG batch {nb}, "
+                               f"denoise step, latent {T}x{hh}x{hw} ({'16x512x512 px' if (T, hh, hw) == (16, 64, 64) else f'{8 * hh}x{8 * hw} px'}), L={L} tokens, CFG batch {nb}, "
                                f"{SAMPLING_STEPS}-step Euler sampling",
                    "tokens": L, "cfg_batch": nb, "parallelism": "single GPU" if world == 1 else f"sp{world} (token axis; exchange around attention: {sp_mode})"},
         "timed": timed_what,
         "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world, 1),
         "step_mfma_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4),
         "roofline": roofline,
+        "roofline_gemm": roofline_gemm,
+        "timing": f"time.perf_counter around EXACTLY {steps} steps between barrier + synchronize, mean (max over ranks); per-kernel figures "
+                  "(roofline, roofline_gemm, rank_shapes) from HIP events on the launch stream",
     }
     if b1 is not None:
         out["b1"] = b1
@@ -695,7 +768,7 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1):
     return out
 
 
-def _plain_step(model, cfg, nb, z, ts, T, hw, L_img, L_txt, dev, g2):
+def _plain_step(model, cfg, nb, z, ts, T, hh, hw, L_img, L_txt, dev, g2):
     """forward + CFG/Euler update at an arbitrary CFG batch (the `b1` side measurement and `--cfg-batch N != 3`)"""
     from open_sora_amd import _C, sampling
 
@@ -703,7 +776,7 @@ def _plain_step(model, cfg, nb, z, ts, T, hw, L_img, L_txt, dev, g2):
     st["x_next"] = torch.empty_like(st["x"])
     txt = (torch.randn(nb, L_txt, cfg["context_in_dim"], device=dev, generator=g2) * 0.2).to(torch.bfloat16)
     y_vec = torch.randn(nb, cfg["vec_in_dim"], device=dev, generator=g2).to(torch.bfloat16)
-    img_ids, txt_ids = sampling.prepare_ids(nb, T, hw, hw, L_txt, dev, torch.bfloat16)
+    img_ids, txt_ids = sampling.prepare_ids(nb, T, hh, hw, L_txt, dev, torch.bfloat16)
     cond = torch.zeros(nb, L_img, 68, device=dev, dtype=torch.bfloat16)  # t2v: masks = 0, masked_ref = 0
     img3 = torch.empty(nb, L_img, 64, device=dev, dtype=torch.bfloat16)
 

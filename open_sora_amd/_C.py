@@ -165,6 +165,28 @@ def ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: 
     return out
 
 
+# bench.py sets this to a list to collect (start, end, FLOPs) around every GEMM launch of a side measurement (never the timed region)
+PROFILE_GEMM = None
+
+
+class _gemm_prof:
+    """context: two HIP events around the launches inside, appended to PROFILE_GEMM with their algorithmic FLOPs"""
+
+    def __init__(self, flops: float):
+        self.flops, self.on = flops, PROFILE_GEMM is not None
+
+    def __enter__(self):
+        if self.on:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILE_GEMM.append((self.e0, self.e1, self.flops))
+        return False
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, *, res=None, gate=None,
          gate_batch_stride: int = 0, gelu_from: int | None = None) -> torch.Tensor:
     """a bf16 [B, L, K] view (last dim contiguous), w bf16 [N, K] (row stride arbitrary), bias f32 [N] | None,
@@ -177,10 +199,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, *, res=None,
         (a.dtype, w.dtype, out.dtype)
     if res is not None:
         assert res.stride() == out.stride() and res.dtype == torch.bfloat16
-    _check(lib.osk_gemm_bf16(a.data_ptr(), a.stride(0), a.stride(1), L, w.data_ptr(), w.stride(0), _p(bias),
-                             out.data_ptr(), out.stride(0), out.stride(1), L, _p(res), _p(gate),
-                             gate_batch_stride, B * L, N, K, N if gelu_from is None else gelu_from,
-                             1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_bf16")
+    with _gemm_prof(2.0 * B * L * N * K):
+        _check(lib.osk_gemm_bf16(a.data_ptr(), a.stride(0), a.stride(1), L, w.data_ptr(), w.stride(0), _p(bias),
+                                 out.data_ptr(), out.stride(0), out.stride(1), L, _p(res), _p(gate),
+                                 gate_batch_stride, B * L, N, K, N if gelu_from is None else gelu_from,
+                                 1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_bf16")
     return out
 
 
@@ -234,8 +257,9 @@ def gemm_pair(first: dict, second: dict, *, gelu_from: int | None = None) -> Non
            for d in (first, second)]
     N, K = first["w"].shape
     assert tuple(second["w"].shape) == (N, K)
-    _check(lib.osk_gemm_bf16_pair(C.addressof(ops[0]), C.addressof(ops[1]), N, K, N if gelu_from is None else gelu_from,
-                                  _stream()), "osk_gemm_bf16_pair")
+    with _gemm_prof(2.0 * (ops[0].M + ops[1].M) * N * K):
+        _check(lib.osk_gemm_bf16_pair(C.addressof(ops[0]), C.addressof(ops[1]), N, K, N if gelu_from is None else gelu_from,
+                                      _stream()), "osk_gemm_bf16_pair")
 
 
 def ln_modulate_fp8(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, mod_batch_stride: int, eps: float = 1e-6):
@@ -283,10 +307,11 @@ def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale:
     assert B * L == M and out.shape[2] == N and w8.shape[1] == K
     if res is not None:
         assert res.stride() == out.stride()
-    _check(lib.osk_gemm_fp8(a8.data_ptr(), 0, a8.stride(0), M, a_scale.data_ptr(), w8.data_ptr(), w8.stride(0),
-                            w_scale.data_ptr(), _p(bias), out.data_ptr(), out.stride(0), out.stride(1), L, _p(res),
-                            _p(gate), gate_batch_stride, M, N, K, N if gelu_from is None else gelu_from,
-                            1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_fp8")
+    with _gemm_prof(2.0 * M * N * K):
+        _check(lib.osk_gemm_fp8(a8.data_ptr(), 0, a8.stride(0), M, a_scale.data_ptr(), w8.data_ptr(), w8.stride(0),
+                                w_scale.data_ptr(), _p(bias), out.data_ptr(), out.stride(0), out.stride(1), L, _p(res),
+                                _p(gate), gate_batch_stride, M, N, K, N if gelu_from is None else gelu_from,
+                                1 if out.dtype == torch.float32 else 0, _stream()), "osk_gemm_fp8")
     return out
 
 

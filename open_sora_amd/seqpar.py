@@ -103,8 +103,10 @@ class DistTransport:
         return self._run(out, lambda: dist.all_to_all_single(out, inp, group=self.group))
 
     def all_reduce_max(self, t: Tensor):
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)   # a few floats, on the compute stream, before the exchange
-        return _Done()
+        """max over the ranks, in place (a few floats: the e4m3 scales of V in fp8 mode).  Issued on the communication stream like
+        every other exchange (round 5 ran it as a blocking collective on the compute stream): what the caller queues before wait()
+        -- the K copy into the gather buffer -- overlaps its latency."""
+        return self._run(t, lambda: dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group))
 
 
 class SeqPar:
@@ -164,29 +166,35 @@ class SeqPar:
         return self.rank * Lloc, (self.rank + 1) * Lloc
 
     # ------------------------------------------------------------------ K/V exchange
-    def _buffers(self, B: int, Lloc: int, H: int, hd: int, device):
-        key = (B, Lloc, H, hd, str(device), mmdit._stream_key(device))
-        b = self._bufs.get(key)
+    MAX_GEOMETRIES = 4   # exchange-buffer sets kept (least recently used first out)
+
+    def _cached(self, key, make):
+        """exchange buffers of one (kind, geometry, device, stream), least-recently-used eviction: an i2v run that alternates between
+        a few shapes keeps all of them (round 5 cleared the WHOLE cache when a fourth geometry appeared and re-allocated
+        2 B L D buffers mid-loop); the set in use -- the one a captured hipGraph replays into -- is always the newest entry."""
+        b = self._bufs.pop(key, None)
         if b is None:
-            if len(self._bufs) > 2:
-                self._bufs.clear()
-            Lp = (Lloc + 63) // 64 * 64
-            k_all = torch.empty(self.P, B, Lloc, H * hd, dtype=BF16, device=device)
-            vt_all = torch.zeros(self.P, B, H, hd, Lp, dtype=BF16, device=device)
-            b = self._bufs[key] = (k_all, vt_all)
+            while len(self._bufs) >= self.MAX_GEOMETRIES:
+                self._bufs.pop(next(iter(self._bufs)))
+            b = make()
+        self._bufs[key] = b
         return b
 
-    def _buffers8(self, B: int, Lloc: int, H: int, hd: int, device):
-        key = ("pv8", B, Lloc, H, hd, str(device), mmdit._stream_key(device))
-        b = self._bufs.get(key)
-        if b is None:
-            if len(self._bufs) > 2:
-                self._bufs.clear()
+    def _buffers(self, B: int, Lloc: int, H: int, hd: int, device):
+        def make():
             Lp = (Lloc + 63) // 64 * 64
-            k_all = torch.empty(self.P, B, Lloc, H * hd, dtype=BF16, device=device)
-            vt8_all = torch.zeros(self.P, B, H, mmdit.ops().vt8_rows(hd), Lp, dtype=torch.uint8, device=device)
-            b = self._bufs[key] = (k_all, vt8_all)
-        return b
+            return (torch.empty(self.P, B, Lloc, H * hd, dtype=BF16, device=device),
+                    torch.zeros(self.P, B, H, hd, Lp, dtype=BF16, device=device))
+
+        return self._cached((B, Lloc, H, hd, str(device), mmdit._stream_key(device)), make)
+
+    def _buffers8(self, B: int, Lloc: int, H: int, hd: int, device):
+        def make():
+            Lp = (Lloc + 63) // 64 * 64
+            return (torch.empty(self.P, B, Lloc, H * hd, dtype=BF16, device=device),
+                    torch.zeros(self.P, B, H, mmdit.ops().vt8_rows(hd), Lp, dtype=torch.uint8, device=device))
+
+        return self._cached(("pv8", B, Lloc, H, hd, str(device), mmdit._stream_key(device)), make)
 
     def gather_kv_start(self, ws, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False):
         """k, v: this rank's [B, L/P, D] views (K already normed + rotated with GLOBAL positions).  Starts the
@@ -199,11 +207,12 @@ class SeqPar:
         B, Lloc, _ = k.shape
         if pv8:
             sv = mmdit.v_scale_fp8(v, H, hd)
-            self.tp.all_reduce_max(sv)
+            wmax = self.tp.all_reduce_max(sv)                         # on the communication stream ...
             k_all, vt8_all = self._buffers8(B, Lloc, H, hd, k.device)
             mmdit.ops().copy_rows(k, k_all[self.rank])
+            wk = self.tp.all_gather(k_all.view(-1), k_all[self.rank].view(-1))   # ... with the K copy and K's gather behind it
+            self._timed_wait(wmax, "vmax")
             mmdit.ops().v_transpose_fp8(v, sv, vt8_all[self.rank], H, hd)
-            wk = self.tp.all_gather(k_all.view(-1), k_all[self.rank].view(-1))
             wv = self.tp.all_gather(vt8_all.view(-1), vt8_all[self.rank].view(-1))
             return "pv8", k_all, vt8_all, sv, wk, wv
         k_all, vt_all = self._buffers(B, Lloc, H, hd, k.device)
@@ -238,18 +247,16 @@ class SeqPar:
 
     # ------------------------------------------------------------------ head-parallel exchange (all-to-all)
     def _heads_buffers(self, B: int, Lloc: int, H: int, hd: int, device):
-        key = ("heads", B, Lloc, H, hd, str(device), mmdit._stream_key(device))
-        b = self._bufs.get(key)
-        if b is None:
-            if len(self._bufs) > 2:
-                self._bufs.clear()
+        def make():
             Hg, Lp = H // self.P, (Lloc + 63) // 64 * 64
             mk = lambda: torch.empty(self.P, B, Lloc, Hg * hd, dtype=BF16, device=device)
-            b = self._bufs[key] = dict(ks=mk(), kr=mk(), vs=mk(), vr=mk(), qs=mk(), qr=mk(), os=mk(), orr=mk(),
-                                       vt=torch.zeros(self.P, B, Hg, hd, Lp, dtype=BF16, device=device))
+            b = dict(ks=mk(), kr=mk(), vs=mk(), vr=mk(), qs=mk(), qr=mk(), os=mk(), orr=mk(),
+                     vt=torch.zeros(self.P, B, Hg, hd, Lp, dtype=BF16, device=device))
             if hd in (72, 128):   # fp8 mode: e4m3 V^T of the received chunks
                 b["vt8"] = torch.zeros(self.P, B, Hg, mmdit.ops().vt8_rows(hd), Lp, dtype=torch.uint8, device=device)
-        return b
+            return b
+
+        return self._cached(("heads", B, Lloc, H, hd, str(device), mmdit._stream_key(device)), make)
 
     def _to_head_chunks(self, dst: Tensor, x: Tensor):
         """[B, L/P, H*hd] (all heads of my tokens) -> dst [P, B, L/P, (H/P)*hd]: chunk j = head group j, for rank j.

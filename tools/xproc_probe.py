@@ -15,6 +15,9 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools import _altlib
+
+_altlib.install()   # OSK_ALT_LIB=<.so>: probe another build of the library (tools/make_nopk_lib.sh); spawned children re-run this import
 import torch
 import torch.multiprocessing as mp
 
