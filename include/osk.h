@@ -9,7 +9,9 @@
  * Conventions
  *  - Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers unless noted.
  *  - `stream` is a hipStream_t passed as void*.  Every function only ENQUEUES work on `stream`:
- *    no allocation, no synchronisation, no global state -> safe under hipGraph capture.
+ *    no allocation, no synchronisation, no global state in any compute entry point -> safe under hipGraph capture.
+ *    (The only process-wide state are the two TOOL switches osk_gemm_tile_override / osk_attention_rows_override -- A/B timing aids
+ *    that default to "by estimate" and are never set by the product path.)
  *  - bf16 tensors are passed as `const void*` / `void*` (16-bit storage); f32 as float*.
  *  - Strides are in ELEMENTS of the tensor's dtype.  "rows_per_batch" addressing: logical row m of a
  *    [B*L, ...] matrix lives at  base + (m / L) * batch_stride + (m % L) * row_stride, so that streams
@@ -24,7 +26,8 @@
 extern "C" {
 #endif
 
-/* 2 (round 5): osk_copy_rows_bf16 added; and the contracts that changed under version 1 during round 4 are now versioned -- the
+/* (round 6 added osk_gemm_group_bf16 without changing any existing contract: the version stays 2.)
+ * 2 (round 5): osk_copy_rows_bf16 added; and the contracts that changed under version 1 during round 4 are now versioned -- the
  * key order osk_v_transpose_bf16 bakes into V^T for head_dim 64 (the 16x16x32 order of head_dim 72: attention_fwd.hip), the entry
  * points osk_gemm_geglu_bf16 / osk_attention_short_bf16 / osk_attention_hd512_fwd_ws_bf16 / osk_causal_conv3d_gnin_ndhwc_bf16.
  * A binding must refuse a library whose version it was not written for (open_sora_amd/_C.py does). */
@@ -78,6 +81,35 @@ typedef struct OskGemmOperands {
   int M;
 } OskGemmOperands;
 int osk_gemm_bf16_pair(const OskGemmOperands* first, const OskGemmOperands* second, int N, int K, int gelu_from, void* stream);
+
+/* ---- a GROUP of up to four Linear problems that share K in ONE launch of the 256 x 256 tile kernel (round 6).
+ * replaces, per block, the QKV projection + the V re-layout of the reference's attention path: layers.py:209-220 (img / txt qkv
+ * Linear + rearrange), :314-320 (linear1 + split + rearrange), math.py:22-36 (attention() permutes V to the kernel's layout) --
+ * the V columns of the projection are written DIRECTLY as the key-major V^T operand of osk_attention_fwd_*_bf16, so the separate
+ * osk_v_transpose_bf16 pass (read + write of V per block) disappears, and the tasks of a block share one tile list (the small
+ * text-stream problems fill the image problems' last round).
+ * Plain task (vt_head_dim == 0): exactly osk_gemm_bf16(op..., N, K, gelu_from, out_f32 = 0), except that the physical columns
+ *   [skip_from, skip_from + skip_len) of W / bias / C are neither computed nor stored (skip_len == 0: none; skip_from % 256 == 0,
+ *   skip_len % 8 == 0, no gate): a single-stream block's linear1 without its V columns -- row layout [q | k | . | mlp].
+ * V^T task (vt_head_dim = 64 / 72 / 128): op.A = the activations X bf16 [op.M = B * L rows, K] (rows_per_batch addressing,
+ *   a_rows_per_batch = L), op.W = W_v bf16 [N = H * hd, K], op.bias = b_v f32 [N] | NULL, op.C = V^T base pointer (bf16),
+ *   c_batch_stride = elements between batch items, c_row_stride = elements between (head, dim) rows (>= round_up(L, 64));
+ *   res / gate NULL; gelu_from / skip_* ignored:
+ *     C[b * c_batch_stride + n * c_row_stride + p] = bf16(sum_k X[b, key(p), k] W_v[n, k] + b_v[n])   for key(p) < L,  else 0,
+ *   p < round_up(L, 64), key(p) = the position -> key map of osk_v_transpose_bf16 for this head_dim (inside every 64-key group) --
+ *   i.e. the result of osk_gemm_bf16 into a [B, L, N] tensor followed by osk_v_transpose_bf16, with the same f32 accumulation
+ *   and ONE rounding (the bias is added after the K loop instead of initialising the accumulators: results may differ from the
+ *   two-kernel path in the last bf16 bit).  A stream stored behind another one on the key axis (img behind txt) passes
+ *   C + its first position (a multiple of 64).
+ * All tasks must qualify for the 256 x 256 tile kernel (M >= 256, N >= 128 (V^T: H * hd >= 256), operands within 4 GiB):
+ * otherwise OSK_EUNSUPPORTED is returned and NOTHING is launched (the caller runs the single calls). */
+typedef struct OskGemmTask {
+  OskGemmOperands op;
+  int N, gelu_from;
+  int skip_from, skip_len;
+  int vt_head_dim;
+} OskGemmTask;
+int osk_gemm_group_bf16(const OskGemmTask* tasks, int n_tasks, int K, void* stream);
 
 /* ---- GEGLU up-projection (the STDiT-generation block's "GEGLU MLP" of BASELINE.json's
  * north_star; the mounted v2.0 reference has no GEGLU call site -- its MLP is Linear -> GELU(tanh) -> Linear, layers.py:277-281 --

@@ -29,6 +29,7 @@ SIGNATURES = {
     "osk_gemm_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64,
                       _i32, _i32, _i32, _i32, _i32, _vp],
     "osk_gemm_bf16_pair": [_vp, _vp, _i32, _i32, _i32, _vp],     # two OskGemmOperands structs by pointer
+    "osk_gemm_group_bf16": [_vp, _i32, _i32, _vp],              # OskGemmTask array by pointer
     "osk_gemm_tile_choice": [_i32, _i32, _i32],
     "osk_gemm_tile_override": [_i32],
     "osk_ln_modulate_fp8": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
@@ -260,6 +261,61 @@ def gemm_pair(first: dict, second: dict, *, gelu_from: int | None = None) -> Non
     with _gemm_prof(2.0 * (ops[0].M + ops[1].M) * N * K):
         _check(lib.osk_gemm_bf16_pair(C.addressof(ops[0]), C.addressof(ops[1]), N, K, N if gelu_from is None else gelu_from,
                                       _stream()), "osk_gemm_bf16_pair")
+
+
+class OskGemmTask(C.Structure):
+    """include/osk.h::OskGemmTask"""
+    _fields_ = [("op", OskGemmOperands), ("N", _i32), ("gelu_from", _i32), ("skip_from", _i32), ("skip_len", _i32), ("vt_head_dim", _i32)]
+
+
+def gemm_group(tasks: list) -> bool:
+    """osk_gemm_group_bf16: up to four problems sharing K in one launch.  Each task is a dict:
+      plain:  a, w, bias, out [, res, gate, gate_batch_stride, gelu_from, skip=(from, len)]  -- gemm()'s arguments; with `skip` the
+              physical columns [from, from + len) of w / bias / out are neither computed nor stored
+      V^T:    x (bf16 [B, L, K] view), w (W_v [H*hd, K]), bias (f32 | None), vt (bf16 [B, H, hd, Lp] contiguous), vt_pos (first position on
+              the key axis, % 64 == 0), hd
+    Returns False -- nothing launched -- when the library declines the group (OSK_EUNSUPPORTED: a task off the 256 x 256 tile path);
+    the caller then runs the single calls."""
+    arr = (OskGemmTask * len(tasks))()
+    K = None
+    flops = 0.0
+    for t, d in zip(arr, tasks):
+        if "vt" in d:
+            x, w, vt = d["x"], d["w"], d["vt"]
+            B, L, k_ = x.shape
+            assert x.dtype == w.dtype == vt.dtype == torch.bfloat16 and vt.is_contiguous() and vt.dim() == 4 and d["vt_pos"] % 64 == 0
+            assert vt.shape[0] == B and vt.shape[1] * vt.shape[2] == w.shape[0] and d["vt_pos"] + (L + 63) // 64 * 64 <= vt.shape[3]
+            t.op = OskGemmOperands(x.data_ptr(), x.stride(0), x.stride(1), L, w.data_ptr(), w.stride(0), _p(d.get("bias")),
+                                   vt.data_ptr() + 2 * d["vt_pos"], vt.stride(0), vt.stride(2), L, None, None, 0, B * L)
+            t.N, t.gelu_from, t.skip_from, t.skip_len, t.vt_head_dim = w.shape[0], w.shape[0], 0, 0, d["hd"]
+            flops += 2.0 * B * L * w.shape[0] * k_
+        else:
+            a, w, out = d["a"], d["w"], d["out"]
+            k_ = a.shape[2]
+            t.op = _gemm_operands_n(a, w, d.get("bias"), out, d.get("res"), d.get("gate"), d.get("gate_batch_stride", 0))
+            sf, sl = d.get("skip", (0, 0))
+            t.N, t.gelu_from, t.skip_from, t.skip_len, t.vt_head_dim = w.shape[0], d.get("gelu_from", w.shape[0]) if d.get("gelu_from") is not None else w.shape[0], sf, sl, 0
+            flops += 2.0 * a.shape[0] * a.shape[1] * (w.shape[0] - sl) * k_
+        assert K in (None, k_), "the tasks of a group share K"
+        K = k_
+    with _gemm_prof(flops):
+        rc = lib.osk_gemm_group_bf16(C.addressof(arr), len(tasks), K, _stream())
+    if rc == OSK_EUNSUPPORTED:
+        return False
+    _check(rc, "osk_gemm_group_bf16")
+    return True
+
+
+def _gemm_operands_n(a, w, bias, out, res, gate, gate_batch_stride) -> OskGemmOperands:
+    """_gemm_operands for a task whose output tensor may be WIDER than the task's N (a skip range / a column slice: the row layout
+    [q | k | . | mlp] is addressed through its row stride)"""
+    B, L, K = a.shape
+    assert out.shape[0] == B and out.shape[1] == L and out.shape[2] >= 1 and w.shape[1] == K
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+    if res is not None:
+        assert res.stride() == out.stride() and res.dtype == torch.bfloat16
+    return OskGemmOperands(a.data_ptr(), a.stride(0), a.stride(1), L, w.data_ptr(), w.stride(0), _p(bias), out.data_ptr(),
+                           out.stride(0), out.stride(1), L, _p(res), _p(gate), gate_batch_stride, B * L)
 
 
 def ln_modulate_fp8(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, mod_batch_stride: int, eps: float = 1e-6):

@@ -32,9 +32,10 @@ struct GeoX {
   }
 };
 
-// NP = 2: TWO problems that differ in their operands and M only (the img- and txt-stream Linear of a double block: same N, K,
-// epilogue kind) walked as ONE tile list -- problem 0's tiles, then problem 1's -- so that the small text GEMM (6 row tiles: a
-// third of the chip for one round) fills the last round of the image GEMM instead of launching alone.
+// NP > 1: several problems that share K walked as ONE tile list -- problem 0's tiles, then problem 1's, ... -- so that a small
+// problem (the text-stream Linear of a double block: 6 row tiles, a third of the chip for one round) fills the last round of a
+// large one instead of launching alone.  Round 6: the problems may differ in N, M, epilogue class, skip range and operand roles
+// (V^T tasks: gemm_params.h) -- everything per-tile is read from the tile's own GemmParams.
 template <int NP>
 struct GemmPack {
   GemmParams p[NP];
@@ -57,22 +58,34 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
   const int wm = wave >> 1, wn = wave & 1;
   const int q4 = lane >> 4, l15 = lane & 15;
 
-  const int nbn = (pk.p[0].N + BN - 1) / BN;                       // N, K, group are the pack's (equal in every problem)
-  const int nt0 = ((pk.p[0].M + 255) / 256) * nbn;
-  const int ntiles = NP == 1 ? nt0 : nt0 + ((pk.p[NP - 1].M + 255) / 256) * nbn;
-  const int grp = pk.p[0].group > 0 ? pk.p[0].group : 1;
-  const int per_group = grp * nbn;
-  // position in the tile list -> (problem, tile origin): tile order of gemm256.hip / gemm256p.hip inside each problem
+  // tiles of each problem (K is the pack's; N, M, group, skip range are per problem), prefix sums
+  int cum[NP + 1];
+  cum[0] = 0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    cum[i + 1] = cum[i] + ((pk.p[i].M + 255) / 256) * ((pk.p[i].N - pk.p[i].skip_len + BN - 1) / BN);
+  const int ntiles = cum[NP];
+  // position in the tile list -> (problem, tile origin): tile order of gemm256.hip / gemm256p.hip inside each problem; n0 is the
+  // PHYSICAL column origin (behind a skipped range: + skip_len)
   auto tile_of = [&](int it, int& sel, int& m0, int& n0) {
     int tile = xcd_remap(it, ntiles);
-    sel = (NP > 1 && tile >= nt0) ? 1 : 0;
-    tile -= sel ? nt0 : 0;
-    const int nbm = (pk.p[sel].M + 255) / 256;
+    sel = 0;
+#pragma unroll
+    for (int i = 1; i < NP; ++i) sel = tile >= cum[i] ? i : sel;
+    int first = 0;
+#pragma unroll
+    for (int i = 1; i < NP; ++i) first = sel == i ? cum[i] : first;
+    tile -= first;
+    const GemmParams& q = pk.p[NP == 1 ? 0 : sel];
+    const int nbn = (q.N - q.skip_len + BN - 1) / BN, nbm = (q.M + 255) / 256;
+    const int grp = q.group > 0 ? q.group : 1;
+    const int per_group = grp * nbn;
     const int g = tile / per_group, r = tile - g * per_group;
     const int rows_here = nbm - g * grp < grp ? nbm - g * grp : grp;
     const int bn = r / rows_here, bm = g * grp + (r - bn * rows_here);
     m0 = bm * 256;
     n0 = bn * BN;
+    n0 += n0 >= q.skip_from ? q.skip_len : 0;
   };
   // LDS-DMA sources: instruction j = wave + 4 i (i = 0..7) covers tile rows [8 j, 8 j + 8); byte offsets from the bases
   const int srow8 = lane >> 3, spos = lane & 7;
@@ -87,17 +100,31 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
       aoff[i] = (unsigned)((b * p.abs_ + (int64_t)l * p.ars) * 2 + c * 16);
       int n = n0 + r;
       n = n < p.N ? n : p.N - 1;
-      woff[i] = (unsigned)((int64_t)n * p.wrs * 2 + c * 16);
+      // (plain tasks: wrpb = INT_MAX -> batch 0, position n; V^T tasks: the activation row of this position of the key axis)
+      const int wb = n / p.wrpb;
+      int pos = n - wb * p.wrpb;
+      if (p.vt) {
+        pos = vt_perm64(pos, p.vt);
+        pos = pos < p.wvalid ? pos : p.wvalid - 1;
+      }
+      woff[i] = (unsigned)((wb * p.wbs + (int64_t)pos * p.wrs) * 2 + c * 16);
     }
   };
   // a tile whose 256 A rows lie inside M and inside one batch, and whose 256 W rows lie inside N: its per-lane source
   // offsets are an affine function of (m0, n0), so the next tile's are this tile's plus a wave-uniform delta
   auto affine = [&](const GemmParams& p, int m0, int n0) {
-    return m0 + 256 <= p.M && n0 + 256 <= p.N && m0 / p.arpb == (m0 + 255) / p.arpb;
+    const int wb = n0 / p.wrpb;
+    return m0 + 256 <= p.M && n0 + 256 <= p.N && m0 / p.arpb == (m0 + 255) / p.arpb &&
+           wb == (n0 + 255) / p.wrpb && n0 - wb * p.wrpb + 256 <= p.wvalid &&   // V^T: one batch, no clamped key (the key order stays inside 64-key groups)
+           !(n0 < p.skip_from && n0 + 256 > p.skip_from);                        // (never true for skip_from % 256 == 0)
   };
   auto a_origin = [&](const GemmParams& p, int m0) -> int64_t {
     const int b = m0 / p.arpb, l = m0 - b * p.arpb;
     return (b * p.abs_ + (int64_t)l * p.ars) * 2;
+  };
+  auto w_origin = [&](const GemmParams& p, int n0) -> int64_t {
+    const int b = n0 / p.wrpb, l = n0 - b * p.wrpb;
+    return (b * p.wbs + (int64_t)l * p.wrs) * 2;
   };
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   // fragment row l15 of a 16-row block, 16-byte chunk q4 (k 8 q4 .. + 7 of the sub-step's 32) under the row's swizzle key
@@ -124,7 +151,7 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
       // tiles and the first tile of the second problem start with their own cold fetch)
       has_next = seln == sel && affine(p, m0, n0) && affine(p, m0n, n0n);
       dA = (unsigned)(a_origin(p, m0n) - a_origin(p, m0));
-      dW = (unsigned)(((int64_t)n0n - n0) * p.wrs * 2);
+      dW = (unsigned)(w_origin(p, n0n) - w_origin(p, n0));
     }
     const uint64_t abase = rfl64((uint64_t)(uintptr_t)p.A), wbase = rfl64((uint64_t)(uintptr_t)p.W);
     const uint64_t bbase = rfl64((uint64_t)(uintptr_t)p.bias);
@@ -145,7 +172,10 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
       aoffp = (unsigned)((b * p.abs_ + (int64_t)l * p.ars) * 2);
       int n = n0 + wave * 64 + lane;
       n = n < p.N ? n : p.N - 1;
-      woffp = (unsigned)((int64_t)n * p.wrs * 2);
+      const int wb = n / p.wrpb;
+      int pos = n - wb * p.wrpb;
+      pos = pos < p.wvalid ? pos : p.wvalid - 1;      // (one dword per line of the tile's rows: the key order inside a group does not matter)
+      woffp = (unsigned)((wb * p.wbs + (int64_t)pos * p.wrs) * 2);
     }
 #define OSKW_OPERANDS                                                                                               \
   ::"v"(faA0), "v"(faW0), "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(aoff[4]), "v"(aoff[5]),          \
@@ -191,7 +221,7 @@ int launch_one(const GemmParams& p, hipStream_t st) {
   OSK_ENSURE_MAX_SMEM(kernel, OSKX_SMEM);
   GemmPack<1> pk;
   pk.p[0] = p;
-  const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const int ntiles = ((p.M + 255) / 256) * ((p.N - p.skip_len + 255) / 256);
   hipLaunchKernelGGL(kernel, dim3(grid_for(ntiles)), dim3(256), OSKX_SMEM, st, pk);
   return (int)hipGetLastError();
 }
@@ -211,15 +241,33 @@ int launch_gemm256x(const GemmParams& p, int out_f32, hipStream_t st) {
   return out_f32 ? launch_one<true>(p, st) : launch_one<false>(p, st);
 }
 
-// two problems with equal N, K, gelu_from and group in one launch (bf16 output)
+static int tiles_of(const GemmParams& p) { return ((p.M + 255) / 256) * ((p.N - p.skip_len + 255) / 256); }
+
+// two problems with equal K in one launch (bf16 output)
 int launch_gemm256x_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t st) {
   auto kernel = gemm256x_kernel<false, 2>;
   OSK_ENSURE_MAX_SMEM(kernel, OSKX_SMEM);
   GemmPack<2> pk;
   pk.p[0] = p0;
   pk.p[1] = p1;
-  const int nbn = (p0.N + 255) / 256;
-  const int ntiles = ((p0.M + 255) / 256 + (p1.M + 255) / 256) * nbn;
+  hipLaunchKernelGGL(kernel, dim3(grid_for(tiles_of(p0) + tiles_of(p1))), dim3(256), OSKX_SMEM, st, pk);
+  return (int)hipGetLastError();
+}
+
+// 1 .. 4 problems with equal K in one launch (bf16 output); a pack of 3 carries an empty fourth problem (M = 0: no tiles)
+int launch_gemm256x_group(const GemmParams* ps, int n, hipStream_t st) {
+  if (n == 1) return launch_one<false>(ps[0], st);
+  if (n == 2) return launch_gemm256x_pair(ps[0], ps[1], st);
+  if (n < 1 || n > 4) return OSK_EINVAL;
+  auto kernel = gemm256x_kernel<false, 4>;
+  OSK_ENSURE_MAX_SMEM(kernel, OSKX_SMEM);
+  GemmPack<4> pk;
+  int ntiles = 0;
+  for (int i = 0; i < 4; ++i) {
+    pk.p[i] = ps[i < n ? i : 0];
+    if (i >= n) pk.p[i].M = 0;
+    ntiles += tiles_of(pk.p[i]);
+  }
   hipLaunchKernelGGL(kernel, dim3(grid_for(ntiles)), dim3(256), OSKX_SMEM, st, pk);
   return (int)hipGetLastError();
 }

@@ -343,3 +343,50 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
   else hipLaunchKernelGGL((gemm_bf16_kernel<false>), grid, block, SMEM_BYTES, st, p);
   return (int)hipGetLastError();
 }
+
+// ---- a group of Linear problems sharing K as ONE launch of the 256 x 256 tile kernel (include/osk.h: OskGemmTask)
+extern "C" int osk_gemm_group_bf16(const OskGemmTask* tasks, int n_tasks, int K, void* stream) {
+  if (!tasks || n_tasks < 1 || n_tasks > 4 || K <= 0 || (K % BK)) return OSK_EINVAL;
+  GemmParams ps[4];
+  for (int i = 0; i < n_tasks; ++i) {
+    const OskGemmTask& t = tasks[i];
+    const OskGemmOperands& o = t.op;
+    GemmParams& p = ps[i];
+    if (t.vt_head_dim == 0) {
+      const int rc = fill_params(p, o.A, o.a_batch_stride, o.a_row_stride, o.a_rows_per_batch, o.W, o.w_row_stride, o.bias, o.C,
+                                 o.c_batch_stride, o.c_row_stride, o.c_rows_per_batch, o.res, o.gate, o.gate_batch_stride, o.M, t.N, K,
+                                 t.gelu_from, 0);
+      if (rc != OSK_OK) return rc;
+      if (t.skip_len < 0 || t.skip_from < 0) return OSK_EINVAL;
+      if (t.skip_len > 0) {
+        if (o.gate || (t.skip_from % 256) || (t.skip_len % 8) || t.skip_from + t.skip_len > t.N) return OSK_EINVAL;
+        p.skip_from = t.skip_from;
+        p.skip_len = t.skip_len;
+      }
+      if (!large_tiles_ok(p) || t.N - t.skip_len < 128) return OSK_EUNSUPPORTED;
+      continue;
+    }
+    // V^T task: the kernel's A operand is the weight, its W operand the activations (gemm_params.h)
+    const int hd = t.vt_head_dim, L = o.a_rows_per_batch;
+    if (hd != 64 && hd != 72 && hd != 128) return OSK_EUNSUPPORTED;
+    if (!o.A || !o.W || !o.C || o.res || o.gate || L <= 0 || o.M <= 0 || (o.M % L) || t.N <= 0 || (t.N % hd)) return OSK_EINVAL;
+    if ((o.a_batch_stride & 7) || (o.a_row_stride & 7) || (o.w_row_stride & 7) || ((uintptr_t)o.A & 15) || ((uintptr_t)o.W & 15) ||
+        ((uintptr_t)o.C & 1) || ((uintptr_t)o.bias & 3))
+      return OSK_EINVAL;
+    const int B = o.M / L, Lp = (L + 63) / 64 * 64;
+    if ((int64_t)B * Lp > 0x7fffff00) return OSK_EUNSUPPORTED;
+    p = GemmParams{};
+    p.A = (const unsigned short*)o.W; p.abs_ = 0; p.ars = o.w_row_stride; p.arpb = t.N;
+    p.W = (const unsigned short*)o.A; p.wrs = o.a_row_stride; p.wbs = o.a_batch_stride; p.wrpb = Lp; p.wvalid = L;
+    p.bias = nullptr; p.rowbias = o.bias;
+    p.C = o.C; p.cbs = 0; p.crs = o.c_row_stride; p.crpb = t.N; p.ccbs = o.c_batch_stride;
+    p.res = nullptr; p.gate = nullptr; p.gbs = 0;
+    p.M = t.N; p.N = B * Lp; p.K = K; p.gelu_from = p.N;
+    p.group = 8;
+    p.vt = hd == 128 ? 2 : 1;
+    const int64_t a_span = (int64_t)(t.N - 1) * o.w_row_stride + K;
+    const int64_t w_span = (int64_t)(B - 1) * o.a_batch_stride + (int64_t)(L - 1) * o.a_row_stride + K;
+    if (!osk_gemm::gemm256_supported(p, a_span, w_span)) return OSK_EUNSUPPORTED;
+  }
+  return osk_gemm::launch_gemm256x_group(ps, n_tasks, (hipStream_t)stream);
+}

@@ -309,6 +309,96 @@ OSK_DEV void geglu_all(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w,
   geglu_interior<Geo>(aq, p, storeoff, n0w / 2, std::make_integer_sequence<int, NB / 2>{});
 }
 
+// ---- V^T class (round 6, osk_gemm_group_bf16's V^T task): the tile is a piece of V^T = W_v X^T -- rows m = (head, dim), columns =
+// (batch, position on the key axis) -- stored at C[b * ccbs + m * crs + position] with the per-ROW bias b_v[m] added here (the K loop's
+// folded bias is per column).  Interior wave tiles (all rows inside M, all 128 positions inside one batch and all their keys valid:
+// the permutation stays inside 64-key groups) use row_pair_wide's 8 rows x 128 byte stores; everything else goes element by element,
+// positions whose key lies behind the sequence end are stored as ZERO (the attention kernels rely on a zero V^T there).
+template <class Geo, int J, int I>
+OSK_DEV uint4 vt_chunk(const osk_v4f* aq, float rb0, float rb1) {
+  constexpr int NB = Geo::NB;
+  float a0[4], a1[4];
+  Geo::template read<J * NB + I>(aq, a0);
+  Geo::template read<J * NB + I + 1>(aq, a1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a0[i] += rb0; a1[i] += rb1; }
+  auto sx = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a1[0], a1[1]), false, false);
+  auto sy = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[2], a1[3]), false, false);
+  return make_uint4(sx[0], sy[0], sx[1], sy[1]);
+}
+
+template <class Geo, int I, int... Js>
+OSK_DEV void vt_row_pair(const osk_v4f* aq, const GemmParams& p, int64_t own, const float* rb, int lane, std::integer_sequence<int, Js...>) {
+  constexpr int NB = Geo::NB;
+  uint4 d[NB];
+  const int j = lane & 3;
+  const bool odd = lane & 1, hi = lane & 2;
+  ((d[Js] = vt_chunk<Geo, Js, I>(aq, rb[I], rb[I + 1])), ...);
+#pragma unroll
+  for (int b = 0; b < NB / 4; ++b) {
+    quad_transpose(d[4 * b].x, d[4 * b + 1].x, d[4 * b + 2].x, d[4 * b + 3].x, odd, hi);
+    quad_transpose(d[4 * b].y, d[4 * b + 1].y, d[4 * b + 2].y, d[4 * b + 3].y, odd, hi);
+    quad_transpose(d[4 * b].z, d[4 * b + 1].z, d[4 * b + 2].z, d[4 * b + 3].z, odd, hi);
+    quad_transpose(d[4 * b].w, d[4 * b + 1].w, d[4 * b + 2].w, d[4 * b + 3].w, odd, hi);
+  }
+  unsigned short* base = reinterpret_cast<unsigned short*>(p.C) + own + 16 * j - (int64_t)j * p.crs;
+#pragma unroll
+  for (int b = 0; b < NB / 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<uint4*>(base + (int64_t)r * p.crs + 64 * b) = d[4 * b + r];
+}
+
+template <class Geo, int... Is>
+OSK_DEV void vt_interior(const osk_v4f* aq, const GemmParams& p, const int64_t* storeoff, const float* rb, int lane, std::integer_sequence<int, Is...>) {
+  (vt_row_pair<Geo, 2 * Is>(aq, p, storeoff[Is], rb, lane, std::make_integer_sequence<int, Geo::NB>{}), ...);
+}
+
+template <class Geo, int T>
+OSK_DEV void vt_tile_edge(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4) {
+  constexpr int NB = Geo::NB;
+  constexpr int J = T / NB, I = T % NB;
+  float acc[4];
+  Geo::template read<T>(aq, acc);
+  const int m = m0w + I * 16 + l15;
+  if (m >= p.M) return;
+  const float rb = p.rowbias ? p.rowbias[m] : 0.f;
+  const int n = n0w + J * 16 + q4 * 4;
+  for (int j = 0; j < 4 && n + j < p.N; ++j) {
+    const int b = (n + j) / p.wrpb, pos = (n + j) - b * p.wrpb;
+    const float t = vt_perm64(pos, p.vt) < p.wvalid ? acc[j] + rb : 0.f;
+    reinterpret_cast<unsigned short*>(p.C)[b * p.ccbs + (int64_t)m * p.crs + pos] = f32_to_bf16_bits(t);
+  }
+}
+
+template <class Geo, int... Ts>
+OSK_DEV void vt_tiles_edge(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4, std::integer_sequence<int, Ts...>) {
+  (vt_tile_edge<Geo, Ts>(aq, p, m0w, n0w, l15, q4), ...);
+}
+
+template <class Geo>
+OSK_DEV void vt_all(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4) {
+  constexpr int NB = Geo::NB, WT = NB * 16;
+  if (m0w >= p.M || n0w >= p.N) return;
+  const int bcol = n0w / p.wrpb, pos0 = n0w - bcol * p.wrpb;                       // wave-uniform
+  const bool interior = m0w + WT <= p.M && n0w + WT <= p.N && pos0 + WT <= p.wrpb && pos0 + WT <= p.wvalid &&
+                        ((((uintptr_t)p.C) & 15) == 0) && ((p.crs & 7) == 0) && ((p.ccbs & 7) == 0);
+  if (!interior) {
+    vt_tiles_edge<Geo>(aq, p, m0w, n0w, l15, q4, std::make_integer_sequence<int, NB * NB>{});
+    return;
+  }
+  float rb[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) rb[i] = p.rowbias ? p.rowbias[m0w + 16 * i + l15] : 0.f;
+  // element offset of the row this lane STORES after the lane-row exchange (row_pair_wide's `own`), + the tile's column origin
+  int64_t storeoff[NB / 2];
+  const int64_t col0 = bcol * p.ccbs + pos0 + (q4 >> 1) * 8;
+#pragma unroll
+  for (int i = 0; i < NB / 2; ++i) storeoff[i] = (int64_t)(m0w + l15 + 16 * (2 * i + (q4 & 1))) * p.crs + col0;
+  const int lane = q4 * 16 + l15;
+  vt_interior<Geo>(aq, p, storeoff, rb, lane, std::make_integer_sequence<int, NB / 2>{});
+}
+
 // the whole 128 x 128 wave tile
 template <class Geo, bool OUT_F32>
 OSK_DEV void epilogue_all(const osk_v4f* aq, const GemmParams& p, int m0w, int n0w, int l15, int q4, bool interior, bool folded) {
@@ -316,6 +406,10 @@ OSK_DEV void epilogue_all(const osk_v4f* aq, const GemmParams& p, int m0w, int n
   if constexpr (!OUT_F32) {
     if (p.geglu) {   // (kernel-argument uniform)
       geglu_all<Geo>(aq, p, m0w, n0w, l15, q4, interior, folded);
+      return;
+    }
+    if (p.vt) {
+      vt_all<Geo>(aq, p, m0w, n0w, l15, q4);
       return;
     }
   }
