@@ -488,6 +488,8 @@ class _Workspace:
         self.h = torch.empty(B, L, R, dtype=BF16, device=device)        # double-block MLP hidden
         Lp = (L + 63) // 64 * 64
         self.vt = torch.empty(B, H, hd, Lp, dtype=BF16, device=device)
+        # the QKV projection writes V directly as V^T (osk_gemm_group_bf16) until the library declines a group of this geometry
+        self.vt_group = hasattr(_OPS, "gemm_group")
 
     def y_double(self, D):
         return self.y[: self.B * self.L * 3 * D].view(self.B, self.L, 3 * D)
@@ -601,10 +603,16 @@ def v_scale_fp8(v: Tensor, H: int, hd: int) -> Tensor:
     return _OPS.v_scale_fp8(v, H, hd)
 
 
+def _bf16_operands(*xs) -> bool:
+    """plain bf16 activations / weights (not the fp8 mode's quantised pairs)"""
+    return all(not isinstance(x, (tuple, Fp8Weight)) for x in xs)
+
+
 def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False,
-                     score_bound: float = 0.0):
+                     score_bound: float = 0.0, vt_ready: bool = False):
     """attention() of math.py:22-36 on the joint [txt;img] sequence; the output overwrites the (dead) v slot.
-    pv8 (fp8 mode, head_dim 72 / 128): V^T as e4m3 with one scale per (batch, head), P.V on the fp8 MFMA."""
+    pv8 (fp8 mode, head_dim 72 / 128): V^T as e4m3 with one scale per (batch, head), P.V on the fp8 MFMA.
+    vt_ready: ws.vt was already written by the projection (osk_gemm_group_bf16's V^T task) -- v then only names the output slot."""
     wsp = _OPS.attention_workspace(q.device)
     if pv8 and hd in (72, 128):
         B = v.shape[0]
@@ -615,7 +623,8 @@ def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd
         _OPS.v_transpose_fp8(v, sv, vt8, H, hd)
         _OPS.attention_fwd_pv8(q, k, vt8, sv, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=wsp)
         return
-    _OPS.v_transpose(v, ws.vt, H, hd)
+    if not vt_ready:
+        _OPS.v_transpose(v, ws.vt, H, hd)
     _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=wsp, score_bound=score_bound)
 
 
@@ -650,14 +659,28 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D:]
     scales = (plan.txt.q_scale, plan.txt.k_scale, plan.img.q_scale, plan.img.k_scale)
     paired = sp is None and len(streams) == 2      # both streams on this rank: their Linear layers go out in pairs
-    if paired:
+    vt_ready = False
+    if (paired and ws.vt_group and not plan.pv8 and Lt % 64 == 0 and _bf16_operands(*acts, plan.img.qkv_w, plan.txt.qkv_w)):
+        # ONE launch for the block's four projection problems: q | k of each stream into the row buffer, V of each stream straight
+        # into ws.vt as the key-major operand of the attention kernel (txt keys first) -- no V round trip, no osk_v_transpose_bf16
+        tasks = []
+        for ((aw, x_s, xm_s, y_s, sh1, sc1), act), pos in zip(zip(streams, acts), (Lt, 0)):     # streams = [img, txt]
+            b = aw.qkv_b
+            tasks.append(dict(a=act, w=aw.qkv_w[:2 * D], bias=None if b is None else b[:2 * D], out=y_s))
+            tasks.append(dict(x=act, w=aw.qkv_w[2 * D:], bias=None if b is None else b[2 * D:], vt=ws.vt, vt_pos=pos, hd=hd))
+        vt_ready = _OPS.gemm_group(tasks)
+        if not vt_ready:
+            ws.vt_group = False                    # (a shape off the 256 x 256 tile path: the single calls from now on)
+    if vt_ready:
+        pass
+    elif paired:
         _linear_pair(*(dict(a=act, w=aw.qkv_w, bias=aw.qkv_b, out=y_s) for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts)))
     elif sp is None:
         for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):
             _linear(act, aw.qkv_w, aw.qkv_b, y_s)
     if sp is None:
         _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
-        _joint_attention(ws, q, k, v, H, hd, plan.pv8, plan.score_bound)
+        _joint_attention(ws, q, k, v, H, hd, plan.pv8, plan.score_bound, vt_ready)
     else:
         for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):  # K, V first: their all-gather overlaps the Q projection
             _linear(act, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
@@ -705,9 +728,19 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
     q, k, v = y[:, :, :D], y[:, :, D: 2 * D], y[:, :, 2 * D: 3 * D]
     scales = (plan.q_scale, plan.k_scale, plan.q_scale, plan.k_scale)
     if sp is None:
-        _linear(act, plan.w1, plan.b1, y, gelu_from=3 * D)
+        vt_ready = False
+        if ws.vt_group and not plan.pv8 and (2 * D) % 256 == 0 and _bf16_operands(act, plan.w1):
+            # linear1 WITHOUT its V columns (row layout [q | k | . | gelu(mlp)]) and V straight into ws.vt, one launch
+            b1 = plan.b1
+            vt_ready = _OPS.gemm_group([
+                dict(a=act, w=plan.w1, bias=b1, out=y, gelu_from=3 * D, skip=(2 * D, D)),
+                dict(x=act, w=plan.w1[2 * D: 3 * D], bias=None if b1 is None else b1[2 * D: 3 * D], vt=ws.vt, vt_pos=0, hd=hd)])
+            if not vt_ready:
+                ws.vt_group = False
+        if not vt_ready:
+            _linear(act, plan.w1, plan.b1, y, gelu_from=3 * D)
         _OPS.qknorm_rope(q, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
-        _joint_attention(ws, q, k, v, H, hd, plan.pv8, plan.score_bound)
+        _joint_attention(ws, q, k, v, H, hd, plan.pv8, plan.score_bound, vt_ready)
     else:
         b1 = plan.b1
         _linear(act, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])

@@ -83,6 +83,53 @@ def gemm_pair(first, second, *, gelu_from=None):
              gelu_from=gelu_from)
 
 
+def gemm_group(tasks):
+    """CPU statement of osk_gemm_group_bf16 (include/osk.h): plain tasks = osk_gemm_bf16 without the skipped physical columns; V^T
+    tasks = the projection rounded once to bf16, written key-major in osk_v_transpose_bf16's order behind `vt_pos`.  Returns False
+    (nothing done) for groups the library declines: a task off the 256 x 256 tile path."""
+    for d in tasks:
+        if "vt" in d:
+            B, L, K = d["x"].shape
+            if d["w"].shape[0] < 256 or B * ((L + 63) // 64 * 64) < 128 or d["hd"] not in (64, 72, 128):
+                return False
+        else:
+            B, L, K = d["a"].shape
+            sl = d.get("skip", (0, 0))[1]
+            if B * L < 256 or d["w"].shape[0] - sl < 128:
+                return False
+            if sl and (d["skip"][0] % 256 or sl % 8 or d.get("gate") is not None):
+                raise RuntimeError("osk_gemm_group_bf16 failed: status -1 (invalid skip range)")
+    for d in tasks:
+        if "vt" in d:
+            x, w, vt, hd = d["x"], d["w"], d["vt"], d["hd"]
+            B, L, K = x.shape
+            _abi_check("osk_gemm_group_bf16 (V^T task)", x.stride(2) == 1, x.stride(0) % 8 == 0, x.stride(1) % 8 == 0, w.stride(0) % 8 == 0,
+                       _al(x, 16), _al(w, 16), d["vt_pos"] % 64 == 0, vt.is_contiguous())
+            v = x.float() @ w.float().T
+            if d.get("bias") is not None:
+                v = v + d["bias"].float()
+            H = w.shape[0] // hd
+            Lp = (L + 63) // 64 * 64
+            part = torch.zeros(B, H, hd, Lp, dtype=torch.bfloat16)
+            v_transpose(v.to(torch.bfloat16), part, H, hd)
+            vt[..., d["vt_pos"]: d["vt_pos"] + Lp] = part
+        else:
+            a, w, out = d["a"], d["w"], d["out"]
+            sf, sl = d.get("skip", (0, 0))
+            N = w.shape[0]
+            gf = d.get("gelu_from")
+            bias = d.get("bias")
+            for lo, hi in ((0, sf), (sf + sl, N)) if sl else ((0, N),):
+                if hi <= lo:
+                    continue
+                g = None if gf is None or gf >= hi else max(gf - lo, 0)
+                res = d.get("res")
+                gate = d.get("gate")
+                gemm(a, w[lo:hi], None if bias is None else bias[lo:hi], out[:, :, lo:hi], res=None if res is None else res[:, :, lo:hi],
+                     gate=None if gate is None else gate[:, lo:hi], gate_batch_stride=d.get("gate_batch_stride", 0), gelu_from=g)
+    return True
+
+
 def ln_modulate_fp8(x, shift, scale, mod_batch_stride, eps=1e-6):
     """osk_ln_modulate_fp8 == osk_ln_modulate_bf16 followed by osk_quantize_rows_fp8 (bit-identical by construction)"""
     xm = torch.empty(x.shape, dtype=torch.bfloat16)

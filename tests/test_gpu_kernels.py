@@ -750,6 +750,109 @@ def test_attention_sequence_parallel_rank_shape_720p(hip_lib, hd, H):
     assert (out.float() - c.float()[None, None]).abs().max().item() <= 2 ** -6 * c.float().abs().max().item() + 1e-3
 
 
+# ----------------------------------------------------------------------------- osk_gemm_group_bf16 (round 6)
+def _vt_reference(hip_lib, x, w, bias, H, hd):
+    """the two-kernel path the V^T task replaces: osk_gemm_bf16 into [B, L, H*hd] + osk_v_transpose_bf16"""
+    B, L, K = x.shape
+    v = torch.empty(B, L, H * hd, dtype=BF, device=DEV)
+    hip_lib.gemm(x, w, bias, v)
+    vt = torch.zeros(B, H, hd, (L + 63) // 64 * 64, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+    return vt
+
+
+@pytest.mark.parametrize("hd,H,B,L,K,with_bias", [(72, 16, 3, 1000, 1152, True), (72, 16, 1, 2048, 1152, False), (64, 6, 2, 777, 384, True),
+                                                    (128, 24, 2, 1300, 3072, True), (128, 4, 1, 4096 + 64, 512, True), (72, 4, 2, 100, 288, True)])
+def test_gemm_group_vt_task_equals_gemm_plus_v_transpose(hip_lib, hd, H, B, L, K, with_bias):
+    """V^T task of osk_gemm_group_bf16: the V projection written directly in the attention kernels' key-major operand layout
+    (per 64-key group in the order of osk_v_transpose_bf16), ragged key count (zero pad), row-batch straddling tiles, against the
+    two-kernel path (one bf16 step: the bias is added after the K loop instead of before it) and against fp64."""
+    N = H * hd
+    x = rnd("x", (B, L, K), seed=201)
+    w = rnd("w", (N, K), std=K ** -0.5, seed=202)
+    bias = rnd("b", (N,), std=0.3, dtype=torch.float32, seed=203) if with_bias else None
+    Lp = (L + 63) // 64 * 64
+    vt = torch.full((B, H, hd, Lp + 64), 7.0, dtype=BF, device=DEV)          # a wider key axis: the task starts at position 64
+    ok = hip_lib.gemm_group([dict(x=x, w=w, bias=bias, vt=vt, vt_pos=64, hd=hd)])
+    assert ok
+    ref = _vt_reference(hip_lib, x, w, bias, H, hd)
+    assert (vt[..., :64] == 7.0).all(), "wrote in front of its first position"
+    got = vt[..., 64:]
+    bf16_ulp_close(got.float().cpu(), ref.float().cpu(), rel=2 ** -7, abs_=2e-3)
+    # fp64: v[b, key, n] at position p of its 64-key group
+    from tests import cpu_ops
+    key = cpu_ops.pos2key(hd, Lp)
+    v64 = x.double().cpu() @ w.double().cpu().T + (bias.double().cpu() if with_bias else 0.0)
+    pad = torch.zeros(B, Lp, N, dtype=torch.float64)
+    pad[:, :L] = v64
+    ref64 = pad[:, key].reshape(B, Lp, H, hd).permute(0, 2, 3, 1)
+    bf16_ulp_close(got.float().cpu(), ref64.float().bfloat16().float(), rel=2 ** -7, abs_=2e-3)
+    valid = (key < L)
+    assert (got[..., ~valid.to(DEV)] == 0).all(), "positions behind the sequence end must be zero"
+
+
+def test_gemm_group_skip_range_and_block_packs(hip_lib):
+    """a single-stream block's linear1 without its V columns (row layout [q | k | . | gelu(mlp)]) + the V^T task in one launch, and a
+    double block's four problems (img / txt q|k + img / txt V^T behind each other on the key axis) -- against the single calls."""
+    H, hd, B, Lt, Li = 16, 72, 2, 128, 1100
+    D, R, L = H * hd, 4 * H * hd, 128 + 1100
+    xm = rnd("xm", (B, L, D), seed=211)
+    w1 = rnd("w1", (3 * D + R, D), std=D ** -0.5, seed=212)
+    b1 = rnd("b1", (3 * D + R,), std=0.2, dtype=torch.float32, seed=213)
+    y_ref = torch.empty(B, L, 3 * D + R, dtype=BF, device=DEV)
+    hip_lib.gemm(xm, w1, b1, y_ref, gelu_from=3 * D)
+    vt_ref = _vt_reference(hip_lib, xm, w1[2 * D: 3 * D], b1[2 * D: 3 * D], H, hd)
+    y = torch.full_like(y_ref, 3.0)
+    Lp = (L + 63) // 64 * 64
+    vt = torch.empty(B, H, hd, Lp, dtype=BF, device=DEV)
+    assert hip_lib.gemm_group([dict(a=xm, w=w1, bias=b1, out=y, gelu_from=3 * D, skip=(2 * D, D)),
+                               dict(x=xm, w=w1[2 * D: 3 * D], bias=b1[2 * D: 3 * D], vt=vt, vt_pos=0, hd=hd)])
+    assert (y[:, :, 2 * D: 3 * D] == 3.0).all(), "the skipped columns were written"
+    assert torch.equal(y[:, :, :2 * D], y_ref[:, :, :2 * D]) and torch.equal(y[:, :, 3 * D:], y_ref[:, :, 3 * D:])
+    bf16_ulp_close(vt.float().cpu(), vt_ref.float().cpu(), rel=2 ** -7, abs_=2e-3)
+    # double block: joint [txt ; img] rows, per-stream weights
+    wq = {s_: rnd("wqkv" + s_, (3 * D, D), std=D ** -0.5, seed=214 + i) for i, s_ in enumerate(("img", "txt"))}
+    bq = {s_: rnd("bqkv" + s_, (3 * D,), std=0.2, dtype=torch.float32, seed=216 + i) for i, s_ in enumerate(("img", "txt"))}
+    y3_ref = torch.empty(B, L, 3 * D, dtype=BF, device=DEV)
+    hip_lib.gemm(xm[:, Lt:], wq["img"], bq["img"], y3_ref[:, Lt:])
+    hip_lib.gemm(xm[:, :Lt], wq["txt"], bq["txt"], y3_ref[:, :Lt])
+    vt2_ref = torch.zeros(B, H, hd, Lp, dtype=BF, device=DEV)
+    hip_lib.v_transpose(y3_ref[:, :, 2 * D:], vt2_ref, H, hd)
+    y3 = torch.full_like(y3_ref, 5.0)
+    vt2 = torch.empty(B, H, hd, Lp, dtype=BF, device=DEV)
+    tasks = []
+    for s_, rows, pos in (("img", slice(Lt, L), Lt), ("txt", slice(0, Lt), 0)):
+        tasks.append(dict(a=xm[:, rows], w=wq[s_][:2 * D], bias=bq[s_][:2 * D], out=y3[:, rows]))
+        tasks.append(dict(x=xm[:, rows], w=wq[s_][2 * D:], bias=bq[s_][2 * D:], vt=vt2, vt_pos=pos, hd=hd))
+    assert hip_lib.gemm_group(tasks)
+    assert (y3[:, :, 2 * D:] == 5.0).all()
+    assert torch.equal(y3[:, :, :2 * D], y3_ref[:, :, :2 * D])
+    bf16_ulp_close(vt2.float().cpu(), vt2_ref.float().cpu(), rel=2 ** -7, abs_=2e-3)
+    # repeatable
+    vt3 = torch.empty_like(vt2)
+    for t_ in tasks:
+        if "vt" in t_:
+            t_["vt"] = vt3
+    assert hip_lib.gemm_group(tasks) and torch.equal(vt3, vt2)
+
+
+def test_gemm_group_declines_shapes_off_the_large_tile_path(hip_lib):
+    """OSK_EUNSUPPORTED -> False, NOTHING launched (the caller then runs the single calls); bad skip ranges are errors"""
+    x = rnd("x", (1, 100, 128), seed=221)
+    w = rnd("w", (128, 128), seed=222)
+    out = torch.full((1, 100, 128), 9.0, dtype=BF, device=DEV)
+    assert hip_lib.gemm_group([dict(a=x, w=w, bias=None, out=out)]) is False          # M < 256
+    vt = torch.full((1, 2, 64, 128), 9.0, dtype=BF, device=DEV)
+    assert hip_lib.gemm_group([dict(x=x, w=w, bias=None, vt=vt, vt_pos=0, hd=64)]) is False     # H * hd < 256
+    torch.cuda.synchronize()
+    assert (out == 9.0).all() and (vt == 9.0).all()
+    x2 = rnd("x2", (1, 512, 128), seed=223)
+    w2 = rnd("w2", (1024, 128), seed=224)
+    out2 = torch.empty(1, 512, 1024, dtype=BF, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip_lib.gemm_group([dict(a=x2, w=w2, bias=None, out=out2, skip=(128, 256))])     # skip_from % 256 != 0
+
+
 # ----------------------------------------------------------------------------- race screens for the asm K loops
 def _attention_determinism(hip_lib, hd):
     # ragged keys + ragged query block, several rounds of workgroups

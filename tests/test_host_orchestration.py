@@ -123,6 +123,44 @@ def test_pe_memo_is_not_fooled_by_refilled_inference_tensors(cpu_mmdit):
     assert float(cpu_mmdit._pe_to_cos_sin(pe2, 8)[0].sum()) == 8.0   # ... until written in place
 
 
+def test_engine_takes_the_group_projection_path(cpu_mmdit):
+    """round 6: the QKV projection of a block goes out as ONE osk_gemm_group_bf16 launch that writes V directly as V^T -- no
+    osk_v_transpose_bf16 call is left in a forward where the geometry qualifies (hd 64 model: 2 D % 256 == 0), the golden still
+    holds (test_engine_orchestration_vs_golden runs the same path), and a library that declines the group is handled by the
+    single calls with the same result."""
+    cfg, B, T, h, w, L_txt = configs.GOLDEN["hd64_eager_fused"]
+    model = _build(cpu_mmdit, cfg)
+    inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF)
+    calls = {"group": 0, "vt": 0}
+    real_group, real_vt = cpu_ops.gemm_group, cpu_ops.v_transpose
+
+    def spy_group(tasks):
+        calls["group"] += 1
+        return real_group(tasks)
+
+    def spy_vt(*a, **k):
+        calls["vt"] += 1
+        return real_vt(*a, **k)
+
+    cpu_ops.gemm_group, cpu_ops.v_transpose = spy_group, spy_vt
+    try:
+        with torch.inference_mode():
+            out = model(**inp)
+            n_blocks = cfg["depth"] + cfg["depth_single_blocks"]
+            if L_txt % 64 == 0:
+                assert calls["group"] == n_blocks, calls
+            # the emulation's own V^T task calls v_transpose once per task; the ENGINE must not call it for qualifying blocks
+            cpu_ops.gemm_group = lambda tasks: False            # a library that declines every group
+            model._osk_ws_cache.clear()
+            calls["vt"] = 0
+            out2 = model(**inp)
+            assert calls["vt"] == n_blocks                      # the legacy path: one osk_v_transpose_bf16 per block
+    finally:
+        cpu_ops.gemm_group, cpu_ops.v_transpose = real_group, real_vt
+    d = (out.float() - out2.float()).abs().max()
+    assert d <= 2.0 ** -6 * out2.float().abs().max() + 1e-3, d
+
+
 def test_processors_install_on_reference_blocks(cpu_mmdit):
     """The plug-in point of the reference itself: block.set_processor(...) on the reference's own
     DoubleStreamBlock / SingleStreamBlock (only where /root/reference is mounted)."""
