@@ -82,12 +82,12 @@ typedef struct OskGemmOperands {
 } OskGemmOperands;
 int osk_gemm_bf16_pair(const OskGemmOperands* first, const OskGemmOperands* second, int N, int K, int gelu_from, void* stream);
 
-/* ---- a GROUP of up to four Linear problems that share K in ONE launch of the 256 x 256 tile kernel (round 6).
+/* ---- a GROUP of up to four Linear problems that share K (at most two plain + two V^T tasks) on the 256 x 256 tile kernel (round 6).
  * replaces, per block, the QKV projection + the V re-layout of the reference's attention path: layers.py:209-220 (img / txt qkv
  * Linear + rearrange), :314-320 (linear1 + split + rearrange), math.py:22-36 (attention() permutes V to the kernel's layout) --
  * the V columns of the projection are written DIRECTLY as the key-major V^T operand of osk_attention_fwd_*_bf16, so the separate
- * osk_v_transpose_bf16 pass (read + write of V per block) disappears, and the tasks of a block share one tile list (the small
- * text-stream problems fill the image problems' last round).
+ * osk_v_transpose_bf16 pass (read + write of V per block) disappears.  The plain tasks go out as one launch (two of equal N: one tile
+ * list, the small text-stream problem fills the image problem's last round), the V^T tasks as one launch of the kernel's V^T form.
  * Plain task (vt_head_dim == 0): exactly osk_gemm_bf16(op..., N, K, gelu_from, out_f32 = 0), except that the physical columns
  *   [skip_from, skip_from + skip_len) of W / bias / C are neither computed nor stored (skip_len == 0: none; skip_from % 256 == 0,
  *   skip_len % 8 == 0, no gate): a single-stream block's linear1 without its V columns -- row layout [q | k | . | mlp].

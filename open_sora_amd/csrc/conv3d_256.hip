@@ -134,8 +134,20 @@ OSK_DEV void pair_x(const osk_v4f* aq, const ConvParams& p, const int64_t* rowof
   float a0[4], a1[4];
   uint2 r0 = make_uint2(0, 0), r1 = r0;
   if constexpr (RES) {
+#ifdef OSK_CONV_NARROW_RES   // (A/B builds of tools/: the residual in the accumulator layout's 8-byte pieces, 2 loads of 16 rows x 32 bytes)
     r0 = *reinterpret_cast<const uint2*>(p.res + rowoff[I] + n);        // rows beyond M read row 0 (clamped offsets)
     r1 = *reinterpret_cast<const uint2*>(p.res + rowoff[I + 1] + n);
+#else
+    // round 6: the residual is read the way the result is STORED -- the 16-byte chunk of this lane's store row (ONE load of 32 rows x
+    // 32 bytes instead of two of 16 x 32: the CU's address path charges per (instruction, line), gemm_epilogue.h's round-5 finding)
+    // -- and brought back to the accumulator layout by the inverse lane-row exchange (v_permlane16_swap is an involution on its
+    // register pair).  Rows beyond M: storeoff is clamped to row 0 like rowoff.
+    const uint4 rc = *reinterpret_cast<const uint4*>(p.res + storeoff[I / 2] + ncol);
+    auto ux = __builtin_amdgcn_permlane16_swap(rc.x, rc.z, false, false);
+    auto uy = __builtin_amdgcn_permlane16_swap(rc.y, rc.w, false, false);
+    r0 = make_uint2(ux[0], uy[0]);
+    r1 = make_uint2(ux[1], uy[1]);
+#endif
   }
   read_x<J * OSKX_NB + I>(aq, a0);
   read_x<J * OSKX_NB + I + 1>(aq, a1);
@@ -239,7 +251,7 @@ OSK_DEV void tiles_x_generic(const osk_v4f* aq, const ConvParams& p, int bm, int
 template <int NBJ>
 OSK_DEV void epilogue_all_x(const osk_v4f* aq, const ConvParams& p, int bm, int r0w, int n0, int n0w, int l15, int q4, unsigned char* smem) {
   constexpr int NB = OSKX_NB, BN = 32 * NBJ;
-  const bool fast = (p.Cout & 15) == 0 && ((((uintptr_t)p.out) & 15) == 0) && (!p.res || (((uintptr_t)p.res) & 7) == 0) &&
+  const bool fast = (p.Cout & 15) == 0 && ((((uintptr_t)p.out) & 15) == 0) && (!p.res || (((uintptr_t)p.res) & 15) == 0) &&
                     (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
   float* ls = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x;

@@ -344,15 +344,18 @@ extern "C" int osk_gemm_bf16(const void* A, int64_t a_batch_stride, int64_t a_ro
   return (int)hipGetLastError();
 }
 
-// ---- a group of Linear problems sharing K as ONE launch of the 256 x 256 tile kernel (include/osk.h: OskGemmTask)
+// ---- a group of Linear problems sharing K (include/osk.h: OskGemmTask): the plain tasks go out through the 256 x 256 tile kernel's
+// single / pair launches (a skipped column range included), the V^T tasks as ONE launch of its V^T instantiation -- two launches
+// for a block's projection instead of GEMM + osk_v_transpose_bf16, with V never written token-major
 extern "C" int osk_gemm_group_bf16(const OskGemmTask* tasks, int n_tasks, int K, void* stream) {
   if (!tasks || n_tasks < 1 || n_tasks > 4 || K <= 0 || (K % BK)) return OSK_EINVAL;
-  GemmParams ps[4];
+  GemmParams plain[4], vts[4];
+  int n_plain = 0, n_vt = 0;
   for (int i = 0; i < n_tasks; ++i) {
     const OskGemmTask& t = tasks[i];
     const OskGemmOperands& o = t.op;
-    GemmParams& p = ps[i];
     if (t.vt_head_dim == 0) {
+      GemmParams& p = plain[n_plain++];
       const int rc = fill_params(p, o.A, o.a_batch_stride, o.a_row_stride, o.a_rows_per_batch, o.W, o.w_row_stride, o.bias, o.C,
                                  o.c_batch_stride, o.c_row_stride, o.c_rows_per_batch, o.res, o.gate, o.gate_batch_stride, o.M, t.N, K,
                                  t.gelu_from, 0);
@@ -367,6 +370,7 @@ extern "C" int osk_gemm_group_bf16(const OskGemmTask* tasks, int n_tasks, int K,
       continue;
     }
     // V^T task: the kernel's A operand is the weight, its W operand the activations (gemm_params.h)
+    GemmParams& p = vts[n_vt++];
     const int hd = t.vt_head_dim, L = o.a_rows_per_batch;
     if (hd != 64 && hd != 72 && hd != 128) return OSK_EUNSUPPORTED;
     if (!o.A || !o.W || !o.C || o.res || o.gate || L <= 0 || o.M <= 0 || (o.M % L) || t.N <= 0 || (t.N % hd)) return OSK_EINVAL;
@@ -376,7 +380,7 @@ extern "C" int osk_gemm_group_bf16(const OskGemmTask* tasks, int n_tasks, int K,
     const int B = o.M / L, Lp = (L + 63) / 64 * 64;
     if ((int64_t)B * Lp > 0x7fffff00) return OSK_EUNSUPPORTED;
     p = GemmParams{};
-    p.A = (const unsigned short*)o.W; p.abs_ = 0; p.ars = o.w_row_stride; p.arpb = t.N;
+    p.A = (const unsigned short*)o.W; p.abs_ = 0; p.ars = o.w_row_stride; p.arpb = 0x7fffffff;
     p.W = (const unsigned short*)o.A; p.wrs = o.a_row_stride; p.wbs = o.a_batch_stride; p.wrpb = Lp; p.wvalid = L;
     p.bias = nullptr; p.rowbias = o.bias;
     p.C = o.C; p.cbs = 0; p.crs = o.c_row_stride; p.crpb = t.N; p.ccbs = o.c_batch_stride;
@@ -388,5 +392,23 @@ extern "C" int osk_gemm_group_bf16(const OskGemmTask* tasks, int n_tasks, int K,
     const int64_t w_span = (int64_t)(B - 1) * o.a_batch_stride + (int64_t)(L - 1) * o.a_row_stride + K;
     if (!osk_gemm::gemm256_supported(p, a_span, w_span)) return OSK_EUNSUPPORTED;
   }
-  return osk_gemm::launch_gemm256x_group(ps, n_tasks, (hipStream_t)stream);
+  if (n_vt > 2 || n_plain > 2) return OSK_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  // every task qualified: launch.  Two plain tasks of equal N / gelu_from / no skip range share a tile list (the pair kernel).
+  if (n_plain == 2 && plain[0].N == plain[1].N && plain[0].gelu_from == plain[1].gelu_from && !plain[0].skip_len && !plain[1].skip_len) {
+    const int big = plain[0].M >= plain[1].M ? 0 : 1;
+    plain[big ^ 1].group = plain[big].group;
+    const int rc = osk_gemm::launch_gemm256x_pair(plain[big], plain[big ^ 1], st);
+    if (rc != OSK_OK) return rc;
+  } else {
+    for (int i = 0; i < n_plain; ++i) {
+      const int rc = osk_gemm::launch_gemm256x(plain[i], 0, st);
+      if (rc != OSK_OK) return rc;
+    }
+  }
+  if (n_vt) {
+    if (n_vt == 2 && vts[1].M * (int64_t)vts[1].N > vts[0].M * (int64_t)vts[0].N) { const GemmParams t_ = vts[0]; vts[0] = vts[1]; vts[1] = t_; }
+    return osk_gemm::launch_gemm256x_vt(vts, n_vt, st);
+  }
+  return OSK_OK;
 }

@@ -408,10 +408,6 @@ OSK_DEV void epilogue_all(const osk_v4f* aq, const GemmParams& p, int m0w, int n
       geglu_all<Geo>(aq, p, m0w, n0w, l15, q4, interior, folded);
       return;
     }
-    if (p.vt) {
-      vt_all<Geo>(aq, p, m0w, n0w, l15, q4);
-      return;
-    }
   }
   if (m0w >= p.M || n0w >= p.N) return;   // the whole wave tile lies outside C (ragged last tile row / column): wave-uniform
   // the fast path stores 16 bytes per lane (bf16) / reads 8-byte residual pieces: C, its strides and the tile origin must allow it

@@ -60,8 +60,8 @@ int launch_gemm256p(const GemmParams& p, int out_f32, hipStream_t st);
 int launch_gemm256x(const GemmParams& p, int out_f32, hipStream_t st);
 // the same kernel over TWO problems that share N, K, gelu_from, group (one tile list: the second problem fills the first one's last round)
 int launch_gemm256x_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t st);
-// up to four problems that share K (any N / M / epilogue class each; skip ranges and V^T tasks included) as ONE tile list
-int launch_gemm256x_group(const GemmParams* ps, int n, hipStream_t st);
+// one or two V^T problems (gemm_params.h: vt != 0) that share K as ONE tile list (gemm256x_vt_kernel)
+int launch_gemm256x_vt(const GemmParams* ps, int n, hipStream_t st);
 // gemm256.hip: the one-tile-per-workgroup frame on OCP e4m3 operands (A, W point at bytes; strides in elements = bytes)
 bool gemm256_fp8_supported(const GemmParams& p, int64_t a_span_elems, int64_t w_span_elems);
 int launch_gemm256_fp8(const GemmParams& p, int bn, int out_f32, hipStream_t st);

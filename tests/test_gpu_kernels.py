@@ -762,7 +762,7 @@ def _vt_reference(hip_lib, x, w, bias, H, hd):
 
 
 @pytest.mark.parametrize("hd,H,B,L,K,with_bias", [(72, 16, 3, 1000, 1152, True), (72, 16, 1, 2048, 1152, False), (64, 6, 2, 777, 384, True),
-                                                    (128, 24, 2, 1300, 3072, True), (128, 4, 1, 4096 + 64, 512, True), (72, 4, 2, 100, 288, True)])
+                                                    (128, 24, 2, 1300, 3072, True), (128, 4, 1, 4096 + 64, 512, True), (72, 4, 2, 100, 320, True)])
 def test_gemm_group_vt_task_equals_gemm_plus_v_transpose(hip_lib, hd, H, B, L, K, with_bias):
     """V^T task of osk_gemm_group_bf16: the V projection written directly in the attention kernels' key-major operand layout
     (per 64-key group in the order of osk_v_transpose_bf16), ragged key count (zero pad), row-batch straddling tiles, against the

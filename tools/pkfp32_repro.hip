@@ -1,0 +1,172 @@
+// Stand-alone reproducer of the packed-FP32 cross-kernel interference on MI355X (gfx950) -- profiles/r03_cross_kernel_interference.md,
+// re-measured in round 6 (profiles/r06b_pk_matrix.jsonl).
+//
+// Observation: a kernel whose hipcc-generated code contains packed-FP32 sequences WITH op_sel half selection
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) returns, now and then, a wrong LOW half of a packed pair while ANOTHER
+// kernel -- a different stream, even a different process -- keeps MFMAs in flight on the same SIMD with a sibling wave in its
+// VALU / memory epilogue.  The victim below is this project's round-3 batched GEMV (x from LDS, weight rows from memory, f32 FMA, wave
+// reduction): no race of its own, identical inputs, differing outputs.  The aggressor is the 256 x 128-tile bf16 GEMM of
+// libosk_hip.so (osk_gemm_bf16 at M = 320: gemm256p_kernel<128>, 180 registers x 2 waves per SIMD -- it leaves room for foreign waves).
+// The same victim compiled with `-Xclang -target-feature -Xclang -packed-fp32-ops` (no packed-FP32 instruction emitted) never fails;
+// that flag is in force for the whole library (open_sora_amd/build.py).
+//
+// Build and run (from the repository root, library built):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pkfp32_repro.hip -o /tmp/pkfp32_repro -ldl            (victim WITH packed FP32)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops tools/pkfp32_repro.hip -o /tmp/pkfp32_repro_nopk -ldl
+//   /tmp/pkfp32_repro open_sora_amd/lib/libosk_hip.so 4000      -> "bad = <hundreds .. thousands> of 4000"  (round 3 / round 6: 3219 .. 4000)
+//   /tmp/pkfp32_repro_nopk open_sora_amd/lib/libosk_hip.so 4000 -> "bad = 0 of 4000"
+//   /tmp/pkfp32_repro none 4000                                  -> no aggressor: "bad = 0 of 4000"
+// Exit code: 0 when no mismatch was seen, 1 otherwise.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(e)                                                                         \
+  do {                                                                                \
+    hipError_t e_ = (e);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_));      \
+      exit(2);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+static __device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+static __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// the victim: this project's batched GEMV as of round 3 (tools/lib/hist is not shipped; the kernel is restated here unchanged).
+// MB = 2 batch rows -> hipcc keeps the two accumulators of a weight row as ONE packed pair.
+template <int MB>
+__global__ void __launch_bounds__(256) gemv_victim(const float* __restrict__ x, int64_t xbs, int Bv, int K, const unsigned short* __restrict__ W,
+                                                   const unsigned short* __restrict__ bias, int rows_per_task, float* __restrict__ out, int64_t obs) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [MB][K]
+  const int task = blockIdx.x;
+  for (int i = threadIdx.x; i < MB * K; i += 256) {
+    const int b = i / K, kk = i - b * K;
+    float t = 0.f;
+    if (b < Bv) t = silu(x[b * xbs + kk]);
+    xs[i] = t;
+  }
+  __syncthreads();
+  const unsigned short* Wt = W + (int64_t)task * rows_per_task * K;
+  const int col0 = task * rows_per_task;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nchunk = K >> 3;
+  for (int r = wave; r < rows_per_task; r += 4) {
+    const unsigned short* wr = Wt + (int64_t)r * K;
+    float acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+      const uint4 u = *reinterpret_cast<const uint4*>(wr + c * 8);
+      float w[8];
+      w[0] = __uint_as_float(u.x << 16); w[1] = __uint_as_float(u.x & 0xFFFF0000u);
+      w[2] = __uint_as_float(u.y << 16); w[3] = __uint_as_float(u.y & 0xFFFF0000u);
+      w[4] = __uint_as_float(u.z << 16); w[5] = __uint_as_float(u.z & 0xFFFF0000u);
+      w[6] = __uint_as_float(u.w << 16); w[7] = __uint_as_float(u.w & 0xFFFF0000u);
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        const float4 x0 = *reinterpret_cast<const float4*>(&xs[b * K + c * 8]);
+        const float4 x1 = *reinterpret_cast<const float4*>(&xs[b * K + c * 8 + 4]);
+        acc[b] += w[0] * x0.x + w[1] * x0.y + w[2] * x0.z + w[3] * x0.w + w[4] * x1.x + w[5] * x1.y + w[6] * x1.z + w[7] * x1.w;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = wave_sum(acc[b]);
+    if (lane == 0) {
+      const float bv = bf16_bits_to_f32(bias[col0 + r]);
+#pragma unroll
+      for (int b = 0; b < MB; ++b)
+        if (b < Bv) out[b * obs + col0 + r] = acc[b] + bv;
+    }
+  }
+}
+
+__global__ void count_diff(const float* a, const float* b, int n, unsigned* flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && __float_as_uint(a[i]) != __float_as_uint(b[i])) atomicAdd(flag, 1u);
+}
+
+typedef int (*gemm_fn)(const void*, int64_t, int64_t, int, const void*, int64_t, const float*, void*, int64_t, int64_t, int, const void*,
+                       const float*, int64_t, int, int, int, int, int, void*);
+
+static unsigned short f2bf(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+int main(int argc, char** argv) {
+  const char* libpath = argc > 1 ? argv[1] : "open_sora_amd/lib/libosk_hip.so";
+  const int iters = argc > 2 ? atoi(argv[2]) : 4000;
+  gemm_fn gemm = nullptr;
+  if (strcmp(libpath, "none") != 0) {
+    void* h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "dlopen(%s): %s\n", libpath, dlerror()); return 2; }
+    gemm = (gemm_fn)dlsym(h, "osk_gemm_bf16");
+    if (!gemm) { fprintf(stderr, "osk_gemm_bf16 not found\n"); return 2; }
+  }
+  // victim problem: 30 layers x 384 rows (180 tasks of 64 rows), K = 576, batch 2 (the adaLN GEMV of the round-3 test model)
+  const int K = 576, NROWS = 30 * 384, RPT = 64, BV = 2;
+  std::vector<unsigned short> hW((size_t)NROWS * K), hb(NROWS);
+  std::vector<float> hx((size_t)BV * K);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+  for (auto& v : hW) v = f2bf(rnd() * 0.06f);
+  for (auto& v : hb) v = f2bf(rnd());
+  for (auto& v : hx) v = rnd() * 1.5f;
+  unsigned short *dW, *db;
+  float *dx, *dout, *dref;
+  unsigned* dflag;
+  CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&db, hb.size() * 2)); CK(hipMalloc(&dx, hx.size() * 4));
+  CK(hipMalloc(&dout, (size_t)BV * NROWS * 4)); CK(hipMalloc(&dref, (size_t)BV * NROWS * 4)); CK(hipMalloc(&dflag, 4));
+  CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+  // aggressor problem: M = 320, N = 1152, K = 576 (gemm256p_kernel<128> in the library)
+  const int AM = 320, AN = 1152, AK = 576;
+  unsigned short *dA, *dAW, *dC;
+  float* dbias;
+  std::vector<unsigned short> hA((size_t)AM * AK), hAW((size_t)AN * AK);
+  for (auto& v : hA) v = f2bf(rnd());
+  for (auto& v : hAW) v = f2bf(rnd() * 0.04f);
+  CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dAW, hAW.size() * 2)); CK(hipMalloc(&dC, (size_t)AM * AN * 2)); CK(hipMalloc(&dbias, AN * 4));
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dAW, hAW.data(), hAW.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(dbias, 0, AN * 4));
+  hipStream_t sv, sa;
+  CK(hipStreamCreate(&sv)); CK(hipStreamCreate(&sa));
+  const size_t sm = (size_t)2 * K * sizeof(float);
+  auto victim = [&](float* o) {
+    hipLaunchKernelGGL(gemv_victim<2>, dim3(NROWS / RPT), dim3(256), sm, sv, dx, (int64_t)K, BV, K, dW, db, RPT, o, (int64_t)NROWS);
+  };
+  victim(dref);
+  CK(hipStreamSynchronize(sv));
+  int bad = 0;
+  for (int i = 0; i < iters; ++i) {
+    if (gemm && i % 4 == 0)
+      for (int j = 0; j < 4; ++j) {
+        const int rc = gemm(dA, 0, AK, AM, dAW, AK, dbias, dC, 0, AN, AM, nullptr, nullptr, 0, AM, AN, AK, AN, 0, (void*)sa);
+        if (rc != 0) { fprintf(stderr, "osk_gemm_bf16 rc = %d\n", rc); return 2; }
+      }
+    CK(hipMemsetAsync(dout, 0, (size_t)BV * NROWS * 4, sv));
+    CK(hipMemsetAsync(dflag, 0, 4, sv));
+    victim(dout);
+    hipLaunchKernelGGL(count_diff, dim3((BV * NROWS + 255) / 256), dim3(256), 0, sv, dout, dref, BV * NROWS, dflag);
+    unsigned f = 0;
+    CK(hipMemcpyAsync(&f, dflag, 4, hipMemcpyDeviceToHost, sv));
+    CK(hipStreamSynchronize(sv));
+    bad += f != 0;
+  }
+  CK(hipDeviceSynchronize());
+  printf("{\"aggressor\": \"%s\", \"iters\": %d, \"bad\": %d}\n", gemm ? "osk_gemm_bf16 M=320 N=1152 K=576 (second stream)" : "none", iters, bad);
+  return bad ? 1 : 0;
+}
