@@ -186,11 +186,11 @@ __global__ void __launch_bounds__(256, 1) gemm256x_kernel(const GemmPack<NP> pk)
 // block) whose A operand is the V weight and whose W operand are the activations -- V^T = W_v X^T written directly in the attention
 // kernels' key-major operand layout (gemm_params.h: vt, wrpb, wvalid, ccbs, rowbias; epilogue class vt_all).  A separate kernel so
 // that the Linear launches above keep their register allocation (one wave per SIMD, 256 accumulators + ~250 VGPRs: a handful more
-// live values spill to scratch) and because this one carries ONE epilogue class instead of nine.  The per-lane source offsets are
-// computed without a per-lane division (one uniform division per operand axis and tile).
+// live values spill to scratch -- measured in this round: +3 k cycles of set-up per tile) and because this one carries ONE epilogue
+// class instead of nine.
 template <int NP>
 __global__ void __launch_bounds__(256, 1) gemm256x_vt_kernel(const GemmPack<NP> pk) {
-  constexpr bool OUT_F32 = false;
+  static_assert(NP <= 2, "a run-time index into a wider pack makes hipcc copy the pack to scratch");
   constexpr int WT = OSKX_NB * 16, BN = 256;   // wave tile side
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -199,96 +199,59 @@ __global__ void __launch_bounds__(256, 1) gemm256x_vt_kernel(const GemmPack<NP> 
   const int wm = wave >> 1, wn = wave & 1;
   const int q4 = lane >> 4, l15 = lane & 15;
 
-  // tiles of each problem (K is the pack's; N, M, group, skip range are per problem), prefix sums
-  int cum[NP + 1];
-  cum[0] = 0;
-#pragma unroll
-  for (int i = 0; i < NP; ++i)
-    cum[i + 1] = cum[i] + ((pk.p[i].M + 255) / 256) * ((pk.p[i].N - pk.p[i].skip_len + BN - 1) / BN);
-  const int ntiles = cum[NP];
-  // position in the tile list -> (problem, tile origin): tile order of gemm256.hip / gemm256p.hip inside each problem; n0 is the
-  // PHYSICAL column origin (behind a skipped range: + skip_len)
-  // (no dynamic index into the by-value pack anywhere in this kernel: `pk.p[sel]` with a run-time sel makes hipcc copy the whole pack to
-  // scratch memory and read every field of the tile's problem from there -- 1500 scratch loads in the epilogue of a 4-problem pack;
-  // fields are picked by a chain of wave-uniform selects over STATIC indices instead: scalar loads from the kernel-argument segment)
-  auto pick = [&](int sel, auto get) {
-    auto v = get(pk.p[0]);
-    if constexpr (NP > 1) v = sel == 1 ? get(pk.p[1]) : v;
-    if constexpr (NP > 2) v = sel == 2 ? get(pk.p[2]) : v;
-    if constexpr (NP > 3) v = sel == 3 ? get(pk.p[3]) : v;
-    return v;
-  };
+  // the two problems differ in N (positions on the key axis) and may differ in M
+  const int nbn0 = (pk.p[0].N + BN - 1) / BN, nbn1 = (pk.p[NP - 1].N + BN - 1) / BN;
+  const int nt0 = ((pk.p[0].M + 255) / 256) * nbn0;
+  const int ntiles = NP == 1 ? nt0 : nt0 + ((pk.p[NP - 1].M + 255) / 256) * nbn1;
+  const int grp = pk.p[0].group > 0 ? pk.p[0].group : 1;
+  // position in the tile list -> (problem, tile origin): tile order of gemm256.hip / gemm256p.hip inside each problem
   auto tile_of = [&](int it, int& sel, int& m0, int& n0) {
     int tile = xcd_remap(it, ntiles);
-    sel = 0;
-#pragma unroll
-    for (int i = 1; i < NP; ++i) sel = tile >= cum[i] ? i : sel;
-    int first = 0;
-#pragma unroll
-    for (int i = 1; i < NP; ++i) first = sel == i ? cum[i] : first;
-    tile -= first;
-    const int qN = pick(sel, [](const GemmParams& q) { return q.N; }), qM = pick(sel, [](const GemmParams& q) { return q.M; });
-    const int qskf = pick(sel, [](const GemmParams& q) { return q.skip_from; }), qskl = pick(sel, [](const GemmParams& q) { return q.skip_len; });
-    const int qgrp = pick(sel, [](const GemmParams& q) { return q.group; });
-    const int nbn = (qN - qskl + BN - 1) / BN, nbm = (qM + 255) / 256;
-    const int grp = qgrp > 0 ? qgrp : 1;
-    const int per_group = grp * nbn;
+    sel = (NP > 1 && tile >= nt0) ? 1 : 0;
+    tile -= sel ? nt0 : 0;
+    const int nbm = (pk.p[sel].M + 255) / 256;
+    const int per_group = grp * (sel ? nbn1 : nbn0);
     const int g = tile / per_group, r = tile - g * per_group;
     const int rows_here = nbm - g * grp < grp ? nbm - g * grp : grp;
     const int bn = r / rows_here, bm = g * grp + (r - bn * rows_here);
     m0 = bm * 256;
     n0 = bn * BN;
-    n0 += n0 >= qskf ? qskl : 0;
-  };
-  // (batch, row inside the batch) of a tile origin on either operand axis -- ONE wave-uniform division per axis and tile (round 6: the
-  // per-lane source offsets below used to divide per lane and row, 17 integer divisions per tile in the un-overlapped set-up phase)
-  struct Org { int ab, al, wb, wl; };
-  auto origin_of = [&](const GemmParams& q, int m0, int n0) {
-    Org o;
-    o.ab = q.arpb == 0x7fffffff ? 0 : m0 / q.arpb;
-    o.al = m0 - o.ab * q.arpb;
-    o.wb = q.wrpb == 0x7fffffff ? 0 : n0 / q.wrpb;     // (plain tasks: wrpb = INT_MAX -> batch 0, position n)
-    o.wl = n0 - o.wb * q.wrpb;
-    return o;
-  };
-  // row r of the tile (already clamped into the matrix) -> element offset of its operand row: the batch wraps at most once inside a
-  // tile when a batch holds >= 256 rows (else: the general division)
-  auto a_row = [&](const GemmParams& q, const Org& o, int m0, int r) -> int64_t {
-    int b = o.ab, l = o.al + r;
-    if (q.arpb >= 256) { const bool wrap = l >= q.arpb; l -= wrap ? q.arpb : 0; b += wrap ? 1 : 0; }
-    else { const int m = m0 + r; b = m / q.arpb; l = m - b * q.arpb; }
-    return b * q.abs_ + (int64_t)l * q.ars;
-  };
-  auto w_row = [&](const GemmParams& q, const Org& o, int n0, int r, bool permute) -> int64_t {
-    int b = o.wb, pos = o.wl + r;
-    if (q.wrpb >= 256) { const bool wrap = pos >= q.wrpb; pos -= wrap ? q.wrpb : 0; b += wrap ? 1 : 0; }
-    else { const int n = n0 + r; b = n / q.wrpb; pos = n - b * q.wrpb; }
-    if (q.vt) {   // V^T tasks: the activation row of this position of the key axis (rows behind the sequence end read clamped, stored as zero)
-      if (permute) pos = vt_perm64(pos, q.vt);
-      pos = pos < q.wvalid ? pos : q.wvalid - 1;
-    }
-    return b * q.wbs + (int64_t)pos * q.wrs;
   };
   // LDS-DMA sources: instruction j = wave + 4 i (i = 0..7) covers tile rows [8 j, 8 j + 8); byte offsets from the bases
   const int srow8 = lane >> 3, spos = lane & 7;
-  auto offsets = [&](const GemmParams& q, const Org& o, int m0, int n0, unsigned* aoff, unsigned* woff) {
-    const int mlast = q.M - 1 - m0, nlast = q.N - 1 - n0;       // last valid row offset inside the tile (>= 0)
+  // A = the V weight (one "batch"); W = the activations: column n of the product = (batch n / wrpb, position n % wrpb) of the key axis,
+  // fed from the activation row key = vt_perm64(position) (osk_v_transpose_bf16's order inside every 64-key group); keys behind the
+  // sequence end read the last key (finite values) and are stored as zero by the epilogue
+  auto w_src = [&](const GemmParams& p, int n, bool permute) -> int64_t {
+    n = n < p.N ? n : p.N - 1;
+    const int wb = n / p.wrpb;
+    int pos = n - wb * p.wrpb;
+    if (permute) pos = vt_perm64(pos, p.vt);
+    pos = pos < p.wvalid ? pos : p.wvalid - 1;
+    return wb * p.wbs + (int64_t)pos * p.wrs;
+  };
+  auto offsets = [&](const GemmParams& p, int m0, int n0, unsigned* aoff, unsigned* woff) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = (wave + 4 * i) * 8 + srow8;
       const int c = spos ^ ((r >> 1) & 7);
-      aoff[i] = (unsigned)(a_row(q, o, m0, r < mlast ? r : mlast) * 2 + c * 16);
-      woff[i] = (unsigned)(w_row(q, o, n0, r < nlast ? r : nlast, true) * 2 + c * 16);
+      int m = m0 + r;
+      m = m < p.M ? m : p.M - 1;
+      aoff[i] = (unsigned)((int64_t)m * p.ars * 2 + c * 16);
+      woff[i] = (unsigned)(w_src(p, n0 + r, true) * 2 + c * 16);
     }
   };
-  // a tile whose 256 A rows lie inside M and inside one batch, and whose 256 W rows lie inside N (V^T: one batch, no clamped key -- the
-  // key order stays inside 64-key groups): its per-lane source offsets are an affine function of (m0, n0), so the next tile's are
-  // this tile's plus a wave-uniform delta
-  auto affine = [&](const GemmParams& q, const Org& o, int m0, int n0) {
-    return m0 + 256 <= q.M && n0 + 256 <= q.N && o.al + 256 <= q.arpb && o.wl + 256 <= q.wrpb && o.wl + 256 <= q.wvalid;
+  // a tile whose 256 weight rows lie inside M and whose 256 positions lie inside one batch with every key valid (the key order stays
+  // inside 64-key groups): its per-lane source offsets are an affine function of (m0, n0)
+  auto affine = [&](const GemmParams& p, int m0, int n0) {
+    const int wb = n0 / p.wrpb, pos0 = n0 - wb * p.wrpb;
+    return m0 + 256 <= p.M && n0 + 256 <= p.N && pos0 + 256 <= p.wrpb && pos0 + 256 <= p.wvalid;
   };
-  auto a_origin = [&](const GemmParams& q, const Org& o) -> int64_t { return (o.ab * q.abs_ + (int64_t)o.al * q.ars) * 2; };
-  auto w_origin = [&](const GemmParams& q, const Org& o) -> int64_t { return (o.wb * q.wbs + (int64_t)o.wl * q.wrs) * 2; };
+  auto a_origin = [&](const GemmParams& p, int m0) -> int64_t { return (int64_t)m0 * p.ars * 2; };
+  auto w_origin = [&](const GemmParams& p, int n0) -> int64_t {
+    const int wb = n0 / p.wrpb, pos0 = n0 - wb * p.wrpb;
+    return (wb * p.wbs + (int64_t)pos0 * p.wrs) * 2;
+  };
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   // fragment row l15 of a 16-row block, 16-byte chunk q4 (k 8 q4 .. + 7 of the sub-step's 32) under the row's swizzle key
   const unsigned sz0 = (unsigned)((q4 ^ ((l15 >> 1) & 7)) << 4);
@@ -303,43 +266,36 @@ __global__ void __launch_bounds__(256, 1) gemm256x_vt_kernel(const GemmPack<NP> 
 #ifdef OSK_GEMM_TILE_TIMING
     const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
 #endif
-    int sel, m0, n0;
+    int sel, m0, n0, seln = 0, m0n = 0, n0n = 0;
     tile_of(it, sel, m0, n0);
-    // the tile's problem as a LOCAL copy picked over static indices (wave-uniform: its fields are scalar kernel-argument loads)
-    // (at most a two-way run-time index: hipcc turns it into a select of kernel-argument offsets; a four-way one copies the pack to scratch)
-    static_assert(NP <= 2, "a wider pack needs another way to pick the tile's problem");
-    const GemmParams& p = pk.p[NP == 1 ? 0 : sel];
-    const Org org = origin_of(p, m0, n0);
-    int seln = 0, m0n = 0, n0n = 0;
-    Org orgn{};
+    const GemmParams& p = pk.p[NP == 1 ? 0 : sel];                 // wave-uniform: kernel-argument loads at a scalar offset
     bool has_next = itn < ntiles;
     unsigned dA = 0, dW = 0;
     if (has_next) {
       tile_of(itn, seln, m0n, n0n);
-      if (seln == sel) orgn = origin_of(p, m0n, n0n);
       // cross-tile prefetch only between two affine tiles of the SAME problem (the deltas are relative to its bases; edge
-      // tiles and the first tile of the next problem start with their own cold fetch)
-      has_next = seln == sel && affine(p, org, m0, n0) && affine(p, orgn, m0n, n0n);
-      dA = (unsigned)(a_origin(p, orgn) - a_origin(p, org));
-      dW = (unsigned)(w_origin(p, orgn) - w_origin(p, org));
+      // tiles and the first tile of the second problem start with their own cold fetch)
+      has_next = seln == sel && affine(p, m0, n0) && affine(p, m0n, n0n);
+      dA = (unsigned)(a_origin(p, m0n) - a_origin(p, m0));
+      dW = (unsigned)(w_origin(p, n0n) - w_origin(p, n0));
     }
     const uint64_t abase = rfl64((uint64_t)(uintptr_t)p.A), wbase = rfl64((uint64_t)(uintptr_t)p.W);
     const uint64_t bbase = rfl64((uint64_t)(uintptr_t)p.bias);
     unsigned aoff[8], woff[8];
-    offsets(p, org, m0, n0, aoff, woff);
+    offsets(p, m0, n0, aoff, woff);
     const int m0w = m0 + wm * WT, n0w = n0 + wn * WT;
-    const bool folded = p.bias != nullptr && n0w + WT <= p.N;                 // wave-uniform
+    const bool folded = false;                                                // (the per-ROW bias b_v is added by the epilogue)
     const unsigned boff = (unsigned)((n0w + q4 * 4) * 4);
     const unsigned flags = rfl(prefetched | (has_next ? 2u : 0u) | (folded ? 4u : 0u));
     const unsigned dAs = rfl(dA), dWs = rfl(dW);
 
-    // prefetch lanes: lane l of wave w touches row 64 w + l of the A tile and of the W tile (one dword per 128-byte line; the key order
-    // inside a 64-key group does not matter here)
+    // prefetch lanes: lane l of wave w touches row 64 w + l of the A tile and of the W tile (one dword per 128-byte line)
     unsigned aoffp, woffp;
     {
-      const int r = wave * 64 + lane, mlast = p.M - 1 - m0, nlast = p.N - 1 - n0;
-      aoffp = (unsigned)(a_row(p, org, m0, r < mlast ? r : mlast) * 2);
-      woffp = (unsigned)(w_row(p, org, n0, r < nlast ? r : nlast, false) * 2);
+      int m = m0 + wave * 64 + lane;
+      m = m < p.M ? m : p.M - 1;
+      aoffp = (unsigned)((int64_t)m * p.ars * 2);
+      woffp = (unsigned)(w_src(p, n0 + wave * 64 + lane, false) * 2);   // (one dword per line of the tile's rows: the order inside a group does not matter)
     }
 #define OSKW_OPERANDS                                                                                               \
   ::"v"(faA0), "v"(faW0), "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(aoff[4]), "v"(aoff[5]),          \
@@ -369,6 +325,8 @@ __global__ void __launch_bounds__(256, 1) gemm256x_vt_kernel(const GemmPack<NP> 
     prefetched = has_next ? 1u : 0u;
   }
 }
+
+#undef OSKW_OPERANDS
 
 int grid_for(int ntiles) {
   int n_cu = osk_device_cus();
