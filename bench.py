@@ -628,7 +628,11 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1, g
             saved = [p_.score_bound for p_ in plans]
             for p_ in plans:
                 p_.score_bound = 0.0
+            mmdit.AUTO_BOUND = False                       # (a): the general body wholesale, as before round 6
             ms_g, at_g, x_gen = timed(3)
+            mmdit.AUTO_BOUND = True                        # (a'): the same withheld bound, bound taken from the operands on the device
+            run_denoise(x, 0, 1)
+            ms_a, at_a, x_auto = timed(3)
             for p_, v_ in zip(plans, saved):
                 p_.score_bound = v_
             # consistency of the two loop bodies at the timed shape (parity iii): the same 3 steps from the same
@@ -636,24 +640,56 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1, g
             # two results differ by f32 rounding of the row sums, carried through 3 x 28 blocks and the bf16 residual stream
             x_fast = run_denoise(x, 0, 3).float()
             rel_fg = float((x_fast - x_gen).norm() / x_gen.norm())
+            rel_fa = float((x_fast - x_auto).norm() / x_auto.norm())
             assert rel_fg < 2e-2, f"bounded (FAST) and general attention bodies disagree at the timed shape: relL2 {rel_fg:.3e}"
-            del x_fast, x_gen
+            assert rel_fa < 2e-2, f"host-bounded and device-bounded (auto) attention disagree at the timed shape: relL2 {rel_fa:.3e}"
+            del x_fast, x_gen, x_auto
             side["general_body"] = {"steps": 3, "ms_per_step": round(ms_g, 3), "attn_avg_launch_ms": round(at_g, 4),
-                                    "attention_body": _C.attention_body(hd, 1, L, 0.0), "what": "same weights, score bound withheld",
+                                    "attention_body": _C.attention_body(hd, 1, L, 0.0), "what": "same weights, score bound withheld, auto dispatch off",
                                     "rel_l2_fast_vs_general_3_steps": round(rel_fg, 6)}
-            gs = torch.Generator(device=dev).manual_seed(7)
-            with torch.no_grad():
-                for b_ in blocks:
-                    for nrm in ([b_.img_attn.norm, b_.txt_attn.norm] if hasattr(b_, "img_attn") else [b_.norm]):
-                        for prm in (nrm.query_norm.scale, nrm.key_norm.scale):
-                            prm.copy_(torch.rand(prm.shape, device=dev, generator=gs) + 0.5)
-            model.invalidate_plan()
-            run_denoise(x, 0, 1)
+            side["auto_bound_unit_scales"] = {"steps": 3, "ms_per_step": round(ms_a, 3), "attn_avg_launch_ms": round(at_a, 4),
+                                              "what": "same weights, score bound withheld: osk_rownorm2_max_bf16 on q and k + the auto-dispatched launch pair "
+                                                      "(bound from the operands, per (batch, head), on the device) -- the cost of not trusting the weights",
+                                              "rel_l2_fast_vs_auto_3_steps": round(rel_fa, 6)}
+
+            def rescale(lo_, hi_, seed_):
+                gs = torch.Generator(device=dev).manual_seed(seed_)
+                with torch.no_grad():
+                    for b_ in blocks:
+                        for nrm in ([b_.img_attn.norm, b_.txt_attn.norm] if hasattr(b_, "img_attn") else [b_.norm]):
+                            for prm in (nrm.query_norm.scale, nrm.key_norm.scale):
+                                prm.copy_(torch.rand(prm.shape, device=dev, generator=gs) * (hi_ - lo_) + lo_)
+                model.invalidate_plan()
+                run_denoise(x, 0, 1)
+
+            def device_bounds():
+                """the (batch, head) bounds the LAST block's attention derived on the device (reporting only: a host read-back)"""
+                ws_ = mmdit._workspace(model, 3, L_txt, L_img, D, int(D * cfg["mlp_ratio"]), H, hd, dev)
+                n2 = getattr(ws_, "qk_n2", None)
+                if n2 is None:
+                    return None
+                b_ = (n2[0] * n2[1]).sqrt().flatten().float().cpu()
+                return {"min": round(float(b_.min()), 2), "max": round(float(b_.max()), 2), "pairs_on_fast_body": int((b_ <= 56.0).sum()), "pairs": int(b_.numel())}
+
+            rescale(0.5, 1.5, 7)
             ms_s, at_s, _ = timed(3)
             rep_s = model.attention_report(1, L)
             side["qk_scales_u05_15"] = {"steps": 3, "ms_per_step": round(ms_s, 3), "attn_avg_launch_ms": round(at_s, 4),
                                         "attention_body": ", ".join(rep_s["bodies"]), "score_bound": round(rep_s["score_bound_max"], 3),
                                         "what": "QK-norm scale vectors ~U(0.5, 1.5) instead of 1 (SURVEY 8(d) second run)"}
+            # scale vectors whose WEIGHT-derived bound exceeds the FAST limit (hd max|w_q| max|w_k| scale log2 e: U(0.5, 2.5) -> 76,
+            # U(0.5, 4) -> 196): round 5 sent such checkpoints to the general body wholesale; now every (batch, head) whose actual
+            # |q| |k| allows it runs the FAST body
+            for name_, lo_, hi_, seed_ in (("qk_scales_u05_25", 0.5, 2.5, 8), ("qk_scales_u05_40", 0.5, 4.0, 9)):
+                rescale(lo_, hi_, seed_)
+                ms_w, at_w, xw = timed(3)
+                rep_w = model.attention_report(1, L)
+                assert torch.isfinite(xw).all()
+                side[name_] = {"steps": 3, "ms_per_step": round(ms_w, 3), "attn_avg_launch_ms": round(at_w, 4),
+                               "weight_derived_score_bound": round(rep_w["score_bound_max"], 2), "blocks_auto_dispatched": rep_w["blocks_auto_dispatched"],
+                               "device_bounds_last_block": device_bounds(),
+                               "what": f"QK-norm scale vectors ~U({lo_}, {hi_}): weight-derived bound above the FAST limit 56 -> bound from the operands, per (batch, head), on the device"}
+                del xw
 
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -272,6 +272,28 @@ int osk_attention_fwd_bounded_bf16(const void* q, int64_t q_batch_stride, int64_
                            float scale, int q_prescaled, int kv_batches, float score_bound,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- the bound taken from the OPERANDS, on the device (round 6).  The weight-derived bound above is sqrt(hd)-loose per side: a
+ * checkpoint whose QK-norm scale vectors (layers.py:102-135) have a few large entries exceeds 56 on paper while its actual q / k rows
+ * stay far below -- and without a bound the step falls to the slower general body.  Here the caller passes NO promise:
+ * osk_rownorm2_max_bf16: out[b * H + h] = max over rows l of sum_d x[b, l, h, d]^2 of a bf16 [B, L, H * hd] view (f32, device
+ *   memory; one read of the tensor; accumulate != 0 folds into the values already there -- several key segments, or ranks
+ *   that max-reduce afterwards).  Run it on the q and on the k the attention call receives.
+ * osk_attention_fwd_auto_bf16: osk_attention_fwd_ws_bf16 on q_prescaled operands (q carries scale * log2 e: the norms must be those
+ *   of the values the MFMA multiplies), q_norm2_max f32 [B, H], k_norm2_max f32 [kv_batches or B, H].  Every work unit derives its
+ *   own bound sqrt(q_norm2_max k_norm2_max) (Cauchy-Schwarz: always valid) and the call enqueues a PAIR of launches over the same
+ *   grid: units whose bound is <= 56 run the FAST body with that bound as softmax reference, the others the general body; the
+ *   workgroups of the other kind exit at once.  No host round trip, no global state, hipGraph-capturable.  Cost over a host-promised
+ *   FAST call: the norm pass (HBM-bound) + one launch of early-exiting workgroups. */
+int osk_rownorm2_max_bf16(const void* x, int64_t batch_stride, int64_t row_stride, int B, int L, int H, int hd,
+                          float* out, int accumulate, void* stream);
+int osk_attention_fwd_auto_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+                           const void* k, int64_t k_seg_stride, int64_t k_batch_stride, int64_t k_row_stride,
+                           const void* vt, int64_t vt_seg_stride,
+                           void* out, int64_t o_batch_stride, int64_t o_row_stride,
+                           float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                           float scale, int q_prescaled, int kv_batches, const float* q_norm2_max, const float* k_norm2_max,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- fp8 P.V variant of the attention (opt-in fp8 mode, BASELINE configs[4]; head_dim 72 / 128): QK^T, the softmax and
  * the output as osk_attention_fwd_ws_bf16, but P (<= 2^8 by construction) and V^T are OCP e4m3 and a 64-key tile's P.V
  * is one v_mfma_f32_32x32x64_f8f6f4 per O^T row tile.

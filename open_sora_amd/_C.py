@@ -48,6 +48,9 @@ SIGNATURES = {
                                   _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _i64, _vp],
     "osk_attention_fwd_bounded_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
                                        _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _f32, _vp, _i64, _vp],
+    "osk_attention_fwd_auto_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp,
+                                    _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
+    "osk_rownorm2_max_bf16": [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "osk_attention_workspace_bytes": [],
     "osk_v_scale_fp8": [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "osk_v_transpose_fp8": [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -488,6 +491,41 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
                                               scale, int(q_prescaled), kv_batches, float(score_bound), _p(workspace),
                                               0 if workspace is None else workspace.numel(), _stream()),
            "osk_attention_fwd_bounded_bf16")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1))
+    return out
+
+
+def rownorm2_max(x: torch.Tensor, out: torch.Tensor, H: int, hd: int, accumulate: bool = False) -> torch.Tensor:
+    """out[b, h] = max_l |x[b, l, h, :]|^2 of a bf16 [B, L, H*hd] view (osk_rownorm2_max_bf16); out f32 [B, H] contiguous"""
+    B, L, _ = x.shape
+    assert x.dtype == torch.bfloat16 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == B * H
+    _check(lib.osk_rownorm2_max_bf16(x.data_ptr(), x.stride(0), x.stride(1), B, L, H, hd, out.data_ptr(), 1 if accumulate else 0, _stream()),
+           "osk_rownorm2_max_bf16")
+    return out
+
+
+def attention_fwd_auto(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, H: int, hd: int, scale: float,
+                       qn2: torch.Tensor, kn2: torch.Tensor, *, lse=None, n_seg: int = 1, seg_len: int | None = None,
+                       k_seg_stride: int = 0, vt_seg_stride: int = 0, q_prescaled: bool = True, kv_batches: int = 0,
+                       workspace: torch.Tensor | None = None):
+    """attention_fwd with the score bound taken from the operands on the device (osk_attention_fwd_auto_bf16): qn2 / kn2 from
+    rownorm2_max() of the q / k of THIS call (f32 [B, H] / [kv_batches or B, H]).  Units whose bound allows it run the FAST body."""
+    B, Lq, _ = q.shape
+    if seg_len is None:
+        seg_len = k.shape[1]
+    assert qn2.dtype == kn2.dtype == torch.float32 and qn2.numel() == B * H and kn2.numel() == (kv_batches or B) * H
+    prof = PROFILE_ATTENTION
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _check(lib.osk_attention_fwd_auto_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride,
+                                           k.stride(0), k.stride(1), vt.data_ptr(), vt_seg_stride, out.data_ptr(),
+                                           out.stride(0), out.stride(1), _p(lse), B, H, Lq, n_seg, seg_len, hd,
+                                           scale, int(q_prescaled), kv_batches, qn2.data_ptr(), kn2.data_ptr(), _p(workspace),
+                                           0 if workspace is None else workspace.numel(), _stream()),
+           "osk_attention_fwd_auto_bf16")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))

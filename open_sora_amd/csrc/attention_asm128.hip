@@ -33,6 +33,9 @@ __global__ void __launch_bounds__(256, 1) attn_asm128_kernel(const AttnParams p)
   int bh, qb, part, tail_unit;
   const bool tail = block_to_work_split(p, (p.Lq + 255) / 256, bh, qb, part, tail_unit);
   const int b = bh / p.H, h = bh - b * p.H;
+  float bound;   // the caller's score bound, or -- auto-dispatched pairs -- the one this (batch, head)'s operands imply (attention_params.h)
+  if (!attn_auto_bound(p, b, h, FAST, bound)) return;
+  (void)bound;   // (this head_dim's FAST body exponentiates the raw scores: the bound only decides which body runs)
 
   // ---- LDS: zero (rows 129..159 of the V^T slots stay zero for good), ones row 128 of both V^T slots
   for (int i = tid; i < OSK128_SMEM / 16; i += 64 * NW) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);

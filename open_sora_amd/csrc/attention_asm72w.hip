@@ -38,6 +38,8 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
   int bh, qb, part, tail_unit;
   const bool tail = block_to_work_split(p, (p.Lq + ROWS - 1) / ROWS, bh, qb, part, tail_unit);
   const int b = bh / p.H, h = bh - b * p.H;
+  float bound;   // the caller's score bound, or -- auto-dispatched pairs -- the one this (batch, head)'s operands imply (attention_params.h)
+  if (!attn_auto_bound(p, b, h, true, bound)) return;
 
   // ---- LDS: zero (a tile slot that is never filled must hold finite data), ones row of both V^T slots,
   //      constant chunk {1.0, 0 x 7} = K's padding dims 72..79
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
     // FAST: the reference "max" is the caller's bound B, constant for the whole launch: Q's padding dim 72 (k-step 4, lanes
     // 32..63, word 0 low half) = -B against the 1.0 in K's padding dim -> the MFMA returns s - B directly, from tile 0 on
     if constexpr (FAST) {
-      if (hi) w[16] = (__float_as_uint(-p.bound) >> 16) & 0xFFFFu;
+      if (hi) w[16] = (__float_as_uint(-bound) >> 16) & 0xFFFFu;
     }
     // Q fragments as VALUES: quad ks of block u; the loop statement takes them as inputs in their fixed AGPRs (acc_quads.h), so the
     // compiler writes them there itself and knows they are live until the loop has read them
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(256, 1) attn_asm72w_kernel(const AttnParams p)
   asm volatile(
 #include "attention_asm72w_f0.inc"
       OSK72_OPERANDS : OSK72W_CLOBBERS);
-  m_ref[0] = m_ref[1] = p.bound;
+  m_ref[0] = m_ref[1] = bound;
 
   // the O^T accumulators as values the compiler knows (acc_quads.h): outputs of an empty statement right behind the loop
   static_assert(OSK72W_AQ0 == 160 && OSK72W_AQ1 == 180 && OSK72W_AQ2 == 200 && OSK72W_AQ3 == 220 && OSK72W_AO_REGS == 160,

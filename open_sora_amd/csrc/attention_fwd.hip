@@ -37,6 +37,8 @@ __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
   int bh, qb;
   unit_to_work(p, nqb, p.tail_first + (int)blockIdx.x, bh, qb);
   const int b = bh / p.H, h = bh - b * p.H;
+  float bound_;
+  if (!attn_auto_bound(p, b, h, true, bound_)) return;   // auto-dispatched pair: this unit was the general twin's (it writes final rows itself)
   const int S = p.tail_split;
   for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
     const int r = blockIdx.y * 64 + i / CPR, c = i % CPR;
@@ -198,6 +200,122 @@ extern "C" int osk_attention_fwd_bounded_bf16(const void* q, int64_t q_batch_str
     case 128: return launch<128>(p, st);
     default: return OSK_EUNSUPPORTED;
   }
+}
+
+// ---- auto-dispatched pair (round 6): the bound comes from the operands themselves, per (batch, head), on the device
+extern "C" int osk_attention_fwd_auto_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,
+                                           const void* k, int64_t k_seg_stride, int64_t k_batch_stride,
+                                           int64_t k_row_stride, const void* vt, int64_t vt_seg_stride,
+                                           void* out, int64_t o_batch_stride, int64_t o_row_stride,
+                                           float* lse, int B, int H, int Lq, int n_seg, int seg_len, int hd,
+                                           float scale, int q_prescaled, int kv_batches, const float* q_norm2_max,
+                                           const float* k_norm2_max, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!q || !k || !vt || !out || !q_norm2_max || !k_norm2_max || B <= 0 || H <= 0 || Lq <= 0 || n_seg <= 0 || seg_len <= 0) return OSK_EINVAL;
+  if ((q_batch_stride & 7) || (q_row_stride & 7) || (k_seg_stride & 7) || (k_batch_stride & 7) ||
+      (k_row_stride & 7) || (vt_seg_stride & 7) || (o_batch_stride & 3) || (o_row_stride & 3))
+    return OSK_EINVAL;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)vt & 15) || ((uintptr_t)out & 7) ||
+      ((uintptr_t)q_norm2_max & 3) || ((uintptr_t)k_norm2_max & 3)) return OSK_EINVAL;
+  if (hd != 64 && hd != 72 && hd != 128) return OSK_EUNSUPPORTED;
+  if (!q_prescaled && scale * 1.4426950408889634f != 1.0f) return OSK_EUNSUPPORTED;   // the norms must be those of the operands the MFMA sees
+  AttnParams p;
+  p.q = (const unsigned short*)q; p.qbs = q_batch_stride; p.qrs = q_row_stride;
+  p.k = (const unsigned short*)k; p.kss = k_seg_stride; p.kbs = k_batch_stride; p.krs = k_row_stride;
+  p.vt = (const unsigned short*)vt; p.vtss = vt_seg_stride;
+  p.out = (unsigned short*)out; p.obs = o_batch_stride; p.ors = o_row_stride;
+  p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.n_seg = n_seg; p.seg_len = seg_len;
+  p.seg_lp = (seg_len + 63) / 64 * 64;
+  p.tps = p.seg_lp / 64;
+  p.sc = 1.0f;
+  p.q_prescaled = 1;
+  if (kv_batches < 0 || kv_batches > B) return OSK_EINVAL;
+  p.Bkv = kv_batches > 0 ? kv_batches : B;
+  p.map = 1;
+  if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 0)) return OSK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  p.bound = 1.0f;                                  // "a bound exists": the FAST body's layout rules (attn_fast_path)
+  const bool fast_possible = osk_attn::attn_fast_path(p);
+  auto run = [&](const AttnParams& a) {
+    switch (hd) {
+      case 64: return a.rows == 512 ? osk_attn::launch_asm64w(a, st) : osk_attn::launch_asm64(a, st);
+      case 72: return a.rows == 512 ? osk_attn::launch_asm72w(a, st) : osk_attn::launch_asm72(a, st);
+      default: return osk_attn::launch_asm128(a, st);
+    }
+  };
+  if (!fast_possible) {                            // several key segments of fewer than 3 tiles: only the general body takes them
+    p.bound = 0.f;
+    launch_shape(p, hd, workspace, workspace_bytes);
+    const int rc = run(p);
+    return rc != 0 || p.tail_split == 1 ? rc : osk_attn::launch_merge(p, hd, st);
+  }
+  // the FAST twin: launch shape as a bounded call's (wide layout, tail split), every workgroup checks its own (batch, head)
+  p.qn2 = q_norm2_max; p.kn2 = k_norm2_max;
+  launch_shape(p, hd, workspace, workspace_bytes);
+  int rc = run(p);
+  if (rc != 0) return rc;
+  // the general twin: 256-row units, no tail split (its units write their final rows; the merge kernel skips them)
+  AttnParams g = p;
+  g.bound = 0.f; g.rows = 256; g.tail_split = 1; g.tail_first = 0x7fffffff; g.ws_o = nullptr; g.ws_lse = nullptr;
+  rc = run(g);
+  if (rc != 0) return rc;
+  return p.tail_split == 1 ? OSK_OK : osk_attn::launch_merge(p, hd, st);
+}
+
+// squared row norms of a bf16 [B, L, H * hd] view, maximum per (batch, head): out[b * H + h] = max_l sum_d x[b, l, h, d]^2  (f32).
+// HBM-bound: one read of the tensor.  accumulate != 0 keeps the values already in `out` (several key segments / sequence-parallel ranks
+// fold into one maximum); else out is zeroed first (stream-ordered).  Non-negative floats order like their bit patterns: integer atomics.
+namespace {
+template <int HD>
+__global__ void __launch_bounds__(256) rownorm2_max_kernel(const unsigned short* __restrict__ x, int64_t bs, int64_t rs, int L, int H,
+                                                           int rows_per_block, unsigned* __restrict__ out) {
+  __shared__ unsigned smax[256];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < H; i += 256) smax[i] = 0;
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = r0 + rows_per_block < L ? r0 + rows_per_block : L;
+  const int pairs = (r1 - r0) * H;                       // (row, head) pairs of this block's slab, head fastest
+  constexpr int CPR = HD / 8;
+  for (int i = threadIdx.x; i < pairs; i += 256) {
+    const int r = r0 + i / H, h = i - (i / H) * H;
+    const unsigned short* px = x + b * bs + (int64_t)r * rs + h * HD;
+    uint4 u[CPR];
+#pragma unroll
+    for (int c = 0; c < CPR; ++c) u[c] = *reinterpret_cast<const uint4*>(px + c * 8);   // all loads first
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPR; ++c) {
+      float f[8];
+      unpack8(u[c], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+    }
+    atomicMax(&smax[h], __float_as_uint(ss));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += 256)
+    if (smax[i]) atomicMax(&out[b * H + i], smax[i]);
+}
+}  // namespace
+
+extern "C" int osk_rownorm2_max_bf16(const void* x, int64_t batch_stride, int64_t row_stride, int B, int L, int H, int hd,
+                                     float* out, int accumulate, void* stream) {
+  if (!x || !out || B <= 0 || L <= 0 || H <= 0 || H > 256 || (batch_stride & 7) || (row_stride & 7) || ((uintptr_t)x & 15) || ((uintptr_t)out & 3))
+    return OSK_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * B * H, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  int rows = (L + 255) / 256;             // about 256 blocks per batch item: few, fat blocks (same-address atomics are slow)
+  if (rows < 16) rows = 16;
+  dim3 grid((L + rows - 1) / rows, B), block(256);
+  unsigned* o = reinterpret_cast<unsigned*>(out);
+  if (hd == 64) hipLaunchKernelGGL(rownorm2_max_kernel<64>, grid, block, 0, st, (const unsigned short*)x, batch_stride, row_stride, L, H, rows, o);
+  else if (hd == 72) hipLaunchKernelGGL(rownorm2_max_kernel<72>, grid, block, 0, st, (const unsigned short*)x, batch_stride, row_stride, L, H, rows, o);
+  else if (hd == 128) hipLaunchKernelGGL(rownorm2_max_kernel<128>, grid, block, 0, st, (const unsigned short*)x, batch_stride, row_stride, L, H, rows, o);
+  else return OSK_EUNSUPPORTED;
+  return (int)hipGetLastError();
 }
 
 extern "C" int osk_attention_fwd_ws_bf16(const void* q, int64_t q_batch_stride, int64_t q_row_stride,

@@ -35,12 +35,33 @@ struct AttnParams {
   // osk_v_transpose_fp8, one f32 scale per (key batch, head)
   const unsigned char* vt8 = nullptr;
   const float* v_scale = nullptr;
+  // device-derived score bound (round 6, osk_attention_fwd_auto_bf16): squared row-norm maxima of the q and k the kernel receives,
+  // per (batch, head) -- qn2 [B, H], kn2 [Bkv, H], from osk_rownorm2_max_bf16.  With both set, every workgroup derives ITS bound
+  // sqrt(qn2 kn2) (Cauchy-Schwarz on the actual operands) and the launch is one of a PAIR over the same grid: the FAST kernel's
+  // workgroups run where that bound is <= OSK_ATTN_MAX_BOUND and exit at once elsewhere, the general kernel's the other way round
+  // (attn_auto_bound below) -- no host round trip, no promise from the caller, hipGraph-capturable.
+  const float* qn2 = nullptr;
+  const float* kn2 = nullptr;
 };
 
 #define OSK_ATTN_MAX_BOUND 56.0f   // P = exp2(s - bound) >= 2^-112 for every admissible score: no underflow to zero
 
 static inline bool attn_fast_path(const AttnParams& p) {   // host side
   return p.bound > 0.f && p.bound <= OSK_ATTN_MAX_BOUND && (p.n_seg == 1 || p.tps >= 3);
+}
+
+// Which of the two kernels of an auto-dispatched pair works on (batch b, head h), and with which bound?  Host-decided launches
+// (qn2 == nullptr): every workgroup runs, bound = the caller's.  Returns false when THIS kernel (fast_kernel: its FAST instantiation)
+// must leave the unit to its twin.  Wave-uniform (scalar loads).
+OSK_DEV bool attn_auto_bound(const AttnParams& p, int b, int h, bool fast_kernel, float& bound) {
+  bound = p.bound;
+  if (!p.qn2) return true;
+  // the norms are those of the bf16 values the MFMA multiplies: |q . k| <= |q| |k| exactly; 1.004 covers the f32 rounding of the
+  // products and the square root; then UP to the next bf16 value (the kernels keep the bound in a bf16 field of Q's padding dim)
+  const float v = __builtin_sqrtf(p.qn2[b * p.H + h] * p.kn2[(b % p.Bkv) * p.H + h]) * 1.004f;
+  bound = __uint_as_float((__float_as_uint(v) + 0xFFFFu) & 0xFFFF0000u);
+  const bool fast_ok = bound <= OSK_ATTN_MAX_BOUND;      // (NaN / inf norms: false -> the general body)
+  return fast_ok == fast_kernel;
 }
 
 // (batch*head, query block) of a workgroup.  map 1 hands every XCD (block b runs on XCD b % 8) a contiguous

@@ -592,6 +592,12 @@ def _mod_views(mod: Tensor, col: int, n: int, D: int):
     return [mod[:, col + i * D: col + (i + 1) * D] for i in range(n)], mod.stride(0)
 
 
+# blocks whose weight-derived score bound exceeds the FAST body's limit take the bound from their operands on the device
+# (osk_attention_fwd_auto_bf16) instead of falling to the general body wholesale; False = round 5's behaviour
+AUTO_BOUND = True
+SCORE_BOUND_LIMIT = 56.0   # csrc/attention_params.h: OSK_ATTN_MAX_BOUND
+
+
 def q_mult(hd: int) -> float:
     """softmax scale * log2(e): folded into q by the QK-norm + RoPE kernel before q's single rounding to bf16, so the
     attention kernels exponentiate (in base 2) what the MFMA hands them (include/osk.h, q_prescaled)."""
@@ -625,6 +631,18 @@ def _joint_attention(ws: _Workspace, q: Tensor, k: Tensor, v: Tensor, H: int, hd
         return
     if not vt_ready:
         _OPS.v_transpose(v, ws.vt, H, hd)
+    if AUTO_BOUND and not (0.0 < score_bound <= SCORE_BOUND_LIMIT) and hasattr(_OPS, "attention_fwd_auto"):
+        # The weight-derived bound does not admit the FAST body (a checkpoint whose QK-norm scale vectors have large entries: the
+        # bound is sqrt(hd)-loose per side).  Take the bound from the operands instead, on the device: squared row-norm maxima of
+        # this call's q and k per (batch, head), then the auto-dispatched launch pair -- every (batch, head) whose actual
+        # |q| |k| <= 56 runs the FAST body, the rest the general one; no host round trip (include/osk.h).
+        n2 = getattr(ws, "qk_n2", None)
+        if n2 is None:
+            n2 = ws.qk_n2 = torch.empty(2, q.shape[0], H, dtype=torch.float32, device=q.device)
+        _OPS.rownorm2_max(q, n2[0], H, hd)
+        _OPS.rownorm2_max(k, n2[1], H, hd)
+        _OPS.attention_fwd_auto(q, k, ws.vt, v, H, hd, hd ** -0.5, n2[0], n2[1], q_prescaled=True, workspace=wsp)
+        return
     _OPS.attention_fwd(q, k, ws.vt, v, H, hd, hd ** -0.5, q_prescaled=True, workspace=wsp, score_bound=score_bound)
 
 
@@ -912,8 +930,11 @@ class MMDiTModel(_OskState, nn.Module):
         plans = [plan_double(b) for b in self.double_blocks] + [plan_single(b) for b in self.single_blocks]
         bounds = [float(p.score_bound) for p in plans]
         bodies = sorted({_OPS.attention_body(hd, n_seg, seg_len, b) for b in bounds}) if hasattr(_OPS, "attention_body") else []
-        return {"score_bound_min": min(bounds), "score_bound_max": max(bounds), "bound_limit": 56.0, "bodies": bodies,
-                "blocks_on_fast_body": sum(1 for b in bounds if 0.0 < b <= 56.0), "blocks": len(bounds)}
+        auto = sum(1 for b in bounds if not (0.0 < b <= SCORE_BOUND_LIMIT)) if AUTO_BOUND and hasattr(_OPS, "attention_fwd_auto") else 0
+        return {"score_bound_min": min(bounds), "score_bound_max": max(bounds), "bound_limit": SCORE_BOUND_LIMIT, "bodies": bodies,
+                "blocks_on_fast_body": sum(1 for b in bounds if 0.0 < b <= SCORE_BOUND_LIMIT), "blocks": len(bounds),
+                # blocks whose weight-derived bound is too large: FAST / general chosen per (batch, head) on the device from the operands
+                "blocks_auto_dispatched": auto}
 
     def invalidate_plan(self):
         self._plan = None

@@ -338,6 +338,25 @@ def attention_fwd(q, k, vt, out, H, hd, scale, *, lse=None, n_seg=1, seg_len=Non
     return out
 
 
+def rownorm2_max(x, out, H, hd, accumulate=False):
+    """CPU statement of osk_rownorm2_max_bf16"""
+    B, L, _ = x.shape
+    n2 = x.float().reshape(B, L, H, hd).pow(2).sum(-1).amax(1)
+    out.copy_(torch.maximum(out, n2) if accumulate else n2)
+    return out
+
+
+def attention_fwd_auto(q, k, vt, out, H, hd, scale, qn2, kn2, *, lse=None, n_seg=1, seg_len=None, k_seg_stride=0, vt_seg_stride=0,
+                       q_prescaled=True, kv_batches=0, workspace=None):
+    """osk_attention_fwd_auto_bf16: the same softmax whichever body a (batch, head) takes; the emulation checks the norms it was handed
+    against the operands (a stale or foreign norm buffer is the host bug this guards)"""
+    B = q.shape[0]
+    want_q = q.float().reshape(B, q.shape[1], H, hd).pow(2).sum(-1).amax(1)
+    assert torch.allclose(qn2.reshape(B, H), want_q, rtol=1e-5), "q_norm2_max does not belong to this q"
+    return attention_fwd(q, k, vt, out, H, hd, scale, lse=lse, n_seg=n_seg, seg_len=seg_len, k_seg_stride=k_seg_stride,
+                         vt_seg_stride=vt_seg_stride, q_prescaled=q_prescaled, kv_batches=kv_batches, workspace=workspace)
+
+
 def copy_rows_ok(src, dst):
     if not (src.dtype == dst.dtype == torch.bfloat16 and src.ndim == dst.ndim and src.ndim in (3, 4)):
         return False

@@ -750,6 +750,112 @@ def test_attention_sequence_parallel_rank_shape_720p(hip_lib, hd, H):
     assert (out.float() - c.float()[None, None]).abs().max().item() <= 2 ** -6 * c.float().abs().max().item() + 1e-3
 
 
+# ----------------------------------------------------------------------------- device-derived score bound (round 6)
+@pytest.mark.parametrize("hd,H", [(72, 8), (64, 6), (128, 4)])
+def test_rownorm2_max(hip_lib, hd, H):
+    B, L = 3, 1000
+    D = H * hd
+    buf = rnd("x", (B, L + 3, D + 64), std=1.3, seed=301)
+    x = buf[:, 3:, :D]                                            # a strided view
+    out = torch.full((B, H), -1.0, dtype=torch.float32, device=DEV)
+    hip_lib.rownorm2_max(x, out, H, hd)
+    ref = x.float().reshape(B, L, H, hd).pow(2).sum(-1).amax(1)
+    assert (out - ref).abs().max().item() <= 1e-4 * ref.max().item()
+    out2 = out.clone() * 0 + 1e9                                   # accumulate keeps what is there
+    hip_lib.rownorm2_max(x, out2, H, hd, accumulate=True)
+    assert (out2 == 1e9).all()
+
+
+def _auto_case(hip_lib, hd, H, B, Lq, Lk, scales, seed, n_seg=1, kv_batches=0):
+    """q, k as the model makes them (unit RMS x per-(batch, head) scale, q pre-scaled); per (batch, head) `scales[b][h]` sets the size
+    of |q| |k| -- some pairs below the FAST limit, some above -- and the auto-dispatched pair must equal fp64 on every one of them"""
+    D = H * hd
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    Bkv = kv_batches or B
+    seg = Lk // n_seg
+
+    def unit(t):
+        sh = t.shape
+        t = t.view(*sh[:-1], H, hd)
+        return (t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6)).view(sh)
+
+    sc = torch.tensor(scales, dtype=torch.float32, device=DEV)                       # [rows, H]
+    sc = sc.repeat((B + sc.shape[0] - 1) // sc.shape[0], 1)[:B]                       # one row per query batch
+    q = unit(torch.randn(B, Lq, D, device=DEV, generator=g)).view(B, Lq, H, hd) * sc[:, None, :, None] * (hd ** -0.5 * 1.4426950408889634)
+    q = q.view(B, Lq, D).to(BF)
+    k = (unit(torch.randn(n_seg, Bkv, seg, D, device=DEV, generator=g)).view(n_seg, Bkv, seg, H, hd) * sc[None, :Bkv, None, :, None]).view(n_seg, Bkv, seg, D).to(BF)
+    v = torch.randn(n_seg, Bkv, seg, D, device=DEV, generator=g).to(BF)
+    segp = (seg + 63) // 64 * 64
+    vt = torch.zeros(n_seg, Bkv, H, hd, segp, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v.view(n_seg * Bkv, seg, D), vt.view(n_seg * Bkv, H, hd, segp), H, hd)
+    n2 = torch.empty(2, max(B, Bkv), H, dtype=torch.float32, device=DEV)
+    hip_lib.rownorm2_max(q, n2[0, :B], H, hd)
+    for s_ in range(n_seg):
+        hip_lib.rownorm2_max(k[s_], n2[1, :Bkv], H, hd, accumulate=s_ > 0)
+    bounds = (n2[0, :B].view(B, H) * n2[1, :Bkv].view(Bkv, H).repeat(B // Bkv, 1)).sqrt()
+    out = torch.empty(B, Lq, D, dtype=BF, device=DEV)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=DEV)
+    ws = hip_lib.attention_workspace(q.device)
+    hip_lib.attention_fwd_auto(q, k[0], vt, out, H, hd, hd ** -0.5, n2[0, :B].contiguous(), n2[1, :Bkv].contiguous(), lse=lse, n_seg=n_seg, seg_len=seg,
+                               k_seg_stride=k.stride(0), vt_seg_stride=vt.stride(0), kv_batches=kv_batches, workspace=ws)
+    kk = k.permute(1, 0, 2, 3).reshape(Bkv, n_seg * seg, H, hd).double().permute(0, 2, 3, 1).repeat(B // Bkv, 1, 1, 1)      # [B, H, hd, Lk]
+    vv = v.permute(1, 0, 2, 3).reshape(Bkv, n_seg * seg, H, hd).double().permute(0, 2, 1, 3).repeat(B // Bkv, 1, 1, 1)
+    s2 = q.double().view(B, Lq, H, hd).permute(0, 2, 1, 3) @ kk                                                            # log2 units
+    p_ = torch.softmax(s2 * 0.6931471805599453, -1)
+    ref = (p_ @ vv).permute(0, 2, 1, 3).reshape(B, Lq, D)
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2.5e-2, err
+    assert (lse.double() - torch.logsumexp(s2 * 0.6931471805599453, -1)).abs().max().item() <= 6e-3
+    return bounds, out
+
+
+@pytest.mark.parametrize("hd,H", [(72, 4), (64, 4), (128, 4)])
+def test_attention_auto_bound_mixes_fast_and_general_units(hip_lib, hd, H):
+    """osk_attention_fwd_auto_bf16: the bound comes from the operands, per (batch, head).  Scales chosen so that the (batch, head)
+    pairs straddle the FAST limit 56 (bound = 1.44 sqrt(hd) s^2 up to rounding): both kernels of the launch pair work, each on its
+    own units, the result equals fp64 everywhere -- wide units (Lq >= 1024), a ragged key tile, a tail split, segments, kv_batches."""
+    c = hd ** 0.5 * 1.4426950408889634
+    lo, hi = (20.0 / c) ** 0.5, (90.0 / c) ** 0.5                       # bounds ~20 (FAST) and ~90 (general)
+    scales = [[lo, hi, lo, hi][:H], [hi, hi, lo, lo][:H]]
+    bounds, _ = _auto_case(hip_lib, hd, H, 2, 1500, 2000 + 37, scales, seed=311)
+    assert (bounds.min().item() < 56.0 < bounds.max().item()), bounds
+    _auto_case(hip_lib, hd, H, 2, 300, 640, scales, seed=312)                                   # 256-row units only
+    _auto_case(hip_lib, hd, H, 2, 1100, 4 * 256, scales, seed=313, n_seg=4)                     # key segments of 4 tiles
+    _auto_case(hip_lib, hd, H, 4, 700, 900, scales, seed=314, kv_batches=2)                     # query batches sharing key sets
+    # every pair FAST / every pair general: the twin launches nothing but early exits
+    _auto_case(hip_lib, hd, H, 2, 1200, 1300, [[lo] * H, [lo] * H], seed=315)
+    _auto_case(hip_lib, hd, H, 2, 1200, 1300, [[hi] * H, [hi] * H], seed=316)
+
+
+def test_attention_auto_bound_adversarial_rows(hip_lib):
+    """rows the weight-derived promise could not cover: one dominant key (its score sits AT the Cauchy-Schwarz bound), all keys equal
+    (softmax = uniform: the output is the mean of V), a zero query row"""
+    hd, H, B, Lq, Lk = 72, 4, 1, 1100, 1500
+    D = H * hd
+    g = torch.Generator(device=DEV).manual_seed(321)
+    q = (torch.randn(B, Lq, D, device=DEV, generator=g) * 0.35).to(BF)
+    k = (torch.randn(B, Lk, D, device=DEV, generator=g) * 0.9).to(BF)
+    v = torch.randn(B, Lk, D, device=DEV, generator=g).to(BF)
+    q[0, 7] = 0                                                   # zero query row: uniform softmax
+    q[0, 9] = (k[0, 123].float() * 0.4).to(BF)                    # aligned with one key of large norm: that key dominates
+    k[0, 123] = k[0, 123] * 3
+    k[0, :, 2 * hd: 3 * hd] = k[0, 0, 2 * hd: 3 * hd]            # head 2: all keys equal
+    vt = torch.zeros(B, H, hd, (Lk + 63) // 64 * 64, dtype=BF, device=DEV)
+    hip_lib.v_transpose(v, vt, H, hd)
+    n2 = torch.empty(2, B, H, dtype=torch.float32, device=DEV)
+    hip_lib.rownorm2_max(q, n2[0], H, hd)
+    hip_lib.rownorm2_max(k, n2[1], H, hd)
+    out = torch.empty(B, Lq, D, dtype=BF, device=DEV)
+    hip_lib.attention_fwd_auto(q, k, vt, out, H, hd, 1.0 / 1.4426950408889634, n2[0], n2[1], q_prescaled=True, workspace=hip_lib.attention_workspace(q.device))
+    s2 = q.double().view(B, Lq, H, hd).permute(0, 2, 1, 3) @ k.double().view(B, Lk, H, hd).permute(0, 2, 3, 1)
+    ref = (torch.softmax(s2 * 0.6931471805599453, -1) @ v.double().view(B, Lk, H, hd).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, Lq, D)
+    assert torch.isfinite(out.float()).all()
+    assert (out.double() - ref).abs().max().item() <= 2.5e-2
+    mean_v = v.double().view(B, Lk, H, hd).mean(1)                # head 2 (equal keys) and row 7 (zero query): the mean of V
+    assert (out[0, :, 2 * hd: 3 * hd].double() - mean_v[0, 2]).abs().max().item() <= 1e-2
+    assert (out[0, 7].double() - mean_v[0].reshape(D)).abs().max().item() <= 1e-2
+
+
 # ----------------------------------------------------------------------------- osk_gemm_group_bf16 (round 6)
 def _vt_reference(hip_lib, x, w, bias, H, hd):
     """the two-kernel path the V^T task replaces: osk_gemm_bf16 into [B, L, H*hd] + osk_v_transpose_bf16"""

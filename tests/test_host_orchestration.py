@@ -161,6 +161,46 @@ def test_engine_takes_the_group_projection_path(cpu_mmdit):
     assert d <= 2.0 ** -6 * out2.float().abs().max() + 1e-3, d
 
 
+def test_blocks_with_a_large_weight_bound_take_the_bound_from_their_operands(cpu_mmdit):
+    """round 6: QK-norm scale vectors whose weight-derived bound exceeds the FAST limit (hd max|w_q| max|w_k| > 56 in log2 units) no
+    longer send the block to the general attention body wholesale: the engine measures the row norms of the q / k it is about to
+    multiply (osk_rownorm2_max_bf16) and calls the auto-dispatched attention with them; same result as the plain call."""
+    cfg, B, T, h, w, L_txt = configs.GOLDEN["hd64_eager_fused"]
+    model = _build(cpu_mmdit, cfg)
+    with torch.no_grad():
+        for blk in list(model.double_blocks) + list(model.single_blocks):
+            for nrm in ([blk.img_attn.norm, blk.txt_attn.norm] if hasattr(blk, "img_attn") else [blk.norm]):
+                nrm.query_norm.scale.mul_(3.0)
+                nrm.key_norm.scale.mul_(3.0)
+    inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF)
+    calls = {"auto": 0, "norm": 0}
+    real_auto, real_norm = cpu_ops.attention_fwd_auto, cpu_ops.rownorm2_max
+
+    def spy_auto(*a, **k):
+        calls["auto"] += 1
+        return real_auto(*a, **k)
+
+    def spy_norm(*a, **k):
+        calls["norm"] += 1
+        return real_norm(*a, **k)
+
+    cpu_ops.attention_fwd_auto, cpu_ops.rownorm2_max = spy_auto, spy_norm
+    try:
+        with torch.inference_mode():
+            out = model(**inp)
+            rep = model.attention_report()
+            n_blocks = cfg["depth"] + cfg["depth_single_blocks"]
+            assert rep["score_bound_min"] > 56.0 and rep["blocks_auto_dispatched"] == n_blocks
+            assert calls["auto"] == n_blocks and calls["norm"] == 2 * n_blocks
+            cpu_mmdit.AUTO_BOUND = False
+            out2 = model(**inp)
+            assert calls["auto"] == n_blocks
+    finally:
+        cpu_ops.attention_fwd_auto, cpu_ops.rownorm2_max = real_auto, real_norm
+        cpu_mmdit.AUTO_BOUND = True
+    assert torch.equal(out, out2)
+
+
 def test_processors_install_on_reference_blocks(cpu_mmdit):
     """The plug-in point of the reference itself: block.set_processor(...) on the reference's own
     DoubleStreamBlock / SingleStreamBlock (only where /root/reference is mounted)."""
