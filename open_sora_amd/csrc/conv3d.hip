@@ -251,15 +251,18 @@ __global__ void __launch_bounds__(256, 2) conv_fewout_kernel(const ConvParams p)
   }
   __syncthreads();
   const int lane = tid & 63, sub = lane >> 4, ch = lane & 15;
-  const int seg = blockIdx.x * 4 + (tid >> 6);                 // 64-voxel segment of an output row
-  const int segs_per_row = p.Wo >> 6;
-  const int nseg = p.B * p.To * p.Ho * segs_per_row;
-  if (seg >= nseg) return;
-  const int w0 = ((seg % segs_per_row) << 6) + 16 * sub;       // this lane's 16 consecutive output voxels: w0 .. w0 + 15
-  int q = seg / segs_per_row;
-  const int ho = q % p.Ho;
-  q /= p.Ho;
+  // a block = the SAME 64-voxel column segment of 4 consecutive output rows, one per wave (round 6; before: 4 consecutive segments of
+  // one row): the 4 waves read input rows ho - 1 .. ho + 4 -- 6 distinct rows for 12 row reads -- so half of the block's loads hit
+  // the CU's L1 instead of going to L2 (the kernel was L2-bound: every input row is read by 3 output rows x 3 frames)
+  const int segs_per_row = p.Wo >> 6, hblocks = (p.Ho + 3) >> 2;
+  int q = blockIdx.x;
+  const int cs = q % segs_per_row;
+  q /= segs_per_row;
+  const int ho = ((q % hblocks) << 2) + (tid >> 6);
+  q /= hblocks;
   const int to = q % p.To, b = q / p.To;
+  if (ho >= p.Ho || b >= p.B) return;
+  const int w0 = (cs << 6) + 16 * sub;                         // this lane's 16 consecutive output voxels: w0 .. w0 + 15
   float acc[16][NC];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
@@ -377,8 +380,7 @@ static int conv_entry(const void* x, int B, int T, int H, int W, int Cin, const 
     if (big) return osk_conv::launch_conv256(p, s);
   }
   if (fewout_supported(p)) {
-    const int nseg = B * To * Ho * (Wo >> 6);
-    const dim3 g((nseg + 3) / 4), blk(256);
+    const dim3 g((unsigned)(B * To * ((Ho + 3) / 4) * (Wo >> 6))), blk(256);
     if (Cout == 1) hipLaunchKernelGGL((conv_fewout_kernel<1>), g, blk, 0, s, p);
     else if (Cout == 2) hipLaunchKernelGGL((conv_fewout_kernel<2>), g, blk, 0, s, p);
     else if (Cout == 3) hipLaunchKernelGGL((conv_fewout_kernel<3>), g, blk, 0, s, p);

@@ -207,6 +207,8 @@ class SeqPar:
         B, Lloc, _ = k.shape
         if pv8:
             sv = mmdit.v_scale_fp8(v, H, hd)
+            # (co-residency rule of INTEGRATION.md section 4: the only REDUCING collective of this file; until its wait() below the
+            #  compute stream runs the K copy only -- no hand-scheduled MFMA kernel overlaps RCCL's reduction kernel)
             wmax = self.tp.all_reduce_max(sv)                         # on the communication stream ...
             k_all, vt8_all = self._buffers8(B, Lloc, H, hd, k.device)
             mmdit.ops().copy_rows(k, k_all[self.rank])
