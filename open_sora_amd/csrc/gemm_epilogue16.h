@@ -35,9 +35,12 @@ OSK_DEV void gelu_tanh_quad(float* acc) {
     asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(x2), "v"(c1), "v"(c0));
     asm("v_pk_mul_f32 %0, %1, %2" : "=v"(u) : "v"(x), "v"(t));
     const osk_v2f e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(e), "v"(one));
+    // (a transcendental's result read by the next VALU instruction needs a wait state the compiler inserts for its own code but cannot
+    //  see inside an asm statement: without the s_nop the high halves of some lanes read the register before v_exp_f32 / v_rcp_f32
+    //  had written it -- found by tests/test_gpu_kernels.py::test_gemm_persistent_multi_tile, odd columns wrong)
+    asm("s_nop 1\n\tv_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(e), "v"(one));
     const osk_v2f r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(r));
+    asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(r));
     acc[2 * h] = y[0];
     acc[2 * h + 1] = y[1];
   }
