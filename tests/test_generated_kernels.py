@@ -271,3 +271,50 @@ def test_asm_accumulators_are_values_the_compiler_knows():
                                                                            repr(os.path.join(d, "acc_quads.h")))
         sp.run([sys.executable, "-c", gen], check=True, env=env, capture_output=True)
         assert open(os.path.join(d, "acc_quads.h")).read() == open(os.path.join(CSRC, "acc_quads.h")).read(), "acc_quads.h is stale: re-run tools/gen_acc_quads.py"
+
+
+def test_no_compiler_instruction_writes_an_agpr_in_the_gemm_kernels(tmp_path):
+    """the accumulators become compiler-visible through an empty asm statement BEHIND the K-loop statement, which only
+    clobbers a0..a255 -- nothing in the constraints forbids the compiler to park a value of its own in an AGPR between the two
+    statements.  The by-construction argument is that it has no reason to (its values live in VGPRs, spills go to scratch); this test
+    pins it on the compiler's actual output: in the device assembly of gemm256x.hip (the hottest wrapper, 256 accumulators + ~250
+    VGPRs: the highest register pressure of the library) no instruction OUTSIDE the inline-asm blocks has an AGPR destination."""
+    import shutil
+    import subprocess as sp
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    from open_sora_amd.build import flags_for
+
+    src = os.path.join(CSRC, "gemm256x.hip")
+    out = str(tmp_path / "gemm256x.s")
+    flags = [f for f in flags_for(src) if f != "-fPIC"]
+    r = sp.run([hipcc, *flags, "--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # hipcc brackets every asm statement with ;;#ASMSTART / ;;#ASMEND.  The K-loop statement is the one that contains MFMAs; the empty
+    # statement that follows it is the binding.  What the compiler schedules BETWEEN the two (scalar compares, SGPR-spill reloads ...)
+    # must not touch an AGPR: until the binding the accumulators are, to the compiler, dead registers it could use as scratch.
+    lines = open(out).read().split("\n")
+    n_loops, between, i = 0, [], 0
+    while i < len(lines):
+        if lines[i].strip().startswith(";;#ASMSTART"):
+            j = i + 1
+            has_mfma = False
+            while not lines[j].strip().startswith(";;#ASMEND"):
+                has_mfma = has_mfma or lines[j].lstrip().startswith("v_mfma")
+                j += 1
+            if has_mfma:                                   # a K-loop statement: collect up to the next asm statement (the binding)
+                n_loops += 1
+                k = j + 1
+                while not lines[k].strip().startswith(";;#ASMSTART"):
+                    t = lines[k].split(";")[0].strip()
+                    if t and not t.endswith(":") and not t.startswith("."):
+                        between.append(t)
+                    k += 1
+                assert lines[k + 1].strip().startswith(";;#ASMEND"), "the statement behind a K loop is not the empty accumulator binding"
+            i = j
+        i += 1
+    assert n_loops >= 4, "the assembly does not look like the GEMM wrappers'"
+    bad = [t for t in between if re.search(r"\ba\d+\b|\ba\[\d", t) or "accvgpr" in t]
+    assert not bad, f"the compiler touches AGPRs between a K loop and its accumulator binding: {bad[:5]}"
