@@ -756,7 +756,7 @@ def dit_line(args, dev, dist, rank, world, model_name, steps, warmup, with_b1, g
                 if rec["kernel"].startswith("gemm256x"):   # the latest record wins
                     traffic_g, traffic_g_src = rec["hbm_bytes_per_step"], rec["source"]
         roofline_gemm = {"bound": "mfma", "kernel": "gemm256_kernel<fp8> (block Linears on the fp8 MFMA)" if args.fp8 else
-                         "gemm256x_kernel<.,1> + gemm256x_kernel<.,2> (img + txt pairs) (+ the Vt group launch: gemm256x_kernel<.,4>)",
+                         "gemm256x_kernel<.,1> + gemm256x_kernel<.,2> (img + txt pairs) + gemm256x_vt_kernel (V^T written by the projection)",
                          "achieved": round(ach_g, 1), "peak": peak_g, "unit": "TFLOP/s", "frac": round(ach_g / peak_g, 4),
                          "traffic": traffic_g, "traffic_kind": "recorded per STEP (PMC passes, see traffic_source)" if traffic_g else "no record",
                          "traffic_source": traffic_g_src,

@@ -13,39 +13,6 @@ using epi::GELU_ALL;
 using epi::GELU_MIXED;
 using epi::GELU_NONE;
 
-// tanh-GELU of an accumulator quad on PACKED f32 arithmetic (round 6): the five full-rate operations of gelu_tanh (osk_common.h) run on
-// register pairs -- v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32, two elements per issue slot -- and only v_exp_f32 / v_rcp_f32 stay
-// per element: 18 instructions per quad instead of 28 (the GELU class costs the epilogue 11.5 k cycles per 256 x 256 tile,
-// 101 k such tiles per XL step).  Same operation order and rounding per element as gelu_tanh -- bit-identical results.
-// Hand-written packed FP32 INSIDE THIS KERNEL ONLY: the library is built with hipcc's own packed-FP32 selection off because such
-// code is a victim of the cross-kernel interference of profiles/r03_cross_kernel_interference.md when ANOTHER wave keeps MFMAs in
-// flight on the same SIMD; gemm256x_kernel owns its SIMD's whole register file (one wave per SIMD: nothing can be co-resident),
-// and round 3 found plain packed chains without op_sel half selection (these) never affected anyway.  gemm256p (two waves per
-// SIMD) keeps the scalar form.
-typedef float osk_v2f __attribute__((ext_vector_type(2)));
-template <int UNUSED = 0>   // (a template: its gfx950 asm is only looked at where it is instantiated -- in device code)
-OSK_DEV void gelu_tanh_quad(float* acc) {
-  constexpr float K0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
-  const osk_v2f c1 = {0.044715f * K0, 0.044715f * K0}, c0 = {K0, K0}, one = {1.0f, 1.0f};
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const osk_v2f x = {acc[2 * h], acc[2 * h + 1]};
-    osk_v2f x2, t, u, d, y;
-    asm("v_pk_mul_f32 %0, %1, %1" : "=v"(x2) : "v"(x));
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(x2), "v"(c1), "v"(c0));
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(u) : "v"(x), "v"(t));
-    const osk_v2f e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
-    // (a transcendental's result read by the next VALU instruction needs a wait state the compiler inserts for its own code but cannot
-    //  see inside an asm statement: without the s_nop the high halves of some lanes read the register before v_exp_f32 / v_rcp_f32
-    //  had written it -- found by tests/test_gpu_kernels.py::test_gemm_persistent_multi_tile, odd columns wrong)
-    asm("s_nop 1\n\tv_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(e), "v"(one));
-    const osk_v2f r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(r));
-    acc[2 * h] = y[0];
-    acc[2 * h + 1] = y[1];
-  }
-}
-
 // one interior tile up to (not including) the store: acc[4] -> final values.  Interior tiles never add the bias here: the
 // accumulators started from it (an interior wave tile has all its columns inside N, which is the kernel's "folded" condition).
 // GATE and the tile's GELU class are compile-time / hoisted: 64 tiles per wave make every per-tile branch count.
@@ -53,12 +20,11 @@ template <class Geo, int T, bool GATE, int GELU>
 OSK_DEV void tile_values_rv(const osk_v4f* aq, const GemmParams& p, int n, const float4& gq, const uint2& rv, float* acc) {
   Geo::template read<T>(aq, acc);
   if constexpr (GELU == GELU_ALL) {
-#ifdef OSK_GEMM_SCALAR_GELU   // (A/B builds of tools/)
+    // (round 6 tried the five full-rate operations of gelu_tanh on hand-written packed-FP32 pairs, 18 instructions per quad instead
+    //  of 28: no measurable gain once the wait states a transcendental's result needs before a packed read were in -- withdrawn,
+    //  profiles/r06g_gelu_packed_ab.jsonl)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = gelu_tanh(acc[i]);
-#else
-    gelu_tanh_quad<>(acc);
-#endif
   } else if constexpr (GELU == GELU_MIXED) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -8,6 +8,7 @@ run() {  # name, counters, command...
   tail -1 $O/$name.log | cut -c1-160
 }
 export OSK_BENCH_NO_GN_FOLD=1
+if [ -z "$PMC_ONLY_DIT" ]; then
 run vae_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
 run vae_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
 # the same step with the opt-in GroupNorm fold (hunyuan_vae.FOLD_GN)
@@ -16,6 +17,7 @@ OSK_VAE_FOLD_GN=1 run vaefold_write "WRITE_SIZE" python bench.py --workload vae 
 if [ -n "$PMC_LINEAR_CONV" ]; then   # the round-1 tile mapping of conv256t for comparison
   run vaelin_fetch "FETCH_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
   run vaelin_write "WRITE_SIZE" python bench.py --workload vae --steps 1 --warmup 0 --no-cpu-baseline
+fi
 fi
 if [ -z "$PMC_ONLY_VAE" ]; then
 run dit_fetch "FETCH_SIZE" python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-b1 --no-extra
@@ -27,7 +29,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/*/*counter_collection.csv")):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        key = next((k for k in ("convsw2_kernel", "convsw_kernel", "conv256x_kernel", "conv256w_kernel", "conv256t_kernel", "gemm256x_kernel", "conv256_kernel", "conv3d_kernel", "gemm256w_kernel", "gemm256p_kernel",
+        key = next((k for k in ("gemm256x_vt_kernel", "conv_fewout_kernel", "rownorm2_max", "attn_asm72w_kernel", "attn_merge", "convsw2_kernel", "convsw_kernel", "conv256x_kernel", "conv256w_kernel", "conv256t_kernel", "gemm256x_kernel", "conv256_kernel", "conv3d_kernel", "gemm256w_kernel", "gemm256p_kernel",
                                 "gemm256_kernel", "gemm_bf16_kernel", "attn_asm72_kernel", "attn_hd512_kernel", "gn_stats",
                                 "gn_apply", "qknorm_rope", "ln_modulate", "v_transpose") if k in n), None)
         if key:
