@@ -34,6 +34,15 @@ class _Counting:
             self.gemm(d["a"], d["w"], d["bias"], d["out"], gelu_from=gelu_from,
                       **{k: d[k] for k in ("res", "gate", "gate_batch_stride") if k in d})
 
+    def gemm_group(self, tasks):     # bf16 mode (round 6): a block's projection as a task list -- the V^T task belongs to the same Linear
+        ok = cpu_ops.gemm_group(tasks)      # as the plain task of its stream: one count per Linear layer, as before
+        if ok:
+            for d in tasks:
+                if "vt" not in d:
+                    self.n_bf16 += 1
+                    self.bf16_shapes.append((d["a"].shape[0] * d["a"].shape[1], d["w"].shape[0], d["a"].shape[2]))
+        return ok
+
     def gemm_fp8(self, *a, **kw):
         self.n_fp8 += 1
         return cpu_ops.gemm_fp8(*a, **kw)
