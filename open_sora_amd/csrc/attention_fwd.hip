@@ -265,6 +265,11 @@ extern "C" int osk_attention_fwd_auto_bf16(const void* q, int64_t q_batch_stride
 // HBM-bound: one read of the tensor.  accumulate != 0 keeps the values already in `out` (several key segments / sequence-parallel ranks
 // fold into one maximum); else out is zeroed first (stream-ordered).  Non-negative floats order like their bit patterns: integer atomics.
 namespace {
+__global__ void zero_u32_kernel(unsigned* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 template <int HD>
 __global__ void __launch_bounds__(256) rownorm2_max_kernel(const unsigned short* __restrict__ x, int64_t bs, int64_t rs, int L, int H,
                                                            int rows_per_block, unsigned* __restrict__ out) {
@@ -303,10 +308,9 @@ extern "C" int osk_rownorm2_max_bf16(const void* x, int64_t batch_stride, int64_
   if (!x || !out || B <= 0 || L <= 0 || H <= 0 || H > 256 || (batch_stride & 7) || (row_stride & 7) || ((uintptr_t)x & 15) || ((uintptr_t)out & 3))
     return OSK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * B * H, st);
-    if (e != hipSuccess) return (int)e;
-  }
+  // (zeroed by a KERNEL, not hipMemsetAsync: under hipGraph capture the memset of these few bytes was not replayed -- a replayed step
+  //  then folded its maxima into the previous replay's, found by tests/test_gpu_mmdit.py::test_denoise_step_is_hipgraph_capturable[device_bound])
+  if (!accumulate) hipLaunchKernelGGL(zero_u32_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, reinterpret_cast<unsigned*>(out), B * H);
   int rows = (L + 255) / 256;             // about 256 blocks per batch item: few, fat blocks (same-address atomics are slow)
   if (rows < 16) rows = 16;
   dim3 grid((L + rows - 1) / rows, B), block(256);
@@ -463,6 +467,11 @@ __global__ void __launch_bounds__(256) v_absmax_kernel(const unsigned short* __r
     if (smax[i]) atomicMax(&amax_bits[b * H + i], smax[i]);
 }
 
+__global__ void v_scale_zero_kernel(unsigned* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 __global__ void v_scale_finalize_kernel(unsigned* __restrict__ amax_bits, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -477,8 +486,7 @@ extern "C" int osk_v_scale_fp8(const void* v, int64_t bs, int64_t rs, float* sca
   if (!v || !scales || B <= 0 || L <= 0 || H <= 0 || H > 256 || (hd & 7) || (bs & 7) || (rs & 7) || ((uintptr_t)v & 15))
     return OSK_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(scales, 0, sizeof(float) * B * H, st);
-  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(v_scale_zero_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, reinterpret_cast<unsigned*>(scales), B * H);   // (a kernel, not hipMemsetAsync: see osk_rownorm2_max_bf16)
   int rows = (L + 127) / 128;            // about 128 blocks per batch item
   if (rows < 16) rows = 16;
   dim3 grid((L + rows - 1) / rows, B), block(256);

@@ -187,13 +187,20 @@ __global__ void __launch_bounds__(256) masked_softmax_kernel(const float* __rest
 
 }  // namespace
 
+namespace {
+__global__ void gn_zero_kernel(double* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.0;
+}
+}  // namespace
+
 extern "C" int osk_groupnorm_stats_ndhwc_bf16(const void* x, int B, int64_t S, int C, int G, double* sums,
                                               void* stream) {
   if (!x || !sums || B <= 0 || S <= 0 || C < 32 || C > 512 || G <= 0) return OSK_EINVAL;
   if ((C & (C - 1)) || C % G || ((C / G) & (C / G - 1)) || C / G > 16 || ((uintptr_t)x & 15)) return OSK_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, st);
-  if (e != hipSuccess) return (int)e;
+  // (zeroed by a kernel, not hipMemsetAsync: a memset of a few bytes was not replayed from a captured hipGraph -- round 6, attention_fwd.hip)
+  hipLaunchKernelGGL(gn_zero_kernel, dim3((2 * B * G + 255) / 256), dim3(256), 0, st, sums, 2 * B * G);
   const int rpp = GN_NT / (C >> 3);
   // 256 blocks per batch item (one per CU) for small tensors, 512 above 64 MB; at least one pass of the 4-deep
   // unrolled loop per block

@@ -119,7 +119,8 @@ def test_s_config_single_step(hip_lib):
     assert_parity(out, truth, ref_bf16, "MMDiT-S single step (cfg 1)")
 
 
-def test_denoise_step_is_hipgraph_capturable(hip_lib):
+@pytest.mark.parametrize("qk_scale", [1.0, 2.5], ids=["host_bound", "device_bound"])
+def test_denoise_step_is_hipgraph_capturable(hip_lib, qk_scale):
     """include/osk.h promises entry points without allocation, synchronisation or global state, i.e. capturable in a
     hipGraph: capture ONE whole denoise step (MMDiT forward on the CFG triple + the fused CFG / Euler update) with
     torch.cuda.graph, replay it on new inputs written into the captured buffers, and compare with the eager step."""
@@ -128,6 +129,16 @@ def test_denoise_step_is_hipgraph_capturable(hip_lib):
     cfg, _, T, h, w, L_txt = configs.GOLDEN["hd72_eager_split"]
     B = 3
     model = _build(cfg)
+    if qk_scale != 1.0:
+        # QK-norm scales whose weight-derived bound exceeds the FAST limit: the blocks take the bound from their operands on the device
+        # (osk_rownorm2_max_bf16 + the auto-dispatched launch pair, round 6) -- a memset, two reductions and two launches per block that
+        # must be capturable like everything else
+        with torch.no_grad():
+            for blk in list(model.double_blocks) + list(model.single_blocks):
+                for nrm in ([blk.img_attn.norm, blk.txt_attn.norm] if hasattr(blk, "img_attn") else [blk.norm]):
+                    nrm.query_norm.scale.mul_(qk_scale)
+                    nrm.key_norm.scale.mul_(qk_scale)
+        model.invalidate_plan()
     inp = torch_inputs(cfg, B, T, h, w, L_txt, dtype=BF, device="cuda")
     x = inp["img"][:1].clone().contiguous()
     x_next = torch.empty_like(x)
@@ -140,6 +151,8 @@ def test_denoise_step_is_hipgraph_capturable(hip_lib):
     with torch.inference_mode():
         step()                                   # warm-up: builds the plan and the workspaces outside the capture
         torch.cuda.synchronize()
+        rep = model.attention_report()
+        assert rep["blocks_auto_dispatched"] == (0 if qk_scale == 1.0 else rep["blocks"]), rep
         x0 = x.clone()
         eager = []
         for i in range(2):                       # eager results for two different latent states

@@ -1,4 +1,3 @@
 cd "$(dirname "$0")/.."
-timeout 300 python tools/_dbg_gelu.py 2>&1 | tail -5
-timeout 900 python -m pytest tests/test_gpu_fp8.py tests/test_gpu_overlap.py tests/test_gpu_seqpar_1gpu.py tests/test_gpu_stdit_shapes.py -x -q -m gpu 2>&1 | tail -5
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "gemm" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_mmdit.py tests/test_gpu_fp8.py -x -q -m gpu -k "hipgraph or fp8 or auto" 2>&1 | tail -6
+timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "auto_bound or rownorm" 2>&1 | tail -3
