@@ -32,6 +32,13 @@ from .make_golden import OUT_DIR
 
 GEOM = dict(B=1, T=16, h=32, w=32, L_txt=512)
 STRIDE, OFFSET = 8, 3
+# Round 6: a second fixture -- the SHIPPED geometry (11B: hidden 3072, 24 x 128, unfused q / k / v projections, Liger RoPE;
+# /root/reference/configs/diffusion/inference/256px.py:36-55) at the reference's own shipped 256 px shape (129 frames of 224 x 288 px
+# -> latent 33 x 28 x 36 -> 33 x 14 x 18 = 8,316 image tokens + 512 text tokens: 8,828 = 137 x 64 + 60, a ragged last key tile), at
+# REDUCED DEPTH 2 + 4 (the full 19 + 38 is 11 G parameters: 44 GB in fp32, beyond this container): every kernel of the hd-128 path at
+# its real width and at the real token count, six blocks deep.
+#     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_fullsize_dit 11b        (~15 min on 8 cores, ~20 GB)
+GEOM_11B = dict(B=1, T=33, h=14, w=18, L_txt=512)
 
 
 def xl_cfg() -> dict:
@@ -39,6 +46,13 @@ def xl_cfg() -> dict:
     return dict(in_channels=64, vec_in_dim=768, context_in_dim=4096, mlp_ratio=4.0, theta=10000, qkv_bias=True,
                 guidance_embed=False, cond_embed=True, fused_qkv=True, use_liger_rope=False,
                 hidden_size=1152, num_heads=16, depth=9, depth_single_blocks=19, axes_dim=[8, 32, 32])
+
+
+def cfg_11b_d2s4() -> dict:
+    # the 11B row of open_sora_amd/configs.py at depth 2 + 4, restated (oracle/ never imports the product package)
+    return dict(in_channels=64, vec_in_dim=768, context_in_dim=4096, mlp_ratio=4.0, theta=10000, qkv_bias=True,
+                guidance_embed=False, cond_embed=True, fused_qkv=False, use_liger_rope=True,
+                hidden_size=3072, num_heads=24, depth=2, depth_single_blocks=4, axes_dim=[16, 56, 56])
 
 
 def summarize(out: torch.Tensor) -> dict:
@@ -53,10 +67,10 @@ def rel_l2(a, b) -> float:
     return float((a - b).norm() / b.norm())
 
 
-def main():
+def main(which: str = "xl"):
     torch.set_num_threads(os.cpu_count() or 1)
     t0 = time.time()
-    cfg = xl_cfg()
+    cfg, GEOM, name = (xl_cfg(), globals()["GEOM"], "mmdit_fullsize_xl") if which == "xl" else (cfg_11b_d2s4(), GEOM_11B, "mmdit_fullsize_11b_d2s4")
     M, _, _ = ref_loader.mmdit()
     sd = {k: torch.from_numpy(v) for k, v in synth.make_params(synth.mmdit_param_shapes(cfg), 0, workers=os.cpu_count()).items()}
     print(f"weights: {time.time() - t0:.0f} s ({sum(v.numel() for v in sd.values()) / 1e9:.2f} G parameters)", flush=True)
@@ -68,7 +82,7 @@ def main():
         truth = model(**inp)
     print(f"fp32 forward: {time.time() - t0:.0f} s  out {tuple(truth.shape)} |out|max {float(truth.abs().max()):.4f}", flush=True)
     out = summarize(truth)
-    np.savez_compressed(os.path.join(OUT_DIR, "mmdit_fullsize_xl.partial.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".partial.npz"), **out)
     model = model.to(torch.bfloat16)
     inp16 = {k: (v if "ids" in k else v.bfloat16()) for k, v in inp.items()}
     with torch.inference_mode():
@@ -79,11 +93,11 @@ def main():
     out["a_ref"] = np.float64((ref.double() - truth.double()).abs().max())
     out["out_absmax"] = np.float64(truth.abs().max())
     print({k: float(out[k]) for k in ("e_ref", "e_ref_s8", "a_ref", "out_absmax")}, flush=True)
-    path = os.path.join(OUT_DIR, "mmdit_fullsize_xl.npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)
-    os.remove(os.path.join(OUT_DIR, "mmdit_fullsize_xl.partial.npz"))
+    os.remove(os.path.join(OUT_DIR, name + ".partial.npz"))
     print(f"{path}: {os.path.getsize(path)} B")
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "xl")

@@ -173,6 +173,56 @@ def test_xl_timed_configuration_vs_reference_fixture(hip_lib):
     assert max(d1, d2) <= 1.5 * e_ref, "batch entries with equal inputs differ beyond the reference-precision error"
 
 
+def test_11b_shipped_shape_vs_reference_fixture(hip_lib):
+    """The reference's SHIPPED geometry at its SHIPPED shape against the reference itself (round 6): hidden 3072, 24 heads x 128,
+    unfused q / k / v projections, Liger RoPE (configs/diffusion/inference/256px.py:36-55) at 33 x 14 x 18 = 8,316 image tokens + 512
+    text tokens (129 frames of 224 x 288 px; 8,828 keys = 137 tiles + a ragged one), depth 2 + 4 (the full 19 + 38 does not fit the
+    build container's memory in fp32).  tests/golden/mmdit_fullsize_11b_d2s4.npz holds what the reference's own MMDiTModel returns
+    (fp32, CPU, oracle/make_golden_fullsize_dit.py 11b) on a token lattice + whole-output moments + e_ref / a_ref of its own eager
+    bf16 run.  The HIP forward runs the CFG triple (B = 3: the launch shapes of `ref_256px_11b` in bench.py); every batch entry must
+    meet SURVEY 8(d)'s rule.  This is the hd-128 FAST attention body, the q | k + V^T group projection with concatenated unfused
+    weights, the half-split RoPE convention and the K = 3072 / 15,360 GEMMs at their real widths, six blocks deep."""
+    import os
+
+    import numpy as np
+
+    from oracle import make_golden_fullsize_dit as FS
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mmdit_fullsize_11b_d2s4.npz")
+    g = np.load(path)
+    cfg = FS.cfg_11b_d2s4()
+    full = pcfg.MMDIT["11B"]
+    assert {k: cfg[k] for k in full if k not in ("depth", "depth_single_blocks")} == {k: v for k, v in full.items() if k not in ("depth", "depth_single_blocks")}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(synth.mmdit_param_shapes(cfg), 0, workers=min(64, os.cpu_count() or 1)).items()}
+    model = _xl_model(cfg, sd)
+    del sd
+    G = FS.GEOM_11B
+    inp = {k: torch.from_numpy(v) for k, v in synth.mmdit_inputs(cfg, 1, G["T"], G["h"], G["w"], G["L_txt"]).items()}
+    inp3 = {k: v.expand(3, *v.shape[1:]).contiguous() for k, v in inp.items()}
+    with torch.inference_mode():
+        out = model(**_to(inp3, BF, DEV)).float().cpu()
+    L = G["T"] * G["h"] * G["w"] + G["L_txt"]
+    assert L == 8828 and list(out.shape) == [3, L - G["L_txt"], cfg["in_channels"]] and torch.isfinite(out).all()
+    rep = model.attention_report(1, L)
+    assert rep["bodies"] == ["attn_asm128_kernel<FAST>"] and rep["blocks_auto_dispatched"] == 0, rep
+    e_ref, a_ref = float(g["e_ref"]), float(g["a_ref"])
+    truth = torch.from_numpy(g["out_s8"])
+    tnorm = float(np.sqrt(g["ch_sq"].sum()))
+    for b in range(3):
+        got = FS.summarize(out[b:b + 1])
+        e = rel_l2(torch.from_numpy(got["out_s8"]), truth)
+        a = float((torch.from_numpy(got["out_s8"]).double() - truth.double()).abs().max())
+        em = float(np.abs(got["ch_mean"] - g["ch_mean"]).max())
+        es = float(np.abs(got["ch_sq"] - g["ch_sq"]).max() / np.abs(g["ch_sq"]).max())
+        print(f"11B (depth 2 + 4) at the shipped 256 px shape, batch entry {b}: lattice relL2 {e:.3e} (reference bf16: {float(g['e_ref_s8']):.3e} lattice, "
+              f"{e_ref:.3e} whole); max-abs {a:.3e} (reference bf16 {a_ref:.3e}); per-channel mean |d| {em:.3e}, mean-square rel {es:.3e}")
+        assert e <= max(1.5 * float(g["e_ref_s8"]), 2.0 ** -8), (b, e)
+        assert a <= 4.0 * a_ref, (b, a)
+        assert em <= 1.5 * e_ref * tnorm / np.sqrt(len(g["ch_mean"])) and es <= 3.0 * e_ref, (b, em, es)
+    d1, d2 = rel_l2(out[1], out[0]), rel_l2(out[2], out[0])
+    assert max(d1, d2) <= 1.5 * e_ref, "batch entries with equal inputs differ beyond the reference-precision error"
+
+
 # ------------------------------------------------------------------------------------------------ 11B geometry (the shipped config)
 def _pe_for(ang, liger: bool):
     """the reference's two positional-embedding formats (layers.py:38-44 / 55-65) from one angle table"""

@@ -1,3 +1,2 @@
 cd "$(dirname "$0")/.."
-timeout 900 python -m pytest tests/test_gpu_mmdit.py tests/test_gpu_fp8.py -x -q -m gpu -k "hipgraph or fp8 or auto" 2>&1 | tail -6
-timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "auto_bound or rownorm" 2>&1 | tail -3
+timeout 1500 python -m pytest tests/test_gpu_baseline_geometry.py -x -q -m gpu -s -k "11b_shipped_shape" 2>&1 | tail -8
