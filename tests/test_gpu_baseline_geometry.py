@@ -221,6 +221,13 @@ def test_11b_shipped_shape_vs_reference_fixture(hip_lib):
         assert em <= 1.5 * e_ref * tnorm / np.sqrt(len(g["ch_mean"])) and es <= 3.0 * e_ref, (b, em, es)
     d1, d2 = rel_l2(out[1], out[0]), rel_l2(out[2], out[0])
     assert max(d1, d2) <= 1.5 * e_ref, "batch entries with equal inputs differ beyond the reference-precision error"
+    # BASELINE configs[4]'s arithmetic on the same fixture: block Linears + attention P.V on the fp8 MFMA; SURVEY 8(d)'s fp8 gate
+    model.enable_fp8()
+    with torch.inference_mode():
+        out8 = model(**_to(inp3, BF, DEV)).float().cpu()
+    e8 = rel_l2(torch.from_numpy(FS.summarize(out8[:1])["out_s8"]), truth)
+    print(f"   fp8 mode on the same fixture: lattice relL2 {e8:.3e} against the reference's fp32 truth (gate 5e-2)")
+    assert torch.isfinite(out8).all() and e8 <= 5e-2, e8
 
 
 # ------------------------------------------------------------------------------------------------ 11B geometry (the shipped config)
