@@ -700,10 +700,26 @@ def run_double_block(plan: _DoublePlan, ws: _Workspace, mod: Tensor, col_img: in
         _OPS.qknorm_rope(q, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
         _joint_attention(ws, q, k, v, H, hd, plan.pv8, plan.score_bound, vt_ready)
     else:
-        for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):  # K, V first: their all-gather overlaps the Q projection
-            _linear(act, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
+        # K, V first: their exchange overlaps the Q projection.  All-gather mode, bf16: V goes straight into this rank's slot of the
+        # gathered V^T buffer (osk_gemm_group_bf16's V^T task, round 6) -- no token-major V, no osk_v_transpose_bf16 pass on the rank
+        vt_ready = False
+        vt_loc = sp.local_vt(ws.B, ws.L, H, hd, ws.x.device) if (ws.vt_group and not plan.pv8 and Lt % 64 == 0 and hasattr(sp, "local_vt") and
+                                                                  _bf16_operands(*acts, *(s_[0].qkv_w for s_ in streams))) else None
+        if vt_loc is not None:
+            tasks = []
+            for ((aw, x_s, xm_s, y_s, sh1, sc1), act) in zip(streams, acts):
+                pos = Lt if (aw is plan.img and Lt) else 0         # local key order: [txt rows ; img rows]
+                b = aw.qkv_b
+                tasks.append(dict(a=act, w=aw.qkv_w[D: 2 * D], bias=None if b is None else b[D: 2 * D], out=y_s[:, :, D:]))
+                tasks.append(dict(x=act, w=aw.qkv_w[2 * D:], bias=None if b is None else b[2 * D:], vt=vt_loc, vt_pos=pos, hd=hd))
+            vt_ready = _OPS.gemm_group(tasks)
+            if not vt_ready:
+                ws.vt_group = False
+        if not vt_ready:
+            for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):
+                _linear(act, aw.qkv_w[D:], None if aw.qkv_b is None else aw.qkv_b[D:], y_s[:, :, D:])
         _OPS.qknorm_rope(None, k, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode)
-        pending = sp.gather_kv_start(ws, k, v, H, hd, plan.pv8)
+        pending = sp.gather_kv_start(ws, k, v, H, hd, plan.pv8, vt_ready=vt_ready)
         for (aw, x_s, xm_s, y_s, sh1, sc1), act in zip(streams, acts):
             _linear(act, aw.qkv_w[:D], None if aw.qkv_b is None else aw.qkv_b[:D], y_s[:, :, :D])
         _OPS.qknorm_rope(q, None, *scales, Lt, rope.cos, rope.sin, csb, H, hd, rope.mode, q_mult=q_mult(hd))
@@ -761,9 +777,19 @@ def run_single_block(plan: _SinglePlan, ws: _Workspace, mod: Tensor, col: int, r
         _joint_attention(ws, q, k, v, H, hd, plan.pv8, plan.score_bound, vt_ready)
     else:
         b1 = plan.b1
-        _linear(act, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])
+        vt_ready = False
+        vt_loc = sp.local_vt(ws.B, ws.L, H, hd, ws.x.device) if (ws.vt_group and not plan.pv8 and hasattr(sp, "local_vt") and
+                                                                  _bf16_operands(act, plan.w1)) else None
+        if vt_loc is not None:     # (see run_double_block)
+            vt_ready = _OPS.gemm_group([
+                dict(a=act, w=plan.w1[D: 2 * D], bias=None if b1 is None else b1[D: 2 * D], out=y[:, :, D:]),
+                dict(x=act, w=plan.w1[2 * D: 3 * D], bias=None if b1 is None else b1[2 * D: 3 * D], vt=vt_loc, vt_pos=0, hd=hd)])
+            if not vt_ready:
+                ws.vt_group = False
+        if not vt_ready:
+            _linear(act, plan.w1[D: 3 * D], None if b1 is None else b1[D: 3 * D], y[:, :, D: 3 * D])
         _OPS.qknorm_rope(None, k, *scales, 0, rope.cos, rope.sin, csb, H, hd, rope.mode)
-        pending = sp.gather_kv_start(ws, k, v, H, hd, plan.pv8)
+        pending = sp.gather_kv_start(ws, k, v, H, hd, plan.pv8, vt_ready=vt_ready)
         mlp_up = lambda: _linear(act, plan.w1[3 * D:], None if b1 is None else b1[3 * D:], y[:, :, 3 * D:], gelu_from=0)
         head_mode = sp.head_parallel(H)
         if not head_mode:    # K / V^T all-gather: the MLP-up and Q projections both overlap it

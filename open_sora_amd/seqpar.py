@@ -196,7 +196,15 @@ class SeqPar:
 
         return self._cached(("pv8", B, Lloc, H, hd, str(device), mmdit._stream_key(device)), make)
 
-    def gather_kv_start(self, ws, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False):
+    def local_vt(self, B: int, Lloc: int, H: int, hd: int, device):
+        """this rank's slot [B, H, hd, round_up(L/P, 64)] of the gathered V^T buffer (all-gather mode, bf16), or None: the projection
+        may write V straight into it as V^T (osk_gemm_group_bf16's V^T task, round 6) -- gather_kv_start(..., vt_ready=True) then
+        skips the osk_v_transpose_bf16 pass"""
+        if self.head_parallel(H):
+            return None
+        return self._buffers(B, Lloc, H, hd, device)[1][self.rank]
+
+    def gather_kv_start(self, ws, k: Tensor, v: Tensor, H: int, hd: int, pv8: bool = False, vt_ready: bool = False):
         """k, v: this rank's [B, L/P, D] views (K already normed + rotated with GLOBAL positions).  Starts the
         exchange of K and V and returns the handles; the caller keeps computing.
         pv8 (fp8 mode): V travels as e4m3 V^T (half the bytes); its per-(batch, head) scale must be the same on
@@ -219,7 +227,8 @@ class SeqPar:
             return "pv8", k_all, vt8_all, sv, wk, wv
         k_all, vt_all = self._buffers(B, Lloc, H, hd, k.device)
         mmdit.ops().copy_rows(k, k_all[self.rank])
-        mmdit.ops().v_transpose(v, vt_all[self.rank], H, hd)
+        if not vt_ready:                       # (vt_ready: the V projection already wrote local_vt())
+            mmdit.ops().v_transpose(v, vt_all[self.rank], H, hd)
         wk = self.tp.all_gather(k_all.view(-1), k_all[self.rank].view(-1))
         wv = self.tp.all_gather(vt_all.view(-1), vt_all[self.rank].view(-1))
         return k_all, vt_all, wk, wv
